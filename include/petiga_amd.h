@@ -1,0 +1,213 @@
+/*
+ * petiga_amd.h -- C ABI of libpetiga_amd.so: the MI355X-native IGA element-assembly engine.
+ *
+ * This is the drop-in boundary for ONE path of dalcinl/PetIGA: the element loop behind
+ *   IGAComputeSystem / IGAComputeMatrix / IGAComputeVector      (src/petigaksp.c:33,79,149)
+ *   IGAComputeFunction / IGAComputeJacobian                     (src/petigasnes.c:23,82)
+ *   IGAComputeIFunction / IGAComputeIJacobian                   (src/petigats.c:23,92)
+ * i.e. IGANextElement -> IGAElementBuildTabulation -> point callback -> IGAPointAddMat ->
+ * IGAElementFixSystem -> IGAElementAssembleMat, re-implemented as HIP kernels for gfx950.
+ *
+ * Everything is plain C: opaque handles, int/double scalars, raw pointers and sizes.  No PETSc,
+ * torch or C++ types cross this boundary.  All citations are file:line of the reference tree.
+ *
+ * Two ways in:
+ *   (1) IGXCreate + IGXAxis* + IGXSetUp ...   mirrors the PetIGA user API (include/petiga.h),
+ *       so a test written against PetIGA reads the same against this library;
+ *   (2) IGXCreateFromTables                    takes the tables a set-up PetIGA `IGA` already
+ *       holds (struct _p_IGA, include/petiga.h:327-391) -- what IGAComputeSystem inside
+ *       libpetiga would bind.
+ *
+ * Error convention: every function returns an int error code, 0 = success, non-zero values are
+ * PETSc's own PetscErrorCode numbers for the same condition (include/petscerror.h) so the
+ * adapter can `CHKERRQ` them unchanged.  IGXGetLastError() returns the message SETERRQ would print.
+ */
+#ifndef PETIGA_AMD_H
+#define PETIGA_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* PetscErrorCode values reused verbatim */
+#define IGX_ERR_SUP             56   /* PETSC_ERR_SUP             */
+#define IGX_ERR_ORDER           58   /* PETSC_ERR_ORDER           */
+#define IGX_ERR_ARG_WRONG       62   /* PETSC_ERR_ARG_WRONG       */
+#define IGX_ERR_ARG_OUTOFRANGE  63   /* PETSC_ERR_ARG_OUTOFRANGE  */
+#define IGX_ERR_ARG_WRONGSTATE  73   /* PETSC_ERR_ARG_WRONGSTATE  */
+#define IGX_ERR_LIB             76   /* PETSC_ERR_LIB (HIP runtime failure) */
+#define IGX_ERR_PLIB            77   /* PETSC_ERR_PLIB            */
+#define IGX_ERR_USER            83   /* PETSC_ERR_USER (e.g. non-positive Jacobian, src/petigaelem.c:989-993) */
+#define IGX_ERR_MEM             55   /* PETSC_ERR_MEM             */
+
+#define IGX_DECIDE (-1)              /* PETSC_DECIDE */
+
+typedef struct _p_IGX    *IGX;       /* replaces `IGA`  (include/petiga.h:327)                  */
+typedef struct _p_IGXMat *IGXMat;    /* replaces the `Mat` of IGACreateMat (src/petigamat.c:345) */
+typedef struct _p_IGXVec *IGXVec;    /* replaces the `Vec` of IGACreateVec (src/petigavec.c:78)  */
+
+const char *IGXGetLastError(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Device point forms.  PetIGA's point callbacks are host function pointers
+ * (IGAFormSystem etc., include/petiga.h:153-197) and cannot run on the GPU; the engine keeps
+ * their contract (point-wise, un-weighted integrand, K[a][i][b][j] / F[a][i] row-major,
+ * src/petigapoint.c:451-462) and binds the function at compile time.  `params` replaces `ctx`.
+ * ------------------------------------------------------------------------------------------ */
+typedef enum {
+  IGX_FORM_NONE        = 0,
+  IGX_FORM_POISSON     = 1, /* System: demo/Poisson{1,2,3}D.c:3-23        K=grad.grad, F=N*1          params: none */
+  IGX_FORM_MASS        = 2, /* System: test/IGACreate.c:45-63             K=Na*Nb (per field), F=N    params: none */
+  IGX_FORM_L2PROJ_X2   = 3, /* System: test/IGAFixTable.c:25-43           K=Na*Nb, F=N*sum x^2        params: none */
+  IGX_FORM_POISSON_F   = 4, /* System: test/IGAFixTable.c:45-64           K=grad.grad, F=N*(-2 dim)   params: none */
+  IGX_FORM_ERRNORM     = 5, /* System: test/IGAErrNorm.c:54-75 (dof=4)    L2 projection of 1,Sx,Sx2,Px              */
+  IGX_FORM_ELASTICITY  = 6, /* System: demo/Elasticity3D.c:13-46 (dof=3)  params: {lambda, mu}                      */
+  IGX_FORM_CAHNHILLIARD= 7, /* IFunction/IJacobian: demo/CahnHilliard3D.c:55-179 (and the 2-D demo)
+                               params: {theta, alpha, cbar, L0, lambda, tau}; L0<=0 selects the 2-D demo's 3*alpha scaling */
+  IGX_FORM_NSVMS       = 8  /* IFunction/IJacobian: demo/NavierStokesVMS.c:78-244 (dof=4)
+                               params: {nu, fx, fy, fz, dt}  (dt: the reference reads TSGetTimeStep at :85,:173) */
+} IGXFormKind;
+
+/* ------------------------------------------------------------------------------------------
+ * (1) Mirror of the PetIGA set-up API
+ * ------------------------------------------------------------------------------------------ */
+int IGXCreate(IGX *iga);                                   /* IGACreate          src/petiga.c:32   */
+int IGXDestroy(IGX *iga);                                  /* IGADestroy         src/petiga.c:79   */
+int IGXSetDim(IGX iga,int dim);                            /* IGASetDim          src/petiga.c:281  */
+int IGXSetDof(IGX iga,int dof);                            /* IGASetDof          src/petiga.c:334  */
+int IGXSetOrder(IGX iga,int order);                        /* IGASetOrder        src/petiga.c:463  (clipped to [1,4]) */
+int IGXSetQuadrature(IGX iga,int i,int q);                 /* IGASetQuadrature   src/petiga.c:530  */
+int IGXSetProcessors(IGX iga,int i,int processors);        /* IGASetProcessors   src/petiga.c:547  */
+int IGXSetComm(IGX iga,int size,int rank);                 /* the (size,rank) of the MPI_Comm given to IGACreate */
+int IGXAxisSetDegree(IGX iga,int i,int p);                 /* IGAAxisSetDegree   src/petigaaxis.c:168 */
+int IGXAxisSetPeriodic(IGX iga,int i,int flag);            /* IGAAxisSetPeriodic src/petigaaxis.c:150 */
+int IGXAxisInitUniform(IGX iga,int i,int N,double Ui,double Uf,int C); /* IGAAxisInitUniform src/petigaaxis.c:401 */
+int IGXAxisSetKnots(IGX iga,int i,int m,const double U[]); /* IGAAxisSetKnots    src/petigaaxis.c:202 */
+int IGXSetUp(IGX iga);                                     /* IGASetUp           src/petiga.c:1450 */
+
+/* Geometry: control net on the geometry grid (n+1 points per axis, i0 fastest), Cartesian X[...][nsd]
+ * and optional NURBS weights W (NULL = polynomial).  Stands for IGASetGeometryDim + the arrays
+ * iga->geometryX / iga->rationalW that IGALoadGeometry fills (src/petigaio.c:201-356). */
+int IGXSetGeometry(IGX iga,int nsd,const double X[],const double W[]);
+
+int IGXSetBoundaryValue(IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryValue src/petigaform.c:324 */
+int IGXSetBoundaryLoad (IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryLoad  src/petigaform.c:340 */
+int IGXClearBoundary(IGX iga);                                             /* IGAFormClearBoundary src/petigaform.c:143 (all faces) */
+int IGXSetFixTable(IGX iga,IGXVec U);                                      /* IGASetFixTable      src/petigaform.c:273 (NULL clears) */
+
+/* IGASetFormSystem / IGASetFormMatrix / ... (src/petigaform.c:388-833): kind + params replace (fn,ctx).
+ * The one kind serves System/Matrix/Vector or Function/Jacobian/IFunction/IJacobian as the reference demo does. */
+int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
+
+/* sizes after IGXSetUp */
+int IGXGetSizes(IGX iga,int elem_sizes[3],int elem_start[3],int elem_width[3],
+                int node_sizes[3],int node_lstart[3],int node_lwidth[3],int node_gstart[3],int node_gwidth[3]);
+int IGXGetProcessors(IGX iga,int proc_sizes[3],int proc_ranks[3]);
+int64_t IGXGetElementCount(IGX iga);   /* local elements */
+
+/* ------------------------------------------------------------------------------------------
+ * (2) Building the same object from a set-up PetIGA `IGA` (what libpetiga would pass)
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  /* per axis: struct _n_IGAAxis (include/petiga.h:80-96) */
+  int           p, m, periodic, nel, nnp;
+  const double *U;        /* [m+1] */
+  const int    *span;     /* [nel] */
+  /* per axis: struct _n_IGABasis (include/petiga.h:122-141) */
+  int           nqp, nen;
+  const int    *offset;   /* [nel]            */
+  const double *detJac;   /* [nel]            */
+  const double *weight;   /* [nel][nqp]       */
+  const double *point;    /* [nel][nqp]       */
+  const double *value;    /* [nel][nqp][nen][5] */
+} IGXAxisTables;
+
+typedef struct {
+  int dim, dof, order;                       /* iga->dim, dof, order                              */
+  IGXAxisTables axis[3];
+  int proc_sizes[3], proc_ranks[3];          /* iga->proc_sizes/ranks                             */
+  int elem_sizes[3], elem_start[3], elem_width[3];
+  int node_sizes[3], node_lstart[3], node_lwidth[3], node_gstart[3], node_gwidth[3];
+  int nsd;                                   /* iga->geometry (0 = none)                          */
+  int rational;                              /* iga->rational                                     */
+  const double *geometryX;                   /* ghosted local [gw2][gw1][gw0][nsd]  (iga->geometryX) */
+  const double *rationalW;                   /* ghosted local [gw2][gw1][gw0]       (iga->rationalW) */
+} IGXTables;
+
+int IGXCreateFromTables(const IGXTables *t,IGX *iga);
+
+/* ------------------------------------------------------------------------------------------
+ * Matrices and vectors (device resident)
+ * ------------------------------------------------------------------------------------------ */
+/* IGACreateMat (src/petigamat.c:345-549): exact pattern of the reference, block CSR with
+ * dof x dof row-major blocks (AIJ for dof=1, BAIJ for dof>1, src/petiga.c:1328).  Rows are the
+ * nodes of the local row box, columns are local column indices; see IGXMatGetLayout. */
+int IGXCreateMat(IGX iga,IGXMat *mat);
+int IGXMatDestroy(IGXMat *mat);
+int IGXMatGetInfo(IGXMat mat,int64_t *nbrows,int64_t *nblocks,int *bs);
+/* device pointers: browptr int64[nbrows+1], bcolidx int32[nblocks], val double[nblocks*bs*bs] */
+int IGXMatGetDeviceArrays(IGXMat mat,const int64_t **browptr,const int32_t **bcolidx,double **val);
+int IGXMatCopyToHost(IGXMat mat,int64_t *browptr,int32_t *bcolidx,double *val); /* any may be NULL */
+/* per axis: number of row / column indices and the global node index each maps to
+ * (rows: node index after periodic wrap; cols likewise) -- the LGMap of src/petigagrid.c:213 */
+int IGXMatGetLayout(IGXMat mat,int nrow[3],int ncol[3]);
+int IGXMatGetAxisMaps(IGXMat mat,int axis,int *rownode /*[nrow]*/,int *colnode /*[ncol]*/);
+
+/* IGACreateVec (src/petigavec.c:78): one value per (row node, field), same row numbering as the matrix */
+int IGXCreateVec(IGX iga,IGXVec *vec);
+int IGXVecDestroy(IGXVec *vec);
+int IGXVecGetSize(IGXVec vec,int64_t *n);
+int IGXVecGetDeviceArray(IGXVec vec,double **array);
+int IGXVecCopyToHost(IGXVec vec,double *host);
+int IGXVecCopyFromHost(IGXVec vec,const double *host);
+
+/* ------------------------------------------------------------------------------------------
+ * The hot path.  Same meaning and argument order as the reference drivers; outputs are zeroed
+ * first, then every local element's K_e/F_e is formed, BC-fixed and added (colour-ordered,
+ * conflict-free, deterministic).  All work is enqueued on the engine's stream
+ * (IGXSetStream); call IGXSynchronize before reading results through raw device pointers.
+ * ------------------------------------------------------------------------------------------ */
+int IGXComputeSystem   (IGX iga,IGXMat A,IGXVec b);                               /* src/petigaksp.c:149 */
+int IGXComputeMatrix   (IGX iga,IGXMat A);                                        /* src/petigaksp.c:79  */
+int IGXComputeVector   (IGX iga,IGXVec b);                                        /* src/petigaksp.c:33  */
+int IGXComputeFunction (IGX iga,IGXVec U,IGXVec F);                               /* src/petigasnes.c:23 */
+int IGXComputeJacobian (IGX iga,IGXVec U,IGXMat J);                               /* src/petigasnes.c:82 */
+int IGXComputeIFunction(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXVec F);    /* src/petigats.c:23   */
+int IGXComputeIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXMat J);    /* src/petigats.c:92   */
+
+/* engine controls */
+int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default stream            */
+int IGXSynchronize(IGX iga);
+/* 0 = automatic; 1 = generic point-form kernel; 2 = MFMA gradient-Gram kernel (forms/degrees it covers) */
+int IGXSetKernel(IGX iga,int which);
+int IGXGetKernelName(IGX iga,char *buf,int len); /* name of the kernel the last IGXCompute* used   */
+/* time of the dominant kernel of the last IGXCompute* call, measured with HIP events on the
+ * engine's stream (ms); IGXSetTiming(1) enables the events */
+int IGXSetTiming(IGX iga,int flag);
+int IGXGetLastTiming(IGX iga,double *total_ms,double *kernel_ms,int *launches);
+
+/* element colouring used by the scatter: colour of local element (i,j,k) and the number of
+ * colours (bit-exact contract, tests/test_coloring.py) */
+int IGXGetColoring(IGX iga,int ncolors[3]);
+int IGXGetElementColor(IGX iga,int axis,int e);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-GPU (one process per GPU): ghost-row exchange buffers.  Rank r's ghost rows (nodes it
+ * holds but does not own) are packed per upper neighbour; the owner adds them.  The transport
+ * (RCCL send/recv or all_to_all over xGMI) is the caller's: torch.distributed in bench.py.
+ * ------------------------------------------------------------------------------------------ */
+int IGXGetNeighborCount(IGX iga,int *nsend,int *nrecv);
+int IGXGetNeighborInfo(IGX iga,int send /*1=send list,0=recv list*/,int k,int *rank,int64_t *mat_doubles,int64_t *vec_doubles);
+int IGXPackGhostRows  (IGX iga,IGXMat A,IGXVec b,int k,double *devbuf);   /* A or b may be NULL */
+int IGXUnpackGhostRows(IGX iga,IGXMat A,IGXVec b,int k,const double *devbuf);
+
+/* library / device info for logs */
+int IGXGetDeviceInfo(char *buf,int len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PETIGA_AMD_H */

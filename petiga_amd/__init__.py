@@ -1,0 +1,280 @@
+"""petiga_amd -- MI355X-native IGA element-assembly engine (one hot path of dalcinl/PetIGA).
+
+This package is a thin ctypes view of the C ABI in include/petiga_amd.h; all compute is in
+libpetiga_amd.so (hand-written HIP for gfx950).  There is no CPU or PyTorch fallback: if the
+library is missing or no GPU is visible, the compute calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+class IGXError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("IGX error %d: %s" % (code, msg))
+        self.code = code
+
+
+def lib(build_if_needed=False):
+    """Load libpetiga_amd.so.  torch (if importable) is imported first so both share one HIP runtime."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    so = os.path.join(_HERE, "libpetiga_amd.so")
+    if build_if_needed:
+        so = _build.build()
+    if not os.path.exists(so):
+        raise ImportError("libpetiga_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    try:
+        import torch  # noqa: F401  (same libamdhip64 for both)
+    except Exception:
+        pass
+    L = C.CDLL(so)
+    V = C.c_void_p
+    L.IGXGetLastError.restype = C.c_char_p
+    L.IGXGetElementCount.restype = C.c_int64
+    L.IGXGetElementCount.argtypes = [V]
+    sig = {
+        "IGXCreate": [C.POINTER(V)], "IGXDestroy": [C.POINTER(V)], "IGXSetDim": [V, C.c_int], "IGXSetDof": [V, C.c_int],
+        "IGXSetOrder": [V, C.c_int], "IGXSetQuadrature": [V, C.c_int, C.c_int], "IGXSetProcessors": [V, C.c_int, C.c_int],
+        "IGXSetComm": [V, C.c_int, C.c_int], "IGXAxisSetDegree": [V, C.c_int, C.c_int], "IGXAxisSetPeriodic": [V, C.c_int, C.c_int],
+        "IGXAxisInitUniform": [V, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], "IGXAxisSetKnots": [V, C.c_int, C.c_int, _dp],
+        "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp],
+        "IGXSetBoundaryValue": [V, C.c_int, C.c_int, C.c_int, C.c_double], "IGXSetBoundaryLoad": [V, C.c_int, C.c_int, C.c_int, C.c_double],
+        "IGXClearBoundary": [V], "IGXSetFixTable": [V, V], "IGXSetForm": [V, C.c_int, _dp, C.c_int],
+        "IGXGetSizes": [V] + [_ip] * 8, "IGXGetProcessors": [V, _ip, _ip],
+        "IGXCreateMat": [V, C.POINTER(V)], "IGXMatDestroy": [C.POINTER(V)],
+        "IGXMatGetInfo": [V, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip],
+        "IGXMatGetDeviceArrays": [V, C.POINTER(V), C.POINTER(V), C.POINTER(V)],
+        "IGXMatCopyToHost": [V, V, V, V], "IGXMatGetLayout": [V, _ip, _ip], "IGXMatGetAxisMaps": [V, C.c_int, _ip, _ip],
+        "IGXCreateVec": [V, C.POINTER(V)], "IGXVecDestroy": [C.POINTER(V)], "IGXVecGetSize": [V, C.POINTER(C.c_int64)],
+        "IGXVecGetDeviceArray": [V, C.POINTER(V)], "IGXVecCopyToHost": [V, _dp], "IGXVecCopyFromHost": [V, _dp],
+        "IGXComputeSystem": [V, V, V], "IGXComputeMatrix": [V, V], "IGXComputeVector": [V, V],
+        "IGXComputeFunction": [V, V, V], "IGXComputeJacobian": [V, V, V],
+        "IGXComputeIFunction": [V, C.c_double, V, C.c_double, V, V], "IGXComputeIJacobian": [V, C.c_double, V, C.c_double, V, V],
+        "IGXSetStream": [V, V], "IGXSynchronize": [V], "IGXSetKernel": [V, C.c_int], "IGXGetKernelName": [V, C.c_char_p, C.c_int],
+        "IGXSetTiming": [V, C.c_int], "IGXGetLastTiming": [V, _dp, _dp, _ip],
+        "IGXGetColoring": [V, _ip], "IGXGetElementColor": [V, C.c_int, C.c_int],
+        "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
+        "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V],
+        "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
+    }
+    for name, args in sig.items():
+        f = getattr(L, name)
+        f.argtypes = args
+        f.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _ck(rc):
+    if rc:
+        raise IGXError(rc, lib().IGXGetLastError().decode())
+
+
+class Vec:
+    def __init__(self, iga):
+        self.iga = iga
+        self.h = C.c_void_p()
+        _ck(lib().IGXCreateVec(iga.h, C.byref(self.h)))
+        n = C.c_int64()
+        _ck(lib().IGXVecGetSize(self.h, C.byref(n)))
+        self.n = n.value
+
+    def __del__(self):
+        try:
+            lib().IGXVecDestroy(C.byref(self.h))
+        except Exception:
+            pass
+
+    def set(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.n
+        _ck(lib().IGXVecCopyFromHost(self.h, a.ctypes.data_as(_dp)))
+        return self
+
+    def get(self):
+        a = np.empty(self.n)
+        _ck(lib().IGXVecCopyToHost(self.h, a.ctypes.data_as(_dp)))
+        return a
+
+    def device_ptr(self):
+        p = C.c_void_p()
+        _ck(lib().IGXVecGetDeviceArray(self.h, C.byref(p)))
+        return p.value
+
+
+class Mat:
+    def __init__(self, iga):
+        self.iga = iga
+        self.h = C.c_void_p()
+        _ck(lib().IGXCreateMat(iga.h, C.byref(self.h)))
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int()
+        _ck(lib().IGXMatGetInfo(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        self.nbrows, self.nblocks, self.bs = a.value, b.value, c.value
+
+    def __del__(self):
+        try:
+            lib().IGXMatDestroy(C.byref(self.h))
+        except Exception:
+            pass
+
+    def device_ptrs(self):
+        a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _ck(lib().IGXMatGetDeviceArrays(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def host(self, values_only=False):
+        val = np.empty(self.nblocks * self.bs * self.bs)
+        if values_only:
+            _ck(lib().IGXMatCopyToHost(self.h, None, None, val.ctypes.data))
+            return val
+        rp = np.empty(self.nbrows + 1, dtype=np.int64)
+        ci = np.empty(self.nblocks, dtype=np.int32)
+        _ck(lib().IGXMatCopyToHost(self.h, rp.ctypes.data, ci.ctypes.data, val.ctypes.data))
+        return rp, ci, val
+
+    def layout(self):
+        nrow, ncol = (C.c_int * 3)(), (C.c_int * 3)()
+        _ck(lib().IGXMatGetLayout(self.h, nrow, ncol))
+        maps = []
+        for d in range(3):
+            r = np.empty(nrow[d], dtype=np.int32)
+            c = np.empty(ncol[d], dtype=np.int32)
+            _ck(lib().IGXMatGetAxisMaps(self.h, d, r.ctypes.data_as(_ip), c.ctypes.data_as(_ip)))
+            maps.append((r, c))
+        return list(nrow), list(ncol), maps
+
+    def to_scipy_global(self):
+        """Global natural-order CSR (node*dof+field) -- the Mat PETSc would hold on one rank."""
+        import scipy.sparse as sp
+        rp, ci, val = self.host()
+        nrow, ncol, maps = self.layout()
+        ns = self.iga.sizes()["node_sizes"]
+        bs = self.bs
+        r = np.arange(self.nbrows, dtype=np.int64)
+        r0, r1, r2 = r % nrow[0], (r // nrow[0]) % nrow[1], r // (nrow[0] * nrow[1])
+        grow = maps[0][0][r0].astype(np.int64) + ns[0] * (maps[1][0][r1].astype(np.int64) + ns[1] * maps[2][0][r2].astype(np.int64))
+        c = ci.astype(np.int64)
+        c0, c1, c2 = c % ncol[0], (c // ncol[0]) % ncol[1], c // (ncol[0] * ncol[1])
+        gcol = maps[0][1][c0].astype(np.int64) + ns[0] * (maps[1][1][c1].astype(np.int64) + ns[1] * maps[2][1][c2].astype(np.int64))
+        browidx = np.repeat(grow, np.diff(rp))
+        nn = int(np.prod(ns))
+        B = sp.bsr_matrix((val.reshape(-1, bs, bs), gcol, np.arange(len(gcol) + 1)), shape=(len(gcol) * bs, nn * bs))
+        # one block per block-row of B; sum block rows that map to the same global node
+        Pm = sp.csr_matrix((np.ones(len(browidx) * bs), (np.repeat(browidx, bs) * bs + np.tile(np.arange(bs), len(browidx)),
+                                                          np.arange(len(browidx) * bs))), shape=(nn * bs, len(browidx) * bs))
+        return (Pm @ B.tocsr()).tocsr()
+
+
+class IGX:
+    """Mirror of the PetIGA calls a driver program makes around IGAComputeSystem & friends."""
+
+    def __init__(self, dim=None, dof=None):
+        self.h = C.c_void_p()
+        _ck(lib().IGXCreate(C.byref(self.h)))
+        if dim is not None:
+            self.set_dim(dim)
+        if dof is not None:
+            self.set_dof(dof)
+
+    def __del__(self):
+        try:
+            lib().IGXDestroy(C.byref(self.h))
+        except Exception:
+            pass
+
+    def set_dim(self, dim): _ck(lib().IGXSetDim(self.h, dim)); self.dim = dim
+    def set_dof(self, dof): _ck(lib().IGXSetDof(self.h, dof)); self.dof = dof
+    def set_order(self, o): _ck(lib().IGXSetOrder(self.h, o))
+    def set_quadrature(self, i, q): _ck(lib().IGXSetQuadrature(self.h, i, q))
+    def set_comm(self, size, rank): _ck(lib().IGXSetComm(self.h, size, rank))
+    def set_processors(self, i, n): _ck(lib().IGXSetProcessors(self.h, i, n))
+
+    def axis_uniform(self, i, p, N, C_=-1, Ui=0.0, Uf=1.0, periodic=False):
+        _ck(lib().IGXAxisSetDegree(self.h, i, p))
+        _ck(lib().IGXAxisSetPeriodic(self.h, i, int(periodic)))
+        _ck(lib().IGXAxisInitUniform(self.h, i, N, Ui, Uf, C_))
+
+    def axis_knots(self, i, p, U, periodic=False):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        _ck(lib().IGXAxisSetDegree(self.h, i, p))
+        _ck(lib().IGXAxisSetPeriodic(self.h, i, int(periodic)))
+        _ck(lib().IGXAxisSetKnots(self.h, i, len(U) - 1, U.ctypes.data_as(_dp)))
+
+    def setup(self): _ck(lib().IGXSetUp(self.h))
+
+    def set_geometry(self, X, W=None):
+        X = np.ascontiguousarray(X, dtype=np.float64)
+        Wp = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+        _ck(lib().IGXSetGeometry(self.h, X.shape[-1], X.ctypes.data_as(_dp), None if Wp is None else Wp.ctypes.data_as(_dp)))
+
+    def set_boundary_value(self, axis, side, field, value): _ck(lib().IGXSetBoundaryValue(self.h, axis, side, field, value))
+    def set_boundary_load(self, axis, side, field, value): _ck(lib().IGXSetBoundaryLoad(self.h, axis, side, field, value))
+    def clear_boundary(self): _ck(lib().IGXClearBoundary(self.h))
+    def set_fixtable(self, vec): _ck(lib().IGXSetFixTable(self.h, vec.h if vec is not None else None))
+
+    def set_form(self, kind, params=()):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _ck(lib().IGXSetForm(self.h, FORMS[kind] if isinstance(kind, str) else kind, p.ctypes.data_as(_dp) if p.size else None, p.size))
+
+    def sizes(self):
+        arrs = [(C.c_int * 3)() for _ in range(8)]
+        _ck(lib().IGXGetSizes(self.h, *arrs))
+        names = ["elem_sizes", "elem_start", "elem_width", "node_sizes", "node_lstart", "node_lwidth", "node_gstart", "node_gwidth"]
+        out = {k: list(a) for k, a in zip(names, arrs)}
+        ps, pr = (C.c_int * 3)(), (C.c_int * 3)()
+        _ck(lib().IGXGetProcessors(self.h, ps, pr))
+        out["proc_sizes"], out["proc_ranks"] = list(ps), list(pr)
+        return out
+
+    def element_count(self): return lib().IGXGetElementCount(self.h)
+    def create_mat(self): return Mat(self)
+    def create_vec(self): return Vec(self)
+
+    def compute_system(self, A, b): _ck(lib().IGXComputeSystem(self.h, A.h, b.h))
+    def compute_matrix(self, A): _ck(lib().IGXComputeMatrix(self.h, A.h))
+    def compute_vector(self, b): _ck(lib().IGXComputeVector(self.h, b.h))
+    def compute_function(self, U, F): _ck(lib().IGXComputeFunction(self.h, U.h, F.h))
+    def compute_jacobian(self, U, J): _ck(lib().IGXComputeJacobian(self.h, U.h, J.h))
+    def compute_ifunction(self, a, V, t, U, F): _ck(lib().IGXComputeIFunction(self.h, a, V.h, t, U.h, F.h))
+    def compute_ijacobian(self, a, V, t, U, J): _ck(lib().IGXComputeIJacobian(self.h, a, V.h, t, U.h, J.h))
+
+    def set_stream(self, stream): _ck(lib().IGXSetStream(self.h, stream))
+    def synchronize(self): _ck(lib().IGXSynchronize(self.h))
+    def set_kernel(self, which): _ck(lib().IGXSetKernel(self.h, which))
+    def set_timing(self, flag=True): _ck(lib().IGXSetTiming(self.h, int(flag)))
+
+    def kernel_name(self):
+        buf = C.create_string_buffer(256)
+        _ck(lib().IGXGetKernelName(self.h, buf, 256))
+        return buf.value.decode()
+
+    def last_timing(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int()
+        _ck(lib().IGXGetLastTiming(self.h, C.byref(a), C.byref(b), C.byref(n)))
+        return a.value, b.value, n.value
+
+    def coloring(self):
+        nc = (C.c_int * 3)()
+        _ck(lib().IGXGetColoring(self.h, nc))
+        return list(nc)
+
+    def element_color(self, axis, e): return lib().IGXGetElementColor(self.h, axis, e)
+
+
+def device_info():
+    buf = C.create_string_buffer(256)
+    lib().IGXGetDeviceInfo(buf, 256)
+    return buf.value.decode()

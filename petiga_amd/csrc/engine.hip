@@ -1,0 +1,522 @@
+// engine.hip -- device side of libpetiga_amd: table upload, sparsity pattern, kernel dispatch, C ABI.
+// Reference citations are file:line of dalcinl/PetIGA @ 2025-04-04.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+#include "igx.hpp"
+#include "generic_kernel.hpp"
+#include "gram_mfma.hpp"
+
+using namespace igx;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+#define HIPCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(IGX_ERR_LIB, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ------------------------------------------------------------------ objects
+struct DevBuf {
+  void *p = nullptr; size_t bytes = 0;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) { if (p) { (void)hipFree(p); p = nullptr; } bytes = n; if (!n) return 0; return hipMalloc(&p, n) == hipSuccess ? 0 : 1; }
+  template <class T> int upload(const std::vector<T> &v) {
+    if (alloc(v.size() * sizeof(T))) return 1;
+    if (v.empty()) return 0;
+    return hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+  }
+  template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix; };
+
+struct _p_IGX {
+  Space s;
+  bool on_device = false;
+  AxisBufs ab[3];
+  DevBuf X, W, fixtable, errflag, scratch;
+  hipStream_t stream = nullptr;
+  int kernel_choice = 0;
+  std::string last_kernel = "none";
+  bool timing = false;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
+  int64_t nbrows = 0, nblocks = 0;
+};
+
+struct _p_IGXMat {
+  IGX iga; int bs; int64_t nbrows, nblocks;
+  DevBuf browptr, bcolidx, val;
+};
+struct _p_IGXVec { IGX iga; int64_t n; DevBuf a; };
+
+extern "C" const char *IGXGetLastError(void) { return g_err.c_str(); }
+
+// ------------------------------------------------------------------ set-up mirror
+extern "C" int IGXCreate(IGX *iga) { if (!iga) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *iga = new _p_IGX(); return 0; }
+extern "C" int IGXDestroy(IGX *iga) {
+  if (!iga || !*iga) return 0;
+  for (auto &e : (*iga)->ev) if (e) (void)hipEventDestroy(e);
+  delete *iga; *iga = nullptr; return 0;
+}
+#define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
+#define AXISCK(g, i) do { NEEDIGA(g); if ((i) < 0 || (i) >= 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,2]"); } while (0)
+static void touch(IGX g) { g->s.setup = false; g->on_device = false; }
+
+extern "C" int IGXSetDim(IGX g, int dim) { NEEDIGA(g); if (dim < 1 || dim > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of parametric dimensions must be in range [1,3]"); g->s.dim = dim; touch(g); return 0; }
+extern "C" int IGXSetDof(IGX g, int dof) { NEEDIGA(g); if (dof < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of DOFs per node must be greater than one"); if (dof > MAXBC) return fail(IGX_ERR_SUP, "device path supports dof <= 8"); g->s.dof = dof; touch(g); return 0; }
+extern "C" int IGXSetOrder(IGX g, int order) { NEEDIGA(g); if (order < 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Order must be nonnegative"); g->s.order = order < 1 ? 1 : (order > 4 ? 4 : order); return 0; }
+extern "C" int IGXSetQuadrature(IGX g, int i, int q) { AXISCK(g, i); if (q == IGX_DECIDE && g->s.axis[i].p > 0) q = g->s.axis[i].p + 1; if (q <= 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of quadrature points must be positive"); g->s.rule_nqp[i] = q; touch(g); return 0; }
+extern "C" int IGXSetProcessors(IGX g, int i, int n) { AXISCK(g, i); g->s.proc_req[i] = n; touch(g); return 0; }
+extern "C" int IGXSetComm(IGX g, int size, int rank) { NEEDIGA(g); if (size < 1 || rank < 0 || rank >= size) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad communicator size/rank"); g->s.comm_size = size; g->s.comm_rank = rank; touch(g); return 0; }
+extern "C" int IGXAxisSetDegree(IGX g, int i, int p) { AXISCK(g, i); if (p < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Polynomial degree must be greater than zero"); if (p > 7) return fail(IGX_ERR_SUP, "degree > 7 not supported"); g->s.axis[i].p = p; touch(g); return 0; }
+extern "C" int IGXAxisSetPeriodic(IGX g, int i, int flag) { AXISCK(g, i); g->s.axis[i].periodic = flag ? 1 : 0; touch(g); return 0; }
+extern "C" int IGXAxisInitUniform(IGX g, int i, int N, double Ui, double Uf, int C) { AXISCK(g, i); std::string e; int rc = axis_init_uniform(g->s.axis[i], N, Ui, Uf, C, e); touch(g); return rc ? fail(rc, e) : 0; }
+extern "C" int IGXAxisSetKnots(IGX g, int i, int m, const double U[]) { AXISCK(g, i); if (!U) return fail(IGX_ERR_ARG_WRONG, "null knots"); std::string e; int rc = axis_set_knots(g->s.axis[i], m, U, e); touch(g); return rc ? fail(rc, e) : 0; }
+extern "C" int IGXSetUp(IGX g) { NEEDIGA(g); std::string e; int rc = space_setup(g->s, e); g->on_device = false; return rc ? fail(rc, e) : 0; }
+
+extern "C" int IGXSetGeometry(IGX g, int nsd, const double X[], const double W[]) {
+  NEEDIGA(g); Space &s = g->s;
+  if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  if (nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+  if (!X) return fail(IGX_ERR_ARG_WRONG, "null control points");
+  int gs[3] = {1, 1, 1};
+  for (int i = 0; i < s.dim; ++i) gs[i] = s.axis[i].span[s.axis[i].nel - 1] + 1;
+  const int *g0 = s.node_gstart, *gw = s.node_gwidth;
+  s.geomX.assign((size_t)gw[0] * gw[1] * gw[2] * nsd, 0.0);
+  s.geomW.clear(); if (W) s.geomW.assign((size_t)gw[0] * gw[1] * gw[2], 0.0);
+  size_t pos = 0;
+  for (int k = g0[2]; k < g0[2] + gw[2]; ++k) for (int j = g0[1]; j < g0[1] + gw[1]; ++j) for (int i = g0[0]; i < g0[0] + gw[0]; ++i, ++pos) {
+    const size_t gi = (size_t)i + (size_t)gs[0] * ((size_t)j + (size_t)gs[1] * (size_t)k);
+    for (int c = 0; c < nsd; ++c) s.geomX[pos * nsd + c] = X[gi * nsd + c];
+    if (W) s.geomW[pos] = W[gi];
+  }
+  s.nsd = nsd; s.rational = W ? 1 : 0;
+  g->on_device = false;
+  return 0;
+}
+
+static int bc_set(BC &bc, int field, double value) {   // src/petigaform.c:100-110
+  int k; for (k = 0; k < bc.count; ++k) if (bc.field[k] == field) break;
+  if (k == bc.count) bc.count++;
+  bc.field[k] = field; bc.value[k] = value; return 0;
+}
+static int bc_args(IGX g, int axis, int side, int field) {
+  if (axis < 0 || axis >= (g->s.dim > 0 ? g->s.dim : 3)) return fail(IGX_ERR_ARG_OUTOFRANGE, "Expecting 0<=axis<dim");
+  if (side < 0 || side >= 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "Expecting 0<=side<2");
+  if (field < 0 || field >= (g->s.dof > 0 ? g->s.dof : 64)) return fail(IGX_ERR_ARG_OUTOFRANGE, "Expecting 0<=field<dof");
+  return 0;
+}
+extern "C" int IGXSetBoundaryValue(IGX g, int axis, int side, int field, double v) { NEEDIGA(g); if (int rc = bc_args(g, axis, side, field)) return rc; return bc_set(g->s.value[axis][side], field, v); }
+extern "C" int IGXSetBoundaryLoad(IGX g, int axis, int side, int field, double v) { NEEDIGA(g); if (int rc = bc_args(g, axis, side, field)) return rc; return bc_set(g->s.load[axis][side], field, v); }
+extern "C" int IGXClearBoundary(IGX g) { NEEDIGA(g); for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) { g->s.value[a][s].count = 0; g->s.load[a][s].count = 0; } return 0; }
+extern "C" int IGXSetForm(IGX g, IGXFormKind kind, const double params[], int nparams) {
+  NEEDIGA(g);
+  if (nparams < 0 || nparams > MAXPARAM) return fail(IGX_ERR_ARG_OUTOFRANGE, "too many form parameters");
+  g->s.form = kind; g->s.params.assign(params ? params : nullptr, params ? params + nparams : nullptr);
+  return 0;
+}
+extern "C" int IGXGetSizes(IGX g, int es[3], int est[3], int ew[3], int ns[3], int nls[3], int nlw[3], int ngs[3], int ngw[3]) {
+  NEEDIGA(g); const Space &s = g->s;
+  if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  for (int i = 0; i < 3; ++i) {
+    if (es) es[i] = s.elem_sizes[i]; if (est) est[i] = s.elem_start[i]; if (ew) ew[i] = s.elem_width[i];
+    if (ns) ns[i] = s.node_sizes[i]; if (nls) nls[i] = s.node_lstart[i]; if (nlw) nlw[i] = s.node_lwidth[i];
+    if (ngs) ngs[i] = s.node_gstart[i]; if (ngw) ngw[i] = s.node_gwidth[i];
+  }
+  return 0;
+}
+extern "C" int IGXGetProcessors(IGX g, int ps[3], int pr[3]) { NEEDIGA(g); for (int i = 0; i < 3; ++i) { if (ps) ps[i] = g->s.proc_sizes[i]; if (pr) pr[i] = g->s.proc_ranks[i]; } return 0; }
+extern "C" int64_t IGXGetElementCount(IGX g) { if (!g || !g->s.setup) return 0; return (int64_t)g->s.elem_width[0] * g->s.elem_width[1] * g->s.elem_width[2]; }
+extern "C" int IGXGetColoring(IGX g, int nc[3]) { NEEDIGA(g); if (!g->s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first"); for (int i = 0; i < 3; ++i) nc[i] = g->s.lay[i].ncolors; return 0; }
+extern "C" int IGXGetElementColor(IGX g, int axis, int e) { if (!g || !g->s.setup || axis < 0 || axis > 2 || e < 0 || e >= (int)g->s.lay[axis].color.size()) return -1; return g->s.lay[axis].color[e]; }
+
+extern "C" int IGXCreateFromTables(const IGXTables *t, IGX *out) {
+  if (!t || !out) return fail(IGX_ERR_ARG_WRONG, "null pointer");
+  std::unique_ptr<_p_IGX> g(new _p_IGX());
+  Space &s = g->s;
+  if (t->dim < 1 || t->dim > 3 || t->dof < 1 || t->dof > MAXBC) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad dim/dof");
+  s.dim = t->dim; s.dof = t->dof; s.order = t->order < 1 ? 1 : (t->order > 4 ? 4 : t->order);
+  s.comm_size = 1; s.comm_rank = 0;
+  for (int i = 0; i < 3; ++i) {
+    s.proc_sizes[i] = i < s.dim ? t->proc_sizes[i] : 1; s.proc_ranks[i] = i < s.dim ? t->proc_ranks[i] : 0;
+    s.comm_size *= s.proc_sizes[i];
+  }
+  for (int i = s.dim - 1; i >= 0; --i) s.comm_rank = s.comm_rank * s.proc_sizes[i] + s.proc_ranks[i];
+  for (int i = 0; i < s.dim; ++i) {
+    const IGXAxisTables &a = t->axis[i];
+    if (!a.U || !a.span || !a.offset || !a.detJac || !a.weight || !a.point || !a.value) return fail(IGX_ERR_ARG_WRONG, "null axis table");
+    Axis &ax = s.axis[i]; ax.p = a.p; ax.m = a.m; ax.periodic = a.periodic; ax.nel = a.nel; ax.nnp = a.nnp;
+    if (a.p > 7) return fail(IGX_ERR_SUP, "degree > 7 not supported");
+    ax.U.assign(a.U, a.U + a.m + 1); ax.span.assign(a.span, a.span + a.nel);
+    Basis1D &b = s.basis[i]; b.nel = a.nel; b.nqp = a.nqp; b.nen = a.nen;
+    b.offset.assign(a.offset, a.offset + a.nel); b.detJac.assign(a.detJac, a.detJac + a.nel);
+    b.weight.assign(a.weight, a.weight + (size_t)a.nel * a.nqp); b.point.assign(a.point, a.point + (size_t)a.nel * a.nqp);
+    b.value.assign(a.value, a.value + (size_t)a.nel * a.nqp * a.nen * 5);
+    s.rule_nqp[i] = a.nqp;
+  }
+  for (int i = s.dim; i < 3; ++i) {
+    Basis1D &b = s.basis[i]; b.nel = 1; b.nqp = 1; b.nen = 1;
+    b.offset.assign(1, 0); b.detJac.assign(1, 1.0); b.weight.assign(1, 1.0); b.point.assign(1, 0.0); b.value.assign(5, 0.0); b.value[0] = 1.0;
+  }
+  for (int i = 0; i < 3; ++i) {
+    const bool in = i < s.dim;
+    s.elem_sizes[i] = in ? t->elem_sizes[i] : 1; s.elem_start[i] = in ? t->elem_start[i] : 0; s.elem_width[i] = in ? t->elem_width[i] : 1;
+    s.node_sizes[i] = in ? t->node_sizes[i] : 1; s.node_lstart[i] = in ? t->node_lstart[i] : 0; s.node_lwidth[i] = in ? t->node_lwidth[i] : 1;
+    s.node_gstart[i] = in ? t->node_gstart[i] : 0; s.node_gwidth[i] = in ? t->node_gwidth[i] : 1;
+  }
+  std::string e;
+  if (int rc = space_layout(s, e)) return fail(rc, e);
+  s.setup = true;
+  if (t->nsd) {
+    if (t->nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+    if (!t->geometryX) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set");
+    const size_t n = (size_t)s.node_gwidth[0] * s.node_gwidth[1] * s.node_gwidth[2];
+    s.geomX.assign(t->geometryX, t->geometryX + n * t->nsd); s.nsd = t->nsd;
+    if (t->rational) { if (!t->rationalW) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set"); s.geomW.assign(t->rationalW, t->rationalW + n); s.rational = 1; }
+  }
+  *out = g.release();
+  return 0;
+}
+
+// ------------------------------------------------------------------ device upload
+static int ensure_device(IGX g) {
+  Space &s = g->s;
+  if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  if (g->on_device) return 0;
+  for (int d = 0; d < 3; ++d) {
+    const Basis1D &b = s.basis[d]; const AxisLayout &L = s.lay[d];
+    const int e0 = s.elem_start[d], ne = s.elem_width[d], nq = b.nqp, na = b.nen;
+    std::vector<double> tab((size_t)ne * nq * na * NDER), w((size_t)ne * nq), pt((size_t)ne * nq), J(ne);
+    std::vector<int> off(ne);
+    for (int e = 0; e < ne; ++e) {
+      J[e] = b.detJac[e0 + e]; off[e] = b.offset[e0 + e] - L.gstart;
+      for (int q = 0; q < nq; ++q) {
+        w[(size_t)e * nq + q] = b.weight[(size_t)(e0 + e) * nq + q]; pt[(size_t)e * nq + q] = b.point[(size_t)(e0 + e) * nq + q];
+        for (int a = 0; a < na; ++a) for (int k = 0; k < NDER; ++k)
+          tab[(((size_t)e * nq + q) * na + a) * NDER + k] = b.value[(((size_t)(e0 + e) * nq + q) * na + a) * 5 + k];
+      }
+    }
+    std::vector<int64_t> prefix(L.nrow + 1, 0);
+    for (int r = 0; r < L.nrow; ++r) prefix[r + 1] = prefix[r] + L.rcnt[r];
+    AxisBufs &B = g->ab[d];
+    if (B.tab.upload(tab) || B.w.upload(w) || B.J.upload(J) || B.pt.upload(pt) || B.off.upload(off) || B.rowmap.upload(L.rowmap) ||
+        B.rcnt.upload(L.rcnt) || B.P.upload(L.P) || B.rcol.upload(L.rcol) || B.prefix.upload(prefix))
+      return fail(IGX_ERR_MEM, "device allocation of axis tables failed");
+  }
+  if (g->X.upload(s.geomX) || g->W.upload(s.geomW)) return fail(IGX_ERR_MEM, "device allocation of geometry failed");
+  if (!g->errflag.p) { if (g->errflag.alloc(sizeof(int))) return fail(IGX_ERR_MEM, "device allocation failed"); HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); }
+  g->nbrows = (int64_t)s.lay[0].nrow * s.lay[1].nrow * s.lay[2].nrow;
+  {
+    int64_t t[3];
+    for (int d = 0; d < 3; ++d) { t[d] = 0; for (int r = 0; r < s.lay[d].nrow; ++r) t[d] += s.lay[d].rcnt[r]; }
+    g->nblocks = t[0] * t[1] * t[2];
+  }
+  g->on_device = true;
+  return 0;
+}
+
+static SpaceDev make_spacedev(IGX g) {
+  const Space &s = g->s; SpaceDev S;
+  memset(&S, 0, sizeof(S));
+  S.dim = s.dim; S.dof = s.dof; S.order = s.order; S.nsd = s.nsd; S.rational = s.rational;
+  for (int d = 0; d < 3; ++d) {
+    AxisDev &A = S.ax[d]; const AxisBufs &B = g->ab[d]; const AxisLayout &L = s.lay[d];
+    A.nel = s.elem_width[d]; A.nqp = s.basis[d].nqp; A.nen = s.basis[d].nen; A.p = L.p;
+    A.estart = s.elem_start[d]; A.esizes = s.elem_sizes[d]; A.periodic = d < s.dim ? s.axis[d].periodic : 0;
+    A.gwidth = L.gwidth; A.nrow = L.nrow; A.ncol = L.ncol;
+    A.tab = B.tab.as<double>(); A.w = B.w.as<double>(); A.J = B.J.as<double>(); A.pt = B.pt.as<double>();
+    A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
+  }
+  S.X = s.nsd ? g->X.as<double>() : nullptr; S.W = s.rational ? g->W.as<double>() : nullptr;
+  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) {
+    auto cp = [&](const BC &h, BCDev &dv) { dv.count = 0; for (int k = 0; k < h.count && dv.count < MAXBC; ++k) if (h.field[k] < s.dof) { dv.field[dv.count] = h.field[k]; dv.value[dv.count] = h.value[k]; dv.count++; } };
+    cp(s.value[a][sd], S.bcv[a][sd]); cp(s.load[a][sd], S.bcl[a][sd]);
+  }
+  S.fixtable = g->fixtable.as<double>();
+  return S;
+}
+
+// ------------------------------------------------------------------ sparsity pattern kernels (IGACreateMat, src/petigamat.c:345-549)
+struct PatDev { int nrow[3], ncol[3], W[3]; const int *rcnt[3]; const int *rcol[3]; const int64_t *prefix[3]; int64_t tot[3]; };
+
+__global__ void k_browptr(PatDev P, int64_t nbrows, int64_t *browptr) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > nbrows) return;
+  if (r == nbrows) { browptr[r] = P.tot[0] * P.tot[1] * P.tot[2]; return; }
+  const int r0 = (int)(r % P.nrow[0]), r1 = (int)((r / P.nrow[0]) % P.nrow[1]), r2 = (int)(r / ((int64_t)P.nrow[0] * P.nrow[1]));
+  const int64_t c1 = P.rcnt[1][r1], c2 = P.rcnt[2][r2];
+  browptr[r] = P.prefix[2][r2] * P.tot[1] * P.tot[0] + c2 * (P.prefix[1][r1] * P.tot[0] + c1 * P.prefix[0][r0]);
+}
+__global__ void k_bcolidx(PatDev P, int64_t nbrows, const int64_t *browptr, int32_t *bcolidx) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nbrows) return;
+  const int r0 = (int)(r % P.nrow[0]), r1 = (int)((r / P.nrow[0]) % P.nrow[1]), r2 = (int)(r / ((int64_t)P.nrow[0] * P.nrow[1]));
+  const int c0 = P.rcnt[0][r0], c1 = P.rcnt[1][r1], c2 = P.rcnt[2][r2];
+  int32_t *dst = bcolidx + browptr[r];
+  for (int k2 = 0; k2 < c2; ++k2) for (int k1 = 0; k1 < c1; ++k1) for (int k0 = 0; k0 < c0; ++k0)
+    *dst++ = P.rcol[0][r0 * P.W[0] + k0] + P.ncol[0] * (P.rcol[1][r1 * P.W[1] + k1] + P.ncol[1] * P.rcol[2][r2 * P.W[2] + k2]);
+}
+
+extern "C" int IGXCreateMat(IGX g, IGXMat *mat) {
+  NEEDIGA(g); if (!mat) return fail(IGX_ERR_ARG_WRONG, "null pointer");
+  if (int rc = ensure_device(g)) return rc;
+  const Space &s = g->s;
+  if ((int64_t)s.lay[0].ncol * s.lay[1].ncol * s.lay[2].ncol > INT32_MAX) return fail(IGX_ERR_SUP, "more than 2^31 column nodes per rank");
+  std::unique_ptr<_p_IGXMat> A(new _p_IGXMat());
+  A->iga = g; A->bs = s.dof; A->nbrows = g->nbrows; A->nblocks = g->nblocks;
+  if (A->browptr.alloc((size_t)(A->nbrows + 1) * sizeof(int64_t)) || A->bcolidx.alloc((size_t)A->nblocks * sizeof(int32_t)) ||
+      A->val.alloc((size_t)A->nblocks * s.dof * s.dof * sizeof(double)))
+    return fail(IGX_ERR_MEM, "device allocation of the matrix failed");
+  PatDev P;
+  for (int d = 0; d < 3; ++d) {
+    P.nrow[d] = s.lay[d].nrow; P.ncol[d] = s.lay[d].ncol; P.W[d] = 2 * s.lay[d].p + 1;
+    P.rcnt[d] = g->ab[d].rcnt.as<int>(); P.rcol[d] = g->ab[d].rcol.as<int>(); P.prefix[d] = g->ab[d].prefix.as<int64_t>();
+    P.tot[d] = 0; for (int r = 0; r < s.lay[d].nrow; ++r) P.tot[d] += s.lay[d].rcnt[r];
+  }
+  const int64_t n1 = A->nbrows + 1;
+  hipLaunchKernelGGL(k_browptr, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, g->stream, P, A->nbrows, A->browptr.as<int64_t>());
+  hipLaunchKernelGGL(k_bcolidx, dim3((unsigned)((A->nbrows + 255) / 256)), dim3(256), 0, g->stream, P, A->nbrows, A->browptr.as<int64_t>(), A->bcolidx.as<int32_t>());
+  HIPCK(hipMemsetAsync(A->val.p, 0, A->val.bytes, g->stream));
+  HIPCK(hipGetLastError());
+  HIPCK(hipStreamSynchronize(g->stream));
+  *mat = A.release();
+  return 0;
+}
+extern "C" int IGXMatDestroy(IGXMat *m) { if (m && *m) { delete *m; *m = nullptr; } return 0; }
+extern "C" int IGXMatGetInfo(IGXMat m, int64_t *nbrows, int64_t *nblocks, int *bs) { if (!m) return fail(IGX_ERR_ARG_WRONG, "null matrix"); if (nbrows) *nbrows = m->nbrows; if (nblocks) *nblocks = m->nblocks; if (bs) *bs = m->bs; return 0; }
+extern "C" int IGXMatGetDeviceArrays(IGXMat m, const int64_t **rp, const int32_t **ci, double **v) { if (!m) return fail(IGX_ERR_ARG_WRONG, "null matrix"); if (rp) *rp = m->browptr.as<int64_t>(); if (ci) *ci = m->bcolidx.as<int32_t>(); if (v) *v = m->val.as<double>(); return 0; }
+extern "C" int IGXMatCopyToHost(IGXMat m, int64_t *rp, int32_t *ci, double *v) {
+  if (!m) return fail(IGX_ERR_ARG_WRONG, "null matrix");
+  HIPCK(hipStreamSynchronize(m->iga->stream));
+  if (rp) HIPCK(hipMemcpy(rp, m->browptr.p, m->browptr.bytes, hipMemcpyDeviceToHost));
+  if (ci) HIPCK(hipMemcpy(ci, m->bcolidx.p, m->bcolidx.bytes, hipMemcpyDeviceToHost));
+  if (v) HIPCK(hipMemcpy(v, m->val.p, m->val.bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int IGXMatGetLayout(IGXMat m, int nrow[3], int ncol[3]) { if (!m) return fail(IGX_ERR_ARG_WRONG, "null matrix"); for (int d = 0; d < 3; ++d) { nrow[d] = m->iga->s.lay[d].nrow; ncol[d] = m->iga->s.lay[d].ncol; } return 0; }
+extern "C" int IGXMatGetAxisMaps(IGXMat m, int axis, int *rownode, int *colnode) {
+  if (!m || axis < 0 || axis > 2) return fail(IGX_ERR_ARG_WRONG, "bad argument");
+  const AxisLayout &L = m->iga->s.lay[axis];
+  if (rownode) memcpy(rownode, L.rownode.data(), L.rownode.size() * sizeof(int));
+  if (colnode) memcpy(colnode, L.colnode.data(), L.colnode.size() * sizeof(int));
+  return 0;
+}
+
+extern "C" int IGXCreateVec(IGX g, IGXVec *vec) {
+  NEEDIGA(g); if (!vec) return fail(IGX_ERR_ARG_WRONG, "null pointer");
+  if (int rc = ensure_device(g)) return rc;
+  std::unique_ptr<_p_IGXVec> v(new _p_IGXVec());
+  v->iga = g; v->n = g->nbrows * g->s.dof;
+  if (v->a.alloc((size_t)v->n * sizeof(double))) return fail(IGX_ERR_MEM, "device allocation of the vector failed");
+  HIPCK(hipMemset(v->a.p, 0, v->a.bytes));
+  *vec = v.release();
+  return 0;
+}
+extern "C" int IGXVecDestroy(IGXVec *v) { if (v && *v) { delete *v; *v = nullptr; } return 0; }
+extern "C" int IGXVecGetSize(IGXVec v, int64_t *n) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); *n = v->n; return 0; }
+extern "C" int IGXVecGetDeviceArray(IGXVec v, double **a) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); *a = v->a.as<double>(); return 0; }
+extern "C" int IGXVecCopyToHost(IGXVec v, double *h) { if (!v || !h) return fail(IGX_ERR_ARG_WRONG, "null argument"); HIPCK(hipStreamSynchronize(v->iga->stream)); HIPCK(hipMemcpy(h, v->a.p, v->a.bytes, hipMemcpyDeviceToHost)); return 0; }
+extern "C" int IGXVecCopyFromHost(IGXVec v, const double *h) { if (!v || !h) return fail(IGX_ERR_ARG_WRONG, "null argument"); HIPCK(hipStreamSynchronize(v->iga->stream)); HIPCK(hipMemcpy(v->a.p, h, v->a.bytes, hipMemcpyHostToDevice)); return 0; }
+
+extern "C" int IGXSetFixTable(IGX g, IGXVec U) {   // src/petigaform.c:273-298
+  NEEDIGA(g);
+  if (!U) { g->fixtable.alloc(0); return 0; }
+  if (U->iga != g) return fail(IGX_ERR_ARG_WRONG, "vector belongs to another IGX");
+  if (g->fixtable.alloc(U->a.bytes)) return fail(IGX_ERR_MEM, "device allocation failed");
+  HIPCK(hipStreamSynchronize(g->stream));
+  HIPCK(hipMemcpy(g->fixtable.p, U->a.p, U->a.bytes, hipMemcpyDeviceToDevice));
+  return 0;
+}
+
+// ------------------------------------------------------------------ engine controls
+extern "C" int IGXSetStream(IGX g, void *stream) { NEEDIGA(g); g->stream = (hipStream_t)stream; return 0; }
+extern "C" int IGXSynchronize(IGX g) {
+  NEEDIGA(g);
+  HIPCK(hipStreamSynchronize(g->stream));
+  if (g->errflag.p) {
+    int flag = 0; HIPCK(hipMemcpy(&flag, g->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) { HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); return fail(flag, "Non-positive det(Jacobian)"); }
+  }
+  return 0;
+}
+extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1 or 2"); g->kernel_choice = which; return 0; }
+extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s", g->last_kernel.c_str()); return 0; }
+extern "C" int IGXSetTiming(IGX g, int flag) {
+  NEEDIGA(g); g->timing = flag != 0;
+  if (g->timing) for (auto &e : g->ev) if (!e) HIPCK(hipEventCreate(&e));
+  return 0;
+}
+extern "C" int IGXGetLastTiming(IGX g, double *total_ms, double *kernel_ms, int *launches) {
+  NEEDIGA(g);
+  if (g->timing && g->ev[0]) {
+    HIPCK(hipEventSynchronize(g->ev[3]));
+    float a = 0, b = 0;
+    HIPCK(hipEventElapsedTime(&a, g->ev[0], g->ev[3]));
+    HIPCK(hipEventElapsedTime(&b, g->ev[1], g->ev[2]));
+    g->last_total_ms = a; g->last_kernel_ms = b;
+  }
+  if (total_ms) *total_ms = g->last_total_ms; if (kernel_ms) *kernel_ms = g->last_kernel_ms; if (launches) *launches = g->last_launches;
+  return 0;
+}
+extern "C" int IGXGetDeviceInfo(char *buf, int len) {
+  int dev = 0; hipDeviceProp_t pr;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { snprintf(buf, (size_t)len, "no HIP device"); return IGX_ERR_LIB; }
+  snprintf(buf, (size_t)len, "%s arch=%s CUs=%d clock=%dMHz mem=%.1fGB", pr.name, pr.gcnArchName, pr.multiProcessorCount, pr.clockRate / 1000, pr.totalGlobalMem / 1e9);
+  return 0;
+}
+
+// ------------------------------------------------------------------ generic kernel dispatch
+template <class Form, int DIM>
+static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
+  const Space &s = g->s;
+  constexpr int DOF = Form::DOF;
+  constexpr bool SECOND = Form::ORDER >= 2;
+  constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
+  if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
+  int nq[3], na[3]; int NQ = 1, NE = 1;
+  for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
+  Carve cv; int pos = 0;
+  auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };   // keep 16-byte alignment
+  for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(nq[d]); }
+  cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
+  cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
+  cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
+  cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
+  cv.G = take((Form::NEED & NEED_G) ? NQ * D2 : 0);
+  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
+  cv.gu = take((Form::NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? NQ * DOF * D2 : 0);
+  cv.lift = take(out.op == OP_SYSTEM ? NQ * DOF * NF : 0);
+  const size_t phi_doubles = (size_t)NQ * NE * NF;
+  const size_t lds_limit = 160 * 1024 - 512;
+  bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;
+  if (phi_in_lds) cv.phi = take((int)phi_doubles); else cv.phi = -1;
+  cv.total = pos;
+  const size_t lds_bytes = (size_t)pos * sizeof(double);
+  if (lds_bytes > lds_limit) return fail(IGX_ERR_SUP, "element work set exceeds the 160 KiB LDS");
+  auto kern = generic_assemble<Form, DIM>;
+  HIPCK(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  ParamsDev prm; memset(&prm, 0, sizeof(prm));
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+
+  const size_t scratch_cap = (size_t)2 << 30;   // HBM slice for Phi when it does not fit in LDS
+  size_t max_blocks = phi_in_lds ? ((size_t)1 << 30) : scratch_cap / (phi_doubles * sizeof(double));
+  if (max_blocks < 1) max_blocks = 1;
+  int launches = 0;
+  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
+      int first = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = first; cr.step[d] = stride; cr.count[d] = count;
+    }
+    if (empty) continue;
+    // split along axis 2 so that a launch never needs more scratch than the cap
+    const size_t per2 = (size_t)cr.count[0] * cr.count[1];
+    int chunk2 = (int)std::max<size_t>(1, std::min<size_t>((size_t)cr.count[2], max_blocks / std::max<size_t>(per2, 1)));
+    if (!phi_in_lds && per2 > max_blocks) return fail(IGX_ERR_SUP, "scratch too small for one element layer");
+    for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
+      ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
+      const size_t nblocks = per2 * sub.count[2];
+      if (!phi_in_lds) {
+        const size_t need = nblocks * phi_doubles * sizeof(double);
+        if (g->scratch.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->scratch.alloc(need)) return fail(IGX_ERR_MEM, "scratch allocation failed"); }
+      }
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, out, sub, cv, g->scratch.as<double>(), phi_doubles);
+      launches++;
+    }
+  }
+  HIPCK(hipGetLastError());
+  g->last_launches = launches;
+  g->last_kernel = std::string("generic_assemble(") + (phi_in_lds ? "phi=LDS" : "phi=HBM") + ")";
+  return 0;
+}
+
+template <int DIM>
+static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
+  const Space &s = g->s;
+  switch (s.form) {
+  case IGX_FORM_POISSON:   return launch_generic<FormPoisson<DIM>, DIM>(g, S, out);
+  case IGX_FORM_POISSON_F: return launch_generic<FormPoissonF<DIM>, DIM>(g, S, out);
+  case IGX_FORM_L2PROJ_X2: return launch_generic<FormL2ProjX2<DIM>, DIM>(g, S, out);
+  case IGX_FORM_ERRNORM:   return launch_generic<FormErrNorm<DIM>, DIM>(g, S, out);
+  case IGX_FORM_MASS:
+    switch (s.dof) {
+    case 1: return launch_generic<FormMass<DIM, 1>, DIM>(g, S, out);
+    case 2: return launch_generic<FormMass<DIM, 2>, DIM>(g, S, out);
+    case 3: return launch_generic<FormMass<DIM, 3>, DIM>(g, S, out);
+    case 4: return launch_generic<FormMass<DIM, 4>, DIM>(g, S, out);
+    default: return fail(IGX_ERR_SUP, "mass form is instantiated for dof 1..4");
+    }
+  case IGX_FORM_ELASTICITY:
+    if constexpr (DIM == 3) return launch_generic<FormElasticity, 3>(g, S, out);
+    else return fail(IGX_ERR_ARG_WRONG, "Elasticity3D form needs dim = 3");
+  case IGX_FORM_CAHNHILLIARD:
+    if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);
+    else return fail(IGX_ERR_ARG_WRONG, "Cahn-Hilliard form needs dim = 2 or 3");
+  case IGX_FORM_NSVMS:
+    if constexpr (DIM == 3) return launch_generic<FormNSVMS, 3>(g, S, out);
+    else return fail(IGX_ERR_ARG_WRONG, "NavierStokesVMS form needs dim = 3");
+  default: return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetForm...() first");   // IGACheckFormOp, include/petiga.h:925-936
+  }
+}
+
+// ------------------------------------------------------------------ the drivers
+static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double shift, double t) {
+  NEEDIGA(g);
+  if (int rc = ensure_device(g)) return rc;
+  const Space &s = g->s;
+  if (s.form == IGX_FORM_NONE) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetForm...() first");
+  const bool hasM = (op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN);
+  const bool hasV = (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
+  if (hasM && (!A || A->iga != g)) return fail(IGX_ERR_ARG_WRONG, "matrix missing or created by another IGX");
+  if (hasV && (!b || b->iga != g)) return fail(IGX_ERR_ARG_WRONG, "vector missing or created by another IGX");
+  if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
+  if (V && V->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
+  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd)
+    if (s.load[a][sd].count && s.nsd) return fail(IGX_ERR_SUP, "boundary loads on mapped geometries are not supported on the device path");
+  OutDev out; memset(&out, 0, sizeof(out));
+  out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>();
+  if (hasM) { out.browptr = A->browptr.as<int64_t>(); out.val = A->val.as<double>(); }
+  if (hasV) out.vec = b->a.as<double>();
+  out.U = U ? U->a.as<double>() : nullptr; out.V = V ? V->a.as<double>() : nullptr;
+  if (g->timing) HIPCK(hipEventRecord(g->ev[0], g->stream));
+  // MatZeroEntries / VecZeroEntries (src/petigaksp.c:166-167)
+  if (hasM) HIPCK(hipMemsetAsync(A->val.p, 0, A->val.bytes, g->stream));
+  if (hasV) HIPCK(hipMemsetAsync(b->a.p, 0, b->a.bytes, g->stream));
+  if (g->timing) HIPCK(hipEventRecord(g->ev[1], g->stream));
+  const SpaceDev S = make_spacedev(g);
+  int rc;
+  bool done = false;
+  if (g->kernel_choice != 1) {
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done);
+    if (rc) return rc;
+  }
+  if (!done) {
+    switch (s.dim) {
+    case 1: rc = dispatch_dim<1>(g, S, out); break;
+    case 2: rc = dispatch_dim<2>(g, S, out); break;
+    default: rc = dispatch_dim<3>(g, S, out); break;
+    }
+    if (rc) return rc;
+  }
+  if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }
+  return 0;
+}
+
+extern "C" int IGXComputeSystem(IGX g, IGXMat A, IGXVec b) { return compute(g, OP_SYSTEM, A, b, nullptr, nullptr, 0, 0); }
+extern "C" int IGXComputeMatrix(IGX g, IGXMat A) { return compute(g, OP_MATRIX, A, nullptr, nullptr, nullptr, 0, 0); }
+extern "C" int IGXComputeVector(IGX g, IGXVec b) { return compute(g, OP_VECTOR, nullptr, b, nullptr, nullptr, 0, 0); }
+extern "C" int IGXComputeFunction(IGX g, IGXVec U, IGXVec F) { if (!U) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_FUNCTION, nullptr, F, U, nullptr, 0, 0); }
+extern "C" int IGXComputeJacobian(IGX g, IGXVec U, IGXMat J) { if (!U) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_JACOBIAN, J, nullptr, U, nullptr, 0, 0); }
+extern "C" int IGXComputeIFunction(IGX g, double a, IGXVec V, double t, IGXVec U, IGXVec F) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IFUNCTION, nullptr, F, U, V, a, t); }
+extern "C" int IGXComputeIJacobian(IGX g, double a, IGXVec V, double t, IGXVec U, IGXMat J) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IJACOBIAN, J, nullptr, U, V, a, t); }
+
+// ------------------------------------------------------------------ multi-GPU ghost rows (filled in by exchange.hpp)
+#include "exchange.hpp"

@@ -1,0 +1,229 @@
+// forms.hpp -- device point forms.  Each struct restates one of the reference's point callbacks
+// (include/petiga.h:153-197) with the same contract: the UN-weighted integrand at one quadrature
+// point, K block [dof][dof] for the basis pair (a,b) and F entries [dof] for basis a.
+//
+// Na / Nb point at the feature vector of one basis function at the point:
+//   [0] = N, [1+i] = dN/dx_i, [1+DIM+i*DIM+j] = d2N/dx_i dx_j      (shape[0], shape[1], shape[2])
+// Every `mat` below is linear in Nb, which the engine uses to apply Dirichlet lifting without
+// storing K_e columns (see generic_kernel.hpp, phase "lift").
+#pragma once
+#include "igx.hpp"
+
+namespace igx {
+
+enum : unsigned { NEED_X = 1u, NEED_U = 2u, NEED_UT = 4u, NEED_GU = 8u, NEED_HU = 16u, NEED_G = 32u };
+
+struct PtView {
+  const double *x;     // physical point [DIM] (parametric point when there is no geometry)
+  const double *u;     // field values      [dof]
+  const double *ut;    // time derivative   [dof]
+  const double *gu;    // gradient          [dof][DIM]
+  const double *hu;    // hessian           [dof][DIM][DIM]
+  const double *G;     // IGAPointFormInvGradGeomMap [DIM][DIM] (src/petigapoint.c:269-294)
+  const double *prm;   // form parameters (replaces ctx)
+  double shift, t;
+};
+
+// demo/Poisson{1,2,3}D.c System (demo/Poisson3D.c:3-23)
+template <int DIM> struct FormPoisson {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i];
+    T[0] = s;
+  }
+  static __device__ __forceinline__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * 1.0; }
+};
+
+// test/IGACreate.c:45-63 System (block-diagonal mass, F = N)
+template <int DIM, int DOF_> struct FormMass {
+  static constexpr int DOF = DOF_, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
+#pragma unroll
+    for (int i = 0; i < DOF * DOF; ++i) T[i] = 0;
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) T[i * DOF + i] = Na[0] * Nb[0];
+  }
+  static __device__ __forceinline__ void vec(const PtView &, const double *Na, double *R) {
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) R[i] = Na[0];
+  }
+};
+
+// test/IGAFixTable.c:25-43 System1 (L2 projection of sum x_i^2)
+template <int DIM> struct FormL2ProjX2 {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X;
+  static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[0] * Nb[0]; }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    double g = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) g += p.x[i] * p.x[i];
+    R[0] = Na[0] * g;
+  }
+};
+
+// test/IGAFixTable.c:45-64 System2 (Poisson, f = -2 dim)
+template <int DIM> struct FormPoissonF {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormPoisson<DIM>::mat(p, Na, Nb, T); }
+  static __device__ __forceinline__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * (-2.0 * DIM); }
+};
+
+// test/IGAErrNorm.c:26-75 System (4 fields: 1, sum x, sum x^2, prod x)
+template <int DIM> struct FormErrNorm {
+  static constexpr int DOF = 4, ORDER = 1; static constexpr unsigned NEED = NEED_X;
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormMass<DIM, 4>::mat(p, Na, Nb, T); }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    double s1 = 0, s2 = 0, pr = 1;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { s1 += p.x[i]; s2 += p.x[i] * p.x[i]; pr *= p.x[i]; }
+    R[0] = Na[0] * 1.0; R[1] = Na[0] * s1; R[2] = Na[0] * s2; R[3] = Na[0] * pr;
+  }
+};
+
+// demo/Elasticity3D.c:13-46 System; params {lambda, mu}.  The reference's [1][1] block carries an
+// extra factor mu on its xx term (line 37); kept.
+struct FormElasticity {
+  static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const double lambda = p.prm[0], mu = p.prm[1];
+    const double Na_x = Na[1], Na_y = Na[2], Na_z = Na[3], Nb_x = Nb[1], Nb_y = Nb[2], Nb_z = Nb[3];
+    T[0] = Na_x * Nb_x * (lambda + 2 * mu) + mu * (Na_y * Nb_y + Na_z * Nb_z);
+    T[1] = Na_x * Nb_y * lambda + Na_y * Nb_x * mu;
+    T[2] = Na_x * Nb_z * lambda + Na_z * Nb_x * mu;
+    T[3] = Na_x * Nb_y * mu + Na_y * Nb_x * lambda;
+    T[4] = Na_y * Nb_y * (lambda + 2 * mu) + mu * (Na_z * Nb_z + Na_x * Nb_x * mu);
+    T[5] = Na_y * Nb_z * lambda + Na_z * Nb_y * mu;
+    T[6] = Na_x * Nb_z * mu + Na_z * Nb_x * lambda;
+    T[7] = Na_y * Nb_z * mu + Na_z * Nb_y * lambda;
+    T[8] = mu * (Na_x * Nb_x + Na_y * Nb_y) + Na_z * Nb_z * (lambda + 2 * mu);
+  }
+  static __device__ __forceinline__ void vec(const PtView &, const double *, double *R) { R[0] = 0; R[1] = 0; R[2] = 0; }
+};
+
+// demo/CahnHilliard3D.c:11-16,39-53,55-179 (Residual / Tangent); 2-D: demo/CahnHilliard2D.c.
+// params {theta, alpha, cbar, L0, lambda, tau}; L0 <= 0 selects the 2-D demo's 3*alpha scaling.
+template <int DIM> struct FormCahnHilliard {
+  static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU;
+  struct Coef { double M, dM, d2M, dmu, d2mu, lap, t1; };
+  static __device__ __forceinline__ Coef coef(const PtView &p) {
+    Coef k; const double c = p.u[0], theta = p.prm[0], alpha = p.prm[1], L0 = p.prm[3], lambda = p.prm[4];
+    const double scale = (L0 > 0) ? L0 * L0 / lambda : 3 * alpha;
+    k.M = c * (1 - c); k.dM = 1 - 2 * c; k.d2M = -2;
+    k.dmu = (0.5 / theta * 1.0 / (c * (1 - c)) - 2) * scale;
+    k.d2mu = (-0.5 / theta * (1 - 2 * c) / (c * c * (1 - c) * (1 - c))) * scale;
+    k.lap = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) k.lap += p.hu[i * (DIM + 1)];
+    k.t1 = k.M * k.dmu + k.dM * k.lap;
+    return k;
+  }
+  static __device__ __forceinline__ double lapN(const double *N) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += N[1 + DIM + i * (DIM + 1)];
+    return s;
+  }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    const Coef k = coef(p);
+    double Ra = Na[0] * p.ut[0];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) Ra += Na[1 + i] * k.t1 * p.gu[i];
+    Ra += lapN(Na) * k.M * k.lap;
+    R[0] = Ra;
+  }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const Coef k = coef(p);
+    const double lapNa = lapN(Na), lapNb = lapN(Nb);
+    double Kab = p.shift * Na[0] * Nb[0];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) Kab += Na[1 + i] * k.t1 * Nb[1 + i];
+    const double t2 = (k.dM * k.dmu + k.M * k.d2mu + k.d2M * k.lap) * Nb[0] + k.dM * lapNb;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) Kab += Na[1 + i] * t2 * p.gu[i];
+    Kab += lapNa * (k.dM * k.lap * Nb[0] + k.M * lapNb);
+    T[0] = Kab;
+  }
+};
+
+// demo/NavierStokesVMS.c:9-244 (Tau, FineScale, Residual, Tangent); params {nu, fx, fy, fz, dt}
+struct FormNSVMS {
+  static constexpr int DOF = 4, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_G;
+  static __device__ __forceinline__ void tau(const PtView &p, double &tauM, double &tauC) {
+    const double *J = p.G; const double nu = p.prm[0], dt = p.prm[4], C_I = 1.0 / 12.0;
+    double G[9], g[3] = {0, 0, 0}, G_G = 0, g_g = 0, u_G_u = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += J[i * 3 + k] * J[j * 3 + k]; G[i * 3 + j] = s; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g[i] += J[i * 3 + j];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) G_G += G[i] * G[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) g_g += g[i] * g[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) u_G_u += p.u[i] * G[i * 3 + j] * p.u[j];
+    tauM = 4 / (dt * dt) + u_G_u + C_I * nu * nu * G_G;
+    tauM = 1 / sqrt(tauM);
+    tauC = tauM * g_g;
+    tauC = 1 / tauC;
+  }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na_, double *R) {
+    const double nu = p.prm[0], fx = p.prm[1], fy = p.prm[2], fz = p.prm[3];
+    double tauM, tauC; tau(p, tauM, tauC);
+    const double ux = p.u[0], uy = p.u[1], uz = p.u[2], pr = p.u[3];
+    const double ux_t = p.ut[0], uy_t = p.ut[1], uz_t = p.ut[2];
+    const double ux_x = p.gu[0], ux_y = p.gu[1], ux_z = p.gu[2], uy_x = p.gu[3], uy_y = p.gu[4], uy_z = p.gu[5];
+    const double uz_x = p.gu[6], uz_y = p.gu[7], uz_z = p.gu[8], p_x = p.gu[9], p_y = p.gu[10], p_z = p.gu[11];
+    const double ux_l = p.hu[0] + p.hu[4] + p.hu[8], uy_l = p.hu[9] + p.hu[13] + p.hu[17], uz_l = p.hu[18] + p.hu[22] + p.hu[26];
+    double ux_s = ux_t + (ux * ux_x + uy * ux_y + uz * ux_z) + p_x - nu * ux_l - fx;
+    double uy_s = uy_t + (ux * uy_x + uy * uy_y + uz * uy_z) + p_y - nu * uy_l - fy;
+    double uz_s = uz_t + (ux * uz_x + uy * uz_y + uz * uz_z) + p_z - nu * uz_l - fz;
+    double p_s = ux_x + uy_y + uz_z;
+    ux_s *= -tauM; uy_s *= -tauM; uz_s *= -tauM; p_s *= -tauC;
+    const double Na = Na_[0], Na_x = Na_[1], Na_y = Na_[2], Na_z = Na_[3];
+    double Rux = -Na * fx, Ruy = -Na * fy, Ruz = -Na * fz, Rp = 0.0;
+    Rux += Na * ux_t - Na_x * pr + nu * (Na_x * (ux_x + ux_x) + Na_y * (ux_y + uy_x) + Na_z * (ux_z + uz_x));
+    Ruy += Na * uy_t - Na_y * pr + nu * (Na_x * (uy_x + ux_y) + Na_y * (uy_y + uy_y) + Na_z * (uy_z + uz_y));
+    Ruz += Na * uz_t - Na_z * pr + nu * (Na_x * (uz_x + ux_z) + Na_y * (uz_y + uy_z) + Na_z * (uz_z + uz_z));
+    Rp += Na * (ux_x + uy_y + uz_z);
+    Rux += -(Na_x * p_s); Ruy += -(Na_y * p_s); Ruz += -(Na_z * p_s);
+    Rp += -(Na_x * ux_s + Na_y * uy_s + Na_z * uz_s);
+    Rux += +Na * ((ux + ux_s) * ux_x + (uy + uy_s) * ux_y + (uz + uz_s) * ux_z);
+    Ruy += +Na * ((ux + ux_s) * uy_x + (uy + uy_s) * uy_y + (uz + uz_s) * uy_z);
+    Ruz += +Na * ((ux + ux_s) * uz_x + (uy + uy_s) * uz_y + (uz + uz_s) * uz_z);
+    Rux += -(Na_x * ux_s * (ux + ux_s) + Na_y * ux_s * (uy + uy_s) + Na_z * ux_s * (uz + uz_s));
+    Ruy += -(Na_x * uy_s * (ux + ux_s) + Na_y * uy_s * (uy + uy_s) + Na_z * uy_s * (uz + uz_s));
+    Ruz += -(Na_x * uz_s * (ux + ux_s) + Na_y * uz_s * (uy + uy_s) + Na_z * uz_s * (uz + uz_s));
+    R[0] = Rux; R[1] = Ruy; R[2] = Ruz; R[3] = Rp;
+  }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na_, const double *Nb_, double *T) {
+    const double nu = p.prm[0], shift = p.shift;
+    double tauM, tauC; tau(p, tauM, tauC);
+    const double ux = p.u[0], uy = p.u[1], uz = p.u[2];
+    const double Na = Na_[0], Na_x = Na_[1], Na_y = Na_[2], Na_z = Na_[3];
+    const double Nb = Nb_[0], Nb_x = Nb_[1], Nb_y = Nb_[2], Nb_z = Nb_[3];
+    const double adva = ux * Na_x + uy * Na_y + uz * Na_z, advb = ux * Nb_x + uy * Nb_y + uz * Nb_z;
+    const double Tii = (+shift * Na * Nb + Na * advb + nu * (Na_x * Nb_x + Na_y * Nb_y + Na_z * Nb_z) + tauM * adva * (shift * Nb + advb));
+    T[0] = nu * Na_x * Nb_x + tauC * Na_x * Nb_x + Tii;
+    T[1] = nu * Na_y * Nb_x + tauC * Na_x * Nb_y;
+    T[2] = nu * Na_z * Nb_x + tauC * Na_x * Nb_z;
+    T[4] = nu * Na_x * Nb_y + tauC * Na_y * Nb_x;
+    T[5] = nu * Na_y * Nb_y + tauC * Na_y * Nb_y + Tii;
+    T[6] = nu * Na_z * Nb_y + tauC * Na_y * Nb_z;
+    T[8] = nu * Na_x * Nb_z + tauC * Na_z * Nb_x;
+    T[9] = nu * Na_y * Nb_z + tauC * Na_z * Nb_y;
+    T[10] = nu * Na_z * Nb_z + tauC * Na_z * Nb_z + Tii;
+    T[3] = -Na_x * Nb + tauM * adva * Nb_x;
+    T[7] = -Na_y * Nb + tauM * adva * Nb_y;
+    T[11] = -Na_z * Nb + tauM * adva * Nb_z;
+    T[12] = +Na * Nb_x + tauM * Na_x * (shift * Nb + advb);
+    T[13] = +Na * Nb_y + tauM * Na_y * (shift * Nb + advb);
+    T[14] = +Na * Nb_z + tauM * Na_z * (shift * Nb + advb);
+    T[15] = +tauM * (Na_x * Nb_x + Na_y * Nb_y + Na_z * Nb_z);
+  }
+};
+
+}  // namespace igx

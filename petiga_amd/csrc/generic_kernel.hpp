@@ -1,0 +1,418 @@
+// generic_kernel.hpp -- the general element kernel: any device form, dim 1..3, any degree / continuity,
+// dof <= 8, optional NURBS geometry.  One workgroup (256 threads = 4 wavefronts) per element of the
+// current colour.  It fuses the reference's per-element stages
+//   IGAElementBuildClosure (src/petigaelem.c:693)   -> phase 0  (gathers of X, W, U, V; BC flags)
+//   IGAElementBuildTabulation (src/petigaelem.c:794) -> phases 1-2 (K1..K6, straight into LDS)
+//   IGAPointFormValue/Grad/Hess (src/petigapoint.c:327) -> phase 3
+//   point callback + IGAPointAddMat/AddVec (src/petigapoint.c:451) -> phases 5-6 (register accumulators)
+//   IGAElementFixSystem/Function/Jacobian (src/petigaelem.c:1360-1500) -> phases 4,5,6
+//   IGAElementAssembleMat/Vec (src/petigaelem.c:1525) -> scatter, conflict-free inside a colour
+// The shape-function table Phi[q][a][NF] lives in LDS when it fits (160 KiB/CU) and in a per-workgroup
+// HBM scratch slice otherwise (flat addressing serves both).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "forms.hpp"
+
+namespace igx {
+
+struct Carve {          // offsets (in doubles) into the dynamic LDS block; -1 = absent
+  int t1d[3], w1d[3];
+  int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
+  int JW, xq, E1, E2, W0, W1, W2, G;
+  int u, ut, gu, hu, lift, phi;
+  int total;            // doubles
+};
+
+template <int DIM> __device__ __forceinline__ constexpr int nfeat(int order) { return order >= 2 ? 1 + DIM + DIM * DIM : 1 + DIM; }
+
+__device__ __forceinline__ double det3(const double *A, int d) {   // A row-major [d][d]
+  if (d == 1) return A[0];
+  if (d == 2) return A[0] * A[3] - A[1] * A[2];
+  return A[0] * (A[4] * A[8] - A[5] * A[7]) - A[1] * (A[3] * A[8] - A[5] * A[6]) + A[2] * (A[3] * A[7] - A[4] * A[6]);
+}
+__device__ __forceinline__ void inv3(const double *A, int d, double det, double *B) {   // closed forms of src/petigainv.f90.in
+  if (d == 1) { B[0] = 1 / det; return; }
+  if (d == 2) { B[0] = A[3] / det; B[1] = -A[1] / det; B[2] = -A[2] / det; B[3] = A[0] / det; return; }
+  B[0] = (A[4] * A[8] - A[5] * A[7]) / det; B[1] = (A[2] * A[7] - A[1] * A[8]) / det; B[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+  B[3] = (A[5] * A[6] - A[3] * A[8]) / det; B[4] = (A[0] * A[8] - A[2] * A[6]) / det; B[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+  B[6] = (A[3] * A[7] - A[4] * A[6]) / det; B[7] = (A[1] * A[6] - A[0] * A[7]) / det; B[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+}
+
+// parametric tensor-product basis value + derivatives of basis function a=(a0,a1,a2) at point q=(q0,q1,q2)
+// (K2, src/petiga3d.F90:32-233) read from the LDS copies of the three 1-D rows.
+template <int DIM, bool SECOND>
+__device__ __forceinline__ void tensor_basis(const double *const t[3], const int na[3], const int aq[3], const int qq[3],
+                                             double &b0, double *b1, double *b2) {
+  double n[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d < DIM) {
+      const double *r = t[d] + (qq[d] * na[d] + aq[d]) * NDER;
+      n[d][0] = r[0]; n[d][1] = r[1]; n[d][2] = SECOND ? r[2] : 0.0;
+    } else { n[d][0] = 1; n[d][1] = 0; n[d][2] = 0; }
+  }
+  b0 = n[0][0] * n[1][0] * n[2][0];
+#pragma unroll
+  for (int i = 0; i < DIM; ++i) b1[i] = n[0][i == 0] * n[1][i == 1] * n[2][i == 2];
+  if (SECOND) {
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+        b2[i * DIM + j] = n[0][(i == 0) + (j == 0)] * n[1][(i == 1) + (j == 1)] * n[2][(i == 2) + (j == 2)];
+  }
+}
+
+template <class Form, int DIM>
+__global__ void __launch_bounds__(256)
+generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv, double *phi_global, size_t phi_stride) {
+  constexpr int DOF = Form::DOF;
+  constexpr bool SECOND = Form::ORDER >= 2;
+  constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM;
+  constexpr int D2 = DIM * DIM;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  // ---- which element
+  int el[3], ID[3], off[3], nq[3], na[3];
+  {
+    int b = blockIdx.x;
+    const int t0 = b % cr.count[0]; b /= cr.count[0];
+    const int t1 = b % cr.count[1]; b /= cr.count[1];
+    const int tt[3] = {t0, t1, b};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      el[d] = cr.start[d] + tt[d] * cr.step[d];
+      ID[d] = el[d] + S.ax[d].estart;
+      off[d] = S.ax[d].off[el[d]];
+      nq[d] = S.ax[d].nqp; na[d] = S.ax[d].nen;
+    }
+  }
+  const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
+  const int op = out.op;
+  const bool hasM = (op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN);
+  const bool hasV = (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
+  const bool useU = out.U != nullptr, useV = out.V != nullptr;
+  const bool geo = S.nsd > 0, rat = S.rational != 0;
+
+  double *t1d[3] = {smem + cv.t1d[0], smem + cv.t1d[1], smem + cv.t1d[2]};
+  double *w1d[3] = {smem + cv.w1d[0], smem + cv.w1d[1], smem + cv.w1d[2]};
+  double *gX = smem + cv.gX, *gW = smem + cv.gW, *Ue = smem + cv.Ue, *Ve = smem + cv.Ve;
+  double *ufix = smem + cv.ufix, *fixval = smem + cv.fixval, *flux = smem + cv.flux;
+  int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
+  double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
+  double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
+  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift;
+  double *phi = (cv.phi >= 0) ? smem + cv.phi : phi_global + (size_t)blockIdx.x * phi_stride;
+  __shared__ int s_anyfix;
+  if (tid == 0) s_anyfix = 0;
+  __syncthreads();
+
+  // ---- phase 0: 1-D rows of this element (LDS-staged knot-span tables), closure gathers, BC flags
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int n = nq[d] * na[d] * NDER;
+    const double *src = S.ax[d].tab + (size_t)el[d] * n;
+    for (int i = tid; i < n; i += nthr) t1d[d][i] = src[i];
+    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = S.ax[d].w[el[d] * nq[d] + i];
+  }
+  const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
+  const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
+  for (int a = tid; a < NE; a += nthr) {
+    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+    const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
+    const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
+    const size_t row = (size_t)S.ax[0].rowmap[i0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[i1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[i2]);
+    if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
+    if (rat) gW[a] = S.W[g];
+    if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
+    if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
+    // IGAElementBuildFix (src/petigaelem.c:1214-1283): faces in (dir, side) order, later faces override
+    const int aa[3] = {a0, a1, a2};
+    for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
+    if (op != OP_MATRIX && op != OP_VECTOR) {
+      for (int d = 0; d < DIM; ++d) {
+        if (S.ax[d].periodic) continue;
+        for (int side = 0; side < 2; ++side) {
+          if (ID[d] != (side ? S.ax[d].esizes - 1 : 0)) continue;
+          if (aa[d] != (side ? na[d] - 1 : 0)) continue;
+          const BCDev &bv = S.bcv[d][side];
+          for (int k = 0; k < bv.count; ++k) {
+            const int c = bv.field[k];
+            if (c >= DOF) continue;
+            fixflag[a * DOF + c] = 1;
+            fixval[a * DOF + c] = S.fixtable ? S.fixtable[row * DOF + c] : bv.value[k];
+            s_anyfix = 1;
+          }
+          const BCDev &bl = S.bcl[d][side];
+          if (bl.count) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132)
+            double A = 1;
+            if (DIM > 1) {
+              for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
+              A *= (DIM == 2) ? 2 : 4;
+            }
+            for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool anyfix = s_anyfix != 0;
+  // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
+  if (anyfix && (useU || useV)) {
+    for (int k = tid; k < NE * DOF; k += nthr)
+      if (fixflag[k]) { if (useU) { ufix[k] = Ue[k]; Ue[k] = fixval[k]; } if (useV) Ve[k] = 0.0; }
+    __syncthreads();
+  }
+
+  // ---- phase 1: per-point geometry (K1, K3 sums, K4, K5)
+  double Jel = 1;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) Jel *= S.ax[d].J[el[d]];
+  for (int q = tid; q < NQ; q += nthr) {
+    const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
+    double detX = 1.0;
+    double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
+    double x0[3], X1[9], X2[27];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
+    if (rat) {
+      w0 = 0;
+      for (int a = 0; a < NE; ++a) {
+        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        double b0, b1[3], b2[9];
+        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+        const double w = gW[a];
+        w0 += w * b0;
+        for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
+        if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
+      }
+      W0[q] = w0;
+      for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
+      if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
+    }
+    if (geo) {
+      for (int i = 0; i < DIM; ++i) x0[i] = 0;
+      for (int i = 0; i < D2; ++i) X1[i] = 0;
+      if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
+      for (int a = 0; a < NE; ++a) {
+        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        double b0, b1[3], b2[9];
+        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+        if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
+          const double w = gW[a];
+          const double r0 = w * b0 / w0;
+          double r1[3];
+          for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
+          if (SECOND)
+            for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+              b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
+          b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+        }
+        for (int i = 0; i < DIM; ++i) {
+          const double x = gX[a * DIM + i];
+          x0[i] += x * b0;
+          for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
+          if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
+        }
+      }
+      detX = det3(X1, DIM);
+      double e1[9];
+      inv3(X1, DIM, detX, e1);           // e1[al][i] = du_al/dx_i
+      for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
+      if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45: E2[c][i][j] = -X2[k][a][b] e1[a][i] e1[b][j] e1[c][k]
+        for (int c = 0; c < DIM; ++c) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
+          double s = 0;
+          for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
+            s -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
+          E2[(q * DIM + c) * D2 + i * DIM + j] = s;
+        }
+      }
+      if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+    }
+    double w = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w *= w1d[d][qq[d]];
+    JW[q] = (Jel * detX) * w;          // detJac[q] *= detX[q]; JW = detJac*weight (src/petigaelem.c:1024, petigapoint.c:461)
+    for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = x0[i];
+    if (Form::NEED & NEED_G) {           // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+      for (int a = 0; a < DIM; ++a) for (int i = 0; i < DIM; ++i) {
+        const double L = S.ax[a].J[el[a]];
+        Gq[q * D2 + a * DIM + i] = geo ? E1[q * D2 + a * DIM + i] / L : ((a == i) ? 1 / L : 0.0);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 2: shape functions Phi[q][a][:] (K2 -> K3 -> K6)
+  for (int idx = tid; idx < NQ * NE; idx += nthr) {
+    const int q = idx / NE, a = idx - q * NE;
+    const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
+    const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+    double b0, b1[3], b2[9];
+    tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+    if (rat) {
+      const double w = gW[a], w0 = W0[q];
+      const double r0 = w * b0 / w0;
+      double r1[3];
+      for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[q * DIM + i]) / w0;
+      if (SECOND)
+        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+          b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[q * D2 + i * DIM + j] - r1[i] * W1[q * DIM + j] - r1[j] * W1[q * DIM + i]) / w0;
+      b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+    }
+    double *o = phi + (size_t)idx * NF;
+    o[0] = b0;
+    if (!geo) {
+      for (int i = 0; i < DIM; ++i) o[1 + i] = b1[i];
+      if (SECOND) for (int i = 0; i < D2; ++i) o[1 + DIM + i] = b2[i];
+    } else {   // ShapeFunctions, src/petigamapshf.f90.in:30-58
+      const double *e1 = E1 + q * D2;
+      for (int i = 0; i < DIM; ++i) { double s = 0; for (int al = 0; al < DIM; ++al) s += b1[al] * e1[al * DIM + i]; o[1 + i] = s; }
+      if (SECOND) {
+        const double *e2 = E2 + (size_t)q * DIM * D2;
+        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
+          double s = 0;
+          for (int al = 0; al < DIM; ++al) {
+            for (int be = 0; be < DIM; ++be) s += b2[al * DIM + be] * e1[al * DIM + i] * e1[be * DIM + j];
+            s += b1[al] * e2[al * D2 + i * DIM + j];
+          }
+          o[1 + DIM + i * DIM + j] = s;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: field values at the points (src/petigaval.F90:182-232)
+  if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
+    for (int idx = tid; idx < NQ * DOF; idx += nthr) {
+      const int q = idx / DOF, c = idx - q * DOF;
+      double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0};
+      for (int a = 0; a < NE; ++a) {
+        const double *f = phi + ((size_t)q * NE + a) * NF;
+        const double Ua = useU ? Ue[a * DOF + c] : 0.0;
+        u += f[0] * Ua;
+        if (useV) ut += f[0] * Ve[a * DOF + c];
+        if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += f[1 + i] * Ua;
+        if (SECOND && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += f[1 + DIM + i] * Ua;
+      }
+      fu[idx] = u; fut[idx] = ut;
+      if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
+      if (SECOND && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
+    }
+  }
+  // ---- phase 4: Dirichlet lifting features: lift[q][j][:] = sum_b fixed(b,j) v_bj Phi[q][b][:]
+  const bool dolift = anyfix && op == OP_SYSTEM;
+  if (dolift) {
+    for (int idx = tid; idx < NQ * DOF * NF; idx += nthr) {
+      const int f = idx % NF, j = (idx / NF) % DOF, q = idx / (NF * DOF);
+      double s = 0;
+      for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) s += fixval[b * DOF + j] * phi[((size_t)q * NE + b) * NF + f];
+      lift[idx] = s;
+    }
+  }
+  __syncthreads();
+
+  auto point = [&](int q) {
+    PtView p;
+    p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
+    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+    return p;
+  };
+  const int W0s = 2 * S.ax[0].p + 1, W1s = 2 * S.ax[1].p + 1, W2s = 2 * S.ax[2].p + 1;
+
+  // ---- phase 5: K_e = sum_q JW k_q  (register accumulators), BC rows/cols, coloured scatter
+  if (hasM) {
+    constexpr int PP = (DOF * DOF <= 4) ? 4 : (DOF * DOF <= 9 ? 2 : 1);   // pairs per thread per pass
+    const int npairs = NE * NE;
+    for (int base = 0; base < npairs; base += nthr * PP) {
+      double acc[PP][DOF * DOF];
+#pragma unroll
+      for (int s = 0; s < PP; ++s)
+#pragma unroll
+        for (int i = 0; i < DOF * DOF; ++i) acc[s][i] = 0;
+      for (int q = 0; q < NQ; ++q) {
+        const PtView p = point(q);
+        const double jw = JW[q];
+#pragma unroll
+        for (int s = 0; s < PP; ++s) {
+          const int pr = base + s * nthr + tid;
+          if (pr < npairs) {
+            const int a = pr / NE, b = pr - a * NE;
+            double T[DOF * DOF];
+            Form::mat(p, phi + ((size_t)q * NE + a) * NF, phi + ((size_t)q * NE + b) * NF, T);
+#pragma unroll
+            for (int i = 0; i < DOF * DOF; ++i) acc[s][i] += T[i] * jw;
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < PP; ++s) {
+        const int pr = base + s * nthr + tid;
+        if (pr >= npairs) continue;
+        const int a = pr / NE, b = pr - a * NE;
+        if (anyfix && op != OP_MATRIX) {   // zero fixed rows / columns, unit diagonal (src/petigaelem.c:1377-1387, :1493-1499)
+#pragma unroll
+          for (int i = 0; i < DOF; ++i)
+#pragma unroll
+            for (int j = 0; j < DOF; ++j)
+              if (fixflag[a * DOF + i] || fixflag[b * DOF + j]) acc[s][i * DOF + j] = (a == b && i == j) ? 1.0 : 0.0;
+        }
+        const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+        const int b0 = b % na[0], b1 = (b / na[0]) % na[1], b2 = b / (na[0] * na[1]);
+        const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
+        const int r0 = S.ax[0].rowmap[i0], r1 = S.ax[1].rowmap[i1], r2 = S.ax[2].rowmap[i2];
+        const int c0 = S.ax[0].rcnt[r0], c1 = S.ax[1].rcnt[r1];
+        const int P0 = S.ax[0].P[i0 * W0s + (b0 - a0 + S.ax[0].p)];
+        const int P1 = S.ax[1].P[i1 * W1s + (b1 - a1 + S.ax[1].p)];
+        const int P2 = S.ax[2].P[i2 * W2s + (b2 - a2 + S.ax[2].p)];
+        const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
+        const size_t pos = (size_t)out.browptr[row] + ((size_t)P2 * c1 + P1) * c0 + P0;
+        double *dst = out.val + pos * (DOF * DOF);
+#pragma unroll
+        for (int i = 0; i < DOF * DOF; ++i) dst[i] += acc[s][i];
+      }
+    }
+  }
+
+  // ---- phase 6: F_e, BC fix-up, coloured scatter
+  if (hasV) {
+    for (int a = tid; a < NE; a += nthr) {
+      double F[DOF];
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) F[i] = 0;
+      for (int q = 0; q < NQ; ++q) {
+        const PtView p = point(q);
+        const double *Na = phi + ((size_t)q * NE + a) * NF;
+        double R[DOF];
+        Form::vec(p, Na, R);
+        if (dolift) {   // F[i] -= K[i][k] v_k, summed through the lifting features (mat is linear in Nb)
+#pragma unroll
+          for (int j = 0; j < DOF; ++j) {
+            double T[DOF * DOF];
+            Form::mat(p, Na, lift + ((size_t)q * DOF + j) * NF, T);
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) R[i] -= T[i * DOF + j];
+          }
+        }
+        const double jw = JW[q];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) F[i] += R[i] * jw;
+      }
+      const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+      const size_t row = (size_t)S.ax[0].rowmap[off[0] + a0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[off[1] + a1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[off[2] + a2]);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) {
+        const int k = a * DOF + i;
+        double v = F[i];
+        if (op == OP_SYSTEM) { v += flux[k]; if (fixflag[k]) v = fixval[k]; }                        // src/petigaelem.c:1371-1387
+        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { v -= flux[k]; if (fixflag[k]) v = ufix[k] - fixval[k]; }   // :1449-1461
+        out.vec[row * DOF + i] += v;
+      }
+    }
+  }
+}
+
+}  // namespace igx

@@ -1,0 +1,126 @@
+// igx.hpp -- internal types of libpetiga_amd (host discretisation + device descriptors).
+// Reference citations are file:line of dalcinl/PetIGA @ 2025-04-04.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "../../include/petiga_amd.h"
+
+namespace igx {
+
+// ------------------------------------------------------------------ host discretisation
+struct Axis {                 // struct _n_IGAAxis, include/petiga.h:80-96
+  int p = 0, m = 0, periodic = 0, nel = 0, nnp = 0;
+  std::vector<double> U;
+  std::vector<int> span;
+};
+
+struct Basis1D {              // struct _n_IGABasis, include/petiga.h:122-141
+  int nel = 0, nqp = 0, nen = 0;
+  std::vector<int> offset;
+  std::vector<double> detJac, weight, point, value;   // value: [nel][nqp][nen][5]
+};
+
+struct BC {                   // struct _IGAFormBC, include/petiga.h:220-225
+  int count = 0;
+  int field[64];
+  double value[64];
+};
+
+int  gauss_legendre(int q, double *X, double *W);
+void bspline_ders(int span, double u, int p, int nders, const double *U, double *out /*[p+1][5]*/);
+int  axis_init_uniform(Axis &ax, int N, double Ui, double Uf, int C, std::string &err);
+int  axis_set_knots(Axis &ax, int m, const double *U, std::string &err);
+void axis_finish(Axis &ax);   // spans + nnp from U
+int  basis_init(Basis1D &b, const Axis &ax, int nqp, std::string &err);
+int  partition(int size, int rank, int dim, const int N[3], int n[3], int coords[3]);
+void distribute(int dim, const int size[3], const int rank[3], const int N[3], int n[3], int s[3]);
+void stencil(const Axis &ax, int i, int *first, int *last);   // src/petigamat.c:197-233
+
+// Per-axis index layout of the local matrix (row box, column box, position tables, colours)
+struct AxisLayout {
+  int p = 0, gstart = 0, gwidth = 1;
+  int alias = 0;                    // periodic axis wrapped inside one rank
+  int nrow = 1, ncol = 1;
+  int cstart = 0;                   // unwrapped node index of local column 0 (non-alias)
+  std::vector<int> rowmap;          // [gwidth] ghost index -> row index
+  std::vector<int> rownode;         // [nrow]   global node (wrapped)
+  std::vector<int> colnode;         // [ncol]   global node (wrapped)
+  std::vector<int> rcnt;            // [nrow]   columns in the row's per-axis stencil
+  std::vector<int> rcol;            // [nrow][2p+1] sorted local column indices (padded -1)
+  std::vector<int> P;               // [gwidth][2p+1] position of column (row + d - p) in the row's list, or -1
+  std::vector<int> owned;           // [nrow] 1 if this rank owns the row node on this axis
+  int ncolors = 1;
+  std::vector<int> color;           // [nel_local]
+};
+
+struct Space {
+  int dim = 0, dof = 0, order = -1;
+  Axis axis[3];
+  int rule_nqp[3] = {-1, -1, -1};
+  Basis1D basis[3];
+  int comm_size = 1, comm_rank = 0;
+  int proc_req[3] = {-1, -1, -1};
+  int proc_sizes[3] = {1, 1, 1}, proc_ranks[3] = {0, 0, 0};
+  int elem_sizes[3] = {1, 1, 1}, elem_start[3] = {0, 0, 0}, elem_width[3] = {1, 1, 1};
+  int node_sizes[3] = {1, 1, 1}, node_lstart[3] = {0, 0, 0}, node_lwidth[3] = {1, 1, 1};
+  int node_gstart[3] = {0, 0, 0}, node_gwidth[3] = {1, 1, 1};
+  int nsd = 0, rational = 0;
+  std::vector<double> geomX, geomW;       // ghosted local
+  BC value[3][2], load[3][2];
+  IGXFormKind form = IGX_FORM_NONE;
+  std::vector<double> params;
+  bool setup = false;
+  AxisLayout lay[3];
+};
+
+int  space_setup(Space &s, std::string &err);          // IGASetUp stages 1+3 (src/petiga.c:1111-1310,1450-1493)
+int  space_layout(Space &s, std::string &err);         // AxisLayout for the three axes
+
+// ------------------------------------------------------------------ device descriptors (POD, passed by value)
+constexpr int MAXBC = 8;      // fields per face the device tables hold (dof <= 8 on the device path)
+constexpr int NDER = 4;       // 1-D derivative slots kept on the device: orders 0..3
+
+struct BCDev { int count; int field[MAXBC]; double value[MAXBC]; };
+
+struct AxisDev {
+  int nel, nqp, nen, p;
+  int estart, esizes, periodic;
+  int gwidth, nrow, ncol;
+  const double *tab;   // [nel][nqp][nen][NDER]
+  const double *w;     // [nel][nqp]
+  const double *J;     // [nel]
+  const double *pt;    // [nel][nqp]
+  const int *off;      // [nel]  ghost-local index of the element's first basis function
+  const int *rowmap;   // [gwidth]
+  const int *rcnt;     // [nrow]
+  const int *P;        // [gwidth][2p+1]
+};
+
+struct SpaceDev {
+  int dim, dof, order, nsd, rational;
+  AxisDev ax[3];
+  const double *X;     // ghosted local [.][nsd] or null
+  const double *W;     // ghosted local or null
+  BCDev bcv[3][2], bcl[3][2];
+  const double *fixtable;  // row-indexed [nrows][dof] or null
+};
+
+struct ColorRange { int start[3], step[3], count[3]; };
+
+enum Op { OP_SYSTEM = 0, OP_MATRIX, OP_VECTOR, OP_FUNCTION, OP_JACOBIAN, OP_IFUNCTION, OP_IJACOBIAN };
+
+struct OutDev {
+  const int64_t *browptr;  // null when no matrix output
+  double *val;
+  double *vec;             // null when no vector output
+  const double *U, *V;     // row-indexed state vectors or null
+  double shift, t;
+  int op;
+  int *errflag;
+};
+
+constexpr int MAXPARAM = 8;
+struct ParamsDev { double v[MAXPARAM]; };
+
+}  // namespace igx

@@ -1,0 +1,76 @@
+"""Shared helpers: build the same discretisation in the CPU oracle and in the engine."""
+import numpy as np
+
+import oracle_api as O
+
+
+def make_pair(dim, dof, p, N, C=None, periodic=None, nqp=None, order=None, knots=None, engine=True):
+    """Returns (oracle, engine) set up identically.  p/N/C/periodic are per-axis lists or scalars."""
+    ls = lambda v, d=None: (list(v) if isinstance(v, (list, tuple)) else [v] * dim) if v is not None else [d] * dim
+    p, N, C, periodic, nqp = ls(p), ls(N), ls(C, -1), ls(periodic, False), ls(nqp, None)
+    orc = O.OracleIGA(dim, dof)
+    eng = None
+    if engine:
+        import petiga_amd as P
+        eng = P.IGX(dim, dof)
+    for i in range(dim):
+        if knots is not None and knots[i] is not None:
+            orc.axis_knots(i, p[i], knots[i], periodic=periodic[i])
+            if eng: eng.axis_knots(i, p[i], knots[i], periodic=periodic[i])
+        else:
+            orc.axis_uniform(i, p[i], N[i], C[i], periodic=periodic[i])
+            if eng: eng.axis_uniform(i, p[i], N[i], C[i], periodic=periodic[i])
+        if nqp[i] is not None:
+            orc.set_quadrature(i, nqp[i])
+            if eng: eng.set_quadrature(i, nqp[i])
+    if order is not None:
+        orc.set_order(order)
+        if eng: eng.set_order(order)
+    orc.setup()
+    if eng: eng.setup()
+    return orc, eng
+
+
+def greville(U, p):
+    n = len(U) - p - 1
+    return np.array([U[i + 1:i + p + 1].mean() for i in range(n)])
+
+
+def warped_geometry(orc, dim, seed=0, rational=True, amp=0.15):
+    """A valid (positive Jacobian) smooth geometry: Greville grid + smooth warp, optional NURBS weights."""
+    rng = np.random.default_rng(seed)
+    g = [greville(orc.axis(i)["U"], orc.axis(i)["p"]) for i in range(dim)]
+    shape = [len(x) for x in g][::-1]
+    mesh = np.meshgrid(*g[::-1], indexing="ij")[::-1]          # mesh[i] varies along axis i, arrays [n2][n1][n0]
+    X = np.stack([m.copy() for m in mesh], axis=-1)
+    ph = rng.uniform(0, 2 * np.pi, size=(dim, dim))
+    for i in range(dim):
+        for j in range(dim):
+            if i != j:
+                X[..., i] += amp / dim * np.sin(2 * np.pi * mesh[j] + ph[i, j]) * (0.5 + 0.5 * mesh[i])
+    X[..., 0] *= 1.3
+    W = rng.uniform(0.8, 1.2, size=shape) if rational else None
+    return X.reshape(-1, dim), (None if W is None else W.reshape(-1))
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    d = np.abs(a - b).max() if a.size else 0.0
+    return d / max(np.abs(b).max(), 1e-300) if b.size else d
+
+
+def compare_mats(eng_mat, orc_mat, tol):
+    """Engine matrix (device BSR) vs oracle CSR: identical pattern, values within tol of max|K|."""
+    Ae = eng_mat.to_scipy_global()
+    Ao = orc_mat.scipy()
+    assert Ae.shape == Ao.shape
+    # pattern: the engine allocates exactly the reference's pattern (explicit zeros included)
+    Ae.sort_indices(); Ao.sort_indices()
+    Pe = Ae.copy(); Pe.data[:] = 1
+    Po = Ao.copy(); Po.data[:] = 1
+    assert (abs(Pe - Po)).nnz == 0, "sparsity pattern differs"
+    D = (Ae - Ao)
+    err = np.abs(D.data).max() if D.nnz else 0.0
+    scale = np.abs(Ao.data).max()
+    assert err <= tol * scale, "matrix values differ: %g (scale %g)" % (err, scale)
+    return err / scale

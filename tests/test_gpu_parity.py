@@ -1,0 +1,243 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical inputs.
+Tolerance: fp64, 1e-12 relative to max|K_e entry| (summation order differs: colour order vs
+lexicographic element order, FMA contraction) -- BASELINE.json north_star "stated fp64 tolerance".
+Indexing, sparsity pattern and colouring are compared exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import scipy.sparse.linalg as sla
+
+import oracle_api as O
+from common import compare_mats, make_pair, rel_err, warped_geometry
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def dirichlet_all(objs, dim, value=1.0, field=0):
+    for g in objs:
+        for d in range(dim):
+            for s in range(2):
+                g.set_boundary_value(d, s, field, value)
+
+
+def system_pair(orc, eng, oform, eform, octx=None, params=()):
+    A_o, b_o = orc.compute_system(oform, octx)
+    eng.set_form(eform, params)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    return A, b, A_o, b_o
+
+
+@pytest.mark.parametrize("dim,p,N", [(1, 3, 7), (2, 2, 8), (2, 3, 5), (3, 1, 4), (3, 2, 6), (3, 3, 5), (3, 4, 3), (3, (3, 2, 1), (4, 5, 6))])
+def test_poisson_system(dim, p, N):
+    orc, eng = make_pair(dim, 1, p, N)
+    dirichlet_all((orc, eng), dim)
+    eng.set_kernel(1)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+
+
+def test_tutorial_sizes_on_device():
+    # docs/manual/TUTORIAL.rst:113-115: 3-D p=2 16^3 -> 5832 rows / 592704 non-zeros
+    orc, eng = make_pair(3, 1, 2, 16)
+    A = eng.create_mat()
+    assert (A.nbrows, A.nblocks) == (5832, 592704)
+    rp, ci, _ = A.host()
+    Ao = orc.create_mat()
+    assert np.array_equal(rp, Ao.rowptr) and np.array_equal(ci, Ao.colidx)
+
+
+def test_poisson_16cube_p3_full():
+    orc, eng = make_pair(3, 1, 3, 16)
+    dirichlet_all((orc, eng), 3)
+    eng.set_kernel(1)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+    # solve on the host from the device matrix: u == 1 + Poisson bump, min at the boundary
+    x = sla.spsolve(A.to_scipy_global().tocsc(), b.get())
+    assert abs(x.min() - 1.0) < 1e-10 and x.max() > 1.0
+
+
+@pytest.mark.parametrize("dim,dof,periodic,p", [(1, 4, (0,), (2,)), (2, 2, (0, 0), (2, 2)), (3, 1, (0, 0, 0), (2, 2, 2)),
+                                               (2, 3, (0, 1), (2, 3)), (2, 3, (1, 0), (2, 3)), (2, 3, (1, 1), (2, 3)), (3, 2, (1, 0, 1), (2, 2, 3))])
+def test_mass_system_periodic(dim, dof, periodic, p):
+    # test/IGACreate.c (test/makefile:25-33), incl. periodic axes with mixed degrees
+    N = 9 if dim < 3 else 7
+    orc, eng = make_pair(dim, dof, list(p), N, periodic=[bool(x) for x in periodic])
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_mass", "mass")
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+    x = sla.spsolve(A.to_scipy_global().tocsc(), b.get())
+    assert x.max() - x.min() < 1e-9
+
+
+@pytest.mark.parametrize("dim,N", [(1, 16), (2, 16), (3, 4)])
+def test_fixtable_flow(dim, N):
+    # test/IGAFixTable.c end to end on the device path, -check_error 1e-6
+    orc, eng = make_pair(dim, 1, 2, N)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_l2proj_x2", "l2proj_x2")
+    compare_mats(A, A_o, TOL)
+    x = sla.spsolve(A.to_scipy_global().tocsc(), b.get())
+    dirichlet_all((orc, eng), dim, 0.0)
+    orc.set_fixtable(x)
+    xv = eng.create_vec().set(x)
+    eng.set_fixtable(xv)
+    A2, b2, A2_o, b2_o = system_pair(orc, eng, "orc_form_poisson_f", "poisson_f")
+    compare_mats(A2, A2_o, TOL)
+    assert rel_err(b2.get(), b2_o) < TOL
+    u = sla.spsolve(A2.to_scipy_global().tocsc(), b2.get())
+    orc.set_fixtable(None)
+    err = np.sqrt(orc.compute_scalar("orc_scalar_x2err", 1, U=u)[0])
+    assert err < 1e-6
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_errnorm_projection(dim):
+    # test/IGAErrNorm.c:134-146: the device-assembled L2 projection reproduces 1, Sx, Sx^2, Px
+    N = 8 if dim < 3 else 4
+    orc, eng = make_pair(dim, 4, 2, N, nqp=3, order=2)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_errnorm", "errnorm")
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+    x = sla.spsolve(A.to_scipy_global().tocsc(), b.get())
+    for order in (0, 1, 2):
+        S = np.sqrt(orc.compute_scalar("orc_scalar_errnorm", 4, U=x, ctx=C.c_int(order)))
+        assert np.all(S < np.sqrt(np.finfo(float).eps))
+
+
+@pytest.mark.parametrize("p,N", [(2, 4), (3, 3)])
+def test_elasticity_system(p, N):
+    # demo/Elasticity3D.c: lambda = mu = 1, clamped face (0,0), u_x = 1 on face (0,1)
+    orc, eng = make_pair(3, 3, p, N)
+    for g in (orc, eng):
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(0, 1, 0, 1.0)
+    for lam, mu in ((1.0, 1.0), (2.5, 0.7)):       # the second pair exposes the reference's mu*mu quirk
+        ctx = O.ElasticityCtx(lam, mu)
+        A, b, A_o, b_o = system_pair(orc, eng, "orc_form_elasticity", "elasticity", ctx, (lam, mu))
+        compare_mats(A, A_o, TOL)
+        assert np.abs(b.get() - b_o).max() <= TOL * max(np.abs(b_o).max(), 1.0)
+
+
+@pytest.mark.parametrize("geo", ["poly", "nurbs"])
+@pytest.mark.parametrize("dim,p,N", [(2, 2, 5), (2, 3, 4), (3, 2, 4), (3, 3, 3)])
+def test_poisson_on_mapped_geometry(dim, p, N, geo):
+    orc, eng = make_pair(dim, 1, p, N)
+    X, W = warped_geometry(orc, dim, seed=dim * 10 + p, rational=(geo == "nurbs"))
+    orc.set_geometry(X, W)
+    eng.set_geometry(X, W)
+    dirichlet_all((orc, eng), dim, 0.5)
+    eng.set_kernel(1)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    compare_mats(A, A_o, 1e-11)
+    assert rel_err(b.get(), b_o) < 1e-11
+
+
+def test_nonuniform_knots_reduced_continuity():
+    # repeated interior knots (C0 and C1 lines), non-uniform spacing
+    U0 = np.array([0, 0, 0, 0, 0.2, 0.2, 0.5, 0.5, 0.5, 0.8, 1, 1, 1, 1.0])
+    U1 = np.array([0, 0, 0, 0.1, 0.35, 0.35, 0.7, 1, 1, 1.0])
+    orc, eng = make_pair(2, 1, [3, 2], [0, 0], knots=[U0, U1])
+    dirichlet_all((orc, eng), 2, 2.0)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+
+
+@pytest.mark.parametrize("dim,N,periodic", [(2, 8, False), (2, 9, True), (3, 5, False), (3, 6, True)])
+def test_cahn_hilliard_residual_and_tangent(dim, N, periodic):
+    # demo/CahnHilliard{2,3}D.c: p=2 C1, random c around cbar, V random, shift = 1/dt
+    orc, eng = make_pair(dim, 1, 2, N, periodic=periodic)
+    h = 1.0 / np.sqrt(dim * N * N)
+    prm = dict(theta=1.5, alpha=200.0, cbar=0.63, L0=1.0 if dim == 3 else -1.0, lam=1.0 * h * h, tau=1.0)
+    ctx = O.CahnHilliardCtx(prm["theta"], prm["alpha"], prm["cbar"], prm["L0"], prm["lam"], prm["tau"])
+    params = (prm["theta"], prm["alpha"], prm["cbar"], prm["L0"], prm["lam"], prm["tau"])
+    rng = np.random.default_rng(7)
+    n = orc.global_size()
+    U = 0.63 + 0.05 * (2 * rng.random(n) - 1)
+    V = rng.standard_normal(n)
+    shift, t = 1.0e3, 0.0
+    F_o = orc.compute_ifunction("orc_form_ch_residual", ctx, shift, V, t, U)
+    J_o = orc.compute_ijacobian("orc_form_ch_tangent", ctx, shift, V, t, U)
+    eng.set_form("cahnhilliard", params)
+    Uv, Vv, F, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec(), eng.create_mat()
+    eng.compute_ifunction(shift, Vv, t, Uv, F)
+    eng.compute_ijacobian(shift, Vv, t, Uv, J)
+    eng.synchronize()
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * np.abs(F_o).max()
+    compare_mats(J, J_o, 1e-11)
+
+
+def test_navier_stokes_vms_residual_and_tangent():
+    # demo/NavierStokesVMS.c:362-385: axes 0,2 periodic, no-slip on axis 1; dof 4
+    p, N = 2, [4, 3, 4]
+    orc, eng = make_pair(3, 4, p, N, periodic=[True, False, True])
+    for g in (orc, eng):
+        for side in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, side, f, 0.0)
+    nu, fx, dt = 1.472e-4, 3.37204e-3, 1e-2
+    ctx = O.NSVMSCtx(nu, fx, 0.0, 0.0, dt)
+    params = (nu, fx, 0.0, 0.0, dt)
+    rng = np.random.default_rng(11)
+    n = orc.global_size()
+    U = rng.standard_normal(n) * 0.3
+    V = rng.standard_normal(n) * 0.1
+    shift = 2.0 / dt
+    F_o = orc.compute_ifunction("orc_form_ns_residual", ctx, shift, V, 0.0, U)
+    J_o = orc.compute_ijacobian("orc_form_ns_tangent", ctx, shift, V, 0.0, U)
+    eng.set_form("nsvms", params)
+    Uv, Vv, F, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec(), eng.create_mat()
+    eng.compute_ifunction(shift, Vv, 0.0, Uv, F)
+    eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * np.abs(F_o).max()
+    compare_mats(J, J_o, 1e-11)
+
+
+def test_matrix_and_vector_drivers_skip_bc():
+    # IGAComputeMatrix / IGAComputeVector apply no BC fix-up (src/petigaksp.c:33-125)
+    orc, eng = make_pair(2, 1, 2, 6)
+    dirichlet_all((orc, eng), 2)
+    orc.clear_boundary()
+    A_o, b_o = orc.compute_system("orc_form_poisson")
+    eng.set_form("poisson")
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_matrix(A)
+    eng.compute_vector(b)
+    eng.synchronize()
+    compare_mats(A, A_o, TOL)
+    assert rel_err(b.get(), b_o) < TOL
+
+
+def test_error_behaviour():
+    import petiga_amd as P
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, 2, 4)
+    g.setup()
+    A, b = g.create_mat(), g.create_vec()
+    with pytest.raises(P.IGXError) as e:        # IGACheckFormOp: PETSC_ERR_ARG_WRONGSTATE (73)
+        g.compute_system(A, b)
+    assert e.value.code == 73
+    g2 = P.IGX(3, 1)
+    with pytest.raises(P.IGXError) as e:        # IGACheckSetUp
+        g2.create_mat()
+    assert e.value.code == 73
+    # tangled geometry -> non-positive Jacobian reported like a debug build of the reference (PETSC_ERR_USER)
+    orc, eng = make_pair(2, 1, 2, 3)
+    X, _ = warped_geometry(orc, 2, rational=False)
+    X[:, 0] *= -1.0
+    eng.set_geometry(X)
+    eng.set_form("poisson")
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    with pytest.raises(P.IGXError) as e:
+        eng.synchronize()
+    assert e.value.code == 83
