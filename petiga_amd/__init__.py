@@ -156,9 +156,8 @@ class Mat:
             maps.append((r, c))
         return list(nrow), list(ncol), maps
 
-    def to_scipy_global(self):
-        """Global natural-order CSR (node*dof+field) -- the Mat PETSc would hold on one rank."""
-        import scipy.sparse as sp
+    def to_coo_global(self):
+        """(rows, cols, vals) in global natural numbering (node*dof+field), one entry per stored scalar."""
         rp, ci, val = self.host()
         nrow, ncol, maps = self.layout()
         ns = self.iga.sizes()["node_sizes"]
@@ -169,13 +168,18 @@ class Mat:
         c = ci.astype(np.int64)
         c0, c1, c2 = c % ncol[0], (c // ncol[0]) % ncol[1], c // (ncol[0] * ncol[1])
         gcol = maps[0][1][c0].astype(np.int64) + ns[0] * (maps[1][1][c1].astype(np.int64) + ns[1] * maps[2][1][c2].astype(np.int64))
-        browidx = np.repeat(grow, np.diff(rp))
-        nn = int(np.prod(ns))
-        B = sp.bsr_matrix((val.reshape(-1, bs, bs), gcol, np.arange(len(gcol) + 1)), shape=(len(gcol) * bs, nn * bs))
-        # one block per block-row of B; sum block rows that map to the same global node
-        Pm = sp.csr_matrix((np.ones(len(browidx) * bs), (np.repeat(browidx, bs) * bs + np.tile(np.arange(bs), len(browidx)),
-                                                          np.arange(len(browidx) * bs))), shape=(nn * bs, len(browidx) * bs))
-        return (Pm @ B.tocsr()).tocsr()
+        brow = np.repeat(grow, np.diff(rp))
+        ii, jj = np.meshgrid(np.arange(bs), np.arange(bs), indexing="ij")
+        rows = (brow[:, None, None] * bs + ii[None]).reshape(-1)
+        cols = (gcol[:, None, None] * bs + jj[None]).reshape(-1)
+        return rows, cols, val.copy()
+
+    def to_scipy_global(self):
+        """Global natural-order CSR (node*dof+field) -- the Mat PETSc would hold on one rank."""
+        import scipy.sparse as sp
+        rows, cols, vals = self.to_coo_global()
+        n = int(np.prod(self.iga.sizes()["node_sizes"])) * self.bs
+        return sp.coo_matrix((vals, (rows, cols)), shape=(n, n)).tocsr()
 
 
 class IGX:

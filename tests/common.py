@@ -60,17 +60,19 @@ def rel_err(a, b):
 
 
 def compare_mats(eng_mat, orc_mat, tol):
-    """Engine matrix (device BSR) vs oracle CSR: identical pattern, values within tol of max|K|."""
-    Ae = eng_mat.to_scipy_global()
-    Ao = orc_mat.scipy()
-    assert Ae.shape == Ao.shape
-    # pattern: the engine allocates exactly the reference's pattern (explicit zeros included)
-    Ae.sort_indices(); Ao.sort_indices()
-    Pe = Ae.copy(); Pe.data[:] = 1
-    Po = Ao.copy(); Po.data[:] = 1
-    assert (abs(Pe - Po)).nnz == 0, "sparsity pattern differs"
-    D = (Ae - Ao)
-    err = np.abs(D.data).max() if D.nnz else 0.0
-    scale = np.abs(Ao.data).max()
+    """Engine matrix (device block CSR) vs oracle CSR: identical pattern (explicit zeros included, as
+    IGACreateMat preallocates it), values within tol of max|K|."""
+    rows, cols, vals = eng_mat.to_coo_global()
+    n = orc_mat.nrows
+    ke = rows * n + cols
+    o = np.argsort(ke, kind="stable")
+    ke, vals = ke[o], vals[o]
+    orow = np.repeat(np.arange(n, dtype=np.int64), np.diff(orc_mat.rowptr))
+    ko = orow * n + orc_mat.colidx.astype(np.int64)
+    oo = np.argsort(ko, kind="stable")
+    ko, vo = ko[oo], orc_mat.val[oo]
+    assert ke.size == ko.size and np.array_equal(ke, ko), "sparsity pattern differs"
+    scale = np.abs(vo).max()
+    err = np.abs(vals - vo).max()
     assert err <= tol * scale, "matrix values differ: %g (scale %g)" % (err, scale)
     return err / scale

@@ -176,7 +176,7 @@ def test_cahn_hilliard_residual_and_tangent(dim, N, periodic):
 
 def test_navier_stokes_vms_residual_and_tangent():
     # demo/NavierStokesVMS.c:362-385: axes 0,2 periodic, no-slip on axis 1; dof 4
-    p, N = 2, [4, 3, 4]
+    p, N = 2, [6, 3, 5]
     orc, eng = make_pair(3, 4, p, N, periodic=[True, False, True])
     for g in (orc, eng):
         for side in range(2):
