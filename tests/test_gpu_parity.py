@@ -241,3 +241,77 @@ def test_error_behaviour():
     with pytest.raises(P.IGXError) as e:
         eng.synchronize()
     assert e.value.code == 83
+
+
+# ---------------------------------------------------------------- the MFMA gradient-Gram kernel (metric path)
+@pytest.mark.parametrize("N,bc", [((5, 5, 5), "all1"), ((4, 6, 9), "mixed"), ((1, 1, 1), "all1"), ((2, 3, 1), "mixed"), ((8, 8, 8), "none"), ((12, 5, 7), "partial")])
+def test_mfma_poisson_p3(N, bc):
+    orc, eng = make_pair(3, 1, 3, list(N))
+    for g in (orc, eng):
+        if bc == "all1":
+            dirichlet_all((g,), 3, 1.0)
+        elif bc == "mixed":      # a different value on every face: corner/edge nodes take the last face's value
+            k = 0
+            for d in range(3):
+                for s in range(2):
+                    g.set_boundary_value(d, s, 0, 0.5 + 0.25 * k)
+                    k += 1
+        elif bc == "partial":
+            g.set_boundary_value(0, 0, 0, 2.0)
+            g.set_boundary_value(2, 1, 0, -1.0)
+    eng.set_kernel(2)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    assert "mfma" in eng.kernel_name()
+    compare_mats(A, A_o, TOL)
+    assert np.abs(b.get() - b_o).max() <= TOL * np.abs(b_o).max()
+    # the generic kernel and the MFMA kernel agree with each other as well
+    eng.set_kernel(1)
+    A2, b2 = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A2, b2)
+    eng.synchronize()
+    assert np.abs(A.host(True) - A2.host(True)).max() <= TOL * np.abs(A_o.val).max()
+
+
+def test_mfma_matrix_driver_and_default_selection():
+    orc, eng = make_pair(3, 1, 3, 6)
+    dirichlet_all((orc, eng), 3)
+    orc.clear_boundary()
+    A_o, _ = orc.compute_system("orc_form_poisson")
+    eng.set_form("poisson")
+    A = eng.create_mat()
+    eng.compute_matrix(A)      # kernel 0 = automatic: picks the MFMA kernel for the metric configuration
+    eng.synchronize()
+    assert "mfma" in eng.kernel_name()
+    compare_mats(A, A_o, TOL)
+
+
+def test_mfma_full_size_properties():
+    """Size-independent properties at a large mesh (no oracle): interior rows of the Poisson matrix sum to
+    zero (partition of unity), the matrix is symmetric, Dirichlet diagonals equal element multiplicity."""
+    import petiga_amd as P
+    N = 48
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, 3, N)
+    g.setup()
+    for d in range(3):
+        for s in range(2):
+            g.set_boundary_value(d, s, 0, 1.0)
+    g.set_form("poisson")
+    A, b = g.create_mat(), g.create_vec()
+    g.compute_system(A, b)
+    g.synchronize()
+    M = A.to_scipy_global()
+    n = N + 3
+    idx = np.arange(n ** 3)
+    i0, i1, i2 = idx % n, (idx // n) % n, idx // (n * n)
+    onb = (i0 == 0) | (i0 == n - 1) | (i1 == 0) | (i1 == n - 1) | (i2 == 0) | (i2 == n - 1)
+    scale = np.abs(M.data).max()
+    assert abs(M - M.T).max() <= 1e-12 * scale
+    near = (np.minimum(i0, n - 1 - i0) <= 3) | (np.minimum(i1, n - 1 - i1) <= 3) | (np.minimum(i2, n - 1 - i2) <= 3)
+    rowsum = np.asarray(M.sum(axis=1)).ravel()
+    assert np.abs(rowsum[~near]).max() <= 1e-12 * scale
+    mult = lambda i: np.minimum(np.minimum(i + 1, 4), np.minimum(n - i, 4))
+    d = M.diagonal()
+    assert np.array_equal(d[onb], (mult(i0) * mult(i1) * mult(i2))[onb].astype(float))
+    assert np.array_equal(b.get()[onb], d[onb])
