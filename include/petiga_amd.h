@@ -183,7 +183,8 @@ int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default s
 int IGXSynchronize(IGX iga);
 /* 0 = automatic; 1 = generic point-form kernel; 2 = MFMA gradient-Gram kernel (forms/degrees it covers) */
 int IGXSetKernel(IGX iga,int which);
-int IGXGetKernelName(IGX iga,char *buf,int len); /* name of the kernel the last IGXCompute* used   */
+int IGXGetKernelName(IGX iga,char *buf,int len);
+/* name of the kernel the last IGXCompute* used   */
 /* time of the dominant kernel of the last IGXCompute* call, measured with HIP events on the
  * engine's stream (ms); IGXSetTiming(1) enables the events */
 int IGXSetTiming(IGX iga,int flag);

@@ -228,6 +228,7 @@ static SpaceDev make_spacedev(IGX g) {
     A.gwidth = L.gwidth; A.nrow = L.nrow; A.ncol = L.ncol;
     A.tab = B.tab.as<double>(); A.w = B.w.as<double>(); A.J = B.J.as<double>(); A.pt = B.pt.as<double>();
     A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
+    A.prefix = B.prefix.as<int64_t>(); A.tot = 0; for (int r = 0; r < L.nrow; ++r) A.tot += L.rcnt[r];
   }
   S.X = s.nsd ? g->X.as<double>() : nullptr; S.W = s.rational ? g->W.as<double>() : nullptr;
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) {

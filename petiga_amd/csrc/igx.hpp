@@ -95,6 +95,8 @@ struct AxisDev {
   const int *rowmap;   // [gwidth]
   const int *rcnt;     // [nrow]
   const int *P;        // [gwidth][2p+1]
+  const int64_t *prefix;  // [nrow+1] exclusive prefix sums of rcnt
+  int64_t tot;         // sum of rcnt
 };
 
 struct SpaceDev {
