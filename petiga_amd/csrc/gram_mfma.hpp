@@ -13,8 +13,10 @@
 // lane l, reg r of tile (ta,tb) holds K_e[a=(l>>4, r, ta)][b=(l&3, (l>>2)&3, tb)].
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <vector>
 #include "igx.hpp"
 
 namespace igx {
@@ -207,52 +209,57 @@ gram_p3_element(SpaceDev S, OutDev out, ColorRange cr, GramArgs ga) {
 
 
 // ======================================================================================================
-// Pencil kernel: one wavefront walks a pencil of elements along axis 2 and lets the MFMA accumulators
+// Pencil kernel: one wavefront walks a pencil of elements along mesh axis 0 and lets the MFMA accumulators
 // combine the contributions of consecutive elements before anything is written.
 //
-// The accumulator tile index is the axis-2 basis index, so a tile (ta,tb) belongs to a pair of axis-2
-// node layers (i3,j3).  Layers are bound to tile slots by  slot = layer & 3 ; an element covers four
-// consecutive layers, i.e. all four slots.  When the walk leaves layer l (after element off2 = l), the
-// 7 tiles with row- or column-slot l&3 are complete for this pencil: they are added to the CSR
-// (row layer l x col layers l..l+3, and row layers l+1..l+3 x col layer l) and zeroed, then the slot is
-// reused by layer l+4.  Per element 7*256 = 1792 entries reach memory instead of 4096, and two pencils
-// conflict only if they share axis-0/axis-1 nodes: 16 colours instead of 64.
-// The loads of the read-modify-write are issued before the element's 768 MFMAs and consumed after them.
+// Roles of the mesh axes here:  W = axis 0 (walked; accumulator tile index, wave-uniform),
+//                               X = axis 1 (tile row slot lane>>4 / column slot lane&3 / k slot lane>>4),
+//                               Y = axis 2 (tile row = accumulator register r / column (lane>>2)&3).
+// A tile (ta,tb) belongs to a pair of axis-0 node layers.  An element covers four consecutive layers; its
+// local basis a0 sits in tile slot a0.  After an element, its first layer leaves the window: the 7 tiles
+// with row- or column-slot 0 are complete for this pencil, are added to the CSR (row layer l x col layers
+// l..l+3, and row layers l+1..l+3 x col layer l), and the window slides (tile (ta,tb) <- (ta+1,tb+1)).
+// Per element 7*256 = 1792 entries reach memory instead of 4096, and two pencils conflict only if they
+// share axis-1/axis-2 nodes: 16 colours instead of 64.  Walking axis 0 keeps a wavefront on the same 16
+// CSR row neighbourhoods for the whole pencil (consecutive layers are consecutive CSR rows), which is what
+// makes the read-modify-write TLB- and DRAM-page-friendly; walking axis 2 (rows 184 MB apart at 256^3)
+// measured 45k cycles per flush.
 //
 // Long pencils are cut into segments.  A segment owns the row layers of its own elements; it first
 // re-computes (without writing) the <=3 elements before its start so that its first rows are complete,
-// and discards rows it does not own.  No axis-2 colouring is needed.
+// and discards rows it does not own.  No colouring along the walk.
 // Elements that touch a Dirichlet face are not walked here: they go to gram_p3_element (BC logic there).
 // ======================================================================================================
 struct PencilArgs {
   double forcing;
-  int e0_start, e0_step, e0_count;
-  int e1_start, e1_step, e1_count;
-  int z_lo, z_hi;          // walked range of local elements along axis 2: [z_lo, z_hi)
+  int ex_start, ex_step, ex_count;   // pencils of this colour: local element indices on the two non-walked axes
+  int ey_start, ey_step, ey_count;
+  int w_lo, w_hi;          // walked range of local elements along the walk axis: [w_lo, w_hi)
   int seg_len, nseg;
-  int blocks_per_seg;      // ceil(pencils / 4): a workgroup (4 wavefronts = 4 pencils) never straddles segments
+  int blocks_per_seg;      // ceil(pencils / 8): a workgroup (8 wavefronts = 8 pencils) never straddles segments
   int ne_max;              // LDS capacity: elements (seg_len + 3 halo) ; layers = ne_max + 3
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
 };
 
 struct PencilLane {        // per-lane constants of a pencil
-  double u0, u1, wq1, v0[4], v1[4];
-  long long A[4];          // prefix1[rho1(r)]*tot0 + cnt1(r)*prefix0[rho0]
-  int B[4], C[4];          // P1(r)*cnt0 + P0 ; cnt1(r)*cnt0
-  double s01;              // forcing * sum_q w0 N0[a1] * sum_q w1 N1[a2] for the F lane
-  long long frow01;        // rowmap0 + nrow0*rowmap1 of the F lane
+  double u0, u1, wqx;
+  const double *vy;        // LDS: this lane's Y-axis basis row [4 q][2] (value, derivative)
+  long long psx; int cx, px;            // X axis: row prefix / row length of this lane's row slot, column position of its column slot
+  long long psy[4]; int cy[4], py[4];   // Y axis, per accumulator register r
+  double sxy;              // forcing * sum_q wx Nx[fx] * sum_q wy Ny[fy] for the F lane
+  long long frowxy;        // F row without the walk-axis part
   int fslot;
 };
 
-// LDS-staged axis-2 data of one segment (the "knot-span tables" of the walk): per element the 1-D basis
-// rows (value, derivative), Gauss weights and half-length; per node layer the row prefix, row length and
-// the 7 column positions of the structured CSR.
+// LDS-staged axis-0 data of one segment (the knot-span tables of the walk): per element the 1-D basis rows
+// (value, derivative), Gauss weights and half-length; per node layer the row prefix, row length and the 7
+// column positions of the structured CSR.
 struct PencilLds {
   double *zt;        // [ne][4 q][4 a][2]
   double *wq;        // [ne][4]
   double *Jz;        // [ne]
-  long long *pre;    // [nl]  prefix2[rho2] * tot1 * tot0
-  int *cnt;          // [nl]  rcnt2[rho2]  (-1: layer does not exist)
+  long long *pre;    // [nl]  prefix0[rho0]
+  int *cnt;          // [nl]  rcnt0[rho0]  (-1: layer does not exist)
   int *rho;          // [nl]
   int *P;            // [nl][8]
   int lay0;          // first layer held
@@ -265,29 +272,34 @@ __device__ __forceinline__ PencilLds pencil_lds_carve(double *sm, int ne_max) {
   t.cnt = reinterpret_cast<int *>(t.pre + nl); t.rho = t.cnt + nl; t.P = t.rho + nl; t.lay0 = 0;
   return t;
 }
-static inline size_t pencil_lds_bytes(int ne_max) {
+__host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
   const int nl = ne_max + 3;
-  return (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
+  const size_t tables = (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
+  return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
 }
 
+// 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4); operands are products of three
+// 1-D factors, the walk-axis factor z (wave-uniform) selects the tile
+template <int W>
 __device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2]*/,
-                                            const double *__restrict__ Wq1, const double *wq2 /*LDS*/, double Jel) {
+                                            const double *__restrict__ Wqy, const double *wqw /*LDS*/, double Jel) {
 #pragma unroll
-  for (int q3 = 0; q3 < 4; ++q3) {
+  for (int qw = 0; qw < 4; ++qw) {
     double z0[4], z1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { z0[t] = zt[(q3 * 4 + t) * 2 + 0]; z1[t] = zt[(q3 * 4 + t) * 2 + 1]; }
-    const double s3 = Jel * wq2[q3];
+    for (int t = 0; t < 4; ++t) { z0[t] = zt[(qw * 4 + t) * 2 + 0]; z1[t] = zt[(qw * 4 + t) * 2 + 1]; }
+    const double s3 = Jel * wqw[qw];
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) {
-      const double jw = L.wq1 * (Wq1[q2] * s3);
+    for (int qy = 0; qy < 4; ++qy) {
+      const double jw = L.wqx * (Wqy[qy] * s3);
+      const double vy0 = L.vy[qy * 2 + 0], vy1 = L.vy[qy * 2 + 1];
 #pragma unroll
-      for (int al = 0; al < 3; ++al) {
-        const double uv = (al == 0 ? L.u1 : L.u0) * (al == 1 ? L.v1[q2] : L.v0[q2]);
+      for (int al = 0; al < 3; ++al) {   // al = 0: d/dw, 1: d/dx, 2: d/dy (the Gram sum runs over all three)
+        const double uv = (al == 1 ? L.u1 : L.u0) * (al == 2 ? vy1 : vy0);
         const double uvj = uv * jw;
         double opA[4], opB[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const double z = (al == 2) ? z1[t] : z0[t]; opA[t] = uvj * z; opB[t] = uv * z; }
+        for (int t = 0; t < 4; ++t) { const double z = (al == 0) ? z1[t] : z0[t]; opA[t] = uvj * z; opB[t] = uv * z; }
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
@@ -298,8 +310,10 @@ __device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane 
   }
 }
 
-// the 7 tiles that leave with layer `lay`: k = 0..3 -> (row lay, col lay+k), k = 4..6 -> (row lay+k-3, col lay)
-struct FlushPlan { bool on[7]; long long base[7]; int cnt2[7], p2[7]; };
+// the 7 tiles that leave with layer `lay`: k = 0..3 -> (row lay, col lay+k), k = 4..6 -> (row lay+k-3, col lay);
+// position of entry (row layer rl, this lane's (a,r) ; col layer cl, this lane's (b1,b2)):
+//   pos = L.A[r] + L.C[r]*prefix0[rl] + L.B[r]*cnt0[rl] + P0[rl][cl-rl+3]
+struct FlushPlan { bool on[7]; long long pre[7]; int cnt[7], p0[7]; };
 
 __device__ __forceinline__ FlushPlan pencil_plan(const PencilLds &T, int nl, int lay, int own_lo, int own_hi) {
   FlushPlan f;
@@ -308,41 +322,51 @@ __device__ __forceinline__ FlushPlan pencil_plan(const PencilLds &T, int nl, int
     const int rl = (k < 4) ? lay : lay + (k - 3), cl = (k < 4) ? lay + k : lay;
     const int ri = rl - T.lay0, ci = cl - T.lay0;
     bool ok = ri >= 0 && ri < nl && ci >= 0 && ci < nl && rl >= own_lo && rl < own_hi;
-    int p2 = -1, c2 = 0; long long pre = 0;
-    if (ok) { c2 = T.cnt[ri]; ok = c2 > 0 && T.cnt[ci] > 0; }
-    if (ok) { p2 = T.P[ri * 8 + (cl - rl + 3)]; pre = T.pre[ri]; ok = p2 >= 0; }
+    int p0 = -1, c0 = 0; long long pre = 0;
+    if (ok) { c0 = T.cnt[ri]; ok = c0 > 0 && T.cnt[ci] > 0; }
+    if (ok) { p0 = T.P[ri * 8 + (cl - rl + 3)]; pre = T.pre[ri]; ok = p0 >= 0; }
     // everything here is wave-uniform: pin it to SGPRs (LDS reads come back in VGPRs)
     const int lo = __builtin_amdgcn_readfirstlane((int)(pre & 0xffffffffll)), hi = __builtin_amdgcn_readfirstlane((int)(pre >> 32));
     f.on[k] = __builtin_amdgcn_readfirstlane((int)ok) != 0;
-    f.base[k] = ((long long)hi << 32) | (unsigned int)lo;
-    f.cnt2[k] = __builtin_amdgcn_readfirstlane(c2); f.p2[k] = __builtin_amdgcn_readfirstlane(p2);
+    f.pre[k] = ((long long)hi << 32) | (unsigned int)lo;
+    f.cnt[k] = __builtin_amdgcn_readfirstlane(c0); f.p0[k] = __builtin_amdgcn_readfirstlane(p0);
   }
   return f;
 }
 
-// read-modify-write of tiles [K0,K1) of the plan: k = 0..3 is tile (0,k), k = 4..6 is tile (k-3,0).  The loads
-// of one call are all in flight together; a second wavefront on the SIMD runs its MFMAs meanwhile.
-template <int K0, int K1>
-__device__ __forceinline__ void pencil_flush(const d4_t (&acc)[4][4], const PencilLane &L, const FlushPlan &f, double *__restrict__ val) {
-  double old[K1 - K0][4];
+// block-CSR position of an entry from the per-axis (row prefix, row length, column position) triples:
+//   pos = ps2*T1*T0 + c2*(ps1*T0 + c1*ps0) + (P2*c1 + P1)*c0 + P0         (see k_browptr / IGXCreateMat)
+template <int W>
+__device__ __forceinline__ long long pencil_pos(const PencilLane &L, int r, long long psw, int cw, int pw, long long T0, long long T10) {
+  long long ps[3]; int c[3], P[3];
+  constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
+  ps[W] = psw; c[W] = cw; P[W] = pw;
+  ps[X] = L.psx; c[X] = L.cx; P[X] = L.px;
+  ps[Y] = L.psy[r]; c[Y] = L.cy[r]; P[Y] = L.py[r];
+  return ps[2] * T10 + (long long)c[2] * (ps[1] * T0 + (long long)c[1] * ps[0]) + ((long long)P[2] * c[1] + P[1]) * c[0] + P[0];
+}
+
+// read-modify-write of the 7 leaving tiles (k = 0..3 is tile (0,k), k = 4..6 is tile (k-3,0)) and of the F entry:
+// all 29 loads are in flight together (one memory round trip), then the adds and the stores.  The partner
+// wavefront on this SIMD issues its 768 MFMAs meanwhile (ping-pong schedule in the kernel).
+template <bool SYSTEM, int W>
+__device__ __forceinline__ void pencil_flush(const d4_t (&acc)[4][4], const PencilLane &L, const FlushPlan &f, const OutDev &out,
+                                             long long T0, long long T10, bool fdo, long long frow, double Facc) {
+  double old[7][4], Fold = 0;
+  if (SYSTEM && fdo) Fold = out.vec[frow];
 #pragma unroll
-  for (int k = K0; k < K1; ++k) {
+  for (int k = 0; k < 7; ++k) {
     if (!f.on[k]) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long pos = f.base[k] + (long long)f.cnt2[k] * L.A[r] + (long long)f.p2[k] * L.C[r] + L.B[r];
-      old[k - K0][r] = val[pos];
-    }
+    for (int r = 0; r < 4; ++r) old[k][r] = out.val[pencil_pos<W>(L, r, f.pre[k], f.cnt[k], f.p0[k], T0, T10)];
   }
+  if (SYSTEM && fdo) out.vec[frow] = Fold + Facc;
 #pragma unroll
-  for (int k = K0; k < K1; ++k) {
+  for (int k = 0; k < 7; ++k) {
     const int ta = (k < 4) ? 0 : k - 3, tb = (k < 4) ? k : 0;
     if (!f.on[k]) continue;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const long long pos = f.base[k] + (long long)f.cnt2[k] * L.A[r] + (long long)f.p2[k] * L.C[r] + L.B[r];
-      val[pos] = old[k - K0][r] + acc[ta][tb][r];
-    }
+    for (int r = 0; r < 4; ++r) out.val[pencil_pos<W>(L, r, f.pre[k], f.cnt[k], f.p0[k], T0, T10)] = old[k][r] + acc[ta][tb][r];
   }
 }
 
@@ -354,101 +378,109 @@ __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, in
     for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = acc[ta + 1][tb + 1];
 #pragma unroll
   for (int t = 0; t < 4; ++t) { acc[3][t] = (d4_t){0, 0, 0, 0}; acc[t][3] = (d4_t){0, 0, 0, 0}; }
-  // F lanes hold (a1, a2, slot = lane>>4): slot t takes over slot t+1's partial sum
+  // F lanes hold (fx, fy, slot = lane>>4): slot t takes over slot t+1's partial sum
   const double up = __shfl_down(Facc, 16);
   Facc = (fslot == 3) ? 0.0 : up;
 }
 
-// leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays
-template <bool SYSTEM>
+// leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays.
+template <bool SYSTEM, int W>
 __device__ __forceinline__ void pencil_leave(d4_t (&acc)[4][4], double &Facc, const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
-                                             int lay, int own_lo, int own_hi, long long nr01) {
+                                             int lay, int own_lo, int own_hi, long long T0, long long T10, long long fstride) {
+  const FlushPlan f = pencil_plan(T, nl, lay, own_lo, own_hi);
+  long long frow = 0; bool fdo = false;
   if (SYSTEM && L.fslot == 0) {
     const int li = lay - T.lay0;
-    if (li >= 0 && li < nl && T.cnt[li] > 0 && lay >= own_lo && lay < own_hi) out.vec[L.frow01 + nr01 * T.rho[li]] += Facc;
+    fdo = li >= 0 && li < nl && T.cnt[li] > 0 && lay >= own_lo && lay < own_hi;
+    if (fdo) frow = L.frowxy + fstride * T.rho[li];
   }
-  const FlushPlan f = pencil_plan(T, nl, lay, own_lo, own_hi);
-  pencil_flush<0, 4>(acc, L, f, out.val);
-  pencil_flush<4, 7>(acc, L, f, out.val);
+  pencil_flush<SYSTEM, W>(acc, L, f, out, T0, T10, fdo, frow, Facc);
   pencil_shift(acc, Facc, L.fslot);
 }
 
-template <bool SYSTEM>
-__global__ void __launch_bounds__(256, 2)
+template <bool SYSTEM, int W>
+__global__ void __launch_bounds__(512, 2)
 gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+  constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int seg = blockIdx.x / pa.blocks_per_seg;
-  const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 4 + wave;
-  const int zs = pa.z_lo + seg * pa.seg_len;
-  const int ze = min(zs + pa.seg_len, pa.z_hi);
-  const int zh = max(zs - 3, pa.z_lo);
-  const int ne = ze - zh, nl = ne + 3;
+  const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 8 + wave;
+  const int ws = pa.w_lo + seg * pa.seg_len;
+  const int we = min(ws + pa.seg_len, pa.w_hi);
+  const int wh = max(ws - 3, pa.w_lo);
+  const int ne = we - wh, nl = ne + 3;
+  const AxisDev &AW = S.ax[W], &AX = S.ax[X], &AY = S.ax[Y];
 
-  // ---- stage the segment's axis-2 tables in LDS (all 256 threads)
+  // ---- stage the segment's walk-axis tables in LDS (all 256 threads)
   PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max);
-  T.lay0 = S.ax[2].off[zh];
+  T.lay0 = AW.off[wh];
   {
     const int tid = threadIdx.x;
-    const double *__restrict__ tab2 = S.ax[2].tab + (size_t)zh * (4 * 4 * NDER);
-    for (int i = tid; i < ne * 32; i += 256) { const int e = i >> 5, j = i & 31; T.zt[i] = tab2[(size_t)e * 64 + (j >> 1) * NDER + (j & 1)]; }
-    for (int i = tid; i < ne * 4; i += 256) T.wq[i] = S.ax[2].w[zh * 4 + i];
-    for (int i = tid; i < ne; i += 256) T.Jz[i] = S.ax[2].J[zh + i];
-    const long long T10 = S.ax[1].tot * S.ax[0].tot;
-    for (int i = tid; i < nl; i += 256) {
+    const double *__restrict__ tabw = AW.tab + (size_t)wh * (4 * 4 * NDER);
+    for (int i = tid; i < ne * 32; i += 512) { const int e = i >> 5, j = i & 31; T.zt[i] = tabw[(size_t)e * 64 + (j >> 1) * NDER + (j & 1)]; }
+    for (int i = tid; i < ne * 4; i += 512) T.wq[i] = AW.w[wh * 4 + i];
+    for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[wh + i];
+    for (int i = tid; i < nl; i += 512) {
       const int lay = T.lay0 + i;
-      if (lay < S.ax[2].gwidth) {
-        const int rho = S.ax[2].rowmap[lay];
-        T.rho[i] = rho; T.cnt[i] = S.ax[2].rcnt[rho]; T.pre[i] = S.ax[2].prefix[rho] * T10;
-        for (int d = 0; d < 7; ++d) T.P[i * 8 + d] = S.ax[2].P[lay * 7 + d];
+      if (lay < AW.gwidth) {
+        const int rho = AW.rowmap[lay];
+        T.rho[i] = rho; T.cnt[i] = AW.rcnt[rho]; T.pre[i] = AW.prefix[rho];
+        for (int d = 0; d < 7; ++d) T.P[i * 8 + d] = AW.P[lay * 7 + d];
       } else { T.rho[i] = 0; T.cnt[i] = -1; T.pre[i] = 0; }
     }
   }
   __syncthreads();
-  if (pencil >= pa.e0_count * pa.e1_count) return;
+  // an idle wavefront (grid padding) keeps running the barrier schedule below on pencil 0 with writes disabled
+  const bool valid = pencil < pa.ex_count * pa.ey_count;
 
-  const int t0 = pencil % pa.e0_count, t1 = pencil / pa.e0_count;
-  const int el0 = pa.e0_start + t0 * pa.e0_step, el1 = pa.e1_start + t1 * pa.e1_step;
-  int own_lo = (seg == 0) ? -1 : S.ax[2].off[zs];
-  int own_hi = (seg == pa.nseg - 1) ? (1 << 30) : S.ax[2].off[ze];
-  if (pa.debug_noflush) { own_lo = 1 << 30; own_hi = 1 << 30; }
-  const int off0 = S.ax[0].off[el0], off1 = S.ax[1].off[el1];
-  const long long nr01 = (long long)S.ax[0].nrow * S.ax[1].nrow;
+  const int pc = valid ? pencil : 0;
+  const int tx = pc % pa.ex_count, ty = pc / pa.ex_count;
+  const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
+  int own_lo = (seg == 0) ? -1 : AW.off[ws];
+  int own_hi = (seg == pa.nseg - 1) ? (1 << 30) : AW.off[we];
+  if (pa.debug_noflush == 1 || !valid) { own_lo = 1 << 30; own_hi = 1 << 30; }
+  const int offx = AX.off[elx], offy = AY.off[ely];
+  const long long T0 = S.ax[0].tot, T10 = S.ax[1].tot * S.ax[0].tot;
+  // row index = rho0 + nrow0*(rho1 + nrow1*rho2): stride of each axis' rho
+  const long long rs[3] = {1, (long long)S.ax[0].nrow, (long long)S.ax[0].nrow * S.ax[1].nrow};
 
   PencilLane L;
   {
-    const double *__restrict__ T0 = S.ax[0].tab + (size_t)el0 * (4 * 4 * NDER);
-    const double *__restrict__ T1 = S.ax[1].tab + (size_t)el1 * (4 * 4 * NDER);
-    const double *__restrict__ Wq0 = S.ax[0].w + el0 * 4;
-    const double *__restrict__ Wq1 = S.ax[1].w + el1 * 4;
-    const int q1 = lane >> 4, i1 = lane & 3, i2 = (lane >> 2) & 3;
-    L.u0 = T0[(q1 * 4 + i1) * NDER + 0]; L.u1 = T0[(q1 * 4 + i1) * NDER + 1]; L.wq1 = Wq0[q1];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { L.v0[q] = T1[(q * 4 + i2) * NDER + 0]; L.v1[q] = T1[(q * 4 + i2) * NDER + 1]; }
-    // scatter constants: this lane's result rows are (a1 = lane>>4, a2 = r), columns (b1 = lane&3, b2 = (lane>>2)&3)
-    const int a1 = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
-    const int i0 = off0 + a1, rho0 = S.ax[0].rowmap[i0], c0 = S.ax[0].rcnt[rho0];
-    const long long PS0 = S.ax[0].prefix[rho0];
-    const int P0 = S.ax[0].P[i0 * 7 + (b1 - a1 + 3)];
+    const double *__restrict__ TX = AX.tab + (size_t)elx * (4 * 4 * NDER);
+    const double *__restrict__ TY = AY.tab + (size_t)ely * (4 * 4 * NDER);
+    const double *__restrict__ WX = AX.w + elx * 4;
+    const double *__restrict__ WYq = AY.w + ely * 4;
+    const int qx = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
+    L.u0 = TX[(qx * 4 + ix) * NDER + 0]; L.u1 = TX[(qx * 4 + ix) * NDER + 1]; L.wqx = WX[qx];
+    {   // Y-axis rows of this pencil -> LDS [a][q][2]; a lane later reads its own row (a = iy) one q at a time
+      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max) - 8 * 32 * 8))) + wave * 32;
+      if (lane < 32) { const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1; vyw[lane] = TY[(qq * 4 + aa) * NDER + kk]; }
+      L.vy = vyw + iy * 8;
+    }
+    // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
+    const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+    const int ixg = offx + a, rhox = AX.rowmap[ixg];
+    L.psx = AX.prefix[rhox]; L.cx = AX.rcnt[rhox]; L.px = AX.P[ixg * 7 + (b1 - a + 3)];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int j1 = off1 + r, rho1 = S.ax[1].rowmap[j1], c1 = S.ax[1].rcnt[rho1];
-      L.A[r] = S.ax[1].prefix[rho1] * S.ax[0].tot + (long long)c1 * PS0;
-      L.B[r] = S.ax[1].P[j1 * 7 + (b2 - r + 3)] * c0 + P0;
-      L.C[r] = c1 * c0;
+      const int iyg = offy + r, rhoy = AY.rowmap[iyg];
+      const long long psv = AY.prefix[rhoy];   // wave-uniform (depends on r only): pin to SGPRs
+      L.psy[r] = ((long long)__builtin_amdgcn_readfirstlane((int)(psv >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(psv & 0xffffffffll));
+      L.cy[r] = __builtin_amdgcn_readfirstlane(AY.rcnt[rhoy]); L.py[r] = AY.P[iyg * 7 + (b2 - r + 3)];
     }
-    // F lane: (fa0 = lane&3, fa1 = (lane>>2)&3, slot = lane>>4)
-    const int fa0 = lane & 3, fa1 = (lane >> 2) & 3;
-    double s0 = 0, s1 = 0;
+    // F lane: (fx = lane&3, fy = (lane>>2)&3, slot = lane>>4)
+    const int fx = lane & 3, fy = (lane >> 2) & 3;
+    double sx = 0, sy = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { s0 += Wq0[q] * T0[(q * 4 + fa0) * NDER]; s1 += Wq1[q] * T1[(q * 4 + fa1) * NDER]; }
-    L.s01 = pa.forcing * (s0 * s1);
-    L.frow01 = (long long)S.ax[0].rowmap[off0 + fa0] + (long long)S.ax[0].nrow * S.ax[1].rowmap[off1 + fa1];
+    for (int q = 0; q < 4; ++q) { sx += WX[q] * TX[(q * 4 + fx) * NDER]; sy += WYq[q] * TY[(q * 4 + fy) * NDER]; }
+    L.sxy = pa.forcing * (sx * sy);
+    L.frowxy = rs[X] * AX.rowmap[offx + fx] + rs[Y] * AY.rowmap[offy + fy];
     L.fslot = lane >> 4;
   }
-  const double *__restrict__ Wq1 = S.ax[1].w + el1 * 4;
-  const double J01 = S.ax[0].J[el0] * S.ax[1].J[el1];
+  const double *__restrict__ WYq = AY.w + ely * 4;
+  const double Jxy = AX.J[elx] * AY.J[ely];
 
   d4_t acc[4][4];
 #pragma unroll
@@ -457,22 +489,32 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = (d4_t){0, 0, 0, 0};
   double Facc = 0;
 
+  // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
+  // and group 1 (waves 4-7) run half a period apart, separated by s_barrier, so that on every SIMD one
+  // wavefront issues its 768 MFMAs while the other one does its read-modify-write:
+  //   group 0:  mfma(0) | flush(0) | mfma(1) | flush(1) | ...
+  //   group 1:          | mfma(0)  | flush(0)| mfma(1)  | ...
+  const int grp = wave >> 2;
+  if (grp == 1) __builtin_amdgcn_s_barrier();
   int lay = T.lay0;
   for (int ei = 0; ei < ne; ++ei) {
-    lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a3 sits in tile slot a3
-    const double *zt = T.zt + ei * 32, *wq2 = T.wq + ei * 4;
-    const double Jel = J01 * T.Jz[ei];
-    pencil_mfma(acc, L, zt, Wq1, wq2, Jel);
+    lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
+    const double *zt = T.zt + ei * 32, *wqw = T.wq + ei * 4;
+    const double Jel = Jxy * T.Jz[ei];
+    pencil_mfma<W>(acc, L, zt, WYq, wqw, Jel);
     if (SYSTEM) {
-      double s2 = 0;
+      double sw = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) s2 += wq2[q] * zt[(q * 4 + L.fslot) * 2];
-      Facc += Jel * (L.s01 * s2);
+      for (int q = 0; q < 4; ++q) sw += wqw[q] * zt[(q * 4 + L.fslot) * 2];
+      Facc += Jel * (L.sxy * sw);
     }
-    pencil_leave<SYSTEM>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, nr01);
+    __builtin_amdgcn_s_barrier();
+    pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
+    __builtin_amdgcn_s_barrier();
   }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
-    for (int k = 1; k <= 3; ++k) pencil_leave<SYSTEM>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, nr01);
+    for (int k = 1; k <= 3; ++k) pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -499,28 +541,36 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
   }
 }
 
-template <bool SYSTEM>
+template <bool SYSTEM, int W>
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches) {
+  constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
-  const int nz = bx.hi[2] - bx.lo[2];
-  for (int c1 = 0; c1 < s.lay[1].ncolors; ++c1) for (int c0 = 0; c0 < s.lay[0].ncolors; ++c0) {
+  const int nw = bx.hi[W] - bx.lo[W];
+  for (int cy = 0; cy < s.lay[Y].ncolors; ++cy) for (int cx = 0; cx < s.lay[X].ncolors; ++cx) {
     PencilArgs pa; pa.forcing = forcing;
-    if (!color_range(s.lay[0], c0, bx.lo[0], bx.hi[0], pa.e0_start, pa.e0_step, pa.e0_count)) continue;
-    if (!color_range(s.lay[1], c1, bx.lo[1], bx.hi[1], pa.e1_start, pa.e1_step, pa.e1_count)) continue;
-    const long long pencils = (long long)pa.e0_count * pa.e1_count;
-    // enough wavefronts for ~4 rounds of the 2048 resident ones (2 per SIMD), segments no shorter than 32 elements
-    int nseg = (int)std::max<long long>(1, std::min<long long>((16384 + pencils - 1) / pencils, std::max(1, nz / 32)));
-    pa.seg_len = (nz + nseg - 1) / nseg; pa.nseg = (nz + pa.seg_len - 1) / pa.seg_len;
-    pa.z_lo = bx.lo[2]; pa.z_hi = bx.hi[2];
-    pa.blocks_per_seg = (int)((pencils + 3) / 4);
+    if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
+    if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
+    const long long pencils = (long long)pa.ex_count * pa.ey_count;
+    // enough wavefronts for ~8 rounds of the 2048 resident ones (2 per SIMD), segments no shorter than 32 elements
+    int nseg = (int)std::max<long long>(1, std::min<long long>((16384 + pencils - 1) / pencils, std::max(1, nw / 32)));
+    pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
+    pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
+    pa.blocks_per_seg = (int)((pencils + 7) / 8);
     pa.ne_max = pa.seg_len + 3;
-    { const char *dbg = getenv("IGX_DEBUG_NOFLUSH"); pa.debug_noflush = (dbg && dbg[0] == '1') ? 1 : 0; }
+    { const char *dbg = getenv("IGX_DEBUG_NOFLUSH"); pa.debug_noflush = dbg ? atoi(dbg) : 0; }
     const size_t lds = pencil_lds_bytes(pa.ne_max);
-    auto kern = gram_p3_pencil<SYSTEM>;
+    auto kern = gram_p3_pencil<SYSTEM, W>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(256), lds, stream, S, out, pa);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
     launches++;
   }
+}
+
+static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
+  if (s.lay[d].alias || s.elem_width[d] < 8) return false;
+  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
+    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
+  return true;
 }
 
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
@@ -539,10 +589,11 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   GramArgs ga; ga.forcing = (s.form == IGX_FORM_POISSON) ? 1.0 : -6.0; ga.nwaves = 0;
   launches = 0;
   const bool sys = out.op == OP_SYSTEM;
-  // can axis 2 be walked?  (one new node layer per element, no wrap inside the rank)
-  bool walk = !s.lay[2].alias && s.elem_width[2] >= 8;
-  for (int e = 0; e + 1 < s.elem_width[2] && walk; ++e)
-    if (s.basis[2].offset[s.elem_start[2] + e + 1] != s.basis[2].offset[s.elem_start[2] + e] + 1) walk = false;
+  // walk axis: the slowest-varying mesh axis that qualifies keeps axis 0 (contiguous CSR columns) on the lanes
+  int walk_axis = -1;
+  { const char *wa = getenv("IGX_WALK_AXIS"); const int pref[3] = {wa ? atoi(wa) : 2, 1, 0};
+    for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
+  const bool walk = walk_axis >= 0;
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk) {
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
@@ -555,7 +606,14 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       if (s.value[d][0].count && s.elem_start[d] == 0) P.lo[d] = 1;
       if (s.value[d][1].count && s.elem_start[d] + s.elem_width[d] == s.elem_sizes[d]) P.hi[d] = s.elem_width[d] - 1;
     }
-    if (sys) launch_pencils<true>(s, S, out, stream, P, ga.forcing, launches); else launch_pencils<false>(s, S, out, stream, P, ga.forcing, launches);
+    switch (walk_axis * 2 + (sys ? 1 : 0)) {
+    case 0: launch_pencils<false, 0>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 1: launch_pencils<true, 0>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 2: launch_pencils<false, 1>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 3: launch_pencils<true, 1>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 4: launch_pencils<false, 2>(s, S, out, stream, P, ga.forcing, launches); break;
+    default: launch_pencils<true, 2>(s, S, out, stream, P, ga.forcing, launches); break;
+    }
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
       Box b = all;
@@ -564,7 +622,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = "gram_p3_pencil(mfma_f64_16x16x4)+gram_p3_element(faces)";
+    kname = std::string("gram_p3_pencil(mfma_f64_16x16x4,walk=") + char('0' + walk_axis) + ")+gram_p3_element(faces)";
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;
