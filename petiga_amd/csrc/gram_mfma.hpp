@@ -277,6 +277,8 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
   const size_t tables = (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
   return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
 }
+// walk along axis 0 only: per-wavefront hold area for the lower-band entries [5 slots][4 r][64 lanes]
+__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 5 * 4 * 64 * 8; }
 
 // 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4); operands are products of three
 // 1-D factors, the walk-axis factor z (wave-uniform) selects the tile
@@ -381,6 +383,71 @@ __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, in
   // F lanes hold (fx, fy, slot = lane>>4): slot t takes over slot t+1's partial sum
   const double up = __shfl_down(Facc, 16);
   Facc = (fslot == 3) ? 0.0 : up;
+}
+
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+
+// Walk along axis 0: leaving layer `lay`, band-row variant.  The CSR keeps the 7 axis-0 neighbours of a row
+// contiguous, so the entries (row lay ; cols lay-3..lay+3) of one (a, r, b1, b2) are 56 contiguous bytes and
+// four lanes (b1 = 0..3) cover 224 contiguous bytes.  The upper half (cols lay..lay+3) is in the accumulator
+// tiles (0,0..3); the lower half (cols lay-3..lay-1) was produced when those layers left (column tiles
+// (k,0)) and is held until now: distance 1 in registers (h1), distances 2 and 3 in LDS.
+template <bool SYSTEM>
+__device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double (&h1)[4], double *hold /*LDS [5][4][64]*/, int lane,
+                                              const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
+                                              int lay, int own_lo, int own_hi, long long T0, long long T10) {
+  const int li = lay - T.lay0;
+  const bool exists = li >= 0 && li < nl && T.cnt[li] > 0;
+  const bool owned = __builtin_amdgcn_readfirstlane((int)(exists && lay >= own_lo && lay < own_hi)) != 0;
+  int p0[7]; bool full = owned; long long ps0 = 0; int c0 = 0;
+  if (owned) {
+#pragma unroll
+    for (int d = 0; d < 7; ++d) { p0[d] = __builtin_amdgcn_readfirstlane(T.P[li * 8 + d]); full = full && (p0[d] == d); }
+    const long long pv = T.pre[li];
+    ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll));
+    c0 = __builtin_amdgcn_readfirstlane(T.cnt[li]);
+  }
+  // lower half from the hold area (read before this step's writes reuse the slots)
+  const int s2 = (lay - 2) & 1, s3 = 2 + ((lay - 3) % 3 + 3) % 3;
+  double lo2[4], lo3[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { lo2[r] = hold[(s2 * 4 + r) * 64 + lane]; lo3[r] = hold[(s3 * 4 + r) * 64 + lane]; }
+  if (owned) {
+    double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0;
+    if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
+    if (full) {   // interior row: one 7-entry run per (lane, r)
+      double o[4][7];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+        const d2u_t a = *reinterpret_cast<const d2u_t *>(p), b = *reinterpret_cast<const d2u_t *>(p + 2), c = *reinterpret_cast<const d2u_t *>(p + 4);
+        o[r][0] = a[0]; o[r][1] = a[1]; o[r][2] = b[0]; o[r][3] = b[1]; o[r][4] = c[0]; o[r][5] = c[1]; o[r][6] = p[6];
+      }
+      if (fdo) out.vec[frow] = Fold + Facc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+        d2u_t a, b, c;
+        a[0] = o[r][0] + lo3[r]; a[1] = o[r][1] + lo2[r]; b[0] = o[r][2] + h1[r]; b[1] = o[r][3] + acc[0][0][r];
+        c[0] = o[r][4] + acc[0][1][r]; c[1] = o[r][5] + acc[0][2][r];
+        *reinterpret_cast<d2u_t *>(p) = a; *reinterpret_cast<d2u_t *>(p + 2) = b; *reinterpret_cast<d2u_t *>(p + 4) = c;
+        p[6] = o[r][6] + acc[0][3][r];
+      }
+    } else {      // rows next to the mesh ends: some columns do not exist
+      if (fdo) out.vec[frow] = Fold + Facc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double v[7] = {lo3[r], lo2[r], h1[r], acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]};
+#pragma unroll
+        for (int d = 0; d < 7; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[d];
+      }
+    }
+  }
+  // column tiles (k,0): entries (row lay+k, col lay) wait for their row
+  const int w2 = lay & 1, w3 = 2 + (lay % 3 + 3) % 3;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { h1[r] = acc[1][0][r]; hold[(w2 * 4 + r) * 64 + lane] = acc[2][0][r]; hold[(w3 * 4 + r) * 64 + lane] = acc[3][0][r]; }
+  pencil_shift(acc, Facc, L.fslot);
 }
 
 // leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays.
@@ -488,6 +555,12 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = (d4_t){0, 0, 0, 0};
   double Facc = 0;
+  double h1[4] = {0, 0, 0, 0};
+  double *hold = nullptr;
+  if (W == 0) {
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (5 * 4 * 64);
+    for (int i = lane; i < 5 * 4 * 64; i += 64) hold[i] = 0.0;
+  }
 
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
   // and group 1 (waves 4-7) run half a period apart, separated by s_barrier, so that on every SIMD one
@@ -509,12 +582,16 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
       Facc += Jel * (L.sxy * sw);
     }
     __builtin_amdgcn_s_barrier();
-    pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
+    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, h1, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10);
+    else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
-    for (int k = 1; k <= 3; ++k) pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
+    for (int k = 1; k <= 3; ++k) {
+      if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, h1, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10);
+      else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
+    }
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -551,14 +628,17 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
-    // enough wavefronts for ~8 rounds of the 2048 resident ones (2 per SIMD), segments no shorter than 32 elements
-    int nseg = (int)std::max<long long>(1, std::min<long long>((16384 + pencils - 1) / pencils, std::max(1, nw / 32)));
+    // Segments: as few as possible (every segment re-computes 3 halo elements).  Bounds: the LDS tables hold
+    // <= 160 elements, and a launch should fill the 256 CUs (one 8-pencil workgroup each) at least twice.
+    const long long bps = (pencils + 7) / 8;
+    int nseg = std::max(1, (nw + 159) / 160);
+    while (bps * nseg < 512 && nw / (nseg + 1) >= 32) nseg++;
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
     pa.blocks_per_seg = (int)((pencils + 7) / 8);
     pa.ne_max = pa.seg_len + 3;
     { const char *dbg = getenv("IGX_DEBUG_NOFLUSH"); pa.debug_noflush = dbg ? atoi(dbg) : 0; }
-    const size_t lds = pencil_lds_bytes(pa.ne_max);
+    const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes() : 0);
     auto kern = gram_p3_pencil<SYSTEM, W>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
@@ -591,7 +671,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool sys = out.op == OP_SYSTEM;
   // walk axis: the slowest-varying mesh axis that qualifies keeps axis 0 (contiguous CSR columns) on the lanes
   int walk_axis = -1;
-  { const char *wa = getenv("IGX_WALK_AXIS"); const int pref[3] = {wa ? atoi(wa) : 2, 1, 0};
+  { const char *wa = getenv("IGX_WALK_AXIS"); const int pref[3] = {wa ? atoi(wa) : 0, 2, 1};
     for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
