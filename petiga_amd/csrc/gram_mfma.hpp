@@ -239,6 +239,7 @@ struct PencilArgs {
   int blocks_per_seg;      // ceil(pencils / 8): a workgroup (8 wavefronts = 8 pencils) never straddles segments
   int ne_max;              // LDS capacity: elements (seg_len + 3 halo) ; layers = ne_max + 3
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
+  long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
 };
 
 struct PencilLane {        // per-lane constants of a pencil
@@ -574,7 +575,10 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
     const double *zt = T.zt + ei * 32, *wqw = T.wq + ei * 4;
     const double Jel = Jxy * T.Jz[ei];
+    long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
+    if (pa.debug_buf) tq0 = __builtin_readcyclecounter();
     pencil_mfma<W>(acc, L, zt, WYq, wqw, Jel);
+    if (pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM) {
       double sw = 0;
 #pragma unroll
@@ -582,8 +586,14 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
       Facc += Jel * (L.sxy * sw);
     }
     __builtin_amdgcn_s_barrier();
+    if (pa.debug_buf) tq2 = __builtin_readcyclecounter();
+    // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
+    // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
+    __builtin_amdgcn_s_setprio(3);
     if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, h1, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
+    __builtin_amdgcn_s_setprio(0);
+    if (pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -638,10 +648,33 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.blocks_per_seg = (int)((pencils + 7) / 8);
     pa.ne_max = pa.seg_len + 3;
     { const char *dbg = getenv("IGX_DEBUG_NOFLUSH"); pa.debug_noflush = dbg ? atoi(dbg) : 0; }
+    pa.debug_buf = nullptr;
+    static int dbg_done = 0;
+    const bool dbg_t = getenv("IGX_DEBUG_TIMING") && !dbg_done;
+    const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
+    if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes() : 0);
     auto kern = gram_p3_pencil<SYSTEM, W>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
+    if (dbg_t) {
+      dbg_done = 1;
+      (void)hipStreamSynchronize(stream);
+      std::vector<long long> h(dbg_n);
+      (void)hipMemcpy(h.data(), pa.debug_buf, dbg_n * 8, hipMemcpyDeviceToHost);
+      double sm = 0, sw = 0, sf = 0, sp = 0; long long cnt = 0; long long hist[16] = {0};
+      for (size_t b = 0; b < dbg_n / 4 / 64; ++b) for (int e = 4; e < 60; ++e) {
+        const long long *d = &h[(b * 64 + e) * 4], *dn = &h[(b * 64 + e + 1) * 4];
+        if (!d[3] || !dn[0]) continue;
+        sm += (double)(d[1] - d[0]); sw += (double)(d[2] - d[1]); sf += (double)(d[3] - d[2]); sp += (double)(dn[0] - d[0]); cnt++;
+        long long fb = (d[3] - d[2]) / 8192; if (fb > 15) fb = 15; hist[fb]++;
+      }
+      fprintf(stderr, "[igx pencil timing] blocks=%d seg_len=%d n=%lld cycles: mfma %.0f | wait@barrier %.0f | flush %.0f | period %.0f\n   flush histogram (8192-cycle bins):",
+              pa.blocks_per_seg * pa.nseg, pa.seg_len, cnt, sm / cnt, sw / cnt, sf / cnt, sp / cnt);
+      for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", hist[i]);
+      fprintf(stderr, "\n");
+      (void)hipFree(pa.debug_buf);
+    }
     launches++;
   }
 }
