@@ -243,7 +243,7 @@ struct PencilArgs {
 };
 
 struct PencilLane {        // per-lane constants of a pencil
-  double u0, u1, wqx;
+  double u0, u1;           // X-axis basis value / derivative of this lane's (qx, ix), scaled by sqrt(w_qx * J_x)
   const double *vy;        // LDS: this lane's Y-axis basis row [4 q][2] (value, derivative)
   long long psx; int cx, px;            // X axis: row prefix / row length of this lane's row slot, column position of its column slot
   long long psy[4]; int cy[4], py[4];   // Y axis, per accumulator register r
@@ -281,33 +281,31 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
 // walk along axis 0 only: per-wavefront hold area for the lower-band entries [5 slots][4 r][64 lanes]
 __host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 5 * 4 * 64 * 8; }
 
-// 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4); operands are products of three
-// 1-D factors, the walk-axis factor z (wave-uniform) selects the tile
+// 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4).  K_e = sum_q (sqrt(JW) grad N_a).(sqrt(JW) grad N_b):
+// the quadrature weight is split as sqrt(JW_q) on both sides, and sqrt(JW_q) itself factorises over the axes, so the
+// three 1-D rows are pre-scaled once (u: per pencil, vy: per pencil in LDS, zt: when the segment is staged) and the
+// A and B operands of a tile pair are the same registers: 5 v_mul_f64 per 16 MFMAs.
 template <int W>
-__device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2]*/,
-                                            const double *__restrict__ Wqy, const double *wqw /*LDS*/, double Jel) {
+__device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2], pre-scaled*/) {
 #pragma unroll
   for (int qw = 0; qw < 4; ++qw) {
     double z0[4], z1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) { z0[t] = zt[(qw * 4 + t) * 2 + 0]; z1[t] = zt[(qw * 4 + t) * 2 + 1]; }
-    const double s3 = Jel * wqw[qw];
 #pragma unroll
     for (int qy = 0; qy < 4; ++qy) {
-      const double jw = L.wqx * (Wqy[qy] * s3);
       const double vy0 = L.vy[qy * 2 + 0], vy1 = L.vy[qy * 2 + 1];
 #pragma unroll
       for (int al = 0; al < 3; ++al) {   // al = 0: d/dw, 1: d/dx, 2: d/dy (the Gram sum runs over all three)
         const double uv = (al == 1 ? L.u1 : L.u0) * (al == 2 ? vy1 : vy0);
-        const double uvj = uv * jw;
-        double opA[4], opB[4];
+        double op[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { const double z = (al == 0) ? z1[t] : z0[t]; opA[t] = uvj * z; opB[t] = uv * z; }
+        for (int t = 0; t < 4; ++t) op[t] = uv * ((al == 0) ? z1[t] : z0[t]);
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
           for (int tb = 0; tb < 4; ++tb)
-            acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(opA[ta], opB[tb], acc[ta][tb], 0, 0, 0);
+            acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ta], op[tb], acc[ta][tb], 0, 0, 0);
       }
     }
   }
@@ -487,8 +485,11 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   {
     const int tid = threadIdx.x;
     const double *__restrict__ tabw = AW.tab + (size_t)wh * (4 * 4 * NDER);
-    for (int i = tid; i < ne * 32; i += 512) { const int e = i >> 5, j = i & 31; T.zt[i] = tabw[(size_t)e * 64 + (j >> 1) * NDER + (j & 1)]; }
-    for (int i = tid; i < ne * 4; i += 512) T.wq[i] = AW.w[wh * 4 + i];
+    for (int i = tid; i < ne * 32; i += 512) {   // j = (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
+      const int e = i >> 5, j = i & 31, q = j >> 3;
+      T.zt[i] = tabw[(size_t)e * 64 + (j >> 1) * NDER + (j & 1)] * sqrt(AW.w[(wh + e) * 4 + q] * AW.J[wh + e]);
+    }
+    for (int i = tid; i < ne * 4; i += 512) T.wq[i] = sqrt(AW.w[wh * 4 + i] * AW.J[wh + (i >> 2)]);
     for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[wh + i];
     for (int i = tid; i < nl; i += 512) {
       const int lay = T.lay0 + i;
@@ -521,10 +522,10 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *__restrict__ WX = AX.w + elx * 4;
     const double *__restrict__ WYq = AY.w + ely * 4;
     const int qx = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
-    L.u0 = TX[(qx * 4 + ix) * NDER + 0]; L.u1 = TX[(qx * 4 + ix) * NDER + 1]; L.wqx = WX[qx];
+    { const double sx = sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * 4 + ix) * NDER + 0] * sx; L.u1 = TX[(qx * 4 + ix) * NDER + 1] * sx; }
     {   // Y-axis rows of this pencil -> LDS [a][q][2]; a lane later reads its own row (a = iy) one q at a time
       double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max) - 8 * 32 * 8))) + wave * 32;
-      if (lane < 32) { const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1; vyw[lane] = TY[(qq * 4 + aa) * NDER + kk]; }
+      if (lane < 32) { const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1; vyw[lane] = TY[(qq * 4 + aa) * NDER + kk] * sqrt(WYq[qq] * AY.J[ely]); }
       L.vy = vyw + iy * 8;
     }
     // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
@@ -543,12 +544,10 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     double sx = 0, sy = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { sx += WX[q] * TX[(q * 4 + fx) * NDER]; sy += WYq[q] * TY[(q * 4 + fy) * NDER]; }
-    L.sxy = pa.forcing * (sx * sy);
+    L.sxy = pa.forcing * (sx * sy) * (AX.J[elx] * AY.J[ely]);
     L.frowxy = rs[X] * AX.rowmap[offx + fx] + rs[Y] * AY.rowmap[offy + fy];
     L.fslot = lane >> 4;
   }
-  const double *__restrict__ WYq = AY.w + ely * 4;
-  const double Jxy = AX.J[elx] * AY.J[ely];
 
   d4_t acc[4][4];
 #pragma unroll
@@ -573,17 +572,16 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   int lay = T.lay0;
   for (int ei = 0; ei < ne; ++ei) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
-    const double *zt = T.zt + ei * 32, *wqw = T.wq + ei * 4;
-    const double Jel = Jxy * T.Jz[ei];
+    const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    pencil_mfma<W>(acc, L, zt, WYq, wqw, Jel);
+    pencil_mfma<W>(acc, L, zt);
     if (pa.debug_buf) tq1 = __builtin_readcyclecounter();
-    if (SYSTEM) {
+    if (SYSTEM) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sw += wqw[q] * zt[(q * 4 + L.fslot) * 2];
-      Facc += Jel * (L.sxy * sw);
+      for (int q = 0; q < 4; ++q) sw += wqs[q] * zt[(q * 4 + L.fslot) * 2];
+      Facc += L.sxy * sw;
     }
     __builtin_amdgcn_s_barrier();
     if (pa.debug_buf) tq2 = __builtin_readcyclecounter();
