@@ -278,14 +278,14 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
   const size_t tables = (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
   return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
 }
-// walk along axis 0 only: per-wavefront hold area for the lower-band entries [5 slots][4 r][64 lanes]
-__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 5 * 4 * 64 * 8; }
+// walk along axis 0 only: per-wavefront hold area for the lower-band entries [6 slots][4 r][64 lanes]
+__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 6 * 4 * 64 * 8; }
 
 // 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4).  K_e = sum_q (sqrt(JW) grad N_a).(sqrt(JW) grad N_b):
 // the quadrature weight is split as sqrt(JW_q) on both sides, and sqrt(JW_q) itself factorises over the axes, so the
 // three 1-D rows are pre-scaled once (u: per pencil, vy: per pencil in LDS, zt: when the segment is staged) and the
 // A and B operands of a tile pair are the same registers: 5 v_mul_f64 per 16 MFMAs.
-template <int W>
+template <int W, bool SYM>
 __device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2], pre-scaled*/) {
 #pragma unroll
   for (int qw = 0; qw < 4; ++qw) {
@@ -304,7 +304,7 @@ __device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane 
 #pragma unroll
         for (int ta = 0; ta < 4; ++ta)
 #pragma unroll
-          for (int tb = 0; tb < 4; ++tb)
+          for (int tb = SYM ? ta : 0; tb < 4; ++tb)   // SYM: K_e is symmetric, tile (tb,ta) is the transpose of (ta,tb)
             acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ta], op[tb], acc[ta][tb], 0, 0, 0);
       }
     }
@@ -372,13 +372,14 @@ __device__ __forceinline__ void pencil_flush(const d4_t (&acc)[4][4], const Penc
 }
 
 // the window slides by one layer: tile (ta,tb) <- tile (ta+1,tb+1); the new last row / column start at zero
+template <bool SYM>
 __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, int fslot) {
 #pragma unroll
   for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
-    for (int tb = 0; tb < 3; ++tb) acc[ta][tb] = acc[ta + 1][tb + 1];
+    for (int tb = SYM ? ta : 0; tb < 3; ++tb) acc[ta][tb] = acc[ta + 1][tb + 1];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { acc[3][t] = (d4_t){0, 0, 0, 0}; acc[t][3] = (d4_t){0, 0, 0, 0}; }
+  for (int t = 0; t < 4; ++t) { acc[t][3] = (d4_t){0, 0, 0, 0}; if (!SYM) acc[3][t] = (d4_t){0, 0, 0, 0}; }
   // F lanes hold (fx, fy, slot = lane>>4): slot t takes over slot t+1's partial sum
   const double up = __shfl_down(Facc, 16);
   Facc = (fslot == 3) ? 0.0 : up;
@@ -389,10 +390,11 @@ typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 // Walk along axis 0: leaving layer `lay`, band-row variant.  The CSR keeps the 7 axis-0 neighbours of a row
 // contiguous, so the entries (row lay ; cols lay-3..lay+3) of one (a, r, b1, b2) are 56 contiguous bytes and
 // four lanes (b1 = 0..3) cover 224 contiguous bytes.  The upper half (cols lay..lay+3) is in the accumulator
-// tiles (0,0..3); the lower half (cols lay-3..lay-1) was produced when those layers left (column tiles
-// (k,0)) and is held until now: distance 1 in registers (h1), distances 2 and 3 in LDS.
+// tiles (0,0..3).  The lower half (cols lay-3..lay-1) is the transpose of the upper halves of the rows that
+// left 1, 2 and 3 steps ago (K_e is symmetric, only tiles ta <= tb are computed): each leaving row parks its
+// tiles (0,1..3) transposed in a per-wavefront LDS area, [6 slots][4 r][64 lanes], until the partner row leaves.
 template <bool SYSTEM>
-__device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double (&h1)[4], double *hold /*LDS [5][4][64]*/, int lane,
+__device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10) {
   const int li = lay - T.lay0;
@@ -406,11 +408,11 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
     ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll));
     c0 = __builtin_amdgcn_readfirstlane(T.cnt[li]);
   }
-  // lower half from the hold area (read before this step's writes reuse the slots)
-  const int s2 = (lay - 2) & 1, s3 = 2 + ((lay - 3) % 3 + 3) % 3;
-  double lo2[4], lo3[4];
+  // lower half: parked by layers lay-1 (slot 0), lay-2 (slots 1,2), lay-3 (slots 3..5); read before this step re-uses the slots
+  const int s2 = 1 + ((lay - 2) & 1), s3 = 3 + ((lay - 3) % 3 + 3) % 3;
+  double lo1[4], lo2[4], lo3[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { lo2[r] = hold[(s2 * 4 + r) * 64 + lane]; lo3[r] = hold[(s3 * 4 + r) * 64 + lane]; }
+  for (int r = 0; r < 4; ++r) { lo1[r] = hold[r * 64 + lane]; lo2[r] = hold[(s2 * 4 + r) * 64 + lane]; lo3[r] = hold[(s3 * 4 + r) * 64 + lane]; }
   if (owned) {
     double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0;
     if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
@@ -427,7 +429,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       for (int r = 0; r < 4; ++r) {
         double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
         d2u_t a, b, c;
-        a[0] = o[r][0] + lo3[r]; a[1] = o[r][1] + lo2[r]; b[0] = o[r][2] + h1[r]; b[1] = o[r][3] + acc[0][0][r];
+        a[0] = o[r][0] + lo3[r]; a[1] = o[r][1] + lo2[r]; b[0] = o[r][2] + lo1[r]; b[1] = o[r][3] + acc[0][0][r];
         c[0] = o[r][4] + acc[0][1][r]; c[1] = o[r][5] + acc[0][2][r];
         *reinterpret_cast<d2u_t *>(p) = a; *reinterpret_cast<d2u_t *>(p + 2) = b; *reinterpret_cast<d2u_t *>(p + 4) = c;
         p[6] = o[r][6] + acc[0][3][r];
@@ -436,17 +438,26 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       if (fdo) out.vec[frow] = Fold + Facc;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const double v[7] = {lo3[r], lo2[r], h1[r], acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]};
+        const double v[7] = {lo3[r], lo2[r], lo1[r], acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]};
 #pragma unroll
         for (int d = 0; d < 7; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[d];
       }
     }
   }
-  // column tiles (k,0): entries (row lay+k, col lay) wait for their row
-  const int w2 = lay & 1, w3 = 2 + (lay % 3 + 3) % 3;
+  // park the transposes of tiles (0,1..3): entry (row lay ; a, r') x (col lay+d ; b1, b2) of this lane is entry
+  // (row lay+d ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
+  {
+    const int A = lane >> 4, B2 = (lane >> 2) & 3, B1 = lane & 3;
+    const int w2 = 1 + (lay & 1), w3 = 3 + (lay % 3 + 3) % 3;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { h1[r] = acc[1][0][r]; hold[(w2 * 4 + r) * 64 + lane] = acc[2][0][r]; hold[(w3 * 4 + r) * 64 + lane] = acc[3][0][r]; }
-  pencil_shift(acc, Facc, L.fslot);
+    for (int rp = 0; rp < 4; ++rp) {
+      const int lc = B1 * 16 + rp * 4 + A;
+      hold[(0 * 4 + B2) * 64 + lc] = acc[0][1][rp];
+      hold[(w2 * 4 + B2) * 64 + lc] = acc[0][2][rp];
+      hold[(w3 * 4 + B2) * 64 + lc] = acc[0][3][rp];
+    }
+  }
+  pencil_shift<true>(acc, Facc, L.fslot);
 }
 
 // leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays.
@@ -461,7 +472,7 @@ __device__ __forceinline__ void pencil_leave(d4_t (&acc)[4][4], double &Facc, co
     if (fdo) frow = L.frowxy + fstride * T.rho[li];
   }
   pencil_flush<SYSTEM, W>(acc, L, f, out, T0, T10, fdo, frow, Facc);
-  pencil_shift(acc, Facc, L.fslot);
+  pencil_shift<false>(acc, Facc, L.fslot);
 }
 
 template <bool SYSTEM, int W>
@@ -555,11 +566,10 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 #pragma unroll
     for (int tb = 0; tb < 4; ++tb) acc[ta][tb] = (d4_t){0, 0, 0, 0};
   double Facc = 0;
-  double h1[4] = {0, 0, 0, 0};
   double *hold = nullptr;
   if (W == 0) {
-    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (5 * 4 * 64);
-    for (int i = lane; i < 5 * 4 * 64; i += 64) hold[i] = 0.0;
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (6 * 4 * 64);
+    for (int i = lane; i < 6 * 4 * 64; i += 64) hold[i] = 0.0;
   }
 
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
@@ -575,7 +585,7 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    pencil_mfma<W>(acc, L, zt);
+    pencil_mfma<W, W == 0>(acc, L, zt);
     if (pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
@@ -588,7 +598,7 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
-    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, h1, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10);
+    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
     __builtin_amdgcn_s_setprio(0);
     if (pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
@@ -597,7 +607,7 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
     for (int k = 1; k <= 3; ++k) {
-      if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, h1, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10);
+      if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10);
       else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
     }
 }

@@ -315,3 +315,56 @@ def test_mfma_full_size_properties():
     d = M.diagonal()
     assert np.array_equal(d[onb], (mult(i0) * mult(i1) * mult(i2))[onb].astype(float))
     assert np.array_equal(b.get()[onb], d[onb])
+
+
+# ---------------------------------------------------------------- pencil walk (combine-before-write) specifics
+@pytest.mark.parametrize("N,bc,walk", [((70, 5, 5), "all1", None), ((66, 4, 5), "none", None), ((72, 4, 4), "axis0", None),
+                                       ((9, 5, 70), "mixed", "2"), ((5, 68, 4), "all1", "1"), ((40, 6, 6), "mixed", None)])
+def test_mfma_pencil_segments_and_walk_axes(N, bc, walk, monkeypatch):
+    """Long pencils are cut into segments with 3 re-computed halo elements; every walk axis is exercised
+    (axis 0: band-row flush with symmetric tiles; axes 1, 2: generic 7-tile flush)."""
+    if walk is not None:
+        monkeypatch.setenv("IGX_WALK_AXIS", walk)
+    orc, eng = make_pair(3, 1, 3, list(N))
+    for g in (orc, eng):
+        if bc == "all1":
+            dirichlet_all((g,), 3, 1.0)
+        elif bc == "mixed":
+            k = 0
+            for d in range(3):
+                for s in range(2):
+                    g.set_boundary_value(d, s, 0, 0.5 + 0.25 * k)
+                    k += 1
+        elif bc == "axis0":
+            g.set_boundary_value(0, 0, 0, 2.0)
+            g.set_boundary_value(0, 1, 0, -1.0)
+    eng.set_kernel(2)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    assert "pencil" in eng.kernel_name() and ("walk=%s" % (walk or "0")) in eng.kernel_name()
+    compare_mats(A, A_o, TOL)
+    assert np.abs(b.get() - b_o).max() <= TOL * max(np.abs(b_o).max(), 1e-300)
+
+
+def test_mfma_falls_back_when_axis0_not_walkable():
+    # axis 0 with C1 lines (two new basis functions per element) cannot be walked: the walk moves to axis 2
+    orc, eng = make_pair(3, 1, 3, [10, 5, 12], C=[1, 2, 2])
+    dirichlet_all((orc, eng), 3, 1.5)
+    eng.set_kernel(2)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    assert "walk=2" in eng.kernel_name()
+    compare_mats(A, A_o, TOL)
+    assert np.abs(b.get() - b_o).max() <= TOL * np.abs(b_o).max()
+
+
+def test_mfma_repeatable_bitwise():
+    """Colour-ordered, conflict-free scatter: two assemblies of the same system are bit-identical."""
+    orc, eng = make_pair(3, 1, 3, [34, 9, 8])
+    dirichlet_all((eng,), 3, 0.75)
+    eng.set_form("poisson")
+    out = []
+    for _ in range(2):
+        A, b = eng.create_mat(), eng.create_vec()
+        eng.compute_system(A, b)
+        eng.synchronize()
+        out.append((A.host(True), b.get()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
