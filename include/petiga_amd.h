@@ -189,6 +189,10 @@ int IGXGetKernelName(IGX iga,char *buf,int len);
  * engine's stream (ms); IGXSetTiming(1) enables the events */
 int IGXSetTiming(IGX iga,int flag);
 int IGXGetLastTiming(IGX iga,double *total_ms,double *kernel_ms,int *launches);
+/* the dominant kernel of the last IGXCompute* call: its name, the time of its launches (HIP events on the
+ * engine's stream, ms), how many launches, how many elements they processed and the MFMA flops it
+ * executes per element (for roofline accounting) */
+int IGXGetDominantKernelTiming(IGX iga,char *name,int len,double *ms,int *launches,int64_t *elements,double *flop_per_element);
 
 /* element colouring used by the scatter: colour of local element (i,j,k) and the number of
  * colours (bit-exact contract, tests/test_coloring.py) */

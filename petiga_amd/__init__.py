@@ -65,6 +65,7 @@ def lib(build_if_needed=False):
         "IGXComputeIFunction": [V, C.c_double, V, C.c_double, V, V], "IGXComputeIJacobian": [V, C.c_double, V, C.c_double, V, V],
         "IGXSetStream": [V, V], "IGXSynchronize": [V], "IGXSetKernel": [V, C.c_int], "IGXGetKernelName": [V, C.c_char_p, C.c_int],
         "IGXSetTiming": [V, C.c_int], "IGXGetLastTiming": [V, _dp, _dp, _ip],
+        "IGXGetDominantKernelTiming": [V, C.c_char_p, C.c_int, _dp, _ip, C.POINTER(C.c_int64), _dp],
         "IGXGetColoring": [V, _ip], "IGXGetElementColor": [V, C.c_int, C.c_int],
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V],
@@ -269,6 +270,12 @@ class IGX:
         a, b, n = C.c_double(), C.c_double(), C.c_int()
         _ck(lib().IGXGetLastTiming(self.h, C.byref(a), C.byref(b), C.byref(n)))
         return a.value, b.value, n.value
+
+    def dominant_kernel(self):
+        buf = C.create_string_buffer(128)
+        ms, n, el, fl = C.c_double(), C.c_int(), C.c_int64(), C.c_double()
+        _ck(lib().IGXGetDominantKernelTiming(self.h, buf, 128, C.byref(ms), C.byref(n), C.byref(el), C.byref(fl)))
+        return dict(name=buf.value.decode(), ms=ms.value, launches=n.value, elements=el.value, executed_flop_per_element=fl.value)
 
     def coloring(self):
         nc = (C.c_int * 3)()

@@ -40,8 +40,9 @@ struct _p_IGX {
   int kernel_choice = 0;
   std::string last_kernel = "none";
   bool timing = false;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
+  DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
 };
 
@@ -361,6 +362,18 @@ extern "C" int IGXGetLastTiming(IGX g, double *total_ms, double *kernel_ms, int 
   if (total_ms) *total_ms = g->last_total_ms; if (kernel_ms) *kernel_ms = g->last_kernel_ms; if (launches) *launches = g->last_launches;
   return 0;
 }
+extern "C" int IGXGetDominantKernelTiming(IGX g, char *name, int len, double *ms, int *launches, int64_t *elements, double *flop_per_element) {
+  NEEDIGA(g);
+  double t = 0;
+  if (g->timing && g->ev[4] && g->dom.launches > 0) {
+    HIPCK(hipEventSynchronize(g->ev[5]));
+    float a = 0; HIPCK(hipEventElapsedTime(&a, g->ev[4], g->ev[5])); t = a;
+  }
+  if (name && len > 0) snprintf(name, (size_t)len, "%s", g->dom.name.c_str());
+  if (ms) *ms = t; if (launches) *launches = g->dom.launches; if (elements) *elements = g->dom.elements;
+  if (flop_per_element) *flop_per_element = g->dom.flop_per_element;
+  return 0;
+}
 extern "C" int IGXGetDeviceInfo(char *buf, int len) {
   int dev = 0; hipDeviceProp_t pr;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) { snprintf(buf, (size_t)len, "no HIP device"); return IGX_ERR_LIB; }
@@ -496,7 +509,8 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   int rc;
   bool done = false;
   if (g->kernel_choice != 1) {
-    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done);
+    g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom);
     if (rc) return rc;
   }
   if (!done) {

@@ -23,6 +23,12 @@ namespace igx {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
+// the launches of the dominant kernel of one assembly, for the roofline line of bench.py
+struct DomInfo {
+  std::string name = "none"; int launches = 0; long long elements = 0; double flop_per_element = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // recorded around those launches when timing is on
+};
+
 struct GramArgs {
   double forcing;      // F_a = forcing * int N_a   (1.0 for Poisson3D, -2*dim for IGAFixTable System2)
   int nwaves;          // elements in this launch
@@ -695,7 +701,7 @@ static bool axis_walkable(const Space &s, int d) {   // one new node layer per e
 }
 
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
-                         std::string &kname, int &launches, std::string &err, bool &done) {
+                         std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom) {
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
   if (s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
@@ -717,7 +723,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool walk = walk_axis >= 0;
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk) {
+    if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
+    if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
+    dom.name = "gram_p3_element"; dom.launches = launches; dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2]; dom.flop_per_element = 2048.0 * 48 * 16;
     kname = "gram_p3_element(mfma_f64_16x16x4)";
   } else {
     // P = elements without a Dirichlet face (pencil kernel), E = the rest (element kernel, which owns the BC logic)
@@ -727,6 +736,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       if (s.value[d][0].count && s.elem_start[d] == 0) P.lo[d] = 1;
       if (s.value[d][1].count && s.elem_start[d] + s.elem_width[d] == s.elem_sizes[d]) P.hi[d] = s.elem_width[d] - 1;
     }
+    const int l0 = launches;
+    if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     switch (walk_axis * 2 + (sys ? 1 : 0)) {
     case 0: launch_pencils<false, 0>(s, S, out, stream, P, ga.forcing, launches); break;
     case 1: launch_pencils<true, 0>(s, S, out, stream, P, ga.forcing, launches); break;
@@ -735,6 +746,11 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     case 4: launch_pencils<false, 2>(s, S, out, stream, P, ga.forcing, launches); break;
     default: launch_pencils<true, 2>(s, S, out, stream, P, ga.forcing, launches); break;
     }
+    if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
+    dom.name = std::string("gram_p3_pencil<walk=") + char('0' + walk_axis) + ">"; dom.launches = launches - l0;
+    dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
+    // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
+    dom.flop_per_element = 2048.0 * 48 * (walk_axis == 0 ? 10 : 16);
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
       Box b = all;
