@@ -201,13 +201,18 @@ int IGXGetElementColor(IGX iga,int axis,int e);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-GPU (one process per GPU): ghost-row exchange buffers.  Rank r's ghost rows (nodes it
- * holds but does not own) are packed per upper neighbour; the owner adds them.  The transport
- * (RCCL send/recv or all_to_all over xGMI) is the caller's: torch.distributed in bench.py.
+ * holds but does not own) are packed per upper neighbour (send list, k < nsend); the owner adds
+ * them (receive list, k < nrecv).  A message is mat_doubles values (if A given) followed by
+ * vec_doubles values (if b given).  Replaces the stash traffic of MatAssemblyBegin/End and
+ * VecAssemblyBegin/End (src/petigaksp.c:197-200).  The transport (RCCL send/recv over xGMI) is the
+ * caller's: torch.distributed in petiga_amd/exchange.py.
  * ------------------------------------------------------------------------------------------ */
 int IGXGetNeighborCount(IGX iga,int *nsend,int *nrecv);
 int IGXGetNeighborInfo(IGX iga,int send /*1=send list,0=recv list*/,int k,int *rank,int64_t *mat_doubles,int64_t *vec_doubles);
 int IGXPackGhostRows  (IGX iga,IGXMat A,IGXVec b,int k,double *devbuf);   /* A or b may be NULL */
 int IGXUnpackGhostRows(IGX iga,IGXMat A,IGXVec b,int k,const double *devbuf);
+/* 1 if this rank owns the node of local row (r0,r1,r2): after the exchange only owned rows are final */
+int IGXRowOwned(IGX iga,int r0,int r1,int r2);
 
 /* library / device info for logs */
 int IGXGetDeviceInfo(char *buf,int len);

@@ -68,7 +68,7 @@ def lib(build_if_needed=False):
         "IGXGetDominantKernelTiming": [V, C.c_char_p, C.c_int, _dp, _ip, C.POINTER(C.c_int64), _dp],
         "IGXGetColoring": [V, _ip], "IGXGetElementColor": [V, C.c_int, C.c_int],
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
-        "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V],
+        "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
@@ -276,6 +276,21 @@ class IGX:
         ms, n, el, fl = C.c_double(), C.c_int(), C.c_int64(), C.c_double()
         _ck(lib().IGXGetDominantKernelTiming(self.h, buf, 128, C.byref(ms), C.byref(n), C.byref(el), C.byref(fl)))
         return dict(name=buf.value.decode(), ms=ms.value, launches=n.value, elements=el.value, executed_flop_per_element=fl.value)
+
+    def neighbors(self, send):
+        """[(peer rank, matrix doubles, vector doubles)] of the send (upper) or receive (lower) list."""
+        ns, nr = C.c_int(), C.c_int()
+        _ck(lib().IGXGetNeighborCount(self.h, C.byref(ns), C.byref(nr)))
+        out = []
+        for k in range(ns.value if send else nr.value):
+            r, m, v = C.c_int(), C.c_int64(), C.c_int64()
+            _ck(lib().IGXGetNeighborInfo(self.h, int(send), k, C.byref(r), C.byref(m), C.byref(v)))
+            out.append((r.value, m.value, v.value))
+        return out
+
+    def pack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXPackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))
+    def unpack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXUnpackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))
+    def row_owned(self, r0, r1=0, r2=0): return bool(lib().IGXRowOwned(self.h, r0, r1, r2))
 
     def coloring(self):
         nc = (C.c_int * 3)()

@@ -1,5 +1,148 @@
-// exchange.hpp -- ghost-row pack/unpack for the multi-GPU path (one process per GPU).
-extern "C" int IGXGetNeighborCount(IGX g, int *nsend, int *nrecv) { NEEDIGA(g); if (nsend) *nsend = 0; if (nrecv) *nrecv = 0; return 0; }
-extern "C" int IGXGetNeighborInfo(IGX g, int, int, int *, int64_t *, int64_t *) { NEEDIGA(g); return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour"); }
-extern "C" int IGXPackGhostRows(IGX g, IGXMat, IGXVec, int, double *) { NEEDIGA(g); return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour"); }
-extern "C" int IGXUnpackGhostRows(IGX g, IGXMat, IGXVec, int, const double *) { NEEDIGA(g); return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour"); }
+// exchange.hpp -- ghost-row pack/unpack for the multi-GPU path (one process per GPU); included by engine.hip.
+//
+// A rank assembles its own elements, so rows of nodes it holds but does not own (the <= p node layers on the
+// high side of each axis, src/petiga.c:1172-1208) are partial sums that belong to an "upper" neighbour: the
+// reference moves them through PETSc's stash in MatAssemblyBegin/End (src/petigaksp.c:197-198).  Here a row
+// of the local matrix always carries the node's full stencil in ascending column order, which is the same
+// set and order on sender and receiver, so a ghost row travels as a plain run of doubles and is ADDED to the
+// owner's row.  One message per neighbour offset o in {0,1}^3 \ {0}: rows whose axis-d index is in the ghost
+// part where o_d = 1 and in the owned part where o_d = 0.  Transport (RCCL send/recv over xGMI) is the
+// caller's (petiga_amd/exchange.py).
+
+struct NbrPlan {
+  int rank;              // peer
+  int start[3], count[3];  // local row-index box on this rank
+  int64_t mat_doubles, vec_doubles;
+};
+
+// node ranges of the rank with processor coordinates c on axis d (same formulas as space_setup)
+static void axis_ranges_of(const Space &s, int d, int c, int &lstart, int &lwidth, int &gstart, int &gwidth) {
+  const Axis &ax = s.axis[d];
+  const int np = s.proc_sizes[d], N = s.elem_sizes[d], q = N / np, r = N % np;
+  const int ew = q + (r > c ? 1 : 0), es = c * q + std::min(c, r);
+  const int ef = es, el = es + ew - 1, p = ax.p;
+  lstart = ax.span[ef] - p; gstart = lstart;
+  const int gend = ax.span[el] + 1;
+  const int lend = (el < N - 1) ? ax.span[el + 1] - p : ax.span[el] + 1;
+  lwidth = lend - lstart; gwidth = gend - gstart;
+  if (c == np - 1) lwidth = ax.nnp - lstart;
+}
+
+static int rank_of(const Space &s, const int c[3]) { return c[0] + s.proc_sizes[0] * (c[1] + s.proc_sizes[1] * c[2]); }
+
+// build the send list (send=true: to upper neighbours) or the receive list (from lower neighbours)
+static std::vector<NbrPlan> neighbour_plans(const Space &s, bool send) {
+  std::vector<NbrPlan> out;
+  if (!s.setup) return out;
+  for (int o = 1; o < 8; ++o) {
+    const int od[3] = {o & 1, (o >> 1) & 1, (o >> 2) & 1};
+    NbrPlan pl; bool ok = true; int pc[3];
+    for (int d = 0; d < 3 && ok; ++d) {
+      const int np = s.proc_sizes[d], me = s.proc_ranks[d];
+      if (d >= s.dim) { if (od[d]) ok = false; pc[d] = 0; pl.start[d] = 0; pl.count[d] = 1; continue; }
+      const bool per = s.axis[d].periodic != 0;
+      int peer = send ? me + od[d] : me - od[d];
+      if (od[d]) {
+        if (np == 1) { ok = false; break; }            // single rank on this axis: nothing to exchange (periodic wraps locally)
+        if (peer < 0 || peer >= np) { if (!per) { ok = false; break; } peer = (peer + np) % np; }
+      }
+      pc[d] = peer;
+      // sender's ranges on this axis
+      const int sc = send ? me : peer;
+      int ls, lw, gs, gw; axis_ranges_of(s, d, sc, ls, lw, gs, gw);
+      const int nghost = gw - lw;
+      if (od[d]) {
+        if (nghost <= 0) { ok = false; break; }
+        if (send) { pl.start[d] = lw; pl.count[d] = nghost; }         // my ghost part
+        else { pl.start[d] = 0; pl.count[d] = nghost; }               // my first owned nodes = the sender's ghosts
+      } else {
+        const int lwme = s.node_lwidth[d], gwme = s.node_gwidth[d];
+        pl.start[d] = 0; pl.count[d] = std::min(lwme, gwme);          // owned part (same on both sides)
+      }
+    }
+    if (!ok) continue;
+    pl.rank = rank_of(s, pc);
+    int64_t t[3];
+    for (int d = 0; d < 3; ++d) { t[d] = 0; for (int k = 0; k < pl.count[d]; ++k) t[d] += s.lay[d].rcnt[pl.start[d] + k]; }
+    pl.mat_doubles = t[0] * t[1] * t[2] * s.dof * s.dof;
+    pl.vec_doubles = (int64_t)pl.count[0] * pl.count[1] * pl.count[2] * s.dof;
+    out.push_back(pl);
+  }
+  return out;
+}
+
+struct PackDev { int start[3], count[3], nrow[3]; const int *rcnt[3]; const int64_t *prefix[3]; int64_t tot[3], sub0[3]; int bs2, dof; };
+
+// one workgroup per row of the sub-box: copy (PACK) or add (UNPACK) the row's blocks / vector entries
+template <bool PACK>
+__global__ void k_ghost_rows(PackDev P, const int64_t *browptr, double *val, double *vec, double *buf, int64_t mat_doubles) {
+  const int64_t r = blockIdx.x;
+  const int k0 = (int)(r % P.count[0]), k1 = (int)((r / P.count[0]) % P.count[1]), k2 = (int)(r / ((int64_t)P.count[0] * P.count[1]));
+  const int r0 = P.start[0] + k0, r1 = P.start[1] + k1, r2 = P.start[2] + k2;
+  const int64_t row = (int64_t)r0 + (int64_t)P.nrow[0] * ((int64_t)r1 + (int64_t)P.nrow[1] * r2);
+  if (val) {
+    const int64_t c1 = P.rcnt[1][r1], c2 = P.rcnt[2][r2], c0 = P.rcnt[0][r0];
+    // offset inside the message: same closed form as browptr, with prefixes relative to the sub-box
+    const int64_t p0 = P.prefix[0][r0] - P.sub0[0], p1 = P.prefix[1][r1] - P.sub0[1], p2 = P.prefix[2][r2] - P.sub0[2];
+    const int64_t off = (p2 * P.tot[1] * P.tot[0] + c2 * (p1 * P.tot[0] + c1 * p0)) * P.bs2;
+    const int64_t n = c0 * c1 * c2 * P.bs2;
+    double *m = val + browptr[row] * P.bs2, *b = buf + off;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { if (PACK) b[i] = m[i]; else m[i] += b[i]; }
+  }
+  if (vec && threadIdx.x < P.dof) {
+    double *v = vec + row * P.dof + threadIdx.x, *b = buf + mat_doubles + r * P.dof + threadIdx.x;
+    if (PACK) *b = *v; else *v += *b;
+  }
+}
+
+static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool pack) {
+  NEEDIGA(g);
+  if (int rc = ensure_device(g)) return rc;
+  const Space &s = g->s;
+  const std::vector<NbrPlan> plans = neighbour_plans(s, pack);
+  if (k < 0 || k >= (int)plans.size()) return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour");
+  if (!devbuf) return fail(IGX_ERR_ARG_WRONG, "null buffer");
+  if (A && A->iga != g) return fail(IGX_ERR_ARG_WRONG, "matrix created by another IGX");
+  if (b && b->iga != g) return fail(IGX_ERR_ARG_WRONG, "vector created by another IGX");
+  const NbrPlan &pl = plans[k];
+  PackDev P;
+  for (int d = 0; d < 3; ++d) {
+    P.start[d] = pl.start[d]; P.count[d] = pl.count[d]; P.nrow[d] = s.lay[d].nrow;
+    P.rcnt[d] = g->ab[d].rcnt.as<int>(); P.prefix[d] = g->ab[d].prefix.as<int64_t>();
+    P.tot[d] = 0; P.sub0[d] = 0;
+    for (int r = 0; r < pl.start[d]; ++r) P.sub0[d] += s.lay[d].rcnt[r];
+    for (int r = 0; r < pl.count[d]; ++r) P.tot[d] += s.lay[d].rcnt[pl.start[d] + r];
+  }
+  P.bs2 = s.dof * s.dof; P.dof = s.dof;
+  const int64_t nrows = (int64_t)pl.count[0] * pl.count[1] * pl.count[2];
+  if (nrows == 0) return 0;
+  const int64_t matd = A ? pl.mat_doubles : 0;
+  if (pack) hipLaunchKernelGGL(k_ghost_rows<true>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, A ? A->browptr.as<int64_t>() : nullptr, A ? A->val.as<double>() : nullptr, b ? b->a.as<double>() : nullptr, devbuf, matd);
+  else hipLaunchKernelGGL(k_ghost_rows<false>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, A ? A->browptr.as<int64_t>() : nullptr, A ? A->val.as<double>() : nullptr, b ? b->a.as<double>() : nullptr, devbuf, matd);
+  HIPCK(hipGetLastError());
+  return 0;
+}
+
+extern "C" int IGXGetNeighborCount(IGX g, int *nsend, int *nrecv) {
+  NEEDIGA(g);
+  if (!g->s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  if (nsend) *nsend = (int)neighbour_plans(g->s, true).size();
+  if (nrecv) *nrecv = (int)neighbour_plans(g->s, false).size();
+  return 0;
+}
+extern "C" int IGXGetNeighborInfo(IGX g, int send, int k, int *rank, int64_t *mat_doubles, int64_t *vec_doubles) {
+  NEEDIGA(g);
+  const std::vector<NbrPlan> plans = neighbour_plans(g->s, send != 0);
+  if (k < 0 || k >= (int)plans.size()) return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour");
+  if (rank) *rank = plans[k].rank; if (mat_doubles) *mat_doubles = plans[k].mat_doubles; if (vec_doubles) *vec_doubles = plans[k].vec_doubles;
+  return 0;
+}
+extern "C" int IGXPackGhostRows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf) { return ghost_rows(g, A, b, k, devbuf, true); }
+extern "C" int IGXUnpackGhostRows(IGX g, IGXMat A, IGXVec b, int k, const double *devbuf) { return ghost_rows(g, A, b, k, const_cast<double *>(devbuf), false); }
+// 1 if this rank owns the row node with local row indices (r0,r1,r2) -- after the exchange only owned rows are final
+extern "C" int IGXRowOwned(IGX g, int r0, int r1, int r2) {
+  if (!g || !g->s.setup) return 0;
+  const int r[3] = {r0, r1, r2};
+  for (int d = 0; d < 3; ++d) { if (r[d] < 0 || r[d] >= g->s.lay[d].nrow) return 0; if (!g->s.lay[d].owned[r[d]]) return 0; }
+  return 1;
+}

@@ -1,6 +1,48 @@
-"""Ghost-row reduction between ranks (one process per GPU): transport over torch.distributed (RCCL)."""
+"""Ghost-row reduction between ranks (one process per GPU).
+
+Each rank packs the rows of nodes it holds but does not own, one message per upper neighbour
+(IGXPackGhostRows), the messages travel point-to-point (RCCL over xGMI: every neighbour pair of a
+2x2x2 grid has its own link, so the <=7 messages of a rank move concurrently), and the owner adds them to
+its rows (IGXUnpackGhostRows).  This is the only collective step of the assembly path; it replaces the
+PETSc stash traffic of MatAssemblyBegin/End + VecAssemblyBegin/End (src/petigaksp.c:197-200).
+"""
+import torch
+import torch.distributed as dist
+
+
+def plan(iga, with_mat=True, with_vec=True):
+    """[(peer, doubles)] for the send list and for the receive list."""
+    size = lambda m, v: (m if with_mat else 0) + (v if with_vec else 0)
+    return ([(r, size(m, v)) for r, m, v in iga.neighbors(True)], [(r, size(m, v)) for r, m, v in iga.neighbors(False)])
+
+
+def p2p_exchange(send_bufs, send_peers, recv_bufs, recv_peers):
+    """One grouped batch of isend/irecv (ncclGroupStart/End under RCCL); a peer gets at most one message."""
+    ops = [dist.P2POp(dist.irecv, b, p) for b, p in zip(recv_bufs, recv_peers)]
+    ops += [dist.P2POp(dist.isend, b, p) for b, p in zip(send_bufs, send_peers)]
+    if not ops:
+        return
+    for w in dist.batch_isend_irecv(ops):
+        w.wait()
 
 
 class GhostExchange:
-    def __init__(self, iga, A, b):
-        raise NotImplementedError("multi-GPU ghost-row exchange is not wired yet")
+    """Pre-allocated device buffers + the reduce step for one (matrix, vector) pair."""
+
+    def __init__(self, iga, A, b, device="cuda"):
+        self.iga, self.A, self.b = iga, A, b
+        s, r = plan(iga, A is not None, b is not None)
+        self.send_peers = [p for p, _ in s]
+        self.recv_peers = [p for p, _ in r]
+        self.send_bufs = [torch.empty(max(n, 1), dtype=torch.float64, device=device) for _, n in s]
+        self.recv_bufs = [torch.empty(max(n, 1), dtype=torch.float64, device=device) for _, n in r]
+        self.bytes_sent = 8 * sum(n for _, n in s)
+
+    def reduce(self):
+        for k, buf in enumerate(self.send_bufs):
+            self.iga.pack_ghost_rows(self.A, self.b, k, buf.data_ptr())
+        self.iga.synchronize()          # packs ran on the engine's stream; the transport uses torch's
+        p2p_exchange(self.send_bufs, self.send_peers, self.recv_bufs, self.recv_peers)
+        torch.cuda.synchronize()
+        for k, buf in enumerate(self.recv_bufs):
+            self.iga.unpack_ghost_rows(self.A, self.b, k, buf.data_ptr())

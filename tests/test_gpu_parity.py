@@ -368,3 +368,76 @@ def test_mfma_repeatable_bitwise():
         eng.synchronize()
         out.append((A.host(True), b.get()))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
+# ---------------------------------------------------------------- multi-rank assembly (all ranks emulated on one GPU)
+def _rank_matrix_rows(eng, A, b):
+    """(global rows, global cols, values, owned mask per entry), vector entries of owned rows."""
+    rows, cols, vals = A.to_coo_global()
+    rp, _, _ = A.host()
+    nrow, _, _ = A.layout()
+    r = np.arange(A.nbrows)
+    own = np.array([eng.row_owned(int(a), int(b_), int(c)) for a, b_, c in zip(r % nrow[0], (r // nrow[0]) % nrow[1], r // (nrow[0] * nrow[1]))])
+    own_entries = np.repeat(np.repeat(own, np.diff(rp)), A.bs * A.bs)
+    return rows, cols, vals, own_entries, own
+
+
+@pytest.mark.parametrize("size,dim,dof,p,N,periodic,form", [(2, 3, 1, 3, (9, 8, 10), (0, 0, 0), "poisson"), (8, 3, 1, 3, (10, 9, 8), (0, 0, 0), "poisson"),
+                                                             (4, 2, 2, 2, (9, 10), (0, 0), "mass"), (4, 3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson"),
+                                                             (8, 3, 1, 3, (20, 18, 16), (0, 0, 0), "poisson")])
+def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
+    """Every rank assembles its own element box, ghost rows are packed / added through the C ABI exactly as
+    petiga_amd/exchange.py does between processes; the owned rows of all ranks together must be the
+    single-rank matrix of the oracle."""
+    import torch
+    import petiga_amd as P
+    periodic = [bool(x) for x in periodic]
+    orc, _ = make_pair(dim, dof, p, list(N), periodic=periodic, engine=False)
+    if form == "poisson":
+        dirichlet_all((orc,), dim, 1.0)
+    A_o, b_o = orc.compute_system("orc_form_" + form)
+    engs, mats, vecs, sendbufs = [], [], [], {}
+    for r in range(size):
+        g = P.IGX(dim, dof)
+        for i in range(dim):
+            g.axis_uniform(i, p, N[i], periodic=periodic[i])
+        g.set_comm(size, r)
+        g.setup()
+        if form == "poisson":
+            dirichlet_all((g,), dim, 1.0)
+        g.set_form(form)
+        A, b = g.create_mat(), g.create_vec()
+        g.compute_system(A, b)
+        for k, (peer, m, v) in enumerate(g.neighbors(True)):
+            buf = torch.empty(m + v, dtype=torch.float64, device="cuda")
+            g.pack_ghost_rows(A, b, k, buf.data_ptr())
+            sendbufs[(r, peer)] = buf
+        g.synchronize()
+        engs.append(g); mats.append(A); vecs.append(b)
+    for r, g in enumerate(engs):
+        for k, (peer, m, v) in enumerate(g.neighbors(False)):
+            buf = sendbufs[(peer, r)]
+            assert buf.numel() == m + v
+            g.unpack_ghost_rows(mats[r], vecs[r], k, buf.data_ptr())
+        g.synchronize()
+    n = orc.global_size()
+    import scipy.sparse as sp
+    M = sp.csr_matrix((n, n))
+    F = np.zeros(n)
+    seen = np.zeros(n, dtype=int)
+    for r, g in enumerate(engs):
+        rows, cols, vals, own_e, own = _rank_matrix_rows(g, mats[r], vecs[r])
+        M = M + sp.coo_matrix((vals[own_e], (rows[own_e], cols[own_e])), shape=(n, n)).tocsr()
+        nrow, _, maps = mats[r].layout()
+        ns = g.sizes()["node_sizes"]
+        rr = np.arange(mats[r].nbrows)
+        grow = maps[0][0][rr % nrow[0]].astype(np.int64) + ns[0] * (maps[1][0][(rr // nrow[0]) % nrow[1]].astype(np.int64) + ns[1] * maps[2][0][rr // (nrow[0] * nrow[1])].astype(np.int64))
+        bv = vecs[r].get().reshape(-1, dof)
+        for c in range(dof):
+            F[grow[own] * dof + c] = bv[own, c]
+            seen[grow[own] * dof + c] += 1
+    assert np.all(seen == 1)
+    Mo = A_o.scipy()
+    D = abs(M - Mo)
+    assert D.max() <= TOL * abs(Mo).max()
+    assert np.abs(F - b_o).max() <= TOL * max(np.abs(b_o).max(), 1e-300)

@@ -1,0 +1,105 @@
+"""CPU tests of the multi-GPU path: (a) the ghost-row exchange plan is consistent across ranks (every send has
+exactly one matching receive of the same size), (b) the point-to-point pattern of petiga_amd/exchange.py runs
+deadlock-free on 2 gloo ranks, (c) the oracle's rank-local assemblies add up to the single-rank matrix."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+import petiga_amd as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_rank(dim, dof, p, N, periodic, size, rank):
+    g = P.IGX(dim, dof)
+    for i in range(dim):
+        g.axis_uniform(i, p, N[i], periodic=periodic[i])
+    g.set_comm(size, rank)
+    g.setup()
+    return g
+
+
+@pytest.mark.parametrize("dim,dof,p,N,periodic", [(3, 1, 3, (8, 8, 8), (0, 0, 0)), (3, 2, 2, (9, 7, 8), (0, 0, 0)), (2, 1, 2, (8, 12), (0, 0)),
+                                                   (3, 1, 2, (8, 8, 8), (1, 0, 1)), (1, 3, 3, (16,), (0,))])
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_exchange_plan_is_consistent(dim, dof, p, N, periodic, size):
+    ranks = [make_rank(dim, dof, p, N, [bool(x) for x in periodic], size, r) for r in range(size)]
+    sends = {(r, peer): (m, v) for r, g in enumerate(ranks) for peer, m, v in g.neighbors(True)}
+    recvs = {(peer, r): (m, v) for r, g in enumerate(ranks) for peer, m, v in g.neighbors(False)}
+    assert sends == recvs
+    for r, g in enumerate(ranks):
+        peers = [peer for peer, _, _ in g.neighbors(True)]
+        assert len(peers) == len(set(peers)) and r not in peers        # one message per peer, never to itself
+        assert len(peers) <= 7
+    # every node is owned by exactly one rank, ghost rows are exactly the not-owned ones
+    sz = ranks[0].sizes()
+    owners = np.zeros(sz["node_sizes"][:dim], dtype=int)
+    for g in ranks:
+        s = g.sizes()
+        sl = tuple(slice(s["node_lstart"][d], s["node_lstart"][d] + s["node_lwidth"][d]) for d in range(dim))
+        owners[sl] += 1
+    assert np.all(owners == 1)
+
+
+def test_oracle_rank_local_assemblies_add_up():
+    def build(size, rank):
+        g = O.OracleIGA(3, 1)
+        for i in range(3):
+            g.axis_uniform(i, 2, 6)
+        if size > 1:
+            g.set_partition(size, rank)
+        g.setup()
+        for d in range(3):
+            for s in range(2):
+                g.set_boundary_value(d, s, 0, 1.0)
+        return g.compute_system("orc_form_poisson")
+    A1, b1 = build(1, 0)
+    acc, accb = np.zeros_like(A1.val), np.zeros_like(b1)
+    for r in range(8):
+        A, b = build(8, r)
+        acc += A.val
+        accb += b
+    assert np.abs(acc - A1.val).max() < 1e-13 * np.abs(A1.val).max()
+    assert np.abs(accb - b1).max() < 1e-13 * np.abs(b1).max()
+
+
+WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+import petiga_amd as P
+from petiga_amd import exchange
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+g = P.IGX(3, 1)
+for i in range(3):
+    g.axis_uniform(i, 3, 8)
+g.set_comm(world, rank)
+g.setup()
+s, r = exchange.plan(g)
+sb = [torch.full((n,), float(rank * 100 + p), dtype=torch.float64) for p, n in s]
+rb = [torch.empty(n, dtype=torch.float64) for p, n in r]
+exchange.p2p_exchange(sb, [p for p, _ in s], rb, [p for p, _ in r])
+for (p, n), b in zip(r, rb):
+    assert b.numel() == n and torch.all(b == float(p * 100 + rank)), (rank, p)
+tot = torch.tensor([float(sum(n for _, n in s)), float(sum(n for _, n in r))])
+dist.all_reduce(tot)
+assert tot[0] == tot[1] and tot[0] > 0
+dist.destroy_process_group()
+print("rank", rank, "ok", len(s), len(r))
+'''
+
+
+@pytest.mark.parametrize("world", [2])
+def test_p2p_pattern_on_gloo(world, tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
