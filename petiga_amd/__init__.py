@@ -20,6 +20,21 @@ _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 
 
+class IGXAxisTables(C.Structure):
+    _fields_ = [("p", C.c_int), ("m", C.c_int), ("periodic", C.c_int), ("nel", C.c_int), ("nnp", C.c_int),
+                ("U", _dp), ("span", _ip), ("nqp", C.c_int), ("nen", C.c_int), ("offset", _ip),
+                ("detJac", _dp), ("weight", _dp), ("point", _dp), ("value", _dp)]
+
+
+class IGXTables(C.Structure):
+    _fields_ = [("dim", C.c_int), ("dof", C.c_int), ("order", C.c_int), ("axis", IGXAxisTables * 3),
+                ("proc_sizes", C.c_int * 3), ("proc_ranks", C.c_int * 3),
+                ("elem_sizes", C.c_int * 3), ("elem_start", C.c_int * 3), ("elem_width", C.c_int * 3),
+                ("node_sizes", C.c_int * 3), ("node_lstart", C.c_int * 3), ("node_lwidth", C.c_int * 3),
+                ("node_gstart", C.c_int * 3), ("node_gwidth", C.c_int * 3),
+                ("nsd", C.c_int), ("rational", C.c_int), ("geometryX", _dp), ("rationalW", _dp)]
+
+
 class IGXError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("IGX error %d: %s" % (code, msg))
@@ -186,8 +201,11 @@ class Mat:
 class IGX:
     """Mirror of the PetIGA calls a driver program makes around IGAComputeSystem & friends."""
 
-    def __init__(self, dim=None, dof=None):
+    def __init__(self, dim=None, dof=None, _handle=None):
         self.h = C.c_void_p()
+        if _handle is not None:
+            self.h = _handle
+            return
         _ck(lib().IGXCreate(C.byref(self.h)))
         if dim is not None:
             self.set_dim(dim)
@@ -199,6 +217,15 @@ class IGX:
             lib().IGXDestroy(C.byref(self.h))
         except Exception:
             pass
+
+    @classmethod
+    def from_tables(cls, tables):
+        """IGXCreateFromTables: the route a set-up PetIGA `IGA` takes."""
+        h = C.c_void_p()
+        _ck(lib().IGXCreateFromTables(C.byref(tables), C.byref(h)))
+        g = cls(_handle=h)
+        g.dim, g.dof = tables.dim, tables.dof
+        return g
 
     def set_dim(self, dim): _ck(lib().IGXSetDim(self.h, dim)); self.dim = dim
     def set_dof(self, dof): _ck(lib().IGXSetDof(self.h, dof)); self.dof = dof

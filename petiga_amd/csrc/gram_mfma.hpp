@@ -22,6 +22,7 @@
 namespace igx {
 
 typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int HOLD_LD = 66;   // padded row stride (doubles) of the pencil kernel's per-wavefront hold area [6 slots][4 r][HOLD_LD]
 
 // the launches of the dominant kernel of one assembly, for the roofline line of bench.py
 struct DomInfo {
@@ -285,7 +286,7 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
   return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
 }
 // walk along axis 0 only: per-wavefront hold area for the lower-band entries [6 slots][4 r][64 lanes]
-__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 6 * 4 * 64 * 8; }
+__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 6 * 4 * 66 * 8; }
 
 // 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4).  K_e = sum_q (sqrt(JW) grad N_a).(sqrt(JW) grad N_b):
 // the quadrature weight is split as sqrt(JW_q) on both sides, and sqrt(JW_q) itself factorises over the axes, so the
@@ -417,8 +418,9 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   // lower half: parked by layers lay-1 (slot 0), lay-2 (slots 1,2), lay-3 (slots 3..5); read before this step re-uses the slots
   const int s2 = 1 + ((lay - 2) & 1), s3 = 3 + ((lay - 3) % 3 + 3) % 3;
   double lo1[4], lo2[4], lo3[4];
+  const int ls = lane ^ (lane >> 4);   // swizzled lane slot: keeps the transposed writes below off a single bank
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { lo1[r] = hold[r * 64 + lane]; lo2[r] = hold[(s2 * 4 + r) * 64 + lane]; lo3[r] = hold[(s3 * 4 + r) * 64 + lane]; }
+  for (int r = 0; r < 4; ++r) { lo1[r] = hold[r * HOLD_LD + ls]; lo2[r] = hold[(s2 * 4 + r) * HOLD_LD + ls]; lo3[r] = hold[(s3 * 4 + r) * HOLD_LD + ls]; }
   if (owned) {
     double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0;
     if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
@@ -457,10 +459,10 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
     const int w2 = 1 + (lay & 1), w3 = 3 + (lay % 3 + 3) % 3;
 #pragma unroll
     for (int rp = 0; rp < 4; ++rp) {
-      const int lc = B1 * 16 + rp * 4 + A;
-      hold[(0 * 4 + B2) * 64 + lc] = acc[0][1][rp];
-      hold[(w2 * 4 + B2) * 64 + lc] = acc[0][2][rp];
-      hold[(w3 * 4 + B2) * 64 + lc] = acc[0][3][rp];
+      const int lc = (B1 * 16 + rp * 4 + A) ^ B1;     // consumer lane, swizzled like its read (lc>>4 == B1)
+      hold[(0 * 4 + B2) * HOLD_LD + lc] = acc[0][1][rp];
+      hold[(w2 * 4 + B2) * HOLD_LD + lc] = acc[0][2][rp];
+      hold[(w3 * 4 + B2) * HOLD_LD + lc] = acc[0][3][rp];
     }
   }
   pencil_shift<true>(acc, Facc, L.fslot);
@@ -574,8 +576,8 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   double Facc = 0;
   double *hold = nullptr;
   if (W == 0) {
-    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (6 * 4 * 64);
-    for (int i = lane; i < 6 * 4 * 64; i += 64) hold[i] = 0.0;
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (6 * 4 * HOLD_LD);
+    for (int i = lane; i < 6 * 4 * HOLD_LD; i += 64) hold[i] = 0.0;
   }
 
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)

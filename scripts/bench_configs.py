@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Times the secondary BASELINE configs (one assembly each) on the current kernels; not the headline bench."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import petiga_amd as P
+
+
+def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=None, C=-1, steps=2):
+    g = P.IGX(dim, dof)
+    for i in range(dim):
+        g.axis_uniform(i, p, N[i], C, periodic=bool(periodic[i]) if periodic else False)
+    g.setup()
+    if bc:
+        bc(g)
+    g.set_form(form, params)
+    A = g.create_mat() if op in ("system", "ijacobian") else None
+    b = g.create_vec()
+    U = V = None
+    if op in ("ifunction", "ijacobian"):
+        rng = np.random.default_rng(0)
+        U = g.create_vec().set(0.63 + 0.05 * (2 * rng.random(b.n) - 1))
+        V = g.create_vec().set(np.zeros(b.n))
+    times = []
+    for _ in range(steps):
+        g.synchronize()
+        t = time.perf_counter()
+        if op == "system":
+            g.compute_system(A, b)
+        elif op == "ijacobian":
+            g.compute_ijacobian(1e3, V, 0.0, U, A)
+        else:
+            g.compute_ifunction(1e3, V, 0.0, U, b)
+        g.synchronize()
+        times.append(time.perf_counter() - t)
+    nel = int(np.prod(N))
+    print(json.dumps(dict(config=name, kernel=g.kernel_name(), elements=nel, ms=min(times) * 1e3, elements_per_s=nel / min(times))))
+
+
+def dirichlet_all(g, dim, v=1.0):
+    for d in range(dim):
+        for s in range(2):
+            g.set_boundary_value(d, s, 0, v)
+
+
+which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c4r"]
+if "c1" in which:
+    run("Poisson2D p=2 64^2", 2, 1, 2, (64, 64), "poisson", bc=lambda g: dirichlet_all(g, 2))
+if "c2" in which:
+    run("Poisson3D p=2 128^3", 3, 1, 2, (128,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3))
+if "c3" in which:
+    def bc3(g):
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(0, 1, 0, 1.0)
+    run("Elasticity3D p=3 64^3 (config 3 is 128^3)", 3, 3, 3, (64,) * 3, "elasticity", (1.0, 1.0), bc=bc3)
+if "c4" in which:
+    h2 = 1.0 / (3 * 128 * 128)
+    run("CahnHilliard3D p=2 128^3 tangent (config 4 is 256^3)", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian")
+if "c4r" in which:
+    h2 = 1.0 / (3 * 128 * 128)
+    run("CahnHilliard3D p=2 128^3 residual", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ifunction")
+if "c5" in which:
+    def bc5(g):
+        for s in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s, f, 0.0)
+    run("NavierStokesVMS p=3 32^3 tangent (config 5 is 192^3 on 8 GPUs)", 3, 4, 3, (32,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian", bc=bc5)

@@ -441,3 +441,49 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     D = abs(M - Mo)
     assert D.max() <= TOL * abs(Mo).max()
     assert np.abs(F - b_o).max() <= TOL * max(np.abs(b_o).max(), 1e-300)
+
+
+# ---------------------------------------------------------------- the PetIGA-binding route: IGXCreateFromTables
+def _tables_from_oracle(orc, dim, dof, keep):
+    """Fill IGXTables from the oracle's IGA struct, field for field what a set-up PetIGA `IGA` holds
+    (struct _p_IGA / _n_IGAAxis / _n_IGABasis, include/petiga.h:80-141,327-391)."""
+    import petiga_amd as P
+    t = P.IGXTables()
+    s = orc.s
+    t.dim, t.dof, t.order = dim, dof, s.order
+    for i in range(dim):
+        ax, bd, a = s.axis[i], s.basis[i], t.axis[i]
+        a.p, a.m, a.periodic, a.nel, a.nnp = ax.p, ax.m, ax.periodic, ax.nel, ax.nnp
+        a.U, a.span = ax.U, ax.span
+        a.nqp, a.nen, a.offset, a.detJac, a.weight, a.point, a.value = bd.nqp, bd.nen, bd.offset, bd.detJac, bd.weight, bd.point, bd.value
+    for name in ("proc_sizes", "proc_ranks", "elem_sizes", "elem_start", "elem_width", "node_sizes", "node_lstart", "node_lwidth", "node_gstart", "node_gwidth"):
+        for i in range(3):
+            getattr(t, name)[i] = getattr(s, name)[i]
+    t.nsd, t.rational = s.nsd, s.rational
+    t.geometryX, t.rationalW = s.geometryX, s.rationalW
+    keep.append(t)
+    return t
+
+
+@pytest.mark.parametrize("dim,dof,p,N,geo,form", [(3, 1, 3, (9, 6, 7), None, "poisson"), (3, 1, 2, (5, 6, 4), "nurbs", "poisson"),
+                                                   (2, 2, 3, (7, 6), None, "mass"), (3, 3, 2, (4, 4, 3), None, "elasticity")])
+def test_create_from_tables_matches_oracle(dim, dof, p, N, geo, form):
+    import petiga_amd as P
+    orc, _ = make_pair(dim, dof, p, list(N), engine=False)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=3, rational=True)
+        orc.set_geometry(X, W)
+    keep = []
+    eng = P.IGX.from_tables(_tables_from_oracle(orc, dim, dof, keep))
+    ctx, params = None, ()
+    if form == "poisson":
+        dirichlet_all((orc, eng), dim, 1.25)
+    if form == "elasticity":
+        ctx, params = O.ElasticityCtx(1.0, 1.0), (1.0, 1.0)
+        for g in (orc, eng):
+            for f in range(3):
+                g.set_boundary_value(0, 0, f, 0.0)
+            g.set_boundary_value(0, 1, 0, 1.0)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_" + form, form, ctx, params)
+    compare_mats(A, A_o, 1e-11 if geo else TOL)
+    assert np.abs(b.get() - b_o).max() <= (1e-11 if geo else TOL) * max(np.abs(b_o).max(), 1.0)
