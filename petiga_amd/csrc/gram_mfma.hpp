@@ -394,6 +394,26 @@ __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, in
 
 typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 
+// Dirichlet data seen by one pencil of the axis-0 walk (all wave-uniform).  A node is fixed by position only:
+// first / last basis function of the first / last element of a non-periodic axis with boundary values
+// (IGAElementBuildFix, src/petigaelem.c:1214-1283); later faces override earlier ones (axis 0, 1, 2; side 0, 1).
+struct PencilBC {
+  bool any;                 // this pencil / rank touches a face with boundary values
+  bool xlo, xhi, ylo, yhi;  // the pencil's element is the first / last one on axis 1 (X) / axis 2 (Y)
+  int wlo, whi;             // fixed node layers on axis 0 (ghost-local), or -1000
+  double vwlo, vwhi, vxlo, vxhi, vylo, vyhi;
+};
+__device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, int lay, double &val) {
+  bool f = false;
+  if (lay == b.wlo) { f = true; val = b.vwlo; }
+  if (lay == b.whi) { f = true; val = b.vwhi; }
+  if (b.xlo && ix == 0) { f = true; val = b.vxlo; }
+  if (b.xhi && ix == 3) { f = true; val = b.vxhi; }
+  if (b.ylo && iy == 0) { f = true; val = b.vylo; }
+  if (b.yhi && iy == 3) { f = true; val = b.vyhi; }
+  return f;
+}
+
 // Walk along axis 0: leaving layer `lay`, band-row variant.  The CSR keeps the 7 axis-0 neighbours of a row
 // contiguous, so the entries (row lay ; cols lay-3..lay+3) of one (a, r, b1, b2) are 56 contiguous bytes and
 // four lanes (b1 = 0..3) cover 224 contiguous bytes.  The upper half (cols lay..lay+3) is in the accumulator
@@ -403,7 +423,7 @@ typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 template <bool SYSTEM>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
-                                              int lay, int own_lo, int own_hi, long long T0, long long T10) {
+                                              int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem) {
   const int li = lay - T.lay0;
   const bool exists = li >= 0 && li < nl && T.cnt[li] > 0;
   const bool owned = __builtin_amdgcn_readfirstlane((int)(exists && lay >= own_lo && lay < own_hi)) != 0;
@@ -424,6 +444,38 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   if (owned) {
     double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0;
     if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
+    double Fnew = Facc;
+    double v[4][7];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { v[r][0] = lo3[r]; v[r][1] = lo2[r]; v[r][2] = lo1[r]; v[r][3] = acc[0][0][r]; v[r][4] = acc[0][1][r]; v[r][5] = acc[0][2][r]; v[r][6] = acc[0][3][r]; }
+    // IGAElementFixSystem (src/petigaelem.c:1377-1387) on the combined band row: F_i -= sum_k K_ik v_k over fixed
+    // columns (linear, so it commutes with the sum over elements), fixed rows / columns become 0, the diagonal of
+    // a fixed row becomes the number of elements of this pencil that hold the node (each sets K_kk = 1, F_k = v)
+    const bool bcrow = SYSTEM && bc.any && (bc.xlo || bc.xhi || bc.ylo || bc.yhi || (lay >= bc.wlo - 3 && lay <= bc.wlo + 3) || (lay >= bc.whi - 3 && lay <= bc.whi + 3));
+    if (bcrow) {
+      const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+      double corr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double rv = 0; const bool rf = pencil_fixed(bc, a, r, lay, rv);
+        double c = 0;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+          double cv = 0; const bool cf = pencil_fixed(bc, b1, b2, lay + d - 3, cv);
+          if (cf) c += v[r][d] * cv;
+          if (rf || cf) v[r][d] = (d == 3 && b1 == a && b2 == r && rf) ? (double)nelem : 0.0;
+        }
+        c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
+        corr[r] = c;
+      }
+      // F lanes are (fx = lane&3, fy = (lane>>2)&3) of slot 0: the row (a = fx, r = fy) lives in lane group fx
+      const int fx = lane & 3, fy = (lane >> 2) & 3;
+      double t = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const double cr = __shfl(corr[r], fx * 16); if (r == fy) t = cr; }
+      double fv = 0; const bool ff = pencil_fixed(bc, fx, fy, lay, fv);
+      Fnew = ff ? (double)nelem * fv : Facc - t;
+    }
     if (full) {   // interior row: one 7-entry run per (lane, r)
       double o[4][7];
 #pragma unroll
@@ -432,24 +484,22 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
         const d2u_t a = *reinterpret_cast<const d2u_t *>(p), b = *reinterpret_cast<const d2u_t *>(p + 2), c = *reinterpret_cast<const d2u_t *>(p + 4);
         o[r][0] = a[0]; o[r][1] = a[1]; o[r][2] = b[0]; o[r][3] = b[1]; o[r][4] = c[0]; o[r][5] = c[1]; o[r][6] = p[6];
       }
-      if (fdo) out.vec[frow] = Fold + Facc;
+      if (fdo) out.vec[frow] = Fold + Fnew;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
         d2u_t a, b, c;
-        a[0] = o[r][0] + lo3[r]; a[1] = o[r][1] + lo2[r]; b[0] = o[r][2] + lo1[r]; b[1] = o[r][3] + acc[0][0][r];
-        c[0] = o[r][4] + acc[0][1][r]; c[1] = o[r][5] + acc[0][2][r];
+        a[0] = o[r][0] + v[r][0]; a[1] = o[r][1] + v[r][1]; b[0] = o[r][2] + v[r][2]; b[1] = o[r][3] + v[r][3];
+        c[0] = o[r][4] + v[r][4]; c[1] = o[r][5] + v[r][5];
         *reinterpret_cast<d2u_t *>(p) = a; *reinterpret_cast<d2u_t *>(p + 2) = b; *reinterpret_cast<d2u_t *>(p + 4) = c;
-        p[6] = o[r][6] + acc[0][3][r];
+        p[6] = o[r][6] + v[r][6];
       }
     } else {      // rows next to the mesh ends: some columns do not exist
-      if (fdo) out.vec[frow] = Fold + Facc;
+      if (fdo) out.vec[frow] = Fold + Fnew;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double v[7] = {lo3[r], lo2[r], lo1[r], acc[0][0][r], acc[0][1][r], acc[0][2][r], acc[0][3][r]};
+      for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int d = 0; d < 7; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[d];
-      }
+        for (int d = 0; d < 7; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[r][d];
     }
   }
   // park the transposes of tiles (0,1..3): entry (row lay ; a, r') x (col lay+d ; b1, b2) of this lane is entry
@@ -580,6 +630,19 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     for (int i = lane; i < 6 * 4 * HOLD_LD; i += 64) hold[i] = 0.0;
   }
 
+  PencilBC bc; bc.any = false; bc.xlo = bc.xhi = bc.ylo = bc.yhi = false; bc.wlo = bc.whi = -1000;
+  bc.vwlo = bc.vwhi = bc.vxlo = bc.vxhi = bc.vylo = bc.vyhi = 0;
+  if (W == 0 && SYSTEM) {
+    bc.xlo = !AX.periodic && S.bcv[X][0].count > 0 && elx + AX.estart == 0;              bc.vxlo = S.bcv[X][0].value[0];
+    bc.xhi = !AX.periodic && S.bcv[X][1].count > 0 && elx + AX.estart == AX.esizes - 1;  bc.vxhi = S.bcv[X][1].value[0];
+    bc.ylo = !AY.periodic && S.bcv[Y][0].count > 0 && ely + AY.estart == 0;              bc.vylo = S.bcv[Y][0].value[0];
+    bc.yhi = !AY.periodic && S.bcv[Y][1].count > 0 && ely + AY.estart == AY.esizes - 1;  bc.vyhi = S.bcv[Y][1].value[0];
+    if (!AW.periodic && S.bcv[W][0].count > 0 && AW.estart == 0) { bc.wlo = AW.off[0]; bc.vwlo = S.bcv[W][0].value[0]; }
+    if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + 3; bc.vwhi = S.bcv[W][1].value[0]; }
+    bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
+  }
+  int held[4] = {0, 0, 0, 0};   // elements walked so far that hold the layer in window slot t
+
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
   // and group 1 (waves 4-7) run half a period apart, separated by s_barrier, so that on every SIMD one
   // wavefront issues its 768 MFMAs while the other one does its read-modify-write:
@@ -606,8 +669,10 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
-    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10);
+    held[0]++; held[1]++; held[2]++; held[3]++;
+    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0]);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
+    held[0] = held[1]; held[1] = held[2]; held[2] = held[3]; held[3] = 0;
     __builtin_amdgcn_s_setprio(0);
     if (pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
@@ -615,7 +680,7 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
     for (int k = 1; k <= 3; ++k) {
-      if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10);
+      if constexpr (W == 0) { pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0]); held[0] = held[1]; held[1] = held[2]; held[2] = held[3]; held[3] = 0; }
       else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
     }
 }
@@ -733,7 +798,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   } else {
     // P = elements without a Dirichlet face (pencil kernel), E = the rest (element kernel, which owns the BC logic)
     Box P = all;
-    if (sys) for (int d = 0; d < 3; ++d) {
+    // (the axis-0 walk applies the Dirichlet fix-up itself; the other walks leave face elements to gram_p3_element)
+    if (sys && walk_axis != 0) for (int d = 0; d < 3; ++d) {
       if (s.axis[d].periodic) continue;
       if (s.value[d][0].count && s.elem_start[d] == 0) P.lo[d] = 1;
       if (s.value[d][1].count && s.elem_start[d] + s.elem_width[d] == s.elem_sizes[d]) P.hi[d] = s.elem_width[d] - 1;
@@ -761,7 +827,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = std::string("gram_p3_pencil(mfma_f64_16x16x4,walk=") + char('0' + walk_axis) + ")+gram_p3_element(faces)";
+    kname = std::string("gram_p3_pencil(mfma_f64_16x16x4,walk=") + char('0' + walk_axis) + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;
