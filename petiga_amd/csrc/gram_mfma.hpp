@@ -285,33 +285,33 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
   const size_t tables = (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
   return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
 }
-// walk along axis 0 only: per-wavefront hold area for the lower-band entries [6 slots][4 r][64 lanes]
-__host__ __device__ static inline size_t pencil_hold_bytes() { return (size_t)8 * 6 * 4 * 66 * 8; }
+// walk along axis 0 only: per-wavefront hold area for the lower-band entries [P(P+1)/2 slots][4 r][HOLD_LD lanes]
+__host__ __device__ static inline size_t pencil_hold_bytes(int P) { return (size_t)8 * (P * (P + 1) / 2) * 4 * HOLD_LD * 8; }
 
 // 768 MFMAs of one element: k-step (qw, qy, alpha), k slot = qx (lane>>4).  K_e = sum_q (sqrt(JW) grad N_a).(sqrt(JW) grad N_b):
 // the quadrature weight is split as sqrt(JW_q) on both sides, and sqrt(JW_q) itself factorises over the axes, so the
 // three 1-D rows are pre-scaled once (u: per pencil, vy: per pencil in LDS, zt: when the segment is staged) and the
 // A and B operands of a tile pair are the same registers: 5 v_mul_f64 per 16 MFMAs.
-template <int W, bool SYM>
-__device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2], pre-scaled*/) {
+template <int W, bool SYM, int NB>
+__device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane &L, const double *zt /*LDS [4][4][2], pre-scaled, zero padded*/) {
 #pragma unroll
-  for (int qw = 0; qw < 4; ++qw) {
-    double z0[4], z1[4];
+  for (int qw = 0; qw < NB; ++qw) {
+    double z0[NB], z1[NB];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) { z0[t] = zt[(qw * 4 + t) * 2 + 0]; z1[t] = zt[(qw * 4 + t) * 2 + 1]; }
+    for (int t = 0; t < NB; ++t) { z0[t] = zt[(qw * 4 + t) * 2 + 0]; z1[t] = zt[(qw * 4 + t) * 2 + 1]; }
 #pragma unroll
-    for (int qy = 0; qy < 4; ++qy) {
+    for (int qy = 0; qy < NB; ++qy) {
       const double vy0 = L.vy[qy * 2 + 0], vy1 = L.vy[qy * 2 + 1];
 #pragma unroll
       for (int al = 0; al < 3; ++al) {   // al = 0: d/dw, 1: d/dx, 2: d/dy (the Gram sum runs over all three)
         const double uv = (al == 1 ? L.u1 : L.u0) * (al == 2 ? vy1 : vy0);
-        double op[4];
+        double op[NB];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) op[t] = uv * ((al == 0) ? z1[t] : z0[t]);
+        for (int t = 0; t < NB; ++t) op[t] = uv * ((al == 0) ? z1[t] : z0[t]);
 #pragma unroll
-        for (int ta = 0; ta < 4; ++ta)
+        for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
-          for (int tb = SYM ? ta : 0; tb < 4; ++tb)   // SYM: K_e is symmetric, tile (tb,ta) is the transpose of (ta,tb)
+          for (int tb = SYM ? ta : 0; tb < NB; ++tb)   // SYM: K_e is symmetric, tile (tb,ta) is the transpose of (ta,tb)
             acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ta], op[tb], acc[ta][tb], 0, 0, 0);
       }
     }
@@ -379,17 +379,17 @@ __device__ __forceinline__ void pencil_flush(const d4_t (&acc)[4][4], const Penc
 }
 
 // the window slides by one layer: tile (ta,tb) <- tile (ta+1,tb+1); the new last row / column start at zero
-template <bool SYM>
+template <bool SYM, int NB>
 __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, int fslot) {
 #pragma unroll
-  for (int ta = 0; ta < 3; ++ta)
+  for (int ta = 0; ta < NB - 1; ++ta)
 #pragma unroll
-    for (int tb = SYM ? ta : 0; tb < 3; ++tb) acc[ta][tb] = acc[ta + 1][tb + 1];
+    for (int tb = SYM ? ta : 0; tb < NB - 1; ++tb) acc[ta][tb] = acc[ta + 1][tb + 1];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) { acc[t][3] = (d4_t){0, 0, 0, 0}; if (!SYM) acc[3][t] = (d4_t){0, 0, 0, 0}; }
+  for (int t = 0; t < NB; ++t) { acc[t][NB - 1] = (d4_t){0, 0, 0, 0}; if (!SYM) acc[NB - 1][t] = (d4_t){0, 0, 0, 0}; }
   // F lanes hold (fx, fy, slot = lane>>4): slot t takes over slot t+1's partial sum
   const double up = __shfl_down(Facc, 16);
-  Facc = (fslot == 3) ? 0.0 : up;
+  Facc = (fslot >= NB - 1) ? 0.0 : up;
 }
 
 typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
@@ -403,67 +403,76 @@ struct PencilBC {
   int wlo, whi;             // fixed node layers on axis 0 (ghost-local), or -1000
   double vwlo, vwhi, vxlo, vxhi, vylo, vyhi;
 };
+template <int P>
 __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, int lay, double &val) {
   bool f = false;
   if (lay == b.wlo) { f = true; val = b.vwlo; }
   if (lay == b.whi) { f = true; val = b.vwhi; }
   if (b.xlo && ix == 0) { f = true; val = b.vxlo; }
-  if (b.xhi && ix == 3) { f = true; val = b.vxhi; }
+  if (b.xhi && ix == P) { f = true; val = b.vxhi; }
   if (b.ylo && iy == 0) { f = true; val = b.vylo; }
-  if (b.yhi && iy == 3) { f = true; val = b.vyhi; }
+  if (b.yhi && iy == P) { f = true; val = b.vyhi; }
   return f;
 }
 
-// Walk along axis 0: leaving layer `lay`, band-row variant.  The CSR keeps the 7 axis-0 neighbours of a row
-// contiguous, so the entries (row lay ; cols lay-3..lay+3) of one (a, r, b1, b2) are 56 contiguous bytes and
-// four lanes (b1 = 0..3) cover 224 contiguous bytes.  The upper half (cols lay..lay+3) is in the accumulator
-// tiles (0,0..3).  The lower half (cols lay-3..lay-1) is the transpose of the upper halves of the rows that
-// left 1, 2 and 3 steps ago (K_e is symmetric, only tiles ta <= tb are computed): each leaving row parks its
-// tiles (0,1..3) transposed in a per-wavefront LDS area, [6 slots][4 r][64 lanes], until the partner row leaves.
-template <bool SYSTEM>
+// Walk along axis 0: leaving layer `lay`, band-row variant (degree P, NB = P+1 basis functions per axis,
+// band width BW = 2P+1).  The CSR keeps the BW axis-0 neighbours of a row contiguous, so the entries
+// (row lay ; cols lay-P..lay+P) of one (a, r, b1, b2) are 8*BW contiguous bytes and NB neighbouring lanes cover
+// NB of those runs back to back (224 bytes at P=3).  The upper half (cols lay..lay+P) is in the accumulator
+// tiles (0,0..P).  The lower half (cols lay-P..lay-1) is the transpose of the upper halves of the rows that
+// left 1..P steps ago (K_e is symmetric, only tiles ta <= tb are computed): each leaving row parks its tiles
+// (0,1..P) transposed in a per-wavefront LDS area, [P(P+1)/2 slots][4 r][HOLD_LD lanes], until the partner
+// row leaves (distance d uses d slots, keyed by the column layer mod d).
+template <bool SYSTEM, int P>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem) {
+  constexpr int NB = P + 1, BW = 2 * P + 1;
   const int li = lay - T.lay0;
   const bool exists = li >= 0 && li < nl && T.cnt[li] > 0;
   const bool owned = __builtin_amdgcn_readfirstlane((int)(exists && lay >= own_lo && lay < own_hi)) != 0;
-  int p0[7]; bool full = owned; long long ps0 = 0; int c0 = 0;
+  int p0[BW]; bool full = owned; long long ps0 = 0; int c0 = 0;
   if (owned) {
 #pragma unroll
-    for (int d = 0; d < 7; ++d) { p0[d] = __builtin_amdgcn_readfirstlane(T.P[li * 8 + d]); full = full && (p0[d] == d); }
+    for (int d = 0; d < BW; ++d) { p0[d] = __builtin_amdgcn_readfirstlane(T.P[li * 8 + d]); full = full && (p0[d] == d); }
     const long long pv = T.pre[li];
     ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(pv >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(pv & 0xffffffffll));
     c0 = __builtin_amdgcn_readfirstlane(T.cnt[li]);
   }
-  // lower half: parked by layers lay-1 (slot 0), lay-2 (slots 1,2), lay-3 (slots 3..5); read before this step re-uses the slots
-  const int s2 = 1 + ((lay - 2) & 1), s3 = 3 + ((lay - 3) % 3 + 3) % 3;
-  double lo1[4], lo2[4], lo3[4];
+  const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+  const bool lane_ok = a < NB && b1 < NB && b2 < NB;      // lanes of the zero padding (P < 3) hold no entry
+  // lower half: distance dd was parked by layer lay-dd; read before this step re-uses the slots
   const int ls = lane ^ (lane >> 4);   // swizzled lane slot: keeps the transposed writes below off a single bank
+  double v[NB][BW];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) { lo1[r] = hold[r * HOLD_LD + ls]; lo2[r] = hold[(s2 * 4 + r) * HOLD_LD + ls]; lo3[r] = hold[(s3 * 4 + r) * HOLD_LD + ls]; }
+  for (int dd = 1; dd <= P; ++dd) {
+    const int slot = dd * (dd - 1) / 2 + (((lay - dd) % dd) + dd) % dd;
+#pragma unroll
+    for (int r = 0; r < NB; ++r) v[r][P - dd] = hold[(slot * 4 + r) * HOLD_LD + ls];
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+#pragma unroll
+    for (int k = 0; k <= P; ++k) v[r][P + k] = acc[0][k][r];
   if (owned) {
-    double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0;
+    double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0 && (lane & 3) < NB && ((lane >> 2) & 3) < NB;
     if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
     double Fnew = Facc;
-    double v[4][7];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v[r][0] = lo3[r]; v[r][1] = lo2[r]; v[r][2] = lo1[r]; v[r][3] = acc[0][0][r]; v[r][4] = acc[0][1][r]; v[r][5] = acc[0][2][r]; v[r][6] = acc[0][3][r]; }
     // IGAElementFixSystem (src/petigaelem.c:1377-1387) on the combined band row: F_i -= sum_k K_ik v_k over fixed
     // columns (linear, so it commutes with the sum over elements), fixed rows / columns become 0, the diagonal of
     // a fixed row becomes the number of elements of this pencil that hold the node (each sets K_kk = 1, F_k = v)
-    const bool bcrow = SYSTEM && bc.any && (bc.xlo || bc.xhi || bc.ylo || bc.yhi || (lay >= bc.wlo - 3 && lay <= bc.wlo + 3) || (lay >= bc.whi - 3 && lay <= bc.whi + 3));
+    const bool bcrow = SYSTEM && bc.any && (bc.xlo || bc.xhi || bc.ylo || bc.yhi || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
     if (bcrow) {
-      const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
-      double corr[4];
+      double corr[NB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double rv = 0; const bool rf = pencil_fixed(bc, a, r, lay, rv);
+      for (int r = 0; r < NB; ++r) {
+        double rv = 0; const bool rf = pencil_fixed<P>(bc, a, r, lay, rv);
         double c = 0;
 #pragma unroll
-        for (int d = 0; d < 7; ++d) {
-          double cv = 0; const bool cf = pencil_fixed(bc, b1, b2, lay + d - 3, cv);
+        for (int d = 0; d < BW; ++d) {
+          double cv = 0; const bool cf = pencil_fixed<P>(bc, b1, b2, lay + d - P, cv);
           if (cf) c += v[r][d] * cv;
-          if (rf || cf) v[r][d] = (d == 3 && b1 == a && b2 == r && rf) ? (double)nelem : 0.0;
+          if (rf || cf) v[r][d] = (d == P && b1 == a && b2 == r && rf) ? (double)nelem : 0.0;
         }
         c += __shfl_xor(c, 1); c += __shfl_xor(c, 2); c += __shfl_xor(c, 4); c += __shfl_xor(c, 8);
         corr[r] = c;
@@ -472,50 +481,55 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       const int fx = lane & 3, fy = (lane >> 2) & 3;
       double t = 0;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const double cr = __shfl(corr[r], fx * 16); if (r == fy) t = cr; }
-      double fv = 0; const bool ff = pencil_fixed(bc, fx, fy, lay, fv);
+      for (int r = 0; r < NB; ++r) { const double cr = __shfl(corr[r], fx * 16); if (r == fy) t = cr; }
+      double fv = 0; const bool ff = pencil_fixed<P>(bc, fx, fy, lay, fv);
       Fnew = ff ? (double)nelem * fv : Facc - t;
     }
-    if (full) {   // interior row: one 7-entry run per (lane, r)
-      double o[4][7];
+    if (full) {   // interior row: one BW-entry run per (lane, r)
+      double o[NB][BW];
+      if (lane_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
-        const d2u_t a = *reinterpret_cast<const d2u_t *>(p), b = *reinterpret_cast<const d2u_t *>(p + 2), c = *reinterpret_cast<const d2u_t *>(p + 4);
-        o[r][0] = a[0]; o[r][1] = a[1]; o[r][2] = b[0]; o[r][3] = b[1]; o[r][4] = c[0]; o[r][5] = c[1]; o[r][6] = p[6];
+        for (int r = 0; r < NB; ++r) {
+          const double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+#pragma unroll
+          for (int k = 0; k < BW / 2; ++k) { const d2u_t x = *reinterpret_cast<const d2u_t *>(p + 2 * k); o[r][2 * k] = x[0]; o[r][2 * k + 1] = x[1]; }
+          o[r][BW - 1] = p[BW - 1];
+        }
       }
       if (fdo) out.vec[frow] = Fold + Fnew;
+      if (lane_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
-        d2u_t a, b, c;
-        a[0] = o[r][0] + v[r][0]; a[1] = o[r][1] + v[r][1]; b[0] = o[r][2] + v[r][2]; b[1] = o[r][3] + v[r][3];
-        c[0] = o[r][4] + v[r][4]; c[1] = o[r][5] + v[r][5];
-        *reinterpret_cast<d2u_t *>(p) = a; *reinterpret_cast<d2u_t *>(p + 2) = b; *reinterpret_cast<d2u_t *>(p + 4) = c;
-        p[6] = o[r][6] + v[r][6];
+        for (int r = 0; r < NB; ++r) {
+          double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+#pragma unroll
+          for (int k = 0; k < BW / 2; ++k) { d2u_t x; x[0] = o[r][2 * k] + v[r][2 * k]; x[1] = o[r][2 * k + 1] + v[r][2 * k + 1]; *reinterpret_cast<d2u_t *>(p + 2 * k) = x; }
+          p[BW - 1] = o[r][BW - 1] + v[r][BW - 1];
+        }
       }
     } else {      // rows next to the mesh ends: some columns do not exist
       if (fdo) out.vec[frow] = Fold + Fnew;
+      if (lane_ok) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < NB; ++r)
 #pragma unroll
-        for (int d = 0; d < 7; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[r][d];
+          for (int d = 0; d < BW; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[r][d];
+      }
     }
   }
-  // park the transposes of tiles (0,1..3): entry (row lay ; a, r') x (col lay+d ; b1, b2) of this lane is entry
-  // (row lay+d ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
-  {
-    const int A = lane >> 4, B2 = (lane >> 2) & 3, B1 = lane & 3;
-    const int w2 = 1 + (lay & 1), w3 = 3 + (lay % 3 + 3) % 3;
+  // park the transposes of tiles (0,1..P): entry (row lay ; a, r') x (col lay+dd ; b1, b2) of this lane is entry
+  // (row lay+dd ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
+  if (b2 < NB) {
 #pragma unroll
-    for (int rp = 0; rp < 4; ++rp) {
-      const int lc = (B1 * 16 + rp * 4 + A) ^ B1;     // consumer lane, swizzled like its read (lc>>4 == B1)
-      hold[(0 * 4 + B2) * HOLD_LD + lc] = acc[0][1][rp];
-      hold[(w2 * 4 + B2) * HOLD_LD + lc] = acc[0][2][rp];
-      hold[(w3 * 4 + B2) * HOLD_LD + lc] = acc[0][3][rp];
+    for (int dd = 1; dd <= P; ++dd) {
+      const int slot = dd * (dd - 1) / 2 + ((lay % dd) + dd) % dd;
+#pragma unroll
+      for (int rp = 0; rp < NB; ++rp) {
+        const int lc = (b1 * 16 + rp * 4 + a) ^ b1;     // consumer lane, swizzled like its read (lc>>4 == b1)
+        hold[(slot * 4 + b2) * HOLD_LD + lc] = acc[0][dd][rp];
+      }
     }
   }
-  pencil_shift<true>(acc, Facc, L.fslot);
+  pencil_shift<true, NB>(acc, Facc, L.fslot);
 }
 
 // leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays.
@@ -530,13 +544,15 @@ __device__ __forceinline__ void pencil_leave(d4_t (&acc)[4][4], double &Facc, co
     if (fdo) frow = L.frowxy + fstride * T.rho[li];
   }
   pencil_flush<SYSTEM, W>(acc, L, f, out, T0, T10, fdo, frow, Facc);
-  pencil_shift<false>(acc, Facc, L.fslot);
+  pencil_shift<false, 4>(acc, Facc, L.fslot);
 }
 
-template <bool SYSTEM, int W>
+template <bool SYSTEM, int W, int P>
 __global__ void __launch_bounds__(512, 2)
-gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+  constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
+  static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -544,28 +560,28 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 8 + wave;
   const int ws = pa.w_lo + seg * pa.seg_len;
   const int we = min(ws + pa.seg_len, pa.w_hi);
-  const int wh = max(ws - 3, pa.w_lo);
-  const int ne = we - wh, nl = ne + 3;
+  const int wh = max(ws - P, pa.w_lo);
+  const int ne = we - wh, nl = ne + P;
   const AxisDev &AW = S.ax[W], &AX = S.ax[X], &AY = S.ax[Y];
 
-  // ---- stage the segment's walk-axis tables in LDS (all 256 threads)
+  // ---- stage the segment's walk-axis tables in LDS (all 512 threads); tables are zero padded to 4 x 4
   PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max);
   T.lay0 = AW.off[wh];
   {
     const int tid = threadIdx.x;
-    const double *__restrict__ tabw = AW.tab + (size_t)wh * (4 * 4 * NDER);
-    for (int i = tid; i < ne * 32; i += 512) {   // j = (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
-      const int e = i >> 5, j = i & 31, q = j >> 3;
-      T.zt[i] = tabw[(size_t)e * 64 + (j >> 1) * NDER + (j & 1)] * sqrt(AW.w[(wh + e) * 4 + q] * AW.J[wh + e]);
+    const double *__restrict__ tabw = AW.tab + (size_t)wh * (NB * NB * NDER);
+    for (int i = tid; i < ne * 32; i += 512) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
+      const int e = i >> 5, j = i & 31, q = j >> 3, aa = (j >> 1) & 3, k = j & 1;
+      T.zt[i] = (q < NB && aa < NB) ? tabw[((size_t)e * NB * NB + q * NB + aa) * NDER + k] * sqrt(AW.w[(wh + e) * NB + q] * AW.J[wh + e]) : 0.0;
     }
-    for (int i = tid; i < ne * 4; i += 512) T.wq[i] = sqrt(AW.w[wh * 4 + i] * AW.J[wh + (i >> 2)]);
+    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3; T.wq[i] = (q < NB) ? sqrt(AW.w[(wh + e) * NB + q] * AW.J[wh + e]) : 0.0; }
     for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[wh + i];
     for (int i = tid; i < nl; i += 512) {
       const int lay = T.lay0 + i;
       if (lay < AW.gwidth) {
         const int rho = AW.rowmap[lay];
         T.rho[i] = rho; T.cnt[i] = AW.rcnt[rho]; T.pre[i] = AW.prefix[rho];
-        for (int d = 0; d < 7; ++d) T.P[i * 8 + d] = AW.P[lay * 7 + d];
+        for (int d = 0; d < BW; ++d) T.P[i * 8 + d] = AW.P[lay * BW + d];
       } else { T.rho[i] = 0; T.cnt[i] = -1; T.pre[i] = 0; }
     }
   }
@@ -586,35 +602,42 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 
   PencilLane L;
   {
-    const double *__restrict__ TX = AX.tab + (size_t)elx * (4 * 4 * NDER);
-    const double *__restrict__ TY = AY.tab + (size_t)ely * (4 * 4 * NDER);
-    const double *__restrict__ WX = AX.w + elx * 4;
-    const double *__restrict__ WYq = AY.w + ely * 4;
+    const double *__restrict__ TX = AX.tab + (size_t)elx * (NB * NB * NDER);
+    const double *__restrict__ TY = AY.tab + (size_t)ely * (NB * NB * NDER);
+    const double *__restrict__ WX = AX.w + elx * NB;
+    const double *__restrict__ WYq = AY.w + ely * NB;
     const int qx = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
-    { const double sx = sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * 4 + ix) * NDER + 0] * sx; L.u1 = TX[(qx * 4 + ix) * NDER + 1] * sx; }
-    {   // Y-axis rows of this pencil -> LDS [a][q][2]; a lane later reads its own row (a = iy) one q at a time
+    L.u0 = 0; L.u1 = 0;
+    if (qx < NB && ix < NB) { const double sx = sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * NB + ix) * NDER + 0] * sx; L.u1 = TX[(qx * NB + ix) * NDER + 1] * sx; }
+    {   // Y-axis rows of this pencil -> LDS [a][q][2] (zero padded); a lane later reads its own row (a = iy) one q at a time
       double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max) - 8 * 32 * 8))) + wave * 32;
-      if (lane < 32) { const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1; vyw[lane] = TY[(qq * 4 + aa) * NDER + kk] * sqrt(WYq[qq] * AY.J[ely]); }
+      if (lane < 32) {
+        const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1;
+        vyw[lane] = (aa < NB && qq < NB) ? TY[(qq * NB + aa) * NDER + kk] * sqrt(WYq[qq] * AY.J[ely]) : 0.0;
+      }
       L.vy = vyw + iy * 8;
     }
     // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
     const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
-    const int ixg = offx + a, rhox = AX.rowmap[ixg];
-    L.psx = AX.prefix[rhox]; L.cx = AX.rcnt[rhox]; L.px = AX.P[ixg * 7 + (b1 - a + 3)];
+    const bool okx = a < NB && b1 < NB;
+    const int ixg = offx + (a < NB ? a : 0), rhox = AX.rowmap[ixg];
+    L.psx = AX.prefix[rhox]; L.cx = AX.rcnt[rhox]; L.px = okx ? AX.P[ixg * BW + (b1 - a + P)] : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int iyg = offy + r, rhoy = AY.rowmap[iyg];
+      const int iyg = offy + (r < NB ? r : 0), rhoy = AY.rowmap[iyg];
       const long long psv = AY.prefix[rhoy];   // wave-uniform (depends on r only): pin to SGPRs
       L.psy[r] = ((long long)__builtin_amdgcn_readfirstlane((int)(psv >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(psv & 0xffffffffll));
-      L.cy[r] = __builtin_amdgcn_readfirstlane(AY.rcnt[rhoy]); L.py[r] = AY.P[iyg * 7 + (b2 - r + 3)];
+      L.cy[r] = __builtin_amdgcn_readfirstlane(AY.rcnt[rhoy]); L.py[r] = (r < NB && b2 < NB) ? AY.P[iyg * BW + (b2 - r + P)] : 0;
     }
     // F lane: (fx = lane&3, fy = (lane>>2)&3, slot = lane>>4)
     const int fx = lane & 3, fy = (lane >> 2) & 3;
     double sx = 0, sy = 0;
+    if (fx < NB && fy < NB) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sx += WX[q] * TX[(q * 4 + fx) * NDER]; sy += WYq[q] * TY[(q * 4 + fy) * NDER]; }
+      for (int q = 0; q < NB; ++q) { sx += WX[q] * TX[(q * NB + fx) * NDER]; sy += WYq[q] * TY[(q * NB + fy) * NDER]; }
+    }
     L.sxy = pa.forcing * (sx * sy) * (AX.J[elx] * AY.J[ely]);
-    L.frowxy = rs[X] * AX.rowmap[offx + fx] + rs[Y] * AY.rowmap[offy + fy];
+    L.frowxy = rs[X] * AX.rowmap[offx + (fx < NB ? fx : 0)] + rs[Y] * AY.rowmap[offy + (fy < NB ? fy : 0)];
     L.fslot = lane >> 4;
   }
 
@@ -626,8 +649,9 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   double Facc = 0;
   double *hold = nullptr;
   if (W == 0) {
-    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * (6 * 4 * HOLD_LD);
-    for (int i = lane; i < 6 * 4 * HOLD_LD; i += 64) hold[i] = 0.0;
+    constexpr int HS = (P * (P + 1) / 2) * 4 * HOLD_LD;
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * HS;
+    for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
 
   PencilBC bc; bc.any = false; bc.xlo = bc.xhi = bc.ylo = bc.yhi = false; bc.wlo = bc.whi = -1000;
@@ -638,14 +662,14 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     bc.ylo = !AY.periodic && S.bcv[Y][0].count > 0 && ely + AY.estart == 0;              bc.vylo = S.bcv[Y][0].value[0];
     bc.yhi = !AY.periodic && S.bcv[Y][1].count > 0 && ely + AY.estart == AY.esizes - 1;  bc.vyhi = S.bcv[Y][1].value[0];
     if (!AW.periodic && S.bcv[W][0].count > 0 && AW.estart == 0) { bc.wlo = AW.off[0]; bc.vwlo = S.bcv[W][0].value[0]; }
-    if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + 3; bc.vwhi = S.bcv[W][1].value[0]; }
+    if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
     bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
   }
   int held[4] = {0, 0, 0, 0};   // elements walked so far that hold the layer in window slot t
 
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
   // and group 1 (waves 4-7) run half a period apart, separated by s_barrier, so that on every SIMD one
-  // wavefront issues its 768 MFMAs while the other one does its read-modify-write:
+  // wavefront issues its MFMAs while the other one does its read-modify-write:
   //   group 0:  mfma(0) | flush(0) | mfma(1) | flush(1) | ...
   //   group 1:          | mfma(0)  | flush(0)| mfma(1)  | ...
   const int grp = wave >> 2;
@@ -656,32 +680,40 @@ gram_p3_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    pencil_mfma<W, W == 0>(acc, L, zt);
+    pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
+      const int fs = L.fslot < NB ? L.fslot : 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) sw += wqs[q] * zt[(q * 4 + L.fslot) * 2];
-      Facc += L.sxy * sw;
+      for (int q = 0; q < NB; ++q) sw += wqs[q] * zt[(q * 4 + fs) * 2];
+      if (L.fslot < NB) Facc += L.sxy * sw;
     }
     __builtin_amdgcn_s_barrier();
     if (pa.debug_buf) tq2 = __builtin_readcyclecounter();
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
-    held[0]++; held[1]++; held[2]++; held[3]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0]);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) held[t]++;
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0]);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
-    held[0] = held[1]; held[1] = held[2]; held[2] = held[3]; held[3] = 0;
+#pragma unroll
+    for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
+    held[NB - 1] = 0;
     __builtin_amdgcn_s_setprio(0);
     if (pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
-    for (int k = 1; k <= 3; ++k) {
-      if constexpr (W == 0) { pencil0_leave<SYSTEM>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0]); held[0] = held[1]; held[1] = held[2]; held[2] = held[3]; held[3] = 0; }
-      else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
+    for (int k = 1; k <= P; ++k) {
+      if constexpr (W == 0) {
+        pencil0_leave<SYSTEM, P>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0]);
+#pragma unroll
+        for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
+        held[NB - 1] = 0;
+      } else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
     }
 }
 
@@ -709,7 +741,7 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
   }
 }
 
-template <bool SYSTEM, int W>
+template <bool SYSTEM, int W, int P>
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
@@ -719,7 +751,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
-    // Segments: as few as possible (every segment re-computes 3 halo elements).  Bounds: the LDS tables hold
+    // Segments: as few as possible (every segment re-computes P halo elements).  Bounds: the LDS tables hold
     // <= 160 elements, and a launch should fill the 256 CUs (one 8-pencil workgroup each) at least twice.
     const long long bps = (pencils + 7) / 8;
     int nseg = std::max(1, (nw + 159) / 160);
@@ -734,11 +766,11 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool dbg_t = getenv("IGX_DEBUG_TIMING") && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes() : 0);
-    auto kern = gram_p3_pencil<SYSTEM, W>;
+    const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes(P) : 0);
+    auto kern = gram_pencil<SYSTEM, W, P>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
-    if (dbg_t) {
+    if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
       dbg_done = 1;
       (void)hipStreamSynchronize(stream);
       std::vector<long long> h(dbg_n);
@@ -776,8 +808,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
   if (s.nsd) return no("mapped geometry");
   if (S.fixtable) return no("fix table");
+  const int deg = s.axis[0].p;
+  if (deg != 2 && deg != 3) return no("needs p=2 or p=3");
   for (int d = 0; d < 3; ++d) {
-    if (s.axis[d].p != 3 || s.basis[d].nqp != 4) return no("needs p=3 and 4 Gauss points per axis");
+    if (s.axis[d].p != deg || s.basis[d].nqp != deg + 1) return no("needs the same degree p and p+1 Gauss points on every axis");
     for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count) return no("boundary loads");
   }
   GramArgs ga; ga.forcing = (s.form == IGX_FORM_POISSON) ? 1.0 : -6.0; ga.nwaves = 0;
@@ -788,7 +822,9 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   { const char *wa = getenv("IGX_WALK_AXIS"); const int pref[3] = {wa ? atoi(wa) : 0, 2, 1};
     for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
+  if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
+  if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
@@ -806,19 +842,21 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     }
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
-    switch (walk_axis * 2 + (sys ? 1 : 0)) {
-    case 0: launch_pencils<false, 0>(s, S, out, stream, P, ga.forcing, launches); break;
-    case 1: launch_pencils<true, 0>(s, S, out, stream, P, ga.forcing, launches); break;
-    case 2: launch_pencils<false, 1>(s, S, out, stream, P, ga.forcing, launches); break;
-    case 3: launch_pencils<true, 1>(s, S, out, stream, P, ga.forcing, launches); break;
-    case 4: launch_pencils<false, 2>(s, S, out, stream, P, ga.forcing, launches); break;
-    default: launch_pencils<true, 2>(s, S, out, stream, P, ga.forcing, launches); break;
+    if (deg == 2) {
+      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches);
+    } else switch (walk_axis * 2 + (sys ? 1 : 0)) {
+    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 2: launch_pencils<false, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 3: launch_pencils<true, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 4: launch_pencils<false, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    default: launch_pencils<true, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     }
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
-    dom.name = std::string("gram_p3_pencil<walk=") + char('0' + walk_axis) + ">"; dom.launches = launches - l0;
+    dom.name = std::string("gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
-    dom.flop_per_element = 2048.0 * 48 * (walk_axis == 0 ? 10 : 16);
+    dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 27 * 6);
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
       Box b = all;
@@ -827,7 +865,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = std::string("gram_p3_pencil(mfma_f64_16x16x4,walk=") + char('0' + walk_axis) + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = std::string("gram_pencil(mfma_f64_16x16x4,p=") + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;

@@ -487,3 +487,34 @@ def test_create_from_tables_matches_oracle(dim, dof, p, N, geo, form):
     A, b, A_o, b_o = system_pair(orc, eng, "orc_form_" + form, form, ctx, params)
     compare_mats(A, A_o, 1e-11 if geo else TOL)
     assert np.abs(b.get() - b_o).max() <= (1e-11 if geo else TOL) * max(np.abs(b_o).max(), 1.0)
+
+
+@pytest.mark.parametrize("N,bc", [((10, 5, 6), "all1"), ((70, 4, 5), "mixed"), ((9, 9, 9), "none"), ((8, 1, 1), "all1"), ((33, 7, 3), "axis0")])
+def test_mfma_pencil_degree2(N, bc):
+    """BASELINE config 2 family (demo/Poisson3D.c at p=2 C1): the pencil kernel with the 3x3x3 basis zero-padded
+    into the 4x4 tile slots, band width 5."""
+    orc, eng = make_pair(3, 1, 2, list(N))
+    for g in (orc, eng):
+        if bc == "all1":
+            dirichlet_all((g,), 3, 1.0)
+        elif bc == "mixed":
+            k = 0
+            for d in range(3):
+                for s in range(2):
+                    g.set_boundary_value(d, s, 0, 0.5 + 0.25 * k)
+                    k += 1
+        elif bc == "axis0":
+            g.set_boundary_value(0, 0, 0, 2.0)
+            g.set_boundary_value(0, 1, 0, -1.0)
+    eng.set_kernel(2)
+    A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
+    assert "p=2" in eng.kernel_name() and "pencil" in eng.kernel_name()
+    compare_mats(A, A_o, TOL)
+    assert np.abs(b.get() - b_o).max() <= TOL * max(np.abs(b_o).max(), 1e-300)
+    eng.set_form("poisson")
+    A2 = eng.create_mat()
+    eng.compute_matrix(A2)          # IGAComputeMatrix: no BC fix-up
+    eng.synchronize()
+    orc.clear_boundary()
+    A2_o, _ = orc.compute_system("orc_form_poisson")
+    compare_mats(A2, A2_o, TOL)
