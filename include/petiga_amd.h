@@ -102,6 +102,13 @@ int IGXSetFixTable(IGX iga,IGXVec U);                                      /* IG
  * The one kind serves System/Matrix/Vector or Function/Jacobian/IFunction/IJacobian as the reference demo does. */
 int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
 
+/* On-disk formats (PETSc binary, big-endian): the discretisation + NURBS control net written by IGAWrite / igakit,
+ * and a Vec in natural order.  IGXRead replaces dim, axes and geometry of `iga` (dof is kept); call IGXSetUp next. */
+int IGXRead (IGX iga,const char filename[]);              /* IGARead     src/petigaio.c:141 -> IGALoad :11  */
+int IGXWrite(IGX iga,const char filename[]);              /* IGAWrite    src/petigaio.c:171 -> IGASave :75  */
+int IGXWriteVec(IGX iga,IGXVec vec,const char filename[]); /* IGAWriteVec src/petigaio.c:640 */
+int IGXReadVec (IGX iga,IGXVec vec,const char filename[]); /* IGAReadVec  src/petigaio.c:690 */
+
 /* sizes after IGXSetUp */
 int IGXGetSizes(IGX iga,int elem_sizes[3],int elem_start[3],int elem_width[3],
                 int node_sizes[3],int node_lstart[3],int node_lwidth[3],int node_gstart[3],int node_gwidth[3]);
@@ -177,6 +184,18 @@ int IGXComputeFunction (IGX iga,IGXVec U,IGXVec F);                             
 int IGXComputeJacobian (IGX iga,IGXVec U,IGXMat J);                               /* src/petigasnes.c:82 */
 int IGXComputeIFunction(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXVec F);    /* src/petigats.c:23   */
 int IGXComputeIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXMat J);    /* src/petigats.c:92   */
+
+/* Functionals of a discrete field: S[k] = sum over this rank's elements and points of JW * scalar_k(point)
+ * (IGAComputeScalar, src/petigacomp.c:35-98, before its MPI_Allreduce: with several ranks the caller sums S over the
+ * ranks, and U must hold the ghost rows' values).  The point callbacks are the ones the reference's tests use:
+ *   IGX_SCALAR_VOLUME  n=1  test/IGAGeometryMap.c:383 (interior pass): volume of the mapped domain; U may be NULL
+ *   IGX_SCALAR_X2ERR   n=1  src/petigacomp.c:102 (ErrorSqr) with Exact = sum x_i^2 (test/IGAFixTable.c:66), dof 1
+ *   IGX_SCALAR_ERRNORM n=4  ErrorSqr with test/IGAErrNorm.c:26 as Exact, dof 4; params {k}: k=0 values, 1 gradients,
+ *                           2 Hessians; U NULL gives the norms of the exact fields (squared, like IGAComputeErrorNorm
+ *                           before its sqrt, src/petigacomp.c:160).
+ * Sums are formed in a fixed order: bitwise repeatable. */
+typedef enum { IGX_SCALAR_VOLUME = 1, IGX_SCALAR_X2ERR = 2, IGX_SCALAR_ERRNORM = 3 } IGXScalarKind;
+int IGXComputeScalar(IGX iga,IGXVec U,int kind,const double params[],int nparams,int n,double S[]);
 
 /* engine controls */
 int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default stream            */

@@ -14,6 +14,7 @@ from . import build as _build
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+SCALARS = dict(volume=1, x2err=2, errnorm=3)
 FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8)
 
 _dp = C.POINTER(C.c_double)
@@ -66,6 +67,8 @@ def lib(build_if_needed=False):
         "IGXSetComm": [V, C.c_int, C.c_int], "IGXAxisSetDegree": [V, C.c_int, C.c_int], "IGXAxisSetPeriodic": [V, C.c_int, C.c_int],
         "IGXAxisInitUniform": [V, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], "IGXAxisSetKnots": [V, C.c_int, C.c_int, _dp],
         "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp],
+        "IGXComputeScalar": [V, V, C.c_int, _dp, C.c_int, C.c_int, _dp],
+        "IGXRead": [V, C.c_char_p], "IGXWrite": [V, C.c_char_p], "IGXWriteVec": [V, V, C.c_char_p], "IGXReadVec": [V, V, C.c_char_p],
         "IGXSetBoundaryValue": [V, C.c_int, C.c_int, C.c_int, C.c_double], "IGXSetBoundaryLoad": [V, C.c_int, C.c_int, C.c_int, C.c_double],
         "IGXClearBoundary": [V], "IGXSetFixTable": [V, V], "IGXSetForm": [V, C.c_int, _dp, C.c_int],
         "IGXGetSizes": [V] + [_ip] * 8, "IGXGetProcessors": [V, _ip, _ip],
@@ -246,6 +249,10 @@ class IGX:
         _ck(lib().IGXAxisSetKnots(self.h, i, len(U) - 1, U.ctypes.data_as(_dp)))
 
     def setup(self): _ck(lib().IGXSetUp(self.h))
+    def read(self, filename): _ck(lib().IGXRead(self.h, str(filename).encode()))
+    def write(self, filename): _ck(lib().IGXWrite(self.h, str(filename).encode()))
+    def write_vec(self, vec, filename): _ck(lib().IGXWriteVec(self.h, vec.h, str(filename).encode()))
+    def read_vec(self, vec, filename): _ck(lib().IGXReadVec(self.h, vec.h, str(filename).encode()))
 
     def set_geometry(self, X, W=None):
         X = np.ascontiguousarray(X, dtype=np.float64)
@@ -269,6 +276,15 @@ class IGX:
         ps, pr = (C.c_int * 3)(), (C.c_int * 3)()
         _ck(lib().IGXGetProcessors(self.h, ps, pr))
         out["proc_sizes"], out["proc_ranks"] = list(ps), list(pr)
+        return out
+
+    def compute_scalar(self, kind, U=None, params=()):
+        """IGAComputeScalar for one of the built-in functionals; returns the rank-local sums."""
+        k = SCALARS[kind] if isinstance(kind, str) else kind
+        n = 4 if k == SCALARS["errnorm"] else 1
+        out = np.zeros(n)
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _ck(lib().IGXComputeScalar(self.h, U.h if U is not None else None, k, p.ctypes.data_as(_dp) if p.size else None, p.size, n, out.ctypes.data_as(_dp)))
         return out
 
     def element_count(self): return lib().IGXGetElementCount(self.h)

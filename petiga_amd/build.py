@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libpetiga_amd.so")
 SOURCES = ["engine.hip", "host.cpp"]
-HEADERS = ["igx.hpp", "forms.hpp", "generic_kernel.hpp", "gram_mfma.hpp", "exchange.hpp", os.path.join("..", "..", "include", "petiga_amd.h")]
+HEADERS = ["igx.hpp", "forms.hpp", "generic_kernel.hpp", "gram_mfma.hpp", "exchange.hpp", "fileio.hpp", os.path.join("..", "..", "include", "petiga_amd.h")]
 
 
 def stale():

@@ -42,6 +42,7 @@ struct _p_IGX {
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
+  DevBuf partials;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
 };
@@ -64,6 +65,7 @@ extern "C" int IGXDestroy(IGX *iga) {
 #define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
 #define AXISCK(g, i) do { NEEDIGA(g); if ((i) < 0 || (i) >= 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,2]"); } while (0)
 static void touch(IGX g) { g->s.setup = false; g->on_device = false; }
+static void drop_net(IGX g) { g->s.netX.clear(); g->s.netW.clear(); g->s.net_nsd = 0; }
 
 extern "C" int IGXSetDim(IGX g, int dim) { NEEDIGA(g); if (dim < 1 || dim > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of parametric dimensions must be in range [1,3]"); g->s.dim = dim; touch(g); return 0; }
 extern "C" int IGXSetDof(IGX g, int dof) { NEEDIGA(g); if (dof < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of DOFs per node must be greater than one"); if (dof > MAXBC) return fail(IGX_ERR_SUP, "device path supports dof <= 8"); g->s.dof = dof; touch(g); return 0; }
@@ -71,31 +73,53 @@ extern "C" int IGXSetOrder(IGX g, int order) { NEEDIGA(g); if (order < 0) return
 extern "C" int IGXSetQuadrature(IGX g, int i, int q) { AXISCK(g, i); if (q == IGX_DECIDE && g->s.axis[i].p > 0) q = g->s.axis[i].p + 1; if (q <= 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of quadrature points must be positive"); g->s.rule_nqp[i] = q; touch(g); return 0; }
 extern "C" int IGXSetProcessors(IGX g, int i, int n) { AXISCK(g, i); g->s.proc_req[i] = n; touch(g); return 0; }
 extern "C" int IGXSetComm(IGX g, int size, int rank) { NEEDIGA(g); if (size < 1 || rank < 0 || rank >= size) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad communicator size/rank"); g->s.comm_size = size; g->s.comm_rank = rank; touch(g); return 0; }
-extern "C" int IGXAxisSetDegree(IGX g, int i, int p) { AXISCK(g, i); if (p < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Polynomial degree must be greater than zero"); if (p > 7) return fail(IGX_ERR_SUP, "degree > 7 not supported"); g->s.axis[i].p = p; touch(g); return 0; }
+extern "C" int IGXAxisSetDegree(IGX g, int i, int p) { AXISCK(g, i); if (p < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Polynomial degree must be greater than zero"); if (p > 7) return fail(IGX_ERR_SUP, "degree > 7 not supported"); g->s.axis[i].p = p; touch(g); drop_net(g); return 0; }
 extern "C" int IGXAxisSetPeriodic(IGX g, int i, int flag) { AXISCK(g, i); g->s.axis[i].periodic = flag ? 1 : 0; touch(g); return 0; }
-extern "C" int IGXAxisInitUniform(IGX g, int i, int N, double Ui, double Uf, int C) { AXISCK(g, i); std::string e; int rc = axis_init_uniform(g->s.axis[i], N, Ui, Uf, C, e); touch(g); return rc ? fail(rc, e) : 0; }
-extern "C" int IGXAxisSetKnots(IGX g, int i, int m, const double U[]) { AXISCK(g, i); if (!U) return fail(IGX_ERR_ARG_WRONG, "null knots"); std::string e; int rc = axis_set_knots(g->s.axis[i], m, U, e); touch(g); return rc ? fail(rc, e) : 0; }
-extern "C" int IGXSetUp(IGX g) { NEEDIGA(g); std::string e; int rc = space_setup(g->s, e); g->on_device = false; return rc ? fail(rc, e) : 0; }
+extern "C" int IGXAxisInitUniform(IGX g, int i, int N, double Ui, double Uf, int C) { AXISCK(g, i); std::string e; int rc = axis_init_uniform(g->s.axis[i], N, Ui, Uf, C, e); touch(g); drop_net(g); return rc ? fail(rc, e) : 0; }
+extern "C" int IGXAxisSetKnots(IGX g, int i, int m, const double U[]) { AXISCK(g, i); if (!U) return fail(IGX_ERR_ARG_WRONG, "null knots"); std::string e; int rc = axis_set_knots(g->s.axis[i], m, U, e); touch(g); drop_net(g); return rc ? fail(rc, e) : 0; }
+static int apply_geometry(IGX g);
+extern "C" int IGXSetUp(IGX g) {
+  NEEDIGA(g); std::string e; int rc = space_setup(g->s, e); g->on_device = false;
+  if (rc) return fail(rc, e);
+  return apply_geometry(g);   // a control net given by IGXRead / an earlier IGXSetGeometry survives re-partitioning
+}
+
+// copy the ghosted-local box of the global control net (what IGALoadGeometry's scatters produce, src/petigaio.c:240-275)
+static int apply_geometry(IGX g) {
+  Space &s = g->s;
+  const int nsd = s.net_nsd;
+  if (!nsd) return 0;
+  if (nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+  int gs[3] = {1, 1, 1};
+  for (int i = 0; i < s.dim; ++i) gs[i] = s.axis[i].span[s.axis[i].nel - 1] + 1;
+  const size_t nnet = (size_t)gs[0] * gs[1] * gs[2];
+  if (s.netX.size() != nnet * nsd) return fail(IGX_ERR_ARG_WRONG, "control net does not match the knot vectors");
+  const bool hasW = !s.netW.empty();
+  const int *g0 = s.node_gstart, *gw = s.node_gwidth;
+  s.geomX.assign((size_t)gw[0] * gw[1] * gw[2] * nsd, 0.0);
+  s.geomW.clear(); if (hasW) s.geomW.assign((size_t)gw[0] * gw[1] * gw[2], 0.0);
+  size_t pos = 0;
+  for (int k = g0[2]; k < g0[2] + gw[2]; ++k) for (int j = g0[1]; j < g0[1] + gw[1]; ++j) for (int i = g0[0]; i < g0[0] + gw[0]; ++i, ++pos) {
+    const size_t gi = (size_t)i + (size_t)gs[0] * ((size_t)j + (size_t)gs[1] * (size_t)k);
+    for (int c = 0; c < nsd; ++c) s.geomX[pos * nsd + c] = s.netX[gi * nsd + c];
+    if (hasW) s.geomW[pos] = s.netW[gi];
+  }
+  s.nsd = nsd; s.rational = hasW ? 1 : 0;
+  g->on_device = false;
+  return 0;
+}
 
 extern "C" int IGXSetGeometry(IGX g, int nsd, const double X[], const double W[]) {
   NEEDIGA(g); Space &s = g->s;
   if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
   if (nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
   if (!X) return fail(IGX_ERR_ARG_WRONG, "null control points");
-  int gs[3] = {1, 1, 1};
-  for (int i = 0; i < s.dim; ++i) gs[i] = s.axis[i].span[s.axis[i].nel - 1] + 1;
-  const int *g0 = s.node_gstart, *gw = s.node_gwidth;
-  s.geomX.assign((size_t)gw[0] * gw[1] * gw[2] * nsd, 0.0);
-  s.geomW.clear(); if (W) s.geomW.assign((size_t)gw[0] * gw[1] * gw[2], 0.0);
-  size_t pos = 0;
-  for (int k = g0[2]; k < g0[2] + gw[2]; ++k) for (int j = g0[1]; j < g0[1] + gw[1]; ++j) for (int i = g0[0]; i < g0[0] + gw[0]; ++i, ++pos) {
-    const size_t gi = (size_t)i + (size_t)gs[0] * ((size_t)j + (size_t)gs[1] * (size_t)k);
-    for (int c = 0; c < nsd; ++c) s.geomX[pos * nsd + c] = X[gi * nsd + c];
-    if (W) s.geomW[pos] = W[gi];
-  }
-  s.nsd = nsd; s.rational = W ? 1 : 0;
-  g->on_device = false;
-  return 0;
+  size_t nnet = 1;
+  for (int i = 0; i < s.dim; ++i) nnet *= (size_t)(s.axis[i].span[s.axis[i].nel - 1] + 1);
+  s.netX.assign(X, X + nnet * nsd);
+  s.netW.clear(); if (W) s.netW.assign(W, W + nnet);
+  s.net_nsd = nsd;
+  return apply_geometry(g);
 }
 
 static int bc_set(BC &bc, int field, double value) {   // src/petigaform.c:100-110
@@ -388,7 +412,9 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;
   constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
-  if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
+  constexpr int NS = nscalar_of<Form>::v;
+  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   Carve cv; int pos = 0;
@@ -399,10 +425,9 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
   cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
   cv.G = take((Form::NEED & NEED_G) ? NQ * D2 : 0);
-  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((Form::NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? NQ * DOF * D2 : 0);
-  cv.lift = take(out.op == OP_SYSTEM ? NQ * DOF * NF : 0);
+  cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   const size_t lds_limit = 160 * 1024 - 512;
   bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;
@@ -419,7 +444,9 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   size_t max_blocks = phi_in_lds ? ((size_t)1 << 30) : scratch_cap / (phi_doubles * sizeof(double));
   if (max_blocks < 1) max_blocks = 1;
   int launches = 0;
-  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  if (NS > 0) nc[0] = nc[1] = nc[2] = 1;   // nothing is scattered: every element in one sweep
+  int64_t elem_base = 0;
   for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
     const int cc[3] = {c0, c1, c2};
     ColorRange cr; bool empty = false;
@@ -427,8 +454,9 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
       const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
       int first = -1, count = 0;
       for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+      if (NS > 0) { first = 0; count = nel; }
       if (count == 0) { empty = true; break; }
-      cr.start[d] = first; cr.step[d] = stride; cr.count[d] = count;
+      cr.start[d] = first; cr.step[d] = (NS > 0) ? 1 : stride; cr.count[d] = count;
     }
     if (empty) continue;
     // split along axis 2 so that a launch never needs more scratch than the cap
@@ -442,7 +470,8 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
         const size_t need = nblocks * phi_doubles * sizeof(double);
         if (g->scratch.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->scratch.alloc(need)) return fail(IGX_ERR_MEM, "scratch allocation failed"); }
       }
-      hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, out, sub, cv, g->scratch.as<double>(), phi_doubles);
+      OutDev o2 = out; o2.elem_base = elem_base; elem_base += (int64_t)nblocks;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, o2, sub, cv, g->scratch.as<double>(), phi_doubles);
       launches++;
     }
   }
@@ -533,5 +562,57 @@ extern "C" int IGXComputeJacobian(IGX g, IGXVec U, IGXMat J) { if (!U) return fa
 extern "C" int IGXComputeIFunction(IGX g, double a, IGXVec V, double t, IGXVec U, IGXVec F) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IFUNCTION, nullptr, F, U, V, a, t); }
 extern "C" int IGXComputeIJacobian(IGX g, double a, IGXVec V, double t, IGXVec U, IGXMat J) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IJACOBIAN, J, nullptr, U, V, a, t); }
 
+// ------------------------------------------------------------------ IGAComputeScalar (src/petigacomp.c:35-98)
+template <int DIM>
+static int dispatch_scalar(IGX g, int kind, const SpaceDev &S, const OutDev &out, int order) {
+  switch (kind) {
+  case IGX_SCALAR_VOLUME:  return launch_generic<ScalarVolume<DIM>, DIM>(g, S, out);
+  case IGX_SCALAR_X2ERR:   return launch_generic<ScalarX2Err<DIM>, DIM>(g, S, out);
+  case IGX_SCALAR_ERRNORM: return order >= 2 ? launch_generic<ScalarErrNorm<DIM, true>, DIM>(g, S, out) : launch_generic<ScalarErrNorm<DIM, false>, DIM>(g, S, out);
+  default: return fail(IGX_ERR_ARG_OUTOFRANGE, "unknown scalar functional");
+  }
+}
+
+extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[], int nparams, int n, double S[]) {
+  NEEDIGA(g);
+  if (int rc = ensure_device(g)) return rc;
+  Space &s = g->s;
+  if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
+  if (!S || n < 1) return fail(IGX_ERR_ARG_WRONG, "null result array");
+  const int ns = (kind == IGX_SCALAR_ERRNORM) ? 4 : 1;
+  if (n != ns) return fail(IGX_ERR_ARG_WRONG, "this functional returns " + std::to_string(ns) + " scalars");
+  if (nparams < 0 || nparams > MAXPARAM || (nparams && !params)) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad parameter list");
+  const int order = (kind == IGX_SCALAR_ERRNORM && nparams > 0) ? (int)params[0] : 0;
+  if (order < 0 || order > 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "derivative order must be in range [0,2]");
+  const int64_t nel = (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+  const int nblk = (int)std::min<int64_t>(1024, (nel + 255) / 256);
+  const int64_t chunk = (nel + nblk - 1) / nblk;
+  const size_t need = ((size_t)nel + nblk + 1) * ns * sizeof(double);
+  if (g->partials.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->partials.alloc(need)) return fail(IGX_ERR_MEM, "partial-sum buffer allocation failed"); }
+  double *part = g->partials.as<double>(), *stage = part + (size_t)nel * ns, *res = stage + (size_t)nblk * ns;
+  OutDev out; memset(&out, 0, sizeof(out));
+  out.op = OP_SCALAR; out.errflag = g->errflag.as<int>(); out.vec = part; out.U = U ? U->a.as<double>() : nullptr;
+  const SpaceDev Sd = make_spacedev(g);
+  const std::vector<double> keep = s.params;            // the functional's parameters travel like a form's
+  s.params.assign(params, params + nparams);
+  int rc;
+  switch (s.dim) {
+  case 1: rc = dispatch_scalar<1>(g, kind, Sd, out, order); break;
+  case 2: rc = dispatch_scalar<2>(g, kind, Sd, out, order); break;
+  default: rc = dispatch_scalar<3>(g, kind, Sd, out, order); break;
+  }
+  s.params = keep;
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_partials, dim3(nblk), dim3(256), 0, g->stream, part, nel, ns, stage, chunk);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, g->stream, stage, (int64_t)nblk, ns, res, (int64_t)nblk);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(S, res, ns * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  HIPCK(hipStreamSynchronize(g->stream));
+  int flag = 0; HIPCK(hipMemcpy(&flag, g->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) { HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); return fail(flag, "Non-positive det(Jacobian) of the geometry mapping"); }
+  return 0;
+}
+
 // ------------------------------------------------------------------ multi-GPU ghost rows (filled in by exchange.hpp)
 #include "exchange.hpp"
+#include "fileio.hpp"

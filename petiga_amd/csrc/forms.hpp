@@ -226,4 +226,62 @@ struct FormNSVMS {
   }
 };
 
+
+// ---- scalar functionals: the point callbacks handed to IGAComputeScalar (src/petigacomp.c:35-98).  scalar() returns
+// the integrand values S[NSCALAR] at one point; the kernel multiplies by JW and sums (IGAPointAddArray, petigapoint.c:461).
+template <class F, class = void> struct nscalar_of { static constexpr int v = 0; };
+template <class F> struct nscalar_of<F, decltype((void)F::NSCALAR)> { static constexpr int v = F::NSCALAR; };
+
+// src/petigacomp.c:102-120 (ErrorSqr) with test/IGAErrNorm.c:26-52 as Exact: fields 1, sum x, sum x^2, prod x;
+// params {k}: k = 0 values, 1 gradients, 2 Hessians.  A null U gives the norms of the exact fields.
+template <int DIM, bool SECOND_> struct ScalarErrNorm {
+  static constexpr int DOF = 4, ORDER = SECOND_ ? 2 : 1, NSCALAR = 4;
+  static constexpr unsigned NEED = NEED_X | NEED_U | NEED_GU | (SECOND_ ? NEED_HU : 0u);
+  static __device__ __forceinline__ void scalar(const PtView &p, double *S) {
+    const int order = (int)p.prm[0];
+    double s1 = 0, s2 = 0, pr = 1;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { s1 += p.x[i]; s2 += p.x[i] * p.x[i]; pr *= p.x[i]; }
+    S[0] = S[1] = S[2] = S[3] = 0;
+    if (order == 0) {
+      const double ve[4] = {1, s1, s2, pr};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { const double e = fabs(ve[c] - p.u[c]); S[c] += e * e; }
+    } else if (order == 1) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i) {
+        const double ve[4] = {0, 1, 2 * p.x[i], pr / p.x[i]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { const double e = fabs(ve[c] - p.gu[c * DIM + i]); S[c] += e * e; }
+      }
+    } else if (SECOND_) {
+#pragma unroll
+      for (int i = 0; i < DIM; ++i)
+#pragma unroll
+        for (int j = 0; j < DIM; ++j) {
+          const double ve[4] = {0, 0, (i == j) ? 2.0 : 0.0, (i == j) ? 0.0 : pr / (p.x[i] * p.x[j])};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const double e = fabs(ve[c] - p.hu[c * DIM * DIM + i * DIM + j]); S[c] += e * e; }
+        }
+    }
+  }
+};
+
+// test/IGAFixTable.c:66-72 (Exact = sum x_i^2) through ErrorSqr, one field
+template <int DIM> struct ScalarX2Err {
+  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 1; static constexpr unsigned NEED = NEED_X | NEED_U;
+  static __device__ __forceinline__ void scalar(const PtView &p, double *S) {
+    double g = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) g += p.x[i] * p.x[i];
+    const double e = fabs(g - p.u[0]); S[0] = e * e;
+  }
+};
+
+// test/IGAGeometryMap.c:383-389 (Scalar), interior pass: the volume of the mapped domain; any dof
+template <int DIM> struct ScalarVolume {
+  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 1; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void scalar(const PtView &, double *S) { S[0] = 1.0; }
+};
+
 }  // namespace igx

@@ -70,6 +70,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   constexpr bool SECOND = Form::ORDER >= 2;
   constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM;
   constexpr int D2 = DIM * DIM;
+  constexpr int NS = nscalar_of<Form>::v;   // > 0: a scalar functional (OP_SCALAR), no matrix / vector phases
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
 
@@ -130,7 +131,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     // IGAElementBuildFix (src/petigaelem.c:1214-1283): faces in (dir, side) order, later faces override
     const int aa[3] = {a0, a1, a2};
     for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
-    if (op != OP_MATRIX && op != OP_VECTOR) {
+    if (op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) {   // IGAComputeScalar reads U as it is (no FixValues)
       for (int d = 0; d < DIM; ++d) {
         if (S.ax[d].periodic) continue;
         for (int side = 0; side < 2; ++side) {
@@ -303,6 +304,26 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
       if (SECOND && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
     }
   }
+  if constexpr (NS > 0) {
+    // ---- IGAComputeScalar (src/petigacomp.c:35-98): S_e = sum_q JW[q] * scalar(q), one partial row per element
+    __syncthreads();
+    for (int q = tid; q < NQ; q += nthr) {
+      PtView p;
+      p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
+      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+      double Sq[NS];
+      Form::scalar(p, Sq);
+      const double jw = JW[q];
+#pragma unroll
+      for (int i = 0; i < NS; ++i) lift[q * NS + i] = Sq[i] * jw;
+    }
+    __syncthreads();
+    if (tid < NS) {   // fixed summation order: bitwise repeatable
+      double s = 0;
+      for (int q = 0; q < NQ; ++q) s += lift[q * NS + tid];
+      out.vec[(out.elem_base + blockIdx.x) * NS + tid] = s;
+    }
+  } else {
   // ---- phase 4: Dirichlet lifting features: lift[q][j][:] = sum_b fixed(b,j) v_bj Phi[q][b][:]
   const bool dolift = anyfix && op == OP_SYSTEM;
   if (dolift) {
@@ -412,6 +433,21 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         out.vec[row * DOF + i] += v;
       }
     }
+  }
+  }   // NS == 0
+}
+
+// deterministic two-stage sum of the per-element partial rows part[n][NS] -> res[NS]
+__global__ void __launch_bounds__(256) k_sum_partials(const double *part, int64_t n, int ns, double *res, int64_t chunk) {
+  __shared__ double red[256];
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
+  for (int c = 0; c < ns; ++c) {
+    double s = 0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) s += part[i * ns + c];
+    red[threadIdx.x] = s; __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) res[(int64_t)blockIdx.x * ns + c] = red[0];
+    __syncthreads();
   }
 }
 

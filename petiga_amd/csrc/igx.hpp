@@ -67,6 +67,8 @@ struct Space {
   int node_gstart[3] = {0, 0, 0}, node_gwidth[3] = {1, 1, 1};
   int nsd = 0, rational = 0;
   std::vector<double> geomX, geomW;       // ghosted local
+  std::vector<double> netX, netW;         // global control net (geometry grid, natural order) kept for IGXWrite / re-partitioning
+  int net_nsd = 0;
   BC value[3][2], load[3][2];
   IGXFormKind form = IGX_FORM_NONE;
   std::vector<double> params;
@@ -110,7 +112,7 @@ struct SpaceDev {
 
 struct ColorRange { int start[3], step[3], count[3]; };
 
-enum Op { OP_SYSTEM = 0, OP_MATRIX, OP_VECTOR, OP_FUNCTION, OP_JACOBIAN, OP_IFUNCTION, OP_IJACOBIAN };
+enum Op { OP_SYSTEM = 0, OP_MATRIX, OP_VECTOR, OP_FUNCTION, OP_JACOBIAN, OP_IFUNCTION, OP_IJACOBIAN, OP_SCALAR };
 
 struct OutDev {
   const int64_t *browptr;  // null when no matrix output
@@ -120,6 +122,7 @@ struct OutDev {
   double shift, t;
   int op;
   int *errflag;
+  int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
 };
 
 constexpr int MAXPARAM = 8;

@@ -76,3 +76,28 @@ def compare_mats(eng_mat, orc_mat, tol):
     err = np.abs(vals - vo).max()
     assert err <= tol * scale, "matrix values differ: %g (scale %g)" % (err, scale)
     return err / scale
+
+
+# ---- PETSc-binary IGA files, written independently of the library (format of IGASave, src/petigaio.c:75-139) ----
+IGA_FILE_CLASSID, VEC_FILE_CLASSID = 1211299, 1211214
+
+
+def iga_file_bytes(degrees, knots, X=None, W=None):
+    """Big-endian: classid, info, dim, {p, nk, U}, [nsd, Vec(classid, n, (x*w.., w) per control point)]."""
+    out = [np.array([IGA_FILE_CLASSID, 1 if X is not None else 0, len(degrees)], dtype=">i4").tobytes()]
+    for p, U in zip(degrees, knots):
+        out.append(np.array([p, len(U)], dtype=">i4").tobytes())
+        out.append(np.asarray(U, dtype=">f8").tobytes())
+    if X is not None:
+        X = np.asarray(X, dtype=np.float64)
+        nsd = X.shape[-1]
+        w = np.ones(len(X)) if W is None else np.asarray(W, dtype=np.float64)
+        xw = np.concatenate([X * w[:, None], w[:, None]], axis=1)
+        out.append(np.array([nsd, VEC_FILE_CLASSID, xw.size], dtype=">i4").tobytes())
+        out.append(xw.astype(">f8").tobytes())
+    return b"".join(out)
+
+
+def vec_file_bytes(v):
+    v = np.asarray(v, dtype=np.float64)
+    return np.array([VEC_FILE_CLASSID, v.size], dtype=">i4").tobytes() + v.astype(">f8").tobytes()

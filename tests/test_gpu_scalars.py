@@ -1,0 +1,93 @@
+"""Functionals on the device: IGXComputeScalar against the oracle's IGAComputeScalar restatement and
+against the closed-form radicals of test/IGAErrNorm.c."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from common import make_pair, warped_geometry
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def _rel(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dim", [1, 2, 3])
+def test_errnorm_radicals(dim):
+    # test/IGAErrNorm.c:96-132: norms of the exact fields on the unit cube, p=2, 3 points per axis
+    n = 8 if dim < 3 else 4
+    orc, eng = make_pair(dim, 4, 2, n, nqp=3, order=2)
+    s = np.sqrt
+    L2 = {1: [1, 1 / s(3), 1 / s(5), 1 / s(3)], 2: [1, s(7) / s(6), s(28) / s(45), 1 / s(9)], 3: [1, s(5) / s(2), s(19) / s(15), 1 / s(27)]}
+    H1 = {1: [0, 1, 2 / s(3), 1], 2: [0, s(2), s(8) / s(3), s(2) / s(3)], 3: [0, s(3), 2, 1 / s(3)]}
+    H2 = {1: [0, 0, 2, 0], 2: [0, 0, s(8), s(2)], 3: [0, 0, s(12), s(2)]}
+    tol = np.sqrt(np.finfo(float).eps)
+    for order, expect in ((0, L2), (1, H1), (2, H2)):
+        S = np.sqrt(eng.compute_scalar("errnorm", None, (order,)))
+        assert np.allclose(S, expect[dim], atol=tol), (order, S, expect[dim])
+        So = orc.compute_scalar("orc_scalar_errnorm", 4, U=np.zeros(orc.global_size()), ctx=C.c_int(order))
+        assert _rel(S ** 2, So) < TOL
+
+
+@pytest.mark.parametrize("dim,p,N,geo", [(1, 3, 9, None), (2, 2, 7, "nurbs"), (2, 3, 5, "poly"), (3, 2, 4, "nurbs"), (3, 3, 3, None), (3, (3, 2, 2), (3, 4, 5), "poly")])
+def test_errnorm_of_random_field(dim, p, N, geo):
+    orc, eng = make_pair(dim, 4, p, N, order=2)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=11, rational=(geo == "nurbs"))
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    u = np.random.default_rng(dim).standard_normal(orc.global_size())
+    U = eng.create_vec().set(u)
+    for order in (0, 1, 2):
+        So = orc.compute_scalar("orc_scalar_errnorm", 4, U=u, ctx=C.c_int(order))
+        S = eng.compute_scalar("errnorm", U, (order,))
+        assert _rel(S, So) < TOL, (order, S, So)
+    S2 = eng.compute_scalar("errnorm", U, (2,))
+    assert np.array_equal(S, S2)          # fixed summation order: bitwise repeatable
+
+
+@pytest.mark.parametrize("dim,p,N,periodic", [(1, 2, 16, False), (2, 2, 9, True), (3, 2, 5, False), (3, 3, 6, False)])
+def test_x2err(dim, p, N, periodic):
+    orc, eng = make_pair(dim, 1, p, N, periodic=[periodic] + [False] * (dim - 1))
+    for g in (orc, eng):                  # IGAComputeScalar does not apply Dirichlet values (no FixValues)
+        g.set_boundary_value(dim - 1, 0, 0, 5.0)
+    u = np.random.default_rng(3).standard_normal(orc.global_size())
+    So = orc.compute_scalar("orc_scalar_x2err", 1, U=u)
+    S = eng.compute_scalar("x2err", eng.create_vec().set(u))
+    assert _rel(S, So) < TOL
+
+
+@pytest.mark.parametrize("dim,dof", [(2, 1), (3, 3)])
+def test_volume_of_mapped_domain(dim, dof):
+    orc, eng = make_pair(dim, dof, 2, 5)
+    assert abs(eng.compute_scalar("volume")[0] - 1.0) < 1e-14
+    X, W = warped_geometry(orc, dim, seed=5, rational=True)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    So = orc.compute_scalar("orc_scalar_volume", 2)
+    S = eng.compute_scalar("volume")
+    assert _rel(S, So[:1]) < TOL
+
+
+def test_scalar_argument_errors():
+    import petiga_amd as P
+    _, eng = make_pair(2, 1, 2, 4)
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_scalar("errnorm", eng.create_vec(), (0,))      # dof 1 vector, functional needs 4 fields
+    assert e.value.code == 62
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_scalar(9)
+    assert e.value.code == 63
+    out = np.zeros(2)
+    assert P.lib().IGXComputeScalar(eng.h, None, 1, None, 0, 2, out.ctypes.data_as(P._dp)) == 62
+
+
+def test_scalar_full_size():
+    # 128^3 p=2: 2.1M elements through the two-stage reduction; volume is exactly 1, x2err of u=0 is int (sum x^2)^2
+    _, eng = make_pair(3, 1, 2, 128)
+    assert abs(eng.compute_scalar("volume")[0] - 1.0) < 1e-12
+    S = eng.compute_scalar("x2err")[0]
+    # int_[0,1]^3 (x^2+y^2+z^2)^2 = 3/5 + 6/9 (exact for a 3-point rule: degree 4 per axis)
+    assert abs(S - (3 / 5 + 6 / 9)) < 1e-12
