@@ -8,6 +8,7 @@
 #include <vector>
 #include "igx.hpp"
 #include "generic_kernel.hpp"
+#include "feature_mfma.hpp"
 #include "gram_mfma.hpp"
 
 using namespace igx;
@@ -31,13 +32,16 @@ struct DevBuf {
 
 struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix; };
 
+// IGX_KERNEL=0..3 presets IGXSetKernel for every new IGX (test / experiment switch)
+static int default_kernel_choice() { const char *e = getenv("IGX_KERNEL"); const int k = e ? atoi(e) : 0; return (k >= 0 && k <= 3) ? k : 0; }
+
 struct _p_IGX {
   Space s;
   bool on_device = false;
   AxisBufs ab[3];
   DevBuf X, W, fixtable, errflag, scratch;
   hipStream_t stream = nullptr;
-  int kernel_choice = 0;
+  int kernel_choice = default_kernel_choice();
   std::string last_kernel = "none";
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
@@ -367,7 +371,7 @@ extern "C" int IGXSynchronize(IGX g) {
   }
   return 0;
 }
-extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1 or 2"); g->kernel_choice = which; return 0; }
+extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1, 2 or 3"); g->kernel_choice = which; return 0; }
 extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s", g->last_kernel.c_str()); return 0; }
 extern "C" int IGXSetTiming(IGX g, int flag) {
   NEEDIGA(g); g->timing = flag != 0;
@@ -405,6 +409,106 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
   return 0;
 }
 
+// ------------------------------------------------------------------ feature-GEMM kernel dispatch (feature_mfma.hpp)
+template <class Form, int DIM, int TA, int I0, int DOFI>
+static void launch_feature_pass(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first) {
+  auto kern = feature_assemble<Form, DIM, TA, I0, DOFI>;
+  if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, out, cr, cv);
+}
+
+// returns 0 and sets done when the feature kernel ran; done stays false when the case is not covered
+template <class Form, int DIM, int TA>
+static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
+  const Space &s = g->s;
+  constexpr int DOF = Form::DOF;
+  constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
+  constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
+  constexpr int DOFI = (TA == 4 && DOF == 4) ? 2 : DOF;      // 256 accumulator VGPRs per wave at most
+  constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
+  int nq[3], na[3]; int NQ = 1, NE = 1;
+  for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
+  const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
+  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  const size_t lds_limit = 160 * 1024 - 512;
+  // few accumulators: keep the element small enough for two workgroups per CU, so one element's tabulation
+  // overlaps another's MFMA phase; many accumulators: one workgroup per CU anyway, take all of the LDS
+  const size_t lds_target = (DOFI * DOF * (TA == 4 ? 4 : 1) <= 12) ? (size_t)78 * 1024 : lds_limit;
+  FCarve cv; size_t lds_bytes = 0; bool fits = false;
+  for (int pass = 0; pass < 2 && !fits; ++pass) {
+    const size_t cap = pass == 0 ? lds_target : lds_limit;
+    for (int nchunk = 1; nchunk <= NQ4 / 4 && !fits; ++nchunk) {
+      const int QC = (((NQ4 + nchunk - 1) / nchunk) + 3) & ~3, NQP = QC * nchunk;
+      int pos = 0;
+      auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };
+      for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(nq[d]); }
+      cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
+      cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
+      cv.JW = take(NQP); cv.xq = take(NQP * DIM); cv.E1 = take(s.nsd ? NQP * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQP * DIM * D2 : 0);
+      cv.W0 = take(s.rational ? NQP : 0); cv.W1 = take(s.rational ? NQP * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQP * D2 : 0);
+      cv.G = take((Form::NEED & NEED_G) ? NQP * D2 : 0);
+      cv.u = take(fields ? QC * DOF : 0); cv.ut = take(fields ? QC * DOF : 0);
+      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? QC * DOF * D2 : 0);
+      const int nparts = std::max(1, std::min(8, 256 / QC));
+      cv.hpart = take(HU_FLY ? nparts * QC * DOF * D2 : 0);
+      cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
+      cv.rowbase = take(NE); cv.cc = take(NE); cv.pax = take(96);
+      cv.phi = take(NFS * QC * NEP);
+      cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
+      lds_bytes = (size_t)pos * sizeof(double);
+      if (lds_bytes <= cap) fits = true;
+    }
+  }
+  if (!fits) return 0;   // not covered: the generic kernel takes it
+  ParamsDev prm; memset(&prm, 0, sizeof(prm));
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+  int launches = 0; bool first = true;
+  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
+      int firstel = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = firstel; cr.step[d] = stride; cr.count[d] = count;
+    }
+    if (empty) continue;
+    const size_t per2 = (size_t)cr.count[0] * cr.count[1];
+    const int chunk2 = (int)std::max<size_t>(1, std::min<size_t>((size_t)cr.count[2], ((size_t)1 << 30) / std::max<size_t>(per2, 1)));
+    for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
+      ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
+      const size_t nblocks = per2 * sub.count[2];
+      launch_feature_pass<Form, DIM, TA, 0, DOFI>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first); launches++;
+      if constexpr (DOFI < DOF) { launch_feature_pass<Form, DIM, TA, DOFI, DOFI>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first); launches++; }
+      first = false;
+    }
+  }
+  HIPCK(hipGetLastError());
+  g->last_launches = launches;
+  g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+  done = true;
+  return 0;
+}
+
+template <class Form, int DIM>
+static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
+  done = false;
+  if constexpr (DIM < 2 || nscalar_of<Form>::v > 0) return 0;
+  else {
+    const Space &s = g->s;
+    if (s.dof != Form::DOF) return 0;
+    const int op = out.op;
+    if (!(op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN)) return 0;
+    int NE = 1; for (int d = 0; d < 3; ++d) NE *= s.basis[d].nen;
+    if (NE > 64) return 0;
+    if (NE <= 16) return launch_feature_ta<Form, DIM, 1>(g, S, out, done);
+    if (NE <= 32) return launch_feature_ta<Form, DIM, 2>(g, S, out, done);
+    return launch_feature_ta<Form, DIM, 4>(g, S, out, done);
+  }
+}
+
 // ------------------------------------------------------------------ generic kernel dispatch
 template <class Form, int DIM>
 static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
@@ -413,6 +517,12 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   constexpr bool SECOND = Form::ORDER >= 2;
   constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   constexpr int NS = nscalar_of<Form>::v;
+  if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
+    bool done = false;
+    if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;
+    if (done) return 0;
+    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2, nen <= 64, a matrix-producing operation)");
+  }
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   int nq[3], na[3]; int NQ = 1, NE = 1;
@@ -537,7 +647,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   const SpaceDev S = make_spacedev(g);
   int rc;
   bool done = false;
-  if (g->kernel_choice != 1) {
+  if (g->kernel_choice != 1 && g->kernel_choice != 3) {
     g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
     rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom);
     if (rc) return rc;

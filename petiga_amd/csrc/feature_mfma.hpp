@@ -1,0 +1,495 @@
+// feature_mfma.hpp -- the general element kernel with the dense K_e contraction on the matrix cores.
+//
+// Every point callback of the reference that fills a matrix (System / Matrix / Jacobian / IJacobian,
+// include/petiga.h:153-197) is BILINEAR in the test function a and the trial function b: with the feature vector
+// Phi(a,q) = (N, dN/dx_i, d2N/dx_i dx_j) of a basis function at point q,
+//     k_q[(a,i),(b,j)] = sum_f Phi_f(a,q) * mat(e_f, Phi(b,q))[i][j]                         (e_f = unit feature),
+// so the reduction over points of rows 11-13 of SURVEY 8(a) (IGAPointAddMat, src/petigapoint.c:451-492) is the GEMM
+//     K_e[(.,i),(.,j)] = A^T B^{ij},   A[(q,f)][a] = Phi_f(a,q),   B^{ij}[(q,f)][b] = JW_q * mat(e_f, Phi(b,q))[i][j],
+// K dimension nqp * (features the form's test side uses).  A lives in LDS (written once by the tabulation phases,
+// which are those of generic_kernel.hpp: closure, K1..K6, field values); every lane builds its B operand in registers
+// with ONE call of the form's own mat() per k-step, which yields all dof*dof blocks at once, and feeds
+// v_mfma_f64_16x16x4_f64.  Any geometry (none / polynomial / NURBS), any device form, dof <= 4, nen <= 64.
+//
+// One workgroup of 4 wavefronts per element of the current colour.  Output tiles (16 test x 16 trial functions):
+//   nen <= 64: 4x4 tiles per (i,j) block, wave w owns trial-function tile column w (B built once, used by 4 MFMAs x
+//   dof^2 blocks);  nen <= 32: 2x2 tiles, one per wave;  nen <= 16: one tile, wave 0.
+// Accumulators: (row fields per launch) x dof x tiles-per-wave x 4 f64.  dof = 4 at nen = 64 needs two launches per
+// colour (row fields {0,1} and {2,3}); everything else one.
+// The quadrature points are processed in chunks so that Phi fits the LDS next to the other element arrays.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "forms.hpp"
+#include "generic_kernel.hpp"
+
+namespace igx {
+
+typedef double fm_d4_t __attribute__((ext_vector_type(4)));
+
+template <class F, class = void> struct shape_order_of { static constexpr int v = F::ORDER; };
+template <class F> struct shape_order_of<F, decltype((void)F::SHAPE_ORDER)> { static constexpr int v = F::SHAPE_ORDER; };
+// bit f set: mat(e_f, .) is not identically zero (features of the TEST function the matrix form reads)
+template <class F, class = void> struct mat_test_mask_of { static constexpr unsigned v = 0xffffffffu; };
+template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> { static constexpr unsigned v = F::MAT_TEST_MASK; };
+
+struct FCarve {            // offsets in doubles into the dynamic LDS block
+  int t1d[3], w1d[3];
+  int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
+  int JW, xq, E1, E2, W0, W1, W2, G;
+  int u, ut, gu, hu, hpart, lift, phi;
+  int rowbase, cc, pax;
+  int total;
+  int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
+};
+
+// Phi(a,q): the full chain K2 -> K3 -> K6 for one (point, basis function) pair; o[NF]
+template <int DIM, bool SECOND>
+__device__ __forceinline__ void shape_features(const double *const t1d[3], const int na[3], const int nq[3], int q, int a,
+                                               bool rat, bool geo, const double *gW, const double *W0, const double *W1, const double *W2,
+                                               const double *E1, const double *E2, double *o) {
+  constexpr int D2 = DIM * DIM;
+  const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
+  const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+  double b0, b1[3], b2[9];
+  tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+  if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
+    const double w = gW[a], w0 = W0[q];
+    const double r0 = w * b0 / w0;
+    double r1[3];
+    for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[q * DIM + i]) / w0;
+    if (SECOND)
+      for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+        b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[q * D2 + i * DIM + j] - r1[i] * W1[q * DIM + j] - r1[j] * W1[q * DIM + i]) / w0;
+    b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+  }
+  o[0] = b0;
+  if (!geo) {
+    for (int i = 0; i < DIM; ++i) o[1 + i] = b1[i];
+    if (SECOND) for (int i = 0; i < D2; ++i) o[1 + DIM + i] = b2[i];
+  } else {     // ShapeFunctions, src/petigamapshf.f90.in:30-58
+    const double *e1 = E1 + q * D2;
+    for (int i = 0; i < DIM; ++i) { double s = 0; for (int al = 0; al < DIM; ++al) s += b1[al] * e1[al * DIM + i]; o[1 + i] = s; }
+    if (SECOND) {
+      const double *e2 = E2 + (size_t)q * DIM * D2;
+      for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
+        double s = 0;
+        for (int al = 0; al < DIM; ++al) {
+          for (int be = 0; be < DIM; ++be) s += b2[al * DIM + be] * e1[al * DIM + i] * e1[be * DIM + j];
+          s += b1[al] * e2[al * D2 + i * DIM + j];
+        }
+        o[1 + DIM + i * DIM + j] = s;
+      }
+    }
+  }
+}
+
+// TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
+template <class Form, int DIM, int TA, int I0, int DOFI>
+__global__ void __launch_bounds__(256)
+feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
+  constexpr int DOF = Form::DOF;
+  constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
+  constexpr bool SECOND_S = shape_order_of<Form>::v >= 2;      // order of the shape-function features mat()/vec() read
+  constexpr int D2 = DIM * DIM;
+  constexpr int NF = SECOND ? 1 + DIM + D2 : 1 + DIM;
+  constexpr int NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;       // features kept in LDS
+  constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
+  constexpr int NTA = (TA == 4) ? 4 : 1;                       // tiles per wave and (i,j) block
+  constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  int el[3], ID[3], off[3], nq[3], na[3];
+  {
+    int b = blockIdx.x;
+    const int t0 = b % cr.count[0]; b /= cr.count[0];
+    const int t1 = b % cr.count[1]; b /= cr.count[1];
+    const int tt[3] = {t0, t1, b};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      el[d] = cr.start[d] + tt[d] * cr.step[d];
+      ID[d] = el[d] + S.ax[d].estart;
+      off[d] = S.ax[d].off[el[d]];
+      nq[d] = S.ax[d].nqp; na[d] = S.ax[d].nen;
+    }
+  }
+  const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
+  const int QC = cv.QC, NEP = cv.NEP, NQP = cv.QC * cv.nchunk;
+  const int op = out.op;
+  const bool hasV = (I0 == 0) && (op == OP_SYSTEM);            // this kernel runs for matrix-producing ops only
+  const bool useU = out.U != nullptr, useV = out.V != nullptr;
+  const bool geo = S.nsd > 0, rat = S.rational != 0;
+
+  double *t1d[3] = {smem + cv.t1d[0], smem + cv.t1d[1], smem + cv.t1d[2]};
+  double *w1d[3] = {smem + cv.w1d[0], smem + cv.w1d[1], smem + cv.w1d[2]};
+  double *gX = smem + cv.gX, *gW = smem + cv.gW, *Ue = smem + cv.Ue, *Ve = smem + cv.Ve;
+  double *ufix = smem + cv.ufix, *fixval = smem + cv.fixval, *flux = smem + cv.flux;
+  int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
+  double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
+  double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
+  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *hpart = smem + cv.hpart, *lift = smem + cv.lift;
+  double *phi = smem + cv.phi;                                  // [NFS][QC][NEP]
+  long long *rowbase = reinterpret_cast<long long *>(smem + cv.rowbase);   // [NE] browptr of the row of basis function a
+  int *cc = reinterpret_cast<int *>(smem + cv.cc);              // [2][NE] rcnt0, rcnt1 of that row
+  int *pax = reinterpret_cast<int *>(smem + cv.pax);            // [3][8][8] column position of b_d in the row of a_d
+  __shared__ int s_anyfix;
+  if (tid == 0) s_anyfix = 0;
+  __syncthreads();
+
+  // ---- phase 0: 1-D rows, closure gathers, BC flags (as generic_kernel.hpp), CSR position tables
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const int n = nq[d] * na[d] * NDER;
+    const double *src = S.ax[d].tab + (size_t)el[d] * n;
+    for (int i = tid; i < n; i += nthr) t1d[d][i] = src[i];
+    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = S.ax[d].w[el[d] * nq[d] + i];
+    const int Wd = 2 * S.ax[d].p + 1;
+    for (int i = tid; i < na[d] * na[d]; i += nthr) {
+      const int ad = i / na[d], bd = i - ad * na[d];
+      pax[d * 64 + ad * 8 + bd] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)];
+    }
+  }
+  const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
+  const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
+  for (int a = tid; a < NE; a += nthr) {
+    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+    const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
+    const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
+    const int r0 = S.ax[0].rowmap[i0], r1 = S.ax[1].rowmap[i1], r2 = S.ax[2].rowmap[i2];
+    const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
+    rowbase[a] = out.browptr[row]; cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
+    if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
+    if (rat) gW[a] = S.W[g];
+    if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
+    if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
+    const int aa[3] = {a0, a1, a2};
+    for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
+    if (op != OP_MATRIX) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283)
+      for (int d = 0; d < DIM; ++d) {
+        if (S.ax[d].periodic) continue;
+        for (int side = 0; side < 2; ++side) {
+          if (ID[d] != (side ? S.ax[d].esizes - 1 : 0)) continue;
+          if (aa[d] != (side ? na[d] - 1 : 0)) continue;
+          const BCDev &bv = S.bcv[d][side];
+          for (int k = 0; k < bv.count; ++k) {
+            const int c = bv.field[k];
+            if (c >= DOF) continue;
+            fixflag[a * DOF + c] = 1;
+            fixval[a * DOF + c] = S.fixtable ? S.fixtable[row * DOF + c] : bv.value[k];
+            s_anyfix = 1;
+          }
+          const BCDev &bl = S.bcl[d][side];
+          if (bl.count) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132)
+            double A = 1;
+            if (DIM > 1) {
+              for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
+              A *= (DIM == 2) ? 2 : 4;
+            }
+            for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool anyfix = s_anyfix != 0;
+  if (anyfix && (useU || useV)) {   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
+    for (int k = tid; k < NE * DOF; k += nthr)
+      if (fixflag[k]) { if (useU) { ufix[k] = Ue[k]; Ue[k] = fixval[k]; } if (useV) Ve[k] = 0.0; }
+    __syncthreads();
+  }
+
+  // ---- phase 1: per-point geometry for all points (K1, K3 sums, K4, K5); padded points get JW = 0
+  double Jel = 1;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) Jel *= S.ax[d].J[el[d]];
+  for (int q = tid; q < NQP; q += nthr) {
+    if (q >= NQ) { JW[q] = 0; for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = 0; continue; }
+    const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
+    double detX = 1.0;
+    double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
+    double x0[3], X1[9], X2[27];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
+    if (rat) {
+      w0 = 0;
+      for (int a = 0; a < NE; ++a) {
+        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        double b0, b1[3], b2[9];
+        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+        const double w = gW[a];
+        w0 += w * b0;
+        for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
+        if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
+      }
+      W0[q] = w0;
+      for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
+      if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
+    }
+    if (geo) {
+      for (int i = 0; i < DIM; ++i) x0[i] = 0;
+      for (int i = 0; i < D2; ++i) X1[i] = 0;
+      if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
+      for (int a = 0; a < NE; ++a) {
+        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        double b0, b1[3], b2[9];
+        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+        if (rat) {
+          const double w = gW[a];
+          const double r0 = w * b0 / w0;
+          double r1[3];
+          for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
+          if (SECOND)
+            for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+              b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
+          b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+        }
+        for (int i = 0; i < DIM; ++i) {
+          const double x = gX[a * DIM + i];
+          x0[i] += x * b0;
+          for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
+          if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
+        }
+      }
+      detX = det3(X1, DIM);
+      double e1[9];
+      inv3(X1, DIM, detX, e1);
+      for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
+      if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45
+        for (int c = 0; c < DIM; ++c) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
+          double s = 0;
+          for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
+            s -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
+          E2[(q * DIM + c) * D2 + i * DIM + j] = s;
+        }
+      }
+      if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+    }
+    double w = 1;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) w *= w1d[d][qq[d]];
+    JW[q] = (Jel * detX) * w;
+    for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = x0[i];
+    if (Form::NEED & NEED_G) {           // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+      for (int a = 0; a < DIM; ++a) for (int i = 0; i < DIM; ++i) {
+        const double L = S.ax[a].J[el[a]];
+        Gq[q * D2 + a * DIM + i] = geo ? E1[q * D2 + a * DIM + i] / L : ((a == i) ? 1 / L : 0.0);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- accumulators
+  const bool wave_active = (TA == 4) || (TA == 2) || (wave == 0);
+  const int tb = (TA == 4) ? wave : (TA == 2 ? (wave & 1) : 0);
+  const int ta0 = (TA == 2) ? (wave >> 1) : 0;                  // first (only, unless TA == 4) row tile of this wave
+  fm_d4_t acc[DOFI * DOF][NTA];
+#pragma unroll
+  for (int k = 0; k < DOFI * DOF; ++k)
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
+  double Facc[DOF];
+#pragma unroll
+  for (int i = 0; i < DOF; ++i) Facc[i] = 0;
+  const bool dolift = anyfix && op == OP_SYSTEM;
+
+  for (int ch = 0; ch < cv.nchunk; ++ch) {
+    const int qc0 = ch * QC;
+    if (ch) __syncthreads();             // the previous chunk's readers are done with phi / the field arrays
+
+    // ---- phase 2: Phi of this chunk, [f][ql][a] with zero padding (a >= nen, q >= nqp)
+    for (int idx = tid; idx < QC * NEP; idx += nthr) {
+      const int ql = idx / NEP, a = idx - ql * NEP, q = qc0 + ql;
+      double o[NFS];
+      if (a < NE && q < NQ) shape_features<DIM, SECOND_S>(t1d, na, nq, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
+      else {
+#pragma unroll
+        for (int f = 0; f < NFS; ++f) o[f] = 0;
+      }
+#pragma unroll
+      for (int f = 0; f < NFS; ++f) phi[(f * QC + ql) * NEP + a] = o[f];
+    }
+    __syncthreads();
+
+    // ---- phase 3: field values at the chunk's points (src/petigaval.F90:182-232)
+    if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
+      for (int idx = tid; idx < QC * DOF; idx += nthr) {
+        const int ql = idx / DOF, c = idx - ql * DOF;
+        double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0};
+        for (int a = 0; a < NE; ++a) {
+          const double Ua = useU ? Ue[a * DOF + c] : 0.0;
+          const double f0 = phi[(0 * QC + ql) * NEP + a];
+          u += f0 * Ua;
+          if (useV) ut += f0 * Ve[a * DOF + c];
+          if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
+          if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
+        }
+        fu[idx] = u; fut[idx] = ut;
+        if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
+        if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
+      }
+      if (HU_FLY) {
+        // Hessians of the fields when the form itself never reads second derivatives of N: formed on the fly
+        // (never stored) by `nparts` threads per point, partial sums added in a fixed order
+        const int nparts = (nthr / QC) < 1 ? 1 : ((nthr / QC) > 8 ? 8 : (nthr / QC));
+        const int per = (NE + nparts - 1) / nparts;
+        for (int idx = tid; idx < QC * nparts; idx += nthr) {
+          const int ql = idx % QC, part = idx / QC, q = qc0 + ql;
+          double hp[DOF][D2];
+#pragma unroll
+          for (int c = 0; c < DOF; ++c)
+#pragma unroll
+            for (int i = 0; i < D2; ++i) hp[c][i] = 0;
+          if (q < NQ && useU) {
+            const int alo = part * per, ahi = (alo + per < NE) ? alo + per : NE;
+            for (int a = alo; a < ahi; ++a) {
+              double o[NF];
+              shape_features<DIM, true>(t1d, na, nq, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
+#pragma unroll
+              for (int c = 0; c < DOF; ++c) {
+                const double Ua = Ue[a * DOF + c];
+#pragma unroll
+                for (int i = 0; i < D2; ++i) hp[c][i] += o[1 + DIM + i] * Ua;
+              }
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < DOF; ++c)
+#pragma unroll
+            for (int i = 0; i < D2; ++i) hpart[((part * QC + ql) * DOF + c) * D2 + i] = hp[c][i];
+        }
+        __syncthreads();
+        for (int idx = tid; idx < QC * DOF * D2; idx += nthr) {
+          double s = 0;
+          for (int part = 0; part < nparts; ++part) s += hpart[(size_t)part * QC * DOF * D2 + idx];
+          fhu[idx] = s;
+        }
+      }
+    }
+    // ---- phase 4: Dirichlet lifting features of the chunk: lift[ql][j][:] = sum_b fixed(b,j) v_bj Phi[q][b][:]
+    if (dolift && hasV) {
+      for (int idx = tid; idx < QC * DOF * NFS; idx += nthr) {
+        const int f = idx % NFS, j = (idx / NFS) % DOF, ql = idx / (NFS * DOF);
+        double s = 0;
+        for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) s += fixval[b * DOF + j] * phi[(f * QC + ql) * NEP + b];
+        lift[idx] = s;
+      }
+    }
+    __syncthreads();
+
+    auto point = [&](int q, int ql) {
+      PtView p;
+      p.x = xq + q * DIM; p.u = fu + ql * DOF; p.ut = fut + ql * DOF; p.gu = fgu + ql * DOF * DIM; p.hu = fhu + ql * DOF * D2;
+      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+      return p;
+    };
+
+    // ---- phase 5: K_e += A^T B on the matrix cores
+    if (wave_active) {
+      const int kq = lane >> 4, col = tb * 16 + (lane & 15);
+      for (int s = 0; s < QC / 4; ++s) {
+        const int ql = 4 * s + kq, q = qc0 + ql;
+        const bool live = q < NQ;
+        const PtView p = point(live ? q : 0, live ? ql : 0);
+        const double jw = JW[q];
+        double nb[NFS];
+#pragma unroll
+        for (int g = 0; g < NFS; ++g) nb[g] = phi[(g * QC + ql) * NEP + col];
+#pragma unroll
+        for (int f = 0; f < NFS; ++f) {
+          if (!((FMASK >> f) & 1u)) continue;
+          double ef[NFS];
+#pragma unroll
+          for (int g = 0; g < NFS; ++g) ef[g] = (g == f) ? 1.0 : 0.0;
+          double T[DOF * DOF];
+          Form::mat(p, ef, nb, T);
+          double A[NTA];
+#pragma unroll
+          for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + (ta0 + t) * 16 + (lane & 15)];
+#pragma unroll
+          for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+            for (int j = 0; j < DOF; ++j) {
+              const double B = live ? T[(I0 + i) * DOF + j] * jw : 0.0;
+#pragma unroll
+              for (int t = 0; t < NTA; ++t)
+                acc[i * DOF + j][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[i * DOF + j][t], 0, 0, 0);
+            }
+        }
+      }
+    }
+
+    // ---- phase 6: F_e (vector part of IGAFormSystem), Dirichlet lifting through linearity of mat in Nb
+    if (hasV && tid < NE) {
+      const int a = tid;
+      const int qn = (qc0 + QC <= NQ) ? QC : (NQ - qc0 > 0 ? NQ - qc0 : 0);
+      for (int ql = 0; ql < qn; ++ql) {
+        const PtView p = point(qc0 + ql, ql);
+        double Na[NFS];
+#pragma unroll
+        for (int f = 0; f < NFS; ++f) Na[f] = phi[(f * QC + ql) * NEP + a];
+        double R[DOF];
+        Form::vec(p, Na, R);
+        if (dolift) {
+#pragma unroll
+          for (int j = 0; j < DOF; ++j) {
+            double T[DOF * DOF];
+            Form::mat(p, Na, lift + ((size_t)ql * DOF + j) * NFS, T);
+#pragma unroll
+            for (int i = 0; i < DOF; ++i) R[i] -= T[i * DOF + j];
+          }
+        }
+        const double jw = JW[qc0 + ql];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) Facc[i] += R[i] * jw;
+      }
+    }
+  }
+
+  // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free)
+  if (wave_active) {
+    const int b = tb * 16 + (lane & 15);
+    if (b < NE) {
+      const int b0 = b % na[0], b1 = (b / na[0]) % na[1], b2 = b / (na[0] * na[1]);
+#pragma unroll
+      for (int t = 0; t < NTA; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
+          if (a >= NE) continue;
+          const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+          const int P0 = pax[0 * 64 + a0 * 8 + b0], P1 = pax[1 * 64 + a1 * 8 + b1], P2 = pax[2 * 64 + a2 * 8 + b2];
+          const size_t pos = (size_t)rowbase[a] + ((size_t)P2 * cc[NE + a] + P1) * cc[a] + P0;
+          double *dst = out.val + pos * (DOF * DOF) + I0 * DOF;
+          double v[DOFI * DOF];
+#pragma unroll
+          for (int k = 0; k < DOFI * DOF; ++k) v[k] = dst[k];
+#pragma unroll
+          for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+            for (int j = 0; j < DOF; ++j) {
+              double x = acc[i * DOF + j][t][r];
+              if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
+              v[i * DOF + j] += x;
+            }
+#pragma unroll
+          for (int k = 0; k < DOFI * DOF; ++k) dst[k] = v[k];
+        }
+    }
+  }
+  if (hasV && tid < NE) {   // src/petigaelem.c:1371-1387
+    const int a = tid;
+    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+    const size_t row = (size_t)S.ax[0].rowmap[off[0] + a0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[off[1] + a1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[off[2] + a2]);
+#pragma unroll
+    for (int i = 0; i < DOF; ++i) {
+      const int k = a * DOF + i;
+      double v = Facc[i] + flux[k];
+      if (fixflag[k]) v = fixval[k];
+      out.vec[row * DOF + i] += v;
+    }
+  }
+}
+
+}  // namespace igx

@@ -27,6 +27,7 @@ struct PtView {
 // demo/Poisson{1,2,3}D.c System (demo/Poisson3D.c:3-23)
 template <int DIM> struct FormPoisson {
   static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = ((1u << DIM) - 1u) << 1;   // gradients only
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
     double s = 0;
 #pragma unroll
@@ -39,6 +40,7 @@ template <int DIM> struct FormPoisson {
 // test/IGACreate.c:45-63 System (block-diagonal mass, F = N)
 template <int DIM, int DOF_> struct FormMass {
   static constexpr int DOF = DOF_, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 1u;   // values only
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
 #pragma unroll
     for (int i = 0; i < DOF * DOF; ++i) T[i] = 0;
@@ -54,6 +56,7 @@ template <int DIM, int DOF_> struct FormMass {
 // test/IGAFixTable.c:25-43 System1 (L2 projection of sum x_i^2)
 template <int DIM> struct FormL2ProjX2 {
   static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X;
+  static constexpr unsigned MAT_TEST_MASK = 1u;
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[0] * Nb[0]; }
   static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
     double g = 0;
@@ -66,6 +69,7 @@ template <int DIM> struct FormL2ProjX2 {
 // test/IGAFixTable.c:45-64 System2 (Poisson, f = -2 dim)
 template <int DIM> struct FormPoissonF {
   static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = FormPoisson<DIM>::MAT_TEST_MASK;
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormPoisson<DIM>::mat(p, Na, Nb, T); }
   static __device__ __forceinline__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * (-2.0 * DIM); }
 };
@@ -73,6 +77,7 @@ template <int DIM> struct FormPoissonF {
 // test/IGAErrNorm.c:26-75 System (4 fields: 1, sum x, sum x^2, prod x)
 template <int DIM> struct FormErrNorm {
   static constexpr int DOF = 4, ORDER = 1; static constexpr unsigned NEED = NEED_X;
+  static constexpr unsigned MAT_TEST_MASK = 1u;
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormMass<DIM, 4>::mat(p, Na, Nb, T); }
   static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
     double s1 = 0, s2 = 0, pr = 1;
@@ -86,6 +91,7 @@ template <int DIM> struct FormErrNorm {
 // extra factor mu on its xx term (line 37); kept.
 struct FormElasticity {
   static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 0xEu;   // gradients only
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
     const double lambda = p.prm[0], mu = p.prm[1];
     const double Na_x = Na[1], Na_y = Na[2], Na_z = Na[3], Nb_x = Nb[1], Nb_y = Nb[2], Nb_z = Nb[3];
@@ -105,6 +111,8 @@ struct FormElasticity {
 // demo/CahnHilliard3D.c:11-16,39-53,55-179 (Residual / Tangent); 2-D: demo/CahnHilliard2D.c.
 // params {theta, alpha, cbar, L0, lambda, tau}; L0 <= 0 selects the 2-D demo's 3*alpha scaling.
 template <int DIM> struct FormCahnHilliard {
+  static constexpr unsigned hess_diag_mask() { unsigned m = 0; for (int i = 0; i < DIM; ++i) m |= 1u << (1 + DIM + i * (DIM + 1)); return m; }
+  static constexpr unsigned MAT_TEST_MASK = 1u | (((1u << DIM) - 1u) << 1) | hess_diag_mask();   // N, grad N, diagonal of hess N (Laplacian)
   static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU;
   struct Coef { double M, dM, d2M, dmu, d2mu, lap, t1; };
   static __device__ __forceinline__ Coef coef(const PtView &p) {
@@ -149,6 +157,7 @@ template <int DIM> struct FormCahnHilliard {
 
 // demo/NavierStokesVMS.c:9-244 (Tau, FineScale, Residual, Tangent); params {nu, fx, fy, fz, dt}
 struct FormNSVMS {
+  static constexpr int SHAPE_ORDER = 1;   // Residual/Tangent read N and grad N only; Hessians are needed of U alone
   static constexpr int DOF = 4, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_G;
   static __device__ __forceinline__ void tau(const PtView &p, double &tauM, double &tauC) {
     const double *J = p.G; const double nu = p.prm[0], dt = p.prm[4], C_I = 1.0 / 12.0;

@@ -10,7 +10,7 @@ sys.path.insert(0, ".")
 import petiga_amd as P
 
 
-def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=None, C=-1, steps=2):
+def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=None, C=-1, steps=2, geo=False):
     g = P.IGX(dim, dof)
     for i in range(dim):
         g.axis_uniform(i, p, N[i], C, periodic=bool(periodic[i]) if periodic else False)
@@ -18,6 +18,16 @@ def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=No
     if bc:
         bc(g)
     g.set_form(form, params)
+    if geo:
+        sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
+        from common import greville
+        import numpy as _np
+        gv = [greville(_np.concatenate([[0.0] * (p + 1), _np.arange(1, N[i]) / N[i], [1.0] * (p + 1)]), p) for i in range(dim)]
+        mesh = _np.meshgrid(*gv[::-1], indexing="ij")[::-1]
+        X = _np.stack([m.copy() for m in mesh], axis=-1)
+        X[..., 0] += 0.05 * _np.sin(2 * _np.pi * mesh[1]); X[..., 1] += 0.05 * _np.sin(2 * _np.pi * mesh[dim - 1])
+        W = 1.0 + 0.1 * _np.cos(2 * _np.pi * mesh[0])
+        g.set_geometry(X.reshape(-1, dim), W.reshape(-1))
     A = g.create_mat() if op in ("system", "ijacobian") else None
     b = g.create_vec()
     U = V = None
@@ -47,6 +57,7 @@ def dirichlet_all(g, dim, v=1.0):
             g.set_boundary_value(d, s, 0, v)
 
 
+import os
 which = sys.argv[1:] or ["c1", "c2", "c3", "c4", "c4r"]
 if "c1" in which:
     run("Poisson2D p=2 64^2", 2, 1, 2, (64, 64), "poisson", bc=lambda g: dirichlet_all(g, 2))
@@ -70,3 +81,7 @@ if "c5" in which:
             for f in range(3):
                 g.set_boundary_value(1, s, f, 0.0)
     run("NavierStokesVMS p=3 32^3 tangent (config 5 is 192^3 on 8 GPUs)", 3, 4, 3, (32,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian", bc=bc5)
+if "c6" in which:
+    run("Poisson3D p=3 64^3 on a NURBS geometry", 3, 1, 3, (64,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
+if "c7" in which:
+    run("Poisson3D p=2 96^3 on a NURBS geometry", 3, 1, 2, (96,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)

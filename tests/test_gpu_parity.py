@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-12
 
 
+@pytest.fixture(autouse=True, params=["auto", "generic"])
+def kernel_family(request, monkeypatch):
+    """Every parity case runs twice: with the automatic kernel choice (MFMA kernels wherever they cover the case)
+    and with the generic point-form kernel preset (IGX_KERNEL is read when an IGX is created)."""
+    monkeypatch.setenv("IGX_KERNEL", "0" if request.param == "auto" else "1")
+    return request.param
+
+
 def dirichlet_all(objs, dim, value=1.0, field=0):
     for g in objs:
         for d in range(dim):
@@ -32,10 +40,11 @@ def system_pair(orc, eng, oform, eform, octx=None, params=()):
 
 
 @pytest.mark.parametrize("dim,p,N", [(1, 3, 7), (2, 2, 8), (2, 3, 5), (3, 1, 4), (3, 2, 6), (3, 3, 5), (3, 4, 3), (3, (3, 2, 1), (4, 5, 6))])
-def test_poisson_system(dim, p, N):
+def test_poisson_system(dim, p, N, kernel_family):
     orc, eng = make_pair(dim, 1, p, N)
     dirichlet_all((orc, eng), dim)
-    eng.set_kernel(1)
+    nen = np.prod([q + 1 for q in (p if isinstance(p, tuple) else [p] * dim)])
+    eng.set_kernel(3 if (kernel_family == "auto" and dim >= 2 and nen <= 64) else 1)   # 3: feature-GEMM MFMA kernel
     A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
     compare_mats(A, A_o, TOL)
     assert rel_err(b.get(), b_o) < TOL
@@ -51,10 +60,10 @@ def test_tutorial_sizes_on_device():
     assert np.array_equal(rp, Ao.rowptr) and np.array_equal(ci, Ao.colidx)
 
 
-def test_poisson_16cube_p3_full():
+def test_poisson_16cube_p3_full(kernel_family):
     orc, eng = make_pair(3, 1, 3, 16)
     dirichlet_all((orc, eng), 3)
-    eng.set_kernel(1)
+    eng.set_kernel(3 if kernel_family == "auto" else 1)
     A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
     compare_mats(A, A_o, TOL)
     assert rel_err(b.get(), b_o) < TOL
@@ -127,13 +136,13 @@ def test_elasticity_system(p, N):
 
 @pytest.mark.parametrize("geo", ["poly", "nurbs"])
 @pytest.mark.parametrize("dim,p,N", [(2, 2, 5), (2, 3, 4), (3, 2, 4), (3, 3, 3)])
-def test_poisson_on_mapped_geometry(dim, p, N, geo):
+def test_poisson_on_mapped_geometry(dim, p, N, geo, kernel_family):
     orc, eng = make_pair(dim, 1, p, N)
     X, W = warped_geometry(orc, dim, seed=dim * 10 + p, rational=(geo == "nurbs"))
     orc.set_geometry(X, W)
     eng.set_geometry(X, W)
     dirichlet_all((orc, eng), dim, 0.5)
-    eng.set_kernel(1)
+    eng.set_kernel(3 if kernel_family == "auto" else 1)
     A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
     compare_mats(A, A_o, 1e-11)
     assert rel_err(b.get(), b_o) < 1e-11
@@ -279,6 +288,7 @@ def test_mfma_matrix_driver_and_default_selection():
     A_o, _ = orc.compute_system("orc_form_poisson")
     eng.set_form("poisson")
     A = eng.create_mat()
+    eng.set_kernel(0)
     eng.compute_matrix(A)      # kernel 0 = automatic: picks the MFMA kernel for the metric configuration
     eng.synchronize()
     assert "mfma" in eng.kernel_name()
