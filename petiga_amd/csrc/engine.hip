@@ -46,7 +46,7 @@ struct _p_IGX {
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
-  DevBuf partials;   // IGXComputeScalar: per-element partial sums + reduction stages
+  DevBuf partials, dbgbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
 };
@@ -414,7 +414,7 @@ template <class Form, int DIM, int TA, int I0, int DOFI>
 static void launch_feature_pass(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first) {
   auto kern = feature_assemble<Form, DIM, TA, I0, DOFI>;
   if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, out, cr, cv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(fm_threads<TA>::v), lds_bytes, g->stream, S, prm, out, cr, cv);
 }
 
 // returns 0 and sets done when the feature kernel ran; done stays false when the case is not covered
@@ -425,7 +425,6 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
   constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
   constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
   constexpr int DOFI = (TA == 4 && DOF == 4) ? 2 : DOF;      // 256 accumulator VGPRs per wave at most
-  constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
@@ -433,7 +432,7 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
   const size_t lds_limit = 160 * 1024 - 512;
   // few accumulators: keep the element small enough for two workgroups per CU, so one element's tabulation
   // overlaps another's MFMA phase; many accumulators: one workgroup per CU anyway, take all of the LDS
-  const size_t lds_target = (DOFI * DOF * (TA == 4 ? 4 : 1) <= 12) ? (size_t)78 * 1024 : lds_limit;
+  const size_t lds_target = (DOFI * DOF * (TA == 4 ? 2 : 1) <= 6) ? (size_t)78 * 1024 : lds_limit;
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
   for (int pass = 0; pass < 2 && !fits; ++pass) {
     const size_t cap = pass == 0 ? lds_target : lds_limit;
@@ -448,11 +447,10 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
       cv.W0 = take(s.rational ? NQP : 0); cv.W1 = take(s.rational ? NQP * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQP * D2 : 0);
       cv.G = take((Form::NEED & NEED_G) ? NQP * D2 : 0);
       cv.u = take(fields ? QC * DOF : 0); cv.ut = take(fields ? QC * DOF : 0);
-      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? QC * DOF * D2 : 0);
-      const int nparts = std::max(1, std::min(8, 256 / QC));
-      cv.hpart = take(HU_FLY ? nparts * QC * DOF * D2 : 0);
+      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
+      cv.hpart = 0;
       cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
-      cv.rowbase = take(NE); cv.cc = take(NE); cv.pax = take(96);
+      cv.rowbase = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
       cv.phi = take(NFS * QC * NEP);
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
@@ -636,6 +634,8 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
     if (s.load[a][sd].count && s.nsd) return fail(IGX_ERR_SUP, "boundary loads on mapped geometries are not supported on the device path");
   OutDev out; memset(&out, 0, sizeof(out));
   out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>();
+  { const char *e = getenv("IGX_DEBUG_FEATURE"); out.debug = e ? atoi(e) : 0; }
+  if (out.debug & 8) { if (!g->dbgbuf.p) g->dbgbuf.alloc(32 * sizeof(long long)); HIPCK(hipMemsetAsync(g->dbgbuf.p, 0, 32 * sizeof(long long), g->stream)); out.dbg = g->dbgbuf.as<long long>(); }
   if (hasM) { out.browptr = A->browptr.as<int64_t>(); out.val = A->val.as<double>(); }
   if (hasV) out.vec = b->a.as<double>();
   out.U = U ? U->a.as<double>() : nullptr; out.V = V ? V->a.as<double>() : nullptr;
@@ -661,6 +661,10 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
     if (rc) return rc;
   }
   if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }
+  if (out.dbg) {
+    long long h[32]; HIPCK(hipStreamSynchronize(g->stream)); HIPCK(hipMemcpy(h, g->dbgbuf.p, sizeof(h), hipMemcpyDeviceToHost));
+    fprintf(stderr, "[feature stamps]"); for (int i = 1; i < (int)h[31] && i < 31; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]); fprintf(stderr, "\n");
+  }
   return 0;
 }
 

@@ -11,11 +11,12 @@
 // with ONE call of the form's own mat() per k-step, which yields all dof*dof blocks at once, and feeds
 // v_mfma_f64_16x16x4_f64.  Any geometry (none / polynomial / NURBS), any device form, dof <= 4, nen <= 64.
 //
-// One workgroup of 4 wavefronts per element of the current colour.  Output tiles (16 test x 16 trial functions):
-//   nen <= 64: 4x4 tiles per (i,j) block, wave w owns trial-function tile column w (B built once, used by 4 MFMAs x
-//   dof^2 blocks);  nen <= 32: 2x2 tiles, one per wave;  nen <= 16: one tile, wave 0.
-// Accumulators: (row fields per launch) x dof x tiles-per-wave x 4 f64.  dof = 4 at nen = 64 needs two launches per
-// colour (row fields {0,1} and {2,3}); everything else one.
+// One workgroup per element of the current colour.  Output tiles (16 test x 16 trial functions):
+//   nen <= 64: 4x4 tiles per (i,j) block, 8 wavefronts: wave w owns trial-function tile column w&3 and the test tile
+//   rows {2(w>>2), 2(w>>2)+1} (B built once per k-step, used by 2 MFMAs x dof^2 blocks); the two waves of a SIMD
+//   cover each other's operand building;  nen <= 32: 2x2 tiles, 4 waves, one tile each;  nen <= 16: one tile, wave 0.
+// Accumulators: (row fields per launch) x dof x tiles-per-wave x 4 f64 <= 144 VGPRs.  dof = 4 at nen = 64 takes two
+// launches per colour (row fields {0,1} and {2,3}); everything else one.
 // The quadrature points are processed in chunks so that Phi fits the LDS next to the other element arrays.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -37,19 +38,20 @@ struct FCarve {            // offsets in doubles into the dynamic LDS block
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, hpart, lift, phi;
-  int rowbase, cc, pax;
+  int rowbase, cc, pax, adec, qdec;
   int total;
   int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
 };
 
 // Phi(a,q): the full chain K2 -> K3 -> K6 for one (point, basis function) pair; o[NF]
 template <int DIM, bool SECOND>
-__device__ __forceinline__ void shape_features(const double *const t1d[3], const int na[3], const int nq[3], int q, int a,
+__device__ __forceinline__ void shape_features(const double *const t1d[3], const int na[3], const int *qdec, const int *adec, int q, int a,
                                                bool rat, bool geo, const double *gW, const double *W0, const double *W1, const double *W2,
                                                const double *E1, const double *E2, double *o) {
   constexpr int D2 = DIM * DIM;
-  const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
-  const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+  const int qp = qdec[q], ap = adec[a];       // packed per-axis indices (no integer division in the hot loops)
+  const int qq[3] = {qp & 255, (qp >> 8) & 255, qp >> 16};
+  const int aq[3] = {ap & 255, (ap >> 8) & 255, ap >> 16};
   double b0, b1[3], b2[9];
   tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
   if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
@@ -83,9 +85,29 @@ __device__ __forceinline__ void shape_features(const double *const t1d[3], const
   }
 }
 
+typedef double fm_d2u_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access at 8-byte alignment
+template <int N> __device__ __forceinline__ void load_run(const double *p, double *v) {
+#pragma unroll
+  for (int k = 0; k + 1 < N; k += 2) { const fm_d2u_t t = *reinterpret_cast<const fm_d2u_t *>(p + k); v[k] = t.x; v[k + 1] = t.y; }
+  if (N & 1) v[N - 1] = p[N - 1];
+}
+template <int N> __device__ __forceinline__ void store_run(double *p, const double *v) {
+#pragma unroll
+  for (int k = 0; k + 1 < N; k += 2) { fm_d2u_t t; t.x = v[k]; t.y = v[k + 1]; *reinterpret_cast<fm_d2u_t *>(p + k) = t; }
+  if (N & 1) p[N - 1] = v[N - 1];
+}
+__device__ __forceinline__ int pow2_floor(int x) { return x < 1 ? 1 : (1 << (31 - __clz(x))); }
+// sum over the `np` (power of two) adjacent lanes of a group; every lane of the group ends with the same value
+__device__ __forceinline__ double group_sum(double v, int np) {
+  for (int m = 1; m < np; m <<= 1) v += __shfl_xor(v, m);
+  return v;
+}
+
 // TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
+template <int TA> struct fm_threads { static constexpr int v = (TA == 4) ? 512 : 256; };
+
 template <class Form, int DIM, int TA, int I0, int DOFI>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(fm_threads<TA>::v)
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
@@ -94,7 +116,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr int NF = SECOND ? 1 + DIM + D2 : 1 + DIM;
   constexpr int NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;       // features kept in LDS
   constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
-  constexpr int NTA = (TA == 4) ? 4 : 1;                       // tiles per wave and (i,j) block
+  constexpr int NTA = (TA == 4) ? 2 : 1;                       // tiles per wave and (i,j) block
+  constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -115,7 +138,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
   }
   const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
-  const int QC = cv.QC, NEP = cv.NEP, NQP = cv.QC * cv.nchunk;
+  const int QC = cv.QC, NQP = cv.QC * cv.nchunk;
   const int op = out.op;
   const bool hasV = (I0 == 0) && (op == OP_SYSTEM);            // this kernel runs for matrix-producing ops only
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
@@ -128,16 +151,29 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
   double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
   double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
-  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *hpart = smem + cv.hpart, *lift = smem + cv.lift;
+  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift;
   double *phi = smem + cv.phi;                                  // [NFS][QC][NEP]
   long long *rowbase = reinterpret_cast<long long *>(smem + cv.rowbase);   // [NE] browptr of the row of basis function a
   int *cc = reinterpret_cast<int *>(smem + cv.cc);              // [2][NE] rcnt0, rcnt1 of that row
   int *pax = reinterpret_cast<int *>(smem + cv.pax);            // [3][8][8] column position of b_d in the row of a_d
+  int *adec = reinterpret_cast<int *>(smem + cv.adec);          // [NEP] a -> a0 | a1<<8 | a2<<16
+  int *qdec = reinterpret_cast<int *>(smem + cv.qdec);          // [NQP] q -> q0 | q1<<8 | q2<<16
   __shared__ int s_anyfix;
   if (tid == 0) s_anyfix = 0;
-  __syncthreads();
+  const bool stamp = out.dbg && blockIdx.x == 7 && tid == 0;
+  int nst = 0;
+#define FM_STAMP() do { if (stamp) out.dbg[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
+  FM_STAMP();
 
-  // ---- phase 0: 1-D rows, closure gathers, BC flags (as generic_kernel.hpp), CSR position tables
+  // ---- phase 0: 1-D rows, index tables, closure gathers, BC flags, CSR position tables
+  for (int a = tid; a < NEP; a += nthr) {
+    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+    adec[a] = (a < NE) ? (a0 | (a1 << 8) | (a2 << 16)) : 0;
+  }
+  for (int q = tid; q < NQP; q += nthr) {
+    const int q0 = q % nq[0], q1 = (q / nq[0]) % nq[1], q2 = q / (nq[0] * nq[1]);
+    qdec[q] = (q < NQ) ? (q0 | (q1 << 8) | (q2 << 16)) : 0;
+  }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int n = nq[d] * na[d] * NDER;
@@ -200,90 +236,152 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     __syncthreads();
   }
 
-  // ---- phase 1: per-point geometry for all points (K1, K3 sums, K4, K5); padded points get JW = 0
+  FM_STAMP();
+  // ---- phase 1: per-point geometry for all points (K1, K3 sums, K4, K5).  np1 adjacent lanes share one point and
+  // split the sum over basis functions; partial sums meet in a fixed butterfly order (repeatable).
   double Jel = 1;
 #pragma unroll
   for (int d = 0; d < 3; ++d) Jel *= S.ax[d].J[el[d]];
-  for (int q = tid; q < NQP; q += nthr) {
-    if (q >= NQ) { JW[q] = 0; for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = 0; continue; }
-    const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
-    double detX = 1.0;
-    double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
-    double x0[3], X1[9], X2[27];
+  {
+    int np1 = pow2_floor(nthr / NQP); if (np1 > 16) np1 = 16;
+    if (!geo && !rat) np1 = 1;
+    const int qstep = nthr / np1;
+    for (int qb = 0; qb < NQP; qb += qstep) {
+      const int q = qb + tid / np1, part = tid & (np1 - 1);
+      const bool valid = q < NQ;
+      const int qs = valid ? q : 0;
+      const int qp = qdec[qs];
+      const int qq[3] = {qp & 255, (qp >> 8) & 255, qp >> 16};
+      double detX = 1.0;
+      double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
+      double x0[3], X1[9], X2[27];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
-    if (rat) {
-      w0 = 0;
-      for (int a = 0; a < NE; ++a) {
-        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
-        double b0, b1[3], b2[9];
-        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-        const double w = gW[a];
-        w0 += w * b0;
-        for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
-        if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
-      }
-      W0[q] = w0;
-      for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
-      if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
-    }
-    if (geo) {
-      for (int i = 0; i < DIM; ++i) x0[i] = 0;
-      for (int i = 0; i < D2; ++i) X1[i] = 0;
-      if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
-      for (int a = 0; a < NE; ++a) {
-        const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
-        double b0, b1[3], b2[9];
-        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-        if (rat) {
+      for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
+      if (rat) {
+        w0 = 0;
+        if (valid) for (int a = part; a < NE; a += np1) {
+          const int ap = adec[a]; const int aq[3] = {ap & 255, (ap >> 8) & 255, ap >> 16};
+          double b0, b1[3], b2[9];
+          tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
           const double w = gW[a];
-          const double r0 = w * b0 / w0;
-          double r1[3];
-          for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
-          if (SECOND)
-            for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-              b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
-          b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+          w0 += w * b0;
+          for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
+          if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
         }
-        for (int i = 0; i < DIM; ++i) {
-          const double x = gX[a * DIM + i];
-          x0[i] += x * b0;
-          for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
-          if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
-        }
+        w0 = group_sum(w0, np1);
+        for (int i = 0; i < DIM; ++i) w1[i] = group_sum(w1[i], np1);
+        if (SECOND) for (int i = 0; i < D2; ++i) w2[i] = group_sum(w2[i], np1);
+        if (!valid) w0 = 1;
       }
-      detX = det3(X1, DIM);
-      double e1[9];
-      inv3(X1, DIM, detX, e1);
-      for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
-      if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45
-        for (int c = 0; c < DIM; ++c) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
-          double s = 0;
-          for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
-            s -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
-          E2[(q * DIM + c) * D2 + i * DIM + j] = s;
+      if (geo) {
+        for (int i = 0; i < DIM; ++i) x0[i] = 0;
+        for (int i = 0; i < D2; ++i) X1[i] = 0;
+        if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
+        if (valid) for (int a = part; a < NE; a += np1) {
+          const int ap = adec[a]; const int aq[3] = {ap & 255, (ap >> 8) & 255, ap >> 16};
+          double b0, b1[3], b2[9];
+          tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+          if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
+            const double w = gW[a];
+            const double r0 = w * b0 / w0;
+            double r1[3];
+            for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
+            if (SECOND)
+              for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+                b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
+            b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+          }
+          for (int i = 0; i < DIM; ++i) {
+            const double x = gX[a * DIM + i];
+            x0[i] += x * b0;
+            for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
+            if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
+          }
         }
+        for (int i = 0; i < DIM; ++i) x0[i] = group_sum(x0[i], np1);
+        for (int i = 0; i < D2; ++i) X1[i] = group_sum(X1[i], np1);
+        if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = group_sum(X2[i], np1);
       }
-      if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
-    }
-    double w = 1;
+      if (part != 0 || q >= NQP) continue;
+      if (!valid) { JW[q] = 0; for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = 0; continue; }   // padded point
+      if (rat) {
+        W0[q] = w0;
+        for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
+        if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
+      }
+      if (geo) {
+        detX = det3(X1, DIM);
+        double e1[9];
+        inv3(X1, DIM, detX, e1);
+        for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
+        if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45
+          for (int c = 0; c < DIM; ++c) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
+            double sm = 0;
+            for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
+              sm -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
+            E2[(q * DIM + c) * D2 + i * DIM + j] = sm;
+          }
+        }
+        if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      }
+      double w = 1;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) w *= w1d[d][qq[d]];
-    JW[q] = (Jel * detX) * w;
-    for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = x0[i];
-    if (Form::NEED & NEED_G) {           // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
-      for (int a = 0; a < DIM; ++a) for (int i = 0; i < DIM; ++i) {
-        const double L = S.ax[a].J[el[a]];
-        Gq[q * D2 + a * DIM + i] = geo ? E1[q * D2 + a * DIM + i] / L : ((a == i) ? 1 / L : 0.0);
+      for (int d = 0; d < 3; ++d) w *= w1d[d][qq[d]];
+      JW[q] = (Jel * detX) * w;
+      for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = x0[i];
+      if (Form::NEED & NEED_G) {           // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+        for (int a = 0; a < DIM; ++a) for (int i = 0; i < DIM; ++i) {
+          const double L = S.ax[a].J[el[a]];
+          Gq[q * D2 + a * DIM + i] = geo ? E1[q * D2 + a * DIM + i] / L : ((a == i) ? 1 / L : 0.0);
+        }
       }
     }
   }
   __syncthreads();
 
+  if (HU_FLY) {
+    // Hessians of the fields when the form itself never reads second derivatives of N: the second-derivative
+    // features are formed on the fly (never stored), nph lanes per point; done for all points before the
+    // accumulators become live
+    int nph = pow2_floor(nthr / NQP); if (nph > 16) nph = 16;
+    const int qstep = nthr / nph;
+    for (int qb = 0; qb < NQP; qb += qstep) {
+      const int q = qb + tid / nph, part = tid & (nph - 1);
+      const bool valid = q < NQ && useU;
+      double hp[DOF][D2];
+#pragma unroll
+      for (int c = 0; c < DOF; ++c)
+#pragma unroll
+        for (int i = 0; i < D2; ++i) hp[c][i] = 0;
+      if (valid) for (int a = part; a < NE; a += nph) {
+        double o[NF];
+        shape_features<DIM, true>(t1d, na, qdec, adec, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
+#pragma unroll
+        for (int c = 0; c < DOF; ++c) {
+          const double Ua = Ue[a * DOF + c];
+#pragma unroll
+          for (int i = 0; i < D2; ++i) hp[c][i] += o[1 + DIM + i] * Ua;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < DOF; ++c)
+#pragma unroll
+        for (int i = 0; i < D2; ++i) hp[c][i] = group_sum(hp[c][i], nph);
+      if (part == 0 && q < NQP) {
+#pragma unroll
+        for (int c = 0; c < DOF; ++c)
+#pragma unroll
+          for (int i = 0; i < D2; ++i) fhu[(q * DOF + c) * D2 + i] = hp[c][i];
+      }
+    }
+    __syncthreads();
+  }
+
+  FM_STAMP();
   // ---- accumulators
-  const bool wave_active = (TA == 4) || (TA == 2) || (wave == 0);
-  const int tb = (TA == 4) ? wave : (TA == 2 ? (wave & 1) : 0);
-  const int ta0 = (TA == 2) ? (wave >> 1) : 0;                  // first (only, unless TA == 4) row tile of this wave
+  const bool wave_active = (TA >= 2) || (wave == 0);
+  const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
+  const int ta0 = (TA == 4) ? 2 * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
   fm_d4_t acc[DOFI * DOF][NTA];
 #pragma unroll
   for (int k = 0; k < DOFI * DOF; ++k)
@@ -302,7 +400,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     for (int idx = tid; idx < QC * NEP; idx += nthr) {
       const int ql = idx / NEP, a = idx - ql * NEP, q = qc0 + ql;
       double o[NFS];
-      if (a < NE && q < NQ) shape_features<DIM, SECOND_S>(t1d, na, nq, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
+      if (a < NE && q < NQ) shape_features<DIM, SECOND_S>(t1d, na, qdec, adec, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
       else {
 #pragma unroll
         for (int f = 0; f < NFS; ++f) o[f] = 0;
@@ -312,58 +410,34 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
     __syncthreads();
 
-    // ---- phase 3: field values at the chunk's points (src/petigaval.F90:182-232)
+    FM_STAMP();
+    // ---- phase 3: field values at the chunk's points (src/petigaval.F90:182-232); np3 lanes per (point, field)
     if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
-      for (int idx = tid; idx < QC * DOF; idx += nthr) {
-        const int ql = idx / DOF, c = idx - ql * DOF;
-        double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0};
-        for (int a = 0; a < NE; ++a) {
-          const double Ua = useU ? Ue[a * DOF + c] : 0.0;
-          const double f0 = phi[(0 * QC + ql) * NEP + a];
-          u += f0 * Ua;
-          if (useV) ut += f0 * Ve[a * DOF + c];
-          if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
-          if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
-        }
-        fu[idx] = u; fut[idx] = ut;
-        if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
-        if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
-      }
-      if (HU_FLY) {
-        // Hessians of the fields when the form itself never reads second derivatives of N: formed on the fly
-        // (never stored) by `nparts` threads per point, partial sums added in a fixed order
-        const int nparts = (nthr / QC) < 1 ? 1 : ((nthr / QC) > 8 ? 8 : (nthr / QC));
-        const int per = (NE + nparts - 1) / nparts;
-        for (int idx = tid; idx < QC * nparts; idx += nthr) {
-          const int ql = idx % QC, part = idx / QC, q = qc0 + ql;
-          double hp[DOF][D2];
-#pragma unroll
-          for (int c = 0; c < DOF; ++c)
-#pragma unroll
-            for (int i = 0; i < D2; ++i) hp[c][i] = 0;
-          if (q < NQ && useU) {
-            const int alo = part * per, ahi = (alo + per < NE) ? alo + per : NE;
-            for (int a = alo; a < ahi; ++a) {
-              double o[NF];
-              shape_features<DIM, true>(t1d, na, nq, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
-#pragma unroll
-              for (int c = 0; c < DOF; ++c) {
-                const double Ua = Ue[a * DOF + c];
-#pragma unroll
-                for (int i = 0; i < D2; ++i) hp[c][i] += o[1 + DIM + i] * Ua;
-              }
-            }
+      {
+        int np3 = pow2_floor(nthr / (QC * DOF)); if (np3 > 16) np3 = 16;
+        const int istep = nthr / np3;
+        for (int ib = 0; ib < QC * DOF; ib += istep) {
+          const int idx = ib + tid / np3, part = tid & (np3 - 1);
+          const bool valid = idx < QC * DOF;
+          const int ids = valid ? idx : 0;
+          const int ql = ids / DOF, c = ids - ql * DOF;
+          double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0};
+          if (valid) for (int a = part; a < NE; a += np3) {
+            const double Ua = useU ? Ue[a * DOF + c] : 0.0;
+            const double f0 = phi[(0 * QC + ql) * NEP + a];
+            u += f0 * Ua;
+            if (useV) ut += f0 * Ve[a * DOF + c];
+            if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
+            if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
           }
-#pragma unroll
-          for (int c = 0; c < DOF; ++c)
-#pragma unroll
-            for (int i = 0; i < D2; ++i) hpart[((part * QC + ql) * DOF + c) * D2 + i] = hp[c][i];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < QC * DOF * D2; idx += nthr) {
-          double s = 0;
-          for (int part = 0; part < nparts; ++part) s += hpart[(size_t)part * QC * DOF * D2 + idx];
-          fhu[idx] = s;
+          u = group_sum(u, np3); ut = group_sum(ut, np3);
+          if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] = group_sum(g[i], np3);
+          if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] = group_sum(h[i], np3);
+          if (valid && part == 0) {
+            fu[idx] = u; fut[idx] = ut;
+            if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
+            if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
+          }
         }
       }
     }
@@ -371,22 +445,23 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     if (dolift && hasV) {
       for (int idx = tid; idx < QC * DOF * NFS; idx += nthr) {
         const int f = idx % NFS, j = (idx / NFS) % DOF, ql = idx / (NFS * DOF);
-        double s = 0;
-        for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) s += fixval[b * DOF + j] * phi[(f * QC + ql) * NEP + b];
-        lift[idx] = s;
+        double sm = 0;
+        for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) sm += fixval[b * DOF + j] * phi[(f * QC + ql) * NEP + b];
+        lift[idx] = sm;
       }
     }
     __syncthreads();
 
     auto point = [&](int q, int ql) {
       PtView p;
-      p.x = xq + q * DIM; p.u = fu + ql * DOF; p.ut = fut + ql * DOF; p.gu = fgu + ql * DOF * DIM; p.hu = fhu + ql * DOF * D2;
+      p.x = xq + q * DIM; p.u = fu + ql * DOF; p.ut = fut + ql * DOF; p.gu = fgu + ql * DOF * DIM; p.hu = fhu + (HU_FLY ? q : ql) * DOF * D2;
       p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
       return p;
     };
 
+    FM_STAMP();
     // ---- phase 5: K_e += A^T B on the matrix cores
-    if (wave_active) {
+    if (wave_active && !(out.debug & 4)) {
       const int kq = lane >> 4, col = tb * 16 + (lane & 15);
       for (int s = 0; s < QC / 4; ++s) {
         const int ql = 4 * s + kq, q = qc0 + ql;
@@ -420,6 +495,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       }
     }
 
+    FM_STAMP();
     // ---- phase 6: F_e (vector part of IGAFormSystem), Dirichlet lifting through linearity of mat in Nb
     if (hasV && tid < NE) {
       const int a = tid;
@@ -447,40 +523,49 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
   }
 
-  // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free)
-  if (wave_active) {
+  FM_STAMP();
+  // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free).
+  // Per tile the four row groups are read together, then written: 4 x DOFI*DOF loads in flight per lane.
+  if (wave_active && !(out.debug & 1)) {
     const int b = tb * 16 + (lane & 15);
-    if (b < NE) {
-      const int b0 = b % na[0], b1 = (b / na[0]) % na[1], b2 = b / (na[0] * na[1]);
+    const int bp = adec[b];
+    const int b0 = bp & 255, b1 = (bp >> 8) & 255, b2 = bp >> 16;
 #pragma unroll
-      for (int t = 0; t < NTA; ++t)
+    for (int t = 0; t < NTA; ++t) {
+      double v[4][DOFI * DOF]; double *dst[4]; bool ok[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
-          if (a >= NE) continue;
-          const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
-          const int P0 = pax[0 * 64 + a0 * 8 + b0], P1 = pax[1 * 64 + a1 * 8 + b1], P2 = pax[2 * 64 + a2 * 8 + b2];
-          const size_t pos = (size_t)rowbase[a] + ((size_t)P2 * cc[NE + a] + P1) * cc[a] + P0;
-          double *dst = out.val + pos * (DOF * DOF) + I0 * DOF;
-          double v[DOFI * DOF];
+      for (int r = 0; r < 4; ++r) {
+        const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
+        ok[r] = (a < NE) && (b < NE);
+        const int as = ok[r] ? a : 0;
+        const int ap = adec[as];
+        const int a0 = ap & 255, a1 = (ap >> 8) & 255, a2 = ap >> 16;
+        const int P0 = pax[0 * 64 + a0 * 8 + b0], P1 = pax[1 * 64 + a1 * 8 + b1], P2 = pax[2 * 64 + a2 * 8 + b2];
+        const size_t pos = (size_t)rowbase[as] + ((size_t)P2 * cc[NE + as] + P1) * cc[as] + P0;
+        dst[r] = out.val + pos * (DOF * DOF) + I0 * DOF;
+        if (ok[r]) load_run<DOFI * DOF>(dst[r], v[r]);
+      }
 #pragma unroll
-          for (int k = 0; k < DOFI * DOF; ++k) v[k] = dst[k];
+      for (int r = 0; r < 4; ++r) {
+        if (!ok[r]) continue;
+        const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
 #pragma unroll
-          for (int i = 0; i < DOFI; ++i)
+        for (int i = 0; i < DOFI; ++i)
 #pragma unroll
-            for (int j = 0; j < DOF; ++j) {
-              double x = acc[i * DOF + j][t][r];
-              if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
-              v[i * DOF + j] += x;
-            }
-#pragma unroll
-          for (int k = 0; k < DOFI * DOF; ++k) dst[k] = v[k];
-        }
+          for (int j = 0; j < DOF; ++j) {
+            double x = acc[i * DOF + j][t][r];
+            if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
+            v[r][i * DOF + j] += x;
+          }
+        store_run<DOFI * DOF>(dst[r], v[r]);
+      }
     }
   }
+  FM_STAMP();
   if (hasV && tid < NE) {   // src/petigaelem.c:1371-1387
     const int a = tid;
-    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+    const int ap = adec[a];
+    const int a0 = ap & 255, a1 = (ap >> 8) & 255, a2 = ap >> 16;
     const size_t row = (size_t)S.ax[0].rowmap[off[0] + a0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[off[1] + a1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[off[2] + a2]);
 #pragma unroll
     for (int i = 0; i < DOF; ++i) {
@@ -490,6 +575,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       out.vec[row * DOF + i] += v;
     }
   }
+  FM_STAMP();
+  if (stamp) out.dbg[31] = nst;
+#undef FM_STAMP
 }
 
 }  // namespace igx

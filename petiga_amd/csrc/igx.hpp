@@ -122,6 +122,8 @@ struct OutDev {
   double shift, t;
   int op;
   int *errflag;
+  int debug;               // experiment switches (IGX_DEBUG_FEATURE): 1 no scatter, 2 atomic scatter, 4 no MFMA phase
+  long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
 };
 
