@@ -410,29 +410,32 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
 }
 
 // ------------------------------------------------------------------ feature-GEMM kernel dispatch (feature_mfma.hpp)
-template <class Form, int DIM, int TA, int I0, int DOFI>
-static void launch_feature_pass(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first) {
-  auto kern = feature_assemble<Form, DIM, TA, I0, DOFI>;
+// one launch per group of DOFI row fields: I0 = 0, DOFI, 2*DOFI, ...
+template <class Form, int DIM, int TA, int NW, int DOFI, int I0>
+static void launch_feature_passes(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first, int &launches) {
+  auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI>;
   if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(fm_threads<TA>::v), lds_bytes, g->stream, S, prm, out, cr, cv);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * NW), lds_bytes, g->stream, S, prm, out, cr, cv);
+  launches++;
+  if constexpr (I0 + DOFI < Form::DOF) launch_feature_passes<Form, DIM, TA, NW, DOFI, I0 + DOFI>(g, S, prm, out, cr, cv, nblocks, lds_bytes, first, launches);
 }
 
 // returns 0 and sets done when the feature kernel ran; done stays false when the case is not covered
-template <class Form, int DIM, int TA>
-static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
+template <class Form, int DIM, int TA, int NW, int DOFI>
+static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   const Space &s = g->s;
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
   constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
-  constexpr int DOFI = (TA == 4 && DOF == 4) ? 2 : DOF;      // 256 accumulator VGPRs per wave at most
+  constexpr int NTA = (TA == 4) ? 16 / NW : 1;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   const size_t lds_limit = 160 * 1024 - 512;
-  // few accumulators: keep the element small enough for two workgroups per CU, so one element's tabulation
-  // overlaps another's MFMA phase; many accumulators: one workgroup per CU anyway, take all of the LDS
-  const size_t lds_target = (DOFI * DOF * (TA == 4 ? 2 : 1) <= 6) ? (size_t)78 * 1024 : lds_limit;
+  // few accumulators per wave: keep the element small enough for two workgroups per CU, so one element's
+  // tabulation and scatter overlap another's MFMA phase; many: one workgroup per CU anyway, take all of the LDS
+  const size_t lds_target = (DOFI * DOF * NTA * 8 <= 104) ? (size_t)78 * 1024 : lds_limit;
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
   for (int pass = 0; pass < 2 && !fits; ++pass) {
     const size_t cap = pass == 0 ? lds_target : lds_limit;
@@ -447,10 +450,11 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
       cv.W0 = take(s.rational ? NQP : 0); cv.W1 = take(s.rational ? NQP * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQP * D2 : 0);
       cv.G = take((Form::NEED & NEED_G) ? NQP * D2 : 0);
       cv.u = take(fields ? QC * DOF : 0); cv.ut = take(fields ? QC * DOF : 0);
-      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
+      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0);
+      cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
       cv.hpart = 0;
       cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
-      cv.rowbase = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
+      cv.rowbase = take(NE); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
       cv.phi = take(NFS * QC * NEP);
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
@@ -478,16 +482,26 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
     for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
       ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
       const size_t nblocks = per2 * sub.count[2];
-      launch_feature_pass<Form, DIM, TA, 0, DOFI>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first); launches++;
-      if constexpr (DOFI < DOF) { launch_feature_pass<Form, DIM, TA, DOFI, DOFI>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first); launches++; }
+      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
   }
   HIPCK(hipGetLastError());
   g->last_launches = launches;
-  g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+  g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
+                   ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
   return 0;
+}
+
+template <class Form, int DIM, int TA>
+static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
+  constexpr int DOF = Form::DOF;
+  // 4x4 tiles: 8 waves, <= 144 accumulator VGPRs per wave (dof 4: two launches of two row fields).  Measured on
+  // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s; three launches of one row
+  // field with 4 waves and two workgroups per CU 1.60 M elements/s (tabulation repeated per launch).
+  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, (DOF == 4 ? 2 : DOF)>(g, S, out, done);
+  else return launch_feature_plan<Form, DIM, TA, 4, DOF>(g, S, out, done);
 }
 
 template <class Form, int DIM>

@@ -38,7 +38,7 @@ struct FCarve {            // offsets in doubles into the dynamic LDS block
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, hpart, lift, phi;
-  int rowbase, cc, pax, adec, qdec;
+  int rowbase, rowid, cc, pax, adec, qdec;
   int total;
   int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
 };
@@ -104,10 +104,10 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 }
 
 // TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
-template <int TA> struct fm_threads { static constexpr int v = (TA == 4) ? 512 : 256; };
 
-template <class Form, int DIM, int TA, int I0, int DOFI>
-__global__ void __launch_bounds__(fm_threads<TA>::v)
+// NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
+template <class Form, int DIM, int TA, int NW, int I0, int DOFI>
+__global__ void __launch_bounds__(64 * NW)
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
@@ -116,7 +116,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr int NF = SECOND ? 1 + DIM + D2 : 1 + DIM;
   constexpr int NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;       // features kept in LDS
   constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
-  constexpr int NTA = (TA == 4) ? 2 : 1;                       // tiles per wave and (i,j) block
+  static_assert(NW == 4 || (NW == 8 && TA == 4), "wave layout");
+  constexpr int NTA = (TA == 4) ? 16 / NW : 1;                 // tiles per wave and (i,j) block
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -154,6 +155,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift;
   double *phi = smem + cv.phi;                                  // [NFS][QC][NEP]
   long long *rowbase = reinterpret_cast<long long *>(smem + cv.rowbase);   // [NE] browptr of the row of basis function a
+  long long *rowid = reinterpret_cast<long long *>(smem + cv.rowid);       // [NE] the row itself
   int *cc = reinterpret_cast<int *>(smem + cv.cc);              // [2][NE] rcnt0, rcnt1 of that row
   int *pax = reinterpret_cast<int *>(smem + cv.pax);            // [3][8][8] column position of b_d in the row of a_d
   int *adec = reinterpret_cast<int *>(smem + cv.adec);          // [NEP] a -> a0 | a1<<8 | a2<<16
@@ -194,7 +196,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
     const int r0 = S.ax[0].rowmap[i0], r1 = S.ax[1].rowmap[i1], r2 = S.ax[2].rowmap[i2];
     const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
-    rowbase[a] = out.browptr[row]; cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
+    rowbase[a] = out.browptr[row]; rowid[a] = (long long)row; cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
     if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
     if (rat) gW[a] = S.W[g];
     if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
@@ -381,7 +383,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // ---- accumulators
   const bool wave_active = (TA >= 2) || (wave == 0);
   const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
-  const int ta0 = (TA == 4) ? 2 * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
+  const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
   fm_d4_t acc[DOFI * DOF][NTA];
 #pragma unroll
   for (int k = 0; k < DOFI * DOF; ++k)
@@ -391,6 +393,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #pragma unroll
   for (int i = 0; i < DOF; ++i) Facc[i] = 0;
   const bool dolift = anyfix && op == OP_SYSTEM;
+  int npv = pow2_floor(nthr / NE); if (npv > 16) npv = 16;
 
   for (int ch = 0; ch < cv.nchunk; ++ch) {
     const int qc0 = ch * QC;
@@ -496,11 +499,12 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
 
     FM_STAMP();
-    // ---- phase 6: F_e (vector part of IGAFormSystem), Dirichlet lifting through linearity of mat in Nb
-    if (hasV && tid < NE) {
-      const int a = tid;
+    // ---- phase 6: F_e (vector part of IGAFormSystem), Dirichlet lifting through linearity of mat in Nb;
+    // npv adjacent lanes share one basis function and split the points
+    if (hasV && tid < NE * npv) {
+      const int a = tid / npv, part = tid & (npv - 1);
       const int qn = (qc0 + QC <= NQ) ? QC : (NQ - qc0 > 0 ? NQ - qc0 : 0);
-      for (int ql = 0; ql < qn; ++ql) {
+      for (int ql = part; ql < qn; ql += npv) {
         const PtView p = point(qc0 + ql, ql);
         double Na[NFS];
 #pragma unroll
@@ -543,7 +547,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const int P0 = pax[0 * 64 + a0 * 8 + b0], P1 = pax[1 * 64 + a1 * 8 + b1], P2 = pax[2 * 64 + a2 * 8 + b2];
         const size_t pos = (size_t)rowbase[as] + ((size_t)P2 * cc[NE + as] + P1) * cc[as] + P0;
         dst[r] = out.val + pos * (DOF * DOF) + I0 * DOF;
-        if (ok[r]) load_run<DOFI * DOF>(dst[r], v[r]);
+        if (ok[r] && !(out.debug & 16)) load_run<DOFI * DOF>(dst[r], v[r]);
+        else { for (int k = 0; k < DOFI * DOF; ++k) v[r][k] = 0; }
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -557,22 +562,25 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
             v[r][i * DOF + j] += x;
           }
-        store_run<DOFI * DOF>(dst[r], v[r]);
+        if (!(out.debug & 32)) store_run<DOFI * DOF>(dst[r], v[r]);
+        else if (v[r][0] == 1.2345e300) dst[r][0] = 0;
       }
     }
   }
   FM_STAMP();
-  if (hasV && tid < NE) {   // src/petigaelem.c:1371-1387
-    const int a = tid;
-    const int ap = adec[a];
-    const int a0 = ap & 255, a1 = (ap >> 8) & 255, a2 = ap >> 16;
-    const size_t row = (size_t)S.ax[0].rowmap[off[0] + a0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[off[1] + a1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[off[2] + a2]);
+  if (hasV && tid < NE * npv) {   // src/petigaelem.c:1371-1387
+    const int a = tid / npv, part = tid & (npv - 1);
 #pragma unroll
-    for (int i = 0; i < DOF; ++i) {
-      const int k = a * DOF + i;
-      double v = Facc[i] + flux[k];
-      if (fixflag[k]) v = fixval[k];
-      out.vec[row * DOF + i] += v;
+    for (int i = 0; i < DOF; ++i) Facc[i] = group_sum(Facc[i], npv);
+    if (part == 0) {
+      const size_t row = (size_t)rowid[a];
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) {
+        const int k = a * DOF + i;
+        double v = Facc[i] + flux[k];
+        if (fixflag[k]) v = fixval[k];
+        out.vec[row * DOF + i] += v;
+      }
     }
   }
   FM_STAMP();

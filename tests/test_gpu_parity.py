@@ -528,3 +528,57 @@ def test_mfma_pencil_degree2(N, bc):
     orc.clear_boundary()
     A2_o, _ = orc.compute_system("orc_form_poisson")
     compare_mats(A2, A2_o, TOL)
+
+
+@pytest.mark.parametrize("case", ["elasticity", "ch3d", "ns", "poisson_nurbs", "mass4_2d", "p1"])
+def test_feature_mfma_kernel_is_selected_and_matches(case):
+    """The automatic choice routes matrix-producing operations of every form to the MFMA feature-GEMM kernel
+    (generic kernel: vectors only, dim 1, nen > 64); its result equals the generic kernel's to 1e-12."""
+    import petiga_amd as P
+    rng = np.random.default_rng(5)
+    if case == "elasticity":
+        _, eng = make_pair(3, 3, 3, 3); form, prm, op = "elasticity", (2.0, 0.5), "system"
+        for f in range(3):
+            eng.set_boundary_value(0, 0, f, 0.25 * f)
+    elif case == "ch3d":
+        _, eng = make_pair(3, 1, 2, 4, order=2); form, prm, op = "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1e-3, 1.0), "ijacobian"
+    elif case == "ns":
+        _, eng = make_pair(3, 4, 3, [7, 3, 8], periodic=[True, False, True], order=2); form, prm, op = "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), "ijacobian"
+        for s in range(2):
+            for f in range(3):
+                eng.set_boundary_value(1, s, f, 0.0)
+    elif case == "poisson_nurbs":
+        orc, eng = make_pair(3, 1, (3, 2, 3), (3, 4, 3)); form, prm, op = "poisson", (), "system"
+        X, W = warped_geometry(orc, 3, seed=2, rational=True)
+        eng.set_geometry(X, W)
+        eng.set_boundary_value(2, 1, 0, 1.5)
+    elif case == "mass4_2d":
+        _, eng = make_pair(2, 4, 3, 5); form, prm, op = "mass", (), "system"
+    else:
+        _, eng = make_pair(3, 1, 1, 5); form, prm, op = "poisson", (), "system"
+        eng.set_boundary_value(0, 0, 0, 1.0)
+    eng.set_form(form, prm)
+    n = eng.create_vec().n
+    U = eng.create_vec().set(0.5 + 0.1 * rng.standard_normal(n)); V = eng.create_vec().set(0.1 * rng.standard_normal(n))
+    out = {}
+    for k in (0, 1):
+        eng.set_kernel(k)
+        A, b = eng.create_mat(), eng.create_vec()
+        if op == "system":
+            eng.compute_system(A, b)
+        else:
+            eng.compute_ijacobian(2.5, V, 0.1, U, A)
+        eng.synchronize()
+        out[k] = (A.host(True), b.get(), eng.kernel_name())
+    assert "feature_assemble(mfma" in out[0][2] and "generic" in out[1][2]
+    scale = np.abs(out[1][0]).max()
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-12 * scale
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-12 * max(np.abs(out[1][1]).max(), 1.0)
+    # bitwise repeatable
+    eng.set_kernel(0)
+    A2 = eng.create_mat(); b2 = eng.create_vec()
+    if op == "system":
+        eng.compute_system(A2, b2)
+    else:
+        eng.compute_ijacobian(2.5, V, 0.1, U, A2)
+    assert np.array_equal(A2.host(True), out[0][0])
