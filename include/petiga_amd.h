@@ -201,7 +201,8 @@ int IGXComputeScalar(IGX iga,IGXVec U,int kind,const double params[],int nparams
 int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default stream            */
 int IGXSynchronize(IGX iga);
 /* 0 = automatic; 1 = generic point-form kernel (no MFMA); 2 = MFMA gradient-Gram pencil kernel (Poisson, uniform
- * degree 2/3, no geometry); 3 = MFMA feature-GEMM element kernel (any form/geometry, dim >= 2, nen <= 64, matrix ops) */
+ * degree 2/3, no geometry); 3 = feature-GEMM element kernel (any form/geometry, dim >= 2, nen <= 64;
+ * K_e on MFMA, vector-only operations share its tabulation) */
 int IGXSetKernel(IGX iga,int which);
 int IGXGetKernelName(IGX iga,char *buf,int len);
 /* name of the kernel the last IGXCompute* used   */

@@ -411,17 +411,17 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
 
 // ------------------------------------------------------------------ feature-GEMM kernel dispatch (feature_mfma.hpp)
 // one launch per group of DOFI row fields: I0 = 0, DOFI, 2*DOFI, ...
-template <class Form, int DIM, int TA, int NW, int DOFI, int I0>
+template <class Form, int DIM, int TA, int NW, int DOFI, int I0, bool HASM>
 static void launch_feature_passes(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first, int &launches) {
-  auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI>;
+  auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI, HASM>;
   if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * NW), lds_bytes, g->stream, S, prm, out, cr, cv);
   launches++;
-  if constexpr (I0 + DOFI < Form::DOF) launch_feature_passes<Form, DIM, TA, NW, DOFI, I0 + DOFI>(g, S, prm, out, cr, cv, nblocks, lds_bytes, first, launches);
+  if constexpr (HASM && I0 + DOFI < Form::DOF) launch_feature_passes<Form, DIM, TA, NW, DOFI, I0 + DOFI, HASM>(g, S, prm, out, cr, cv, nblocks, lds_bytes, first, launches);
 }
 
 // returns 0 and sets done when the feature kernel ran; done stays false when the case is not covered
-template <class Form, int DIM, int TA, int NW, int DOFI>
+template <class Form, int DIM, int TA, int NW, int DOFI, bool HASM>
 static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   const Space &s = g->s;
   constexpr int DOF = Form::DOF;
@@ -433,9 +433,12 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   const size_t lds_limit = 160 * 1024 - 512;
-  // few accumulators per wave: keep the element small enough for two workgroups per CU, so one element's
-  // tabulation and scatter overlap another's MFMA phase; many: one workgroup per CU anyway, take all of the LDS
-  const size_t lds_target = (DOFI * DOF * NTA * 8 <= 104) ? (size_t)78 * 1024 : lds_limit;
+  // Fewest chunks of points wins almost everywhere (measured: CahnHilliard p=2 tangent 12.5 vs 9.9 M elements/s,
+  // NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 for one chunk vs a 78 KiB cap).  The exception is a scalar form at
+  // nen = 64, whose 16 accumulator VGPRs leave room for two workgroups per CU: there half of the LDS is better
+  // (Poisson p=3 on a NURBS geometry: 8.2 vs 6.4 M elements/s).
+  static const int lds_kb_env = [] { const char *e = getenv("IGX_FEATURE_LDS_KB"); return e ? atoi(e) : 0; }();   // experiment switch
+  const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit);
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
   for (int pass = 0; pass < 2 && !fits; ++pass) {
     const size_t cap = pass == 0 ? lds_target : lds_limit;
@@ -454,7 +457,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
       cv.hpart = 0;
       cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
-      cv.rowbase = take(NE); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
+      cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
       cv.phi = take(NFS * QC * NEP);
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
@@ -482,14 +485,15 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
     for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
       ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
       const size_t nblocks = per2 * sub.count[2];
-      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first, launches);
+      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
   }
   HIPCK(hipGetLastError());
   g->last_launches = launches;
-  g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
+  if (HASM) g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
                    ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+  else g->last_kernel = std::string("feature_assemble(vector only,waves=") + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
   return 0;
 }
@@ -500,8 +504,13 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
   // 4x4 tiles: 8 waves, <= 144 accumulator VGPRs per wave (dof 4: two launches of two row fields).  Measured on
   // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s; three launches of one row
   // field with 4 waves and two workgroups per CU 1.60 M elements/s (tabulation repeated per launch).
-  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, (DOF == 4 ? 2 : DOF)>(g, S, out, done);
-  else return launch_feature_plan<Form, DIM, TA, 4, DOF>(g, S, out, done);
+  const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+  if (!hasM) {
+    if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, DOF, false>(g, S, out, done);
+    else return launch_feature_plan<Form, DIM, TA, 4, DOF, false>(g, S, out, done);
+  }
+  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, (DOF == 4 ? 2 : DOF), true>(g, S, out, done);
+  else return launch_feature_plan<Form, DIM, TA, 4, DOF, true>(g, S, out, done);
 }
 
 template <class Form, int DIM>
@@ -511,8 +520,6 @@ static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &don
   else {
     const Space &s = g->s;
     if (s.dof != Form::DOF) return 0;
-    const int op = out.op;
-    if (!(op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN)) return 0;
     int NE = 1; for (int d = 0; d < 3; ++d) NE *= s.basis[d].nen;
     if (NE > 64) return 0;
     if (NE <= 16) return launch_feature_ta<Form, DIM, 1>(g, S, out, done);
@@ -533,7 +540,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;
     if (done) return 0;
-    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2, nen <= 64, a matrix-producing operation)");
+    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
   }
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");

@@ -106,7 +106,8 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 // TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
 
 // NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
-template <class Form, int DIM, int TA, int NW, int I0, int DOFI>
+// HASM = false: vector-only operations (Vector / Function / IFunction) -- same tabulation, no matrix phases.
+template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM>
 __global__ void __launch_bounds__(64 * NW)
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   constexpr int DOF = Form::DOF;
@@ -141,7 +142,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
   const int QC = cv.QC, NQP = cv.QC * cv.nchunk;
   const int op = out.op;
-  const bool hasV = (I0 == 0) && (op == OP_SYSTEM);            // this kernel runs for matrix-producing ops only
+  const bool hasV = (I0 == 0) && (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
   const bool geo = S.nsd > 0, rat = S.rational != 0;
 
@@ -196,14 +197,16 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
     const int r0 = S.ax[0].rowmap[i0], r1 = S.ax[1].rowmap[i1], r2 = S.ax[2].rowmap[i2];
     const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
-    rowbase[a] = out.browptr[row]; rowid[a] = (long long)row; cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
+    rowid[a] = (long long)row;
+    if (HASM) rowbase[a] = out.browptr[row];
+    cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
     if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
     if (rat) gW[a] = S.W[g];
     if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
     if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
     const int aa[3] = {a0, a1, a2};
     for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
-    if (op != OP_MATRIX) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283)
+    if (op != OP_MATRIX && op != OP_VECTOR) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283)
       for (int d = 0; d < DIM; ++d) {
         if (S.ax[d].periodic) continue;
         for (int side = 0; side < 2; ++side) {
@@ -384,9 +387,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool wave_active = (TA >= 2) || (wave == 0);
   const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
   const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
-  fm_d4_t acc[DOFI * DOF][NTA];
+  fm_d4_t acc[HASM ? DOFI * DOF : 1][NTA];
 #pragma unroll
-  for (int k = 0; k < DOFI * DOF; ++k)
+  for (int k = 0; k < (HASM ? DOFI * DOF : 1); ++k)
 #pragma unroll
     for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
   double Facc[DOF];
@@ -464,7 +467,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
     FM_STAMP();
     // ---- phase 5: K_e += A^T B on the matrix cores
-    if (wave_active && !(out.debug & 4)) {
+    if (HASM && wave_active && !(out.debug & 4)) {
       const int kq = lane >> 4, col = tb * 16 + (lane & 15);
       for (int s = 0; s < QC / 4; ++s) {
         const int ql = 4 * s + kq, q = qc0 + ql;
@@ -530,7 +533,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free).
   // Per tile the four row groups are read together, then written: 4 x DOFI*DOF loads in flight per lane.
-  if (wave_active && !(out.debug & 1)) {
+  if (HASM && wave_active && !(out.debug & 1)) {
     const int b = tb * 16 + (lane & 15);
     const int bp = adec[b];
     const int b0 = bp & 255, b1 = (bp >> 8) & 255, b2 = bp >> 16;
@@ -568,7 +571,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
   }
   FM_STAMP();
-  if (hasV && tid < NE * npv) {   // src/petigaelem.c:1371-1387
+  if (hasV && tid < NE * npv) {   // IGAElementFixSystem / FixFunction on F_e, IGAElementAssembleVec
     const int a = tid / npv, part = tid & (npv - 1);
 #pragma unroll
     for (int i = 0; i < DOF; ++i) Facc[i] = group_sum(Facc[i], npv);
@@ -577,8 +580,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
         const int k = a * DOF + i;
-        double v = Facc[i] + flux[k];
-        if (fixflag[k]) v = fixval[k];
+        double v = Facc[i];
+        if (op == OP_SYSTEM) { v += flux[k]; if (fixflag[k]) v = fixval[k]; }                                         // src/petigaelem.c:1371-1387
+        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { v -= flux[k]; if (fixflag[k]) v = ufix[k] - fixval[k]; }  // :1449-1461
         out.vec[row * DOF + i] += v;
       }
     }

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Times the secondary BASELINE configs (one assembly each) on the current kernels; not the headline bench."""
 import json
+import os
 import sys
 import time
 
@@ -48,7 +49,10 @@ def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=No
         g.synchronize()
         times.append(time.perf_counter() - t)
     nel = int(np.prod(N))
-    print(json.dumps(dict(config=name, kernel=g.kernel_name(), elements=nel, ms=min(times) * 1e3, elements_per_s=nel / min(times))))
+    if os.environ.get("BENCH_COMPACT"):
+        print("%-44s %8.2f ms %7.2f M el/s  %s" % (name[:44], min(times) * 1e3, nel / min(times) / 1e6, g.kernel_name()))
+    else:
+        print(json.dumps(dict(config=name, kernel=g.kernel_name(), elements=nel, ms=min(times) * 1e3, elements_per_s=nel / min(times))))
 
 
 def dirichlet_all(g, dim, v=1.0):
@@ -85,3 +89,21 @@ if "c6" in which:
     run("Poisson3D p=3 64^3 on a NURBS geometry", 3, 1, 3, (64,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "c7" in which:
     run("Poisson3D p=2 96^3 on a NURBS geometry", 3, 1, 2, (96,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
+if "full3" in which:
+    run("Elasticity3D p=3 128^3 (config 3, full size)", 3, 3, 3, (128,) * 3, "elasticity", (1.0, 1.0), bc=bc3 if "c3" in which else (lambda g: [g.set_boundary_value(0, 0, f, 0.0) for f in range(3)] and g.set_boundary_value(0, 1, 0, 1.0)))
+if "full4" in which:
+    h2 = 1.0 / (3 * 256 * 256)
+    run("CahnHilliard3D p=2 256^3 tangent (config 4, full size, one GPU)", 3, 1, 2, (256,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian")
+    run("CahnHilliard3D p=2 256^3 residual (config 4, full size, one GPU)", 3, 1, 2, (256,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ifunction")
+if "full5" in which:
+    def bc5f(g):
+        for s in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s, f, 0.0)
+    run("NavierStokesVMS p=3 96^3 tangent (config 5 is 192^3 on 8 GPUs: this is one GPU's share)", 3, 4, 3, (96,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian", bc=bc5f)
+if "c5r" in which:
+    def bc5r(g):
+        for s in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s, f, 0.0)
+    run("NavierStokesVMS p=3 48^3 residual", 3, 4, 3, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ifunction", bc=bc5r)
