@@ -509,7 +509,8 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
     if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, DOF, false>(g, S, out, done);
     else return launch_feature_plan<Form, DIM, TA, 4, DOF, false>(g, S, out, done);
   }
-  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, (DOF == 4 ? 2 : DOF), true>(g, S, out, done);
+  constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
+  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, ((DOF == 4 && !GRAM) ? 2 : DOF), true>(g, S, out, done);
   else return launch_feature_plan<Form, DIM, TA, 4, DOF, true>(g, S, out, done);
 }
 

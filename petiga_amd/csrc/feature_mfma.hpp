@@ -33,6 +33,16 @@ template <class F> struct shape_order_of<F, decltype((void)F::SHAPE_ORDER)> { st
 template <class F, class = void> struct mat_test_mask_of { static constexpr unsigned v = 0xffffffffu; };
 template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> { static constexpr unsigned v = F::MAT_TEST_MASK; };
 
+// Forms whose matrix integrand has point-independent coefficients in the physical-space features (Poisson, mass,
+// linear elasticity): K_e[(a,i),(b,j)] = sum_{f,g} C^{ij}_{fg} M_fg[a][b] with the feature Gram matrices
+// M_fg = sum_q JW Phi_f(a,q) Phi_g(b,q).  Only the M_fg go through the matrix cores (K dimension nqp instead of
+// nqp * features, and one accumulator set per (f,g) pair instead of per (i,j) block); C = mat(e_f, e_g) is applied
+// once, at the scatter.  MAT_PAIR_MASK: bit f*8+g set when C_{fg} is not identically zero (f, g < 8).
+template <class F, class = void> struct mat_pair_mask_of { static constexpr unsigned long long v = 0ull; };
+template <class F> struct mat_pair_mask_of<F, decltype((void)F::MAT_PAIR_MASK)> { static constexpr unsigned long long v = F::MAT_PAIR_MASK; };
+constexpr int fm_popcount(unsigned long long m) { int n = 0; while (m) { n += (int)(m & 1ull); m >>= 1; } return n; }
+constexpr int fm_pair_index(unsigned long long mask, int f, int g) { return fm_popcount(mask & ((1ull << (f * 8 + g)) - 1ull)); }
+
 struct FCarve {            // offsets in doubles into the dynamic LDS block
   int t1d[3], w1d[3];
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
@@ -121,6 +131,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr int NTA = (TA == 4) ? 16 / NW : 1;                 // tiles per wave and (i,j) block
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
+  constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+  constexpr bool GRAM = PAIRS != 0ull;                          // constant-coefficient form: accumulate feature Gram matrices
+  static_assert(!GRAM || (DOFI == DOF && I0 == 0 && NFS <= 8), "Gram path forms all row fields in one launch");
+  constexpr int NACC = !HASM ? 1 : (GRAM ? fm_popcount(PAIRS) : DOFI * DOF);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -387,9 +401,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool wave_active = (TA >= 2) || (wave == 0);
   const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
   const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
-  fm_d4_t acc[HASM ? DOFI * DOF : 1][NTA];
+  fm_d4_t acc[NACC][NTA];
 #pragma unroll
-  for (int k = 0; k < (HASM ? DOFI * DOF : 1); ++k)
+  for (int k = 0; k < NACC; ++k)
 #pragma unroll
     for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
   double Facc[DOF];
@@ -477,6 +491,23 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         double nb[NFS];
 #pragma unroll
         for (int g = 0; g < NFS; ++g) nb[g] = phi[(g * QC + ql) * NEP + col];
+        if constexpr (GRAM) {
+#pragma unroll
+          for (int f = 0; f < NFS; ++f) {
+            if (!((PAIRS >> (f * 8)) & 0xffull)) continue;
+            double A[NTA];
+#pragma unroll
+            for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + (ta0 + t) * 16 + (lane & 15)];
+#pragma unroll
+            for (int g = 0; g < NFS; ++g) {
+              if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+              const double B = live ? nb[g] * jw : 0.0;
+#pragma unroll
+              for (int t = 0; t < NTA; ++t)
+                acc[fm_pair_index(PAIRS, f, g)][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[fm_pair_index(PAIRS, f, g)][t], 0, 0, 0);
+            }
+          }
+        } else {
 #pragma unroll
         for (int f = 0; f < NFS; ++f) {
           if (!((FMASK >> f) & 1u)) continue;
@@ -497,6 +528,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
               for (int t = 0; t < NTA; ++t)
                 acc[i * DOF + j][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[i * DOF + j][t], 0, 0, 0);
             }
+        }
         }
       }
     }
@@ -553,6 +585,29 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         if (ok[r] && !(out.debug & 16)) load_run<DOFI * DOF>(dst[r], v[r]);
         else { for (int k = 0; k < DOFI * DOF; ++k) v[r][k] = 0; }
       }
+      double kij[GRAM ? 4 : 1][GRAM ? DOF * DOF : 1];
+      if constexpr (GRAM) {   // K^{ij} = sum_{fg} C^{ij}_{fg} M_fg; C = mat(e_f, e_g) folds to the form's constants
+        PtView p0; p0.x = xq; p0.u = fu; p0.ut = fut; p0.gu = fgu; p0.hu = fhu; p0.G = Gq; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < DOF * DOF; ++k) kij[r][k] = 0;
+#pragma unroll
+        for (int f = 0; f < NFS; ++f)
+#pragma unroll
+          for (int g = 0; g < NFS; ++g) {
+            if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+            double ef[NFS], eg[NFS];
+#pragma unroll
+            for (int k = 0; k < NFS; ++k) { ef[k] = (k == f) ? 1.0 : 0.0; eg[k] = (k == g) ? 1.0 : 0.0; }
+            double T[DOF * DOF];
+            Form::mat(p0, ef, eg, T);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int k = 0; k < DOF * DOF; ++k) kij[r][k] += T[k] * acc[fm_pair_index(PAIRS, f, g)][t][r];
+          }
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (!ok[r]) continue;
@@ -561,7 +616,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         for (int i = 0; i < DOFI; ++i)
 #pragma unroll
           for (int j = 0; j < DOF; ++j) {
-            double x = acc[i * DOF + j][t][r];
+            double x;
+            if constexpr (GRAM) x = kij[r][i * DOF + j]; else x = acc[i * DOF + j][t][r];
             if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
             v[r][i * DOF + j] += x;
           }

@@ -41,6 +41,7 @@ template <int DIM> struct FormPoisson {
 template <int DIM, int DOF_> struct FormMass {
   static constexpr int DOF = DOF_, ORDER = 1; static constexpr unsigned NEED = 0;
   static constexpr unsigned MAT_TEST_MASK = 1u;   // values only
+  static constexpr unsigned long long MAT_PAIR_MASK = 1ull;   // N x N
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
 #pragma unroll
     for (int i = 0; i < DOF * DOF; ++i) T[i] = 0;
@@ -57,6 +58,7 @@ template <int DIM, int DOF_> struct FormMass {
 template <int DIM> struct FormL2ProjX2 {
   static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X;
   static constexpr unsigned MAT_TEST_MASK = 1u;
+  static constexpr unsigned long long MAT_PAIR_MASK = 1ull;
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[0] * Nb[0]; }
   static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
     double g = 0;
@@ -78,6 +80,7 @@ template <int DIM> struct FormPoissonF {
 template <int DIM> struct FormErrNorm {
   static constexpr int DOF = 4, ORDER = 1; static constexpr unsigned NEED = NEED_X;
   static constexpr unsigned MAT_TEST_MASK = 1u;
+  static constexpr unsigned long long MAT_PAIR_MASK = 1ull;
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormMass<DIM, 4>::mat(p, Na, Nb, T); }
   static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
     double s1 = 0, s2 = 0, pr = 1;
@@ -92,6 +95,7 @@ template <int DIM> struct FormErrNorm {
 struct FormElasticity {
   static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
   static constexpr unsigned MAT_TEST_MASK = 0xEu;   // gradients only
+  static constexpr unsigned long long MAT_PAIR_MASK = (0xEull << 8) | (0xEull << 16) | (0xEull << 24);   // lambda, mu constant: all grad x grad pairs
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
     const double lambda = p.prm[0], mu = p.prm[1];
     const double Na_x = Na[1], Na_y = Na[2], Na_z = Na[3], Nb_x = Nb[1], Nb_y = Nb[2], Nb_z = Nb[3];
