@@ -84,10 +84,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local)
+    # IGX_BENCH_BACKEND=gloo is a test transport (ranks may then share one GPU); the product transport is RCCL
+    backend = os.environ.get("IGX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import petiga_amd as P
     from petiga_amd import exchange
@@ -131,7 +133,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     total_elems = args.size ** 3

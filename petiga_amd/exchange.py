@@ -18,12 +18,20 @@ def plan(iga, with_mat=True, with_vec=True):
 
 def p2p_exchange(send_bufs, send_peers, recv_bufs, recv_peers):
     """One grouped batch of isend/irecv (ncclGroupStart/End under RCCL); a peer gets at most one message."""
+    if not send_bufs and not recv_bufs:
+        return
+    staged = dist.get_backend() == "gloo" and any(b.is_cuda for b in list(send_bufs) + list(recv_bufs))
+    if staged:   # test transport (no RCCL): gloo moves host memory only, so stage through the host
+        dev_recv = recv_bufs
+        send_bufs = [b.cpu() for b in send_bufs]
+        recv_bufs = [torch.empty(b.shape, dtype=b.dtype) for b in dev_recv]
     ops = [dist.P2POp(dist.irecv, b, p) for b, p in zip(recv_bufs, recv_peers)]
     ops += [dist.P2POp(dist.isend, b, p) for b, p in zip(send_bufs, send_peers)]
-    if not ops:
-        return
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    if staged:
+        for d, h in zip(dev_recv, recv_bufs):
+            d.copy_(h)
 
 
 class GhostExchange:
