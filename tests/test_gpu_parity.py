@@ -394,7 +394,9 @@ def _rank_matrix_rows(eng, A, b):
 
 @pytest.mark.parametrize("size,dim,dof,p,N,periodic,form", [(2, 3, 1, 3, (9, 8, 10), (0, 0, 0), "poisson"), (8, 3, 1, 3, (10, 9, 8), (0, 0, 0), "poisson"),
                                                              (4, 2, 2, 2, (9, 10), (0, 0), "mass"), (4, 3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson"),
-                                                             (8, 3, 1, 3, (20, 18, 16), (0, 0, 0), "poisson")])
+                                                             (8, 3, 1, 3, (20, 18, 16), (0, 0, 0), "poisson"),
+                                                             (4, 3, 3, 2, (6, 7, 5), (0, 0, 0), "elasticity+nurbs"), (8, 3, 1, 3, (7, 8, 9), (0, 0, 0), "poisson+nurbs"),
+                                                             (3, 2, 1, 3, (11, 4), (0, 0), "poisson+nurbs")])
 def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     """Every rank assembles its own element box, ghost rows are packed / added through the C ABI exactly as
     petiga_amd/exchange.py does between processes; the owned rows of all ranks together must be the
@@ -403,9 +405,15 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     import petiga_amd as P
     periodic = [bool(x) for x in periodic]
     orc, _ = make_pair(dim, dof, p, list(N), periodic=periodic, engine=False)
+    geo = form.endswith("+nurbs")
+    form = form.split("+")[0]
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=9, rational=True, amp=0.1)
+        orc.set_geometry(X, W)
     if form == "poisson":
         dirichlet_all((orc,), dim, 1.0)
-    A_o, b_o = orc.compute_system("orc_form_" + form)
+    octx, prm = (O.ElasticityCtx(1.3, 0.8), (1.3, 0.8)) if form == "elasticity" else (None, ())
+    A_o, b_o = orc.compute_system("orc_form_" + form, octx)
     engs, mats, vecs, sendbufs = [], [], [], {}
     for r in range(size):
         g = P.IGX(dim, dof)
@@ -413,9 +421,11 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
             g.axis_uniform(i, p, N[i], periodic=periodic[i])
         g.set_comm(size, r)
         g.setup()
+        if geo:
+            g.set_geometry(X, W)          # the global control net; the rank keeps its ghosted box
         if form == "poisson":
             dirichlet_all((g,), dim, 1.0)
-        g.set_form(form)
+        g.set_form(form, prm)
         A, b = g.create_mat(), g.create_vec()
         g.compute_system(A, b)
         for k, (peer, m, v) in enumerate(g.neighbors(True)):
