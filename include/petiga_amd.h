@@ -67,8 +67,11 @@ typedef enum {
   IGX_FORM_ELASTICITY  = 6, /* System: demo/Elasticity3D.c:13-46 (dof=3)  params: {lambda, mu}                      */
   IGX_FORM_CAHNHILLIARD= 7, /* IFunction/IJacobian: demo/CahnHilliard3D.c:55-179 (and the 2-D demo)
                                params: {theta, alpha, cbar, L0, lambda, tau}; L0<=0 selects the 2-D demo's 3*alpha scaling */
-  IGX_FORM_NSVMS       = 8  /* IFunction/IJacobian: demo/NavierStokesVMS.c:78-244 (dof=4)
+  IGX_FORM_NSVMS       = 8, /* IFunction/IJacobian: demo/NavierStokesVMS.c:78-244 (dof=4)
                                params: {nu, fx, fy, fz, dt}  (dt: the reference reads TSGetTimeStep at :85,:173) */
+  IGX_FORM_BOUNDARYINTEGRAL = 9, /* System: demo/BoundaryIntegral.c:26-56  interior Laplace, F=N*1 on visited faces (Neumann) */
+  IGX_FORM_NITSCHE     = 10 /* System: demo/NitscheMethod.c:69-110  Poisson with Nitsche terms on visited faces (normals,
+                               normal mesh size through IGAPointFormInvGradGeomMap); params: {max degree k} */
 } IGXFormKind;
 
 /* ------------------------------------------------------------------------------------------
@@ -96,6 +99,9 @@ int IGXSetGeometry(IGX iga,int nsd,const double X[],const double W[]);
 int IGXSetBoundaryValue(IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryValue src/petigaform.c:324 */
 int IGXSetBoundaryLoad (IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryLoad  src/petigaform.c:340 */
 int IGXClearBoundary(IGX iga);                                             /* IGAFormClearBoundary src/petigaform.c:143 (all faces) */
+/* boundary-form pass of face (axis,side): the form is also integrated over that face, one point layer at the face, with
+ * p->atboundary / p->normal semantics (IGAElementNextForm src/petigaelem.c:427; normals src/petigaval.F90:45-99) */
+int IGXSetBoundaryForm(IGX iga,int axis,int side,int flag);                /* IGASetBoundaryForm  src/petigaform.c:356 */
 int IGXSetFixTable(IGX iga,IGXVec U);                                      /* IGASetFixTable      src/petigaform.c:273 (NULL clears) */
 
 /* IGASetFormSystem / IGASetFormMatrix / ... (src/petigaform.c:388-833): kind + params replace (fn,ctx).

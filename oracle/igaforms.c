@@ -93,6 +93,55 @@ int orc_form_errnorm(OrcPoint *p,double *K,double *F,void *ctx)
   return 0;
 }
 
+/* demo/BoundaryIntegral.c:26-56 (System): Laplace inside, Neumann data 1 on the visited faces */
+int orc_form_boundary_integral(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  int a,b,i,nen=p->nen,dim=p->dim; const double *N0=p->shape[0],*N1=p->shape[1];
+  (void)ctx;
+  if (!p->atboundary) {
+    for (a=0; a<nen; a++) {
+      for (b=0; b<nen; b++) { double s=0; for (i=0;i<dim;i++) s += N1[a*dim+i]*N1[b*dim+i]; K[a*nen+b] = s; }
+      F[a] = 0.0;
+    }
+  } else {
+    for (a=0; a<nen; a++) F[a] = N0[a]*1.0;
+  }
+  return 0;
+}
+
+/* demo/NitscheMethod.c:48-110 (Degree, NormalMeshSize, System); ctx = int* maximum degree (Degree(p) in the demo) */
+int orc_form_nitsche(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  int a,b,i,j,nen=p->nen,dim=p->dim; const double *N0=p->shape[0],*N1=p->shape[1];
+  double x[3]={0,0,0};
+  orc_point_geommap(p,x);
+  if (!p->atboundary) {
+    double f = -2.0*dim;
+    for (a=0; a<nen; a++) {
+      for (b=0; b<nen; b++) { double s=0; for (i=0;i<dim;i++) s += N1[a*dim+i]*N1[b*dim+i]; K[a*nen+b] = s; }
+      F[a] = N0[a]*f;
+    }
+  } else {
+    double g = sum_sq(dim,x), G[9], N[3], s=0, k = (double)*(int*)ctx, Cc, h, alpha;
+    const double *n = p->normal;
+    orc_point_invgradgeommap(p,G);
+    for (i=0;i<dim;i++) { N[i]=0; for (j=0;j<dim;j++) N[i] += G[i*dim+j]*n[j]; s += N[i]*N[i]; }
+    h = 2/sqrt(s); Cc = 5*(k+1); alpha = Cc/h;
+    for (a=0; a<nen; a++) {
+      double dna=0; for (i=0;i<dim;i++) dna += N1[a*dim+i]*n[i];
+      for (b=0; b<nen; b++) {
+        double dnb=0; for (i=0;i<dim;i++) dnb += N1[b*dim+i]*n[i];
+        K[a*nen+b] += - N0[a]*dnb;
+        K[a*nen+b] += - N0[b]*dna;
+        K[a*nen+b] += + alpha*N0[a]*N0[b];
+      }
+      F[a] += - dna*g;
+      F[a] += + alpha*N0[a]*g;
+    }
+  }
+  return 0;
+}
+
 /* src/petigacomp.c:102-120 (ErrorSqr) specialised to test/IGAErrNorm.c's Exact; ctx = int* order.
  * U == all-zero vector reproduces "norm of the exact solution" (vecU NULL in the reference). */
 int orc_scalar_errnorm(OrcPoint *p,const double *U,int n,double *S,void *ctx)

@@ -165,6 +165,8 @@ int orc_form_poisson   (OrcPoint*,double*,double*,void*);  /* demo/Poisson{1,2,3
 int orc_form_mass      (OrcPoint*,double*,double*,void*);  /* test/IGACreate.c System: M, int N */
 int orc_form_l2proj_x2 (OrcPoint*,double*,double*,void*);  /* test/IGAFixTable.c System1 */
 int orc_form_poisson_f (OrcPoint*,double*,double*,void*);  /* test/IGAFixTable.c System2 */
+int orc_form_boundary_integral(OrcPoint*,double*,double*,void*);  /* demo/BoundaryIntegral.c System */
+int orc_form_nitsche(OrcPoint*,double*,double*,void*);            /* demo/NitscheMethod.c System; ctx = int* degree */
 int orc_form_errnorm   (OrcPoint*,double*,double*,void*);  /* test/IGAErrNorm.c System (dof=4) */
 int orc_form_elasticity(OrcPoint*,double*,double*,void*);  /* demo/Elasticity3D.c System */
 int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);

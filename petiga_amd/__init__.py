@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SCALARS = dict(volume=1, x2err=2, errnorm=3)
-FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8)
+FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10)
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -70,7 +70,7 @@ def lib(build_if_needed=False):
         "IGXComputeScalar": [V, V, C.c_int, _dp, C.c_int, C.c_int, _dp],
         "IGXRead": [V, C.c_char_p], "IGXWrite": [V, C.c_char_p], "IGXWriteVec": [V, V, C.c_char_p], "IGXReadVec": [V, V, C.c_char_p],
         "IGXSetBoundaryValue": [V, C.c_int, C.c_int, C.c_int, C.c_double], "IGXSetBoundaryLoad": [V, C.c_int, C.c_int, C.c_int, C.c_double],
-        "IGXClearBoundary": [V], "IGXSetFixTable": [V, V], "IGXSetForm": [V, C.c_int, _dp, C.c_int],
+        "IGXClearBoundary": [V], "IGXSetBoundaryForm": [V, C.c_int, C.c_int, C.c_int], "IGXSetFixTable": [V, V], "IGXSetForm": [V, C.c_int, _dp, C.c_int],
         "IGXGetSizes": [V] + [_ip] * 8, "IGXGetProcessors": [V, _ip, _ip],
         "IGXCreateMat": [V, C.POINTER(V)], "IGXMatDestroy": [C.POINTER(V)],
         "IGXMatGetInfo": [V, C.POINTER(C.c_int64), C.POINTER(C.c_int64), _ip],
@@ -262,6 +262,7 @@ class IGX:
     def set_boundary_value(self, axis, side, field, value): _ck(lib().IGXSetBoundaryValue(self.h, axis, side, field, value))
     def set_boundary_load(self, axis, side, field, value): _ck(lib().IGXSetBoundaryLoad(self.h, axis, side, field, value))
     def clear_boundary(self): _ck(lib().IGXClearBoundary(self.h))
+    def set_boundary_form(self, axis, side, flag=True): _ck(lib().IGXSetBoundaryForm(self.h, axis, side, int(bool(flag))))
     def set_fixtable(self, vec): _ck(lib().IGXSetFixTable(self.h, vec.h if vec is not None else None))
 
     def set_form(self, kind, params=()):

@@ -30,7 +30,7 @@ struct DevBuf {
   template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
-struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix; };
+struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix, bnd; };
 
 // IGX_KERNEL=0..3 presets IGXSetKernel for every new IGX (test / experiment switch)
 static int default_kernel_choice() { const char *e = getenv("IGX_KERNEL"); const int k = e ? atoi(e) : 0; return (k >= 0 && k <= 3) ? k : 0; }
@@ -139,7 +139,13 @@ static int bc_args(IGX g, int axis, int side, int field) {
 }
 extern "C" int IGXSetBoundaryValue(IGX g, int axis, int side, int field, double v) { NEEDIGA(g); if (int rc = bc_args(g, axis, side, field)) return rc; return bc_set(g->s.value[axis][side], field, v); }
 extern "C" int IGXSetBoundaryLoad(IGX g, int axis, int side, int field, double v) { NEEDIGA(g); if (int rc = bc_args(g, axis, side, field)) return rc; return bc_set(g->s.load[axis][side], field, v); }
-extern "C" int IGXClearBoundary(IGX g) { NEEDIGA(g); for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) { g->s.value[a][s].count = 0; g->s.load[a][s].count = 0; } return 0; }
+extern "C" int IGXClearBoundary(IGX g) { NEEDIGA(g); for (int a = 0; a < 3; ++a) for (int s = 0; s < 2; ++s) { g->s.value[a][s].count = 0; g->s.load[a][s].count = 0; g->s.visit[a][s] = false; } return 0; }
+extern "C" int IGXSetBoundaryForm(IGX g, int axis, int side, int flag) {   // IGASetBoundaryForm -> IGAFormSetBoundaryForm, src/petigaform.c:134
+  NEEDIGA(g);
+  if (axis < 0 || axis >= 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,2]");
+  if (side < 0 || side >= 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,1]");
+  g->s.visit[axis][side] = flag != 0; return 0;
+}
 extern "C" int IGXSetForm(IGX g, IGXFormKind kind, const double params[], int nparams) {
   NEEDIGA(g);
   if (nparams < 0 || nparams > MAXPARAM) return fail(IGX_ERR_ARG_OUTOFRANGE, "too many form parameters");
@@ -230,7 +236,20 @@ static int ensure_device(IGX g) {
     std::vector<int64_t> prefix(L.nrow + 1, 0);
     for (int r = 0; r < L.nrow; ++r) prefix[r + 1] = prefix[r] + L.rcnt[r];
     AxisBufs &B = g->ab[d];
-    if (B.tab.upload(tab) || B.w.upload(w) || B.J.upload(J) || B.pt.upload(pt) || B.off.upload(off) || B.rowmap.upload(L.rowmap) ||
+    std::vector<double> bnd((size_t)2 * na * NDER, 0.0);
+    for (int sd = 0; sd < 2; ++sd) {
+      std::vector<double> bv = b.bnd_value[sd];
+      if (bv.size() < (size_t)na * 5) {   // axis beyond dim, or tables handed over without the end-of-axis rows: evaluate here
+        bv.assign((size_t)na * 5, 0.0);
+        const Axis &ax = s.axis[d];
+        if (d < s.dim && !ax.U.empty() && !ax.span.empty()) {
+          const int k = sd ? ax.span[ax.nel - 1] : ax.span[0];
+          bspline_ders(k, sd ? ax.U[k + 1] : ax.U[k], ax.p, std::min(ax.p, 4), ax.U.data(), bv.data());
+        } else bv[0] = 1.0;
+      }
+      for (int a = 0; a < na; ++a) for (int k = 0; k < NDER; ++k) bnd[((size_t)sd * na + a) * NDER + k] = bv[(size_t)a * 5 + k];
+    }
+    if (B.bnd.upload(bnd) || B.tab.upload(tab) || B.w.upload(w) || B.J.upload(J) || B.pt.upload(pt) || B.off.upload(off) || B.rowmap.upload(L.rowmap) ||
         B.rcnt.upload(L.rcnt) || B.P.upload(L.P) || B.rcol.upload(L.rcol) || B.prefix.upload(prefix))
       return fail(IGX_ERR_MEM, "device allocation of axis tables failed");
   }
@@ -256,6 +275,8 @@ static SpaceDev make_spacedev(IGX g) {
     A.estart = s.elem_start[d]; A.esizes = s.elem_sizes[d]; A.periodic = d < s.dim ? s.axis[d].periodic : 0;
     A.gwidth = L.gwidth; A.nrow = L.nrow; A.ncol = L.ncol;
     A.tab = B.tab.as<double>(); A.w = B.w.as<double>(); A.J = B.J.as<double>(); A.pt = B.pt.as<double>();
+    A.bnd = B.bnd.as<double>();
+    if (d < s.dim && !s.axis[d].U.empty() && !s.axis[d].span.empty()) { const Axis &ax = s.axis[d]; A.bndpt[0] = ax.U[ax.span[0]]; A.bndpt[1] = ax.U[ax.span[ax.nel - 1] + 1]; }
     A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
     A.prefix = B.prefix.as<int64_t>(); A.tot = 0; for (int r = 0; r < L.nrow; ++r) A.tot += L.rcnt[r];
   }
@@ -457,7 +478,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
       cv.hpart = 0;
       cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
-      cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2);
+      cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
       cv.phi = take(NFS * QC * NEP);
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
@@ -486,6 +507,32 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
       const size_t nblocks = per2 * sub.count[2];
       launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first, launches);
+      first = false;
+    }
+  }
+  // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447): the elements of this rank on a visited face,
+  // one point layer at the face; their K_e / F_e add to what the interior pass left (stream order)
+  for (int bid = 0; bid < 2 * DIM; ++bid) {
+    const int ax = bid / 2, sd = bid % 2;
+    if (!s.visit[ax][sd]) continue;
+    const int eface = sd ? s.elem_sizes[ax] - 1 : 0;
+    if (eface < s.elem_start[ax] || eface >= s.elem_start[ax] + s.elem_width[ax]) continue;   // face is on another rank
+    OutDev ob = out; ob.bid = bid;
+    int nc2[3] = {nc[0], nc[1], nc[2]}; nc2[ax] = 1;
+    for (int c2 = 0; c2 < nc2[2]; ++c2) for (int c1 = 0; c1 < nc2[1]; ++c1) for (int c0 = 0; c0 < nc2[0]; ++c0) {
+      const int cc[3] = {c0, c1, c2};
+      ColorRange cr; bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        if (d == ax) { cr.start[d] = eface - s.elem_start[ax]; cr.step[d] = 1; cr.count[d] = 1; continue; }
+        const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
+        int firstel = -1, count = 0;
+        for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+        if (count == 0) { empty = true; break; }
+        cr.start[d] = firstel; cr.step[d] = stride; cr.count[d] = count;
+      }
+      if (empty) continue;
+      const size_t nblocks = (size_t)cr.count[0] * cr.count[1] * cr.count[2];
+      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, ob, cr, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
   }
@@ -543,6 +590,8 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
   }
+  if (NS == 0) for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd)
+    if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes need the feature kernel (dim >= 2, nen <= 64, IGXSetKernel 0 or 3)");
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   int nq[3], na[3]; int NQ = 1, NE = 1;
@@ -633,6 +682,8 @@ static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
   case IGX_FORM_CAHNHILLIARD:
     if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);
     else return fail(IGX_ERR_ARG_WRONG, "Cahn-Hilliard form needs dim = 2 or 3");
+  case IGX_FORM_BOUNDARYINTEGRAL: return launch_generic<FormBoundaryIntegral<DIM>, DIM>(g, S, out);
+  case IGX_FORM_NITSCHE:          return launch_generic<FormNitsche<DIM>, DIM>(g, S, out);
   case IGX_FORM_NSVMS:
     if constexpr (DIM == 3) return launch_generic<FormNSVMS, 3>(g, S, out);
     else return fail(IGX_ERR_ARG_WRONG, "NavierStokesVMS form needs dim = 3");
@@ -655,7 +706,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd)
     if (s.load[a][sd].count && s.nsd) return fail(IGX_ERR_SUP, "boundary loads on mapped geometries are not supported on the device path");
   OutDev out; memset(&out, 0, sizeof(out));
-  out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>();
+  out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>(); out.bid = -1;
   { const char *e = getenv("IGX_DEBUG_FEATURE"); out.debug = e ? atoi(e) : 0; }
   if (out.debug & 8) { if (!g->dbgbuf.p) g->dbgbuf.alloc(32 * sizeof(long long)); HIPCK(hipMemsetAsync(g->dbgbuf.p, 0, 32 * sizeof(long long), g->stream)); out.dbg = g->dbgbuf.as<long long>(); }
   if (hasM) { out.browptr = A->browptr.as<int64_t>(); out.val = A->val.as<double>(); }
@@ -727,7 +778,7 @@ extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[]
   if (g->partials.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->partials.alloc(need)) return fail(IGX_ERR_MEM, "partial-sum buffer allocation failed"); }
   double *part = g->partials.as<double>(), *stage = part + (size_t)nel * ns, *res = stage + (size_t)nblk * ns;
   OutDev out; memset(&out, 0, sizeof(out));
-  out.op = OP_SCALAR; out.errflag = g->errflag.as<int>(); out.vec = part; out.U = U ? U->a.as<double>() : nullptr;
+  out.op = OP_SCALAR; out.bid = -1; out.errflag = g->errflag.as<int>(); out.vec = part; out.U = U ? U->a.as<double>() : nullptr;
   const SpaceDev Sd = make_spacedev(g);
   const std::vector<double> keep = s.params;            // the functional's parameters travel like a form's
   s.params.assign(params, params + nparams);

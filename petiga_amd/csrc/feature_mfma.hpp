@@ -48,7 +48,7 @@ struct FCarve {            // offsets in doubles into the dynamic LDS block
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, hpart, lift, phi;
-  int rowbase, rowid, cc, pax, adec, qdec;
+  int rowbase, rowid, cc, pax, adec, qdec, nrm;
   int total;
   int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
 };
@@ -132,6 +132,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+  constexpr bool HASB = has_boundary_of<Form>::v;                // the callback has an `atboundary` branch (bmat / bvec)
+  static_assert(!(HASB && PAIRS != 0ull), "forms with a boundary branch do not take the Gram path");
   constexpr bool GRAM = PAIRS != 0ull;                          // constant-coefficient form: accumulate feature Gram matrices
   static_assert(!GRAM || (DOFI == DOF && I0 == 0 && NFS <= 8), "Gram path forms all row fields in one launch");
   constexpr int NACC = !HASM ? 1 : (GRAM ? fm_popcount(PAIRS) : DOFI * DOF);
@@ -153,6 +155,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       nq[d] = S.ax[d].nqp; na[d] = S.ax[d].nen;
     }
   }
+  // boundary-form pass: one point on the face axis, basis from the end-of-axis table (src/petigaelem.c:796-823)
+  const int bid = out.bid; const bool bpass = bid >= 0;
+  const int baxis = bpass ? (bid >> 1) : -1, bside = bid & 1;
+  if (bpass) nq[baxis] = 1;
   const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
   const int QC = cv.QC, NQP = cv.QC * cv.nchunk;
   const int op = out.op;
@@ -166,7 +172,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   double *ufix = smem + cv.ufix, *fixval = smem + cv.fixval, *flux = smem + cv.flux;
   int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
   double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
-  double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
+  double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G, *nrm = smem + cv.nrm;
   double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift;
   double *phi = smem + cv.phi;                                  // [NFS][QC][NEP]
   long long *rowbase = reinterpret_cast<long long *>(smem + cv.rowbase);   // [NE] browptr of the row of basis function a
@@ -194,9 +200,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int n = nq[d] * na[d] * NDER;
-    const double *src = S.ax[d].tab + (size_t)el[d] * n;
+    const bool face = (d == baxis);
+    const double *src = face ? S.ax[d].bnd + (size_t)bside * n : S.ax[d].tab + (size_t)el[d] * n;
     for (int i = tid; i < n; i += nthr) t1d[d][i] = src[i];
-    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = S.ax[d].w[el[d] * nq[d] + i];
+    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = face ? 1.0 : S.ax[d].w[el[d] * nq[d] + i];
     const int Wd = 2 * S.ax[d].p + 1;
     for (int i = tid; i < na[d] * na[d]; i += nthr) {
       const int ad = i / na[d], bd = i - ad * na[d];
@@ -260,7 +267,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // split the sum over basis functions; partial sums meet in a fixed butterfly order (repeatable).
   double Jel = 1;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) Jel *= S.ax[d].J[el[d]];
+  for (int d = 0; d < 3; ++d) if (d != baxis) Jel *= S.ax[d].J[el[d]];   // bnd_detJac = 1
   {
     int np1 = pow2_floor(nthr / NQP); if (np1 > 16) np1 = 16;
     if (!geo && !rat) np1 = 1;
@@ -275,7 +282,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
       double x0[3], X1[9], X2[27];
 #pragma unroll
-      for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
+      for (int d = 0; d < DIM; ++d) x0[d] = (d == baxis) ? S.ax[d].bndpt[bside] : S.ax[d].pt[el[d] * nq[d] + qq[d]];
       if (rat) {
         w0 = 0;
         if (valid) for (int a = part; a < NE; a += np1) {
@@ -342,6 +349,26 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           }
         }
         if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      }
+      if (bpass) {   // K7: IGA_GetNormal, src/petigaval.F90:45-99; detJac *= detS instead of detX (src/petigaelem.c:1012-1029)
+        double n[3] = {0, 0, 0}, dS = 1;
+        if (!geo) n[baxis] = 1.0;
+        else if (DIM == 3) {
+          const int r1 = (baxis + 1) % 3, r2 = (baxis + 2) % 3;
+          const double s0 = X1[0 * DIM + r1], s1 = X1[1 * DIM + r1], s2 = X1[2 * DIM + r1];
+          const double t0 = X1[0 * DIM + r2], t1 = X1[1 * DIM + r2], t2 = X1[2 * DIM + r2];
+          n[0] = s1 * t2 - s2 * t1; n[1] = s2 * t0 - s0 * t2; n[2] = s0 * t1 - s1 * t0;
+          dS = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+          n[0] /= dS; n[1] /= dS; n[2] /= dS;
+        } else if (DIM == 2) {
+          double t0, t1;
+          if (baxis == 0) { t0 = +X1[0 * DIM + 1]; t1 = +X1[1 * DIM + 1]; } else { t0 = -X1[0 * DIM + 0]; t1 = -X1[1 * DIM + 0]; }
+          n[0] = +t1; n[1] = -t0;
+          dS = sqrt(n[0] * n[0] + n[1] * n[1]);
+          n[0] /= dS; n[1] /= dS;
+        }
+        for (int i = 0; i < DIM; ++i) nrm[q * DIM + i] = bside ? n[i] : -n[i];
+        detX = dS;
       }
       double w = 1;
 #pragma unroll
@@ -476,6 +503,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       PtView p;
       p.x = xq + q * DIM; p.u = fu + ql * DOF; p.ut = fut + ql * DOF; p.gu = fgu + ql * DOF * DIM; p.hu = fhu + (HU_FLY ? q : ql) * DOF * D2;
       p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+      p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
       return p;
     };
 
@@ -510,12 +538,13 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         } else {
 #pragma unroll
         for (int f = 0; f < NFS; ++f) {
-          if (!((FMASK >> f) & 1u)) continue;
+          if (!((FMASK >> f) & 1u) && !(HASB && bpass)) continue;
           double ef[NFS];
 #pragma unroll
           for (int g = 0; g < NFS; ++g) ef[g] = (g == f) ? 1.0 : 0.0;
           double T[DOF * DOF];
-          Form::mat(p, ef, nb, T);
+          if constexpr (HASB) { if (bpass) Form::bmat(p, ef, nb, T); else Form::mat(p, ef, nb, T); }
+          else Form::mat(p, ef, nb, T);
           double A[NTA];
 #pragma unroll
           for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + (ta0 + t) * 16 + (lane & 15)];
@@ -545,12 +574,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #pragma unroll
         for (int f = 0; f < NFS; ++f) Na[f] = phi[(f * QC + ql) * NEP + a];
         double R[DOF];
-        Form::vec(p, Na, R);
+        if constexpr (HASB) { if (bpass) Form::bvec(p, Na, R); else Form::vec(p, Na, R); }
+        else Form::vec(p, Na, R);
         if (dolift) {
 #pragma unroll
           for (int j = 0; j < DOF; ++j) {
             double T[DOF * DOF];
-            Form::mat(p, Na, lift + ((size_t)ql * DOF + j) * NFS, T);
+            if constexpr (HASB) { if (bpass) Form::bmat(p, Na, lift + ((size_t)ql * DOF + j) * NFS, T); else Form::mat(p, Na, lift + ((size_t)ql * DOF + j) * NFS, T); }
+            else Form::mat(p, Na, lift + ((size_t)ql * DOF + j) * NFS, T);
 #pragma unroll
             for (int i = 0; i < DOF; ++i) R[i] -= T[i * DOF + j];
           }
@@ -587,7 +618,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       }
       double kij[GRAM ? 4 : 1][GRAM ? DOF * DOF : 1];
       if constexpr (GRAM) {   // K^{ij} = sum_{fg} C^{ij}_{fg} M_fg; C = mat(e_f, e_g) folds to the form's constants
-        PtView p0; p0.x = xq; p0.u = fu; p0.ut = fut; p0.gu = fgu; p0.hu = fhu; p0.G = Gq; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t;
+        PtView p0; p0.x = xq; p0.u = fu; p0.ut = fut; p0.gu = fgu; p0.hu = fhu; p0.G = Gq; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t; p0.normal = nullptr; p0.atboundary = 0; p0.boundary_id = -1;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -618,7 +649,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           for (int j = 0; j < DOF; ++j) {
             double x;
             if constexpr (GRAM) x = kij[r][i * DOF + j]; else x = acc[i * DOF + j][t][r];
-            if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j) ? 1.0 : 0.0;
+            if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
             v[r][i * DOF + j] += x;
           }
         if (!(out.debug & 32)) store_run<DOFI * DOF>(dst[r], v[r]);
@@ -637,8 +668,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       for (int i = 0; i < DOF; ++i) {
         const int k = a * DOF + i;
         double v = Facc[i];
-        if (op == OP_SYSTEM) { v += flux[k]; if (fixflag[k]) v = fixval[k]; }                                         // src/petigaelem.c:1371-1387
-        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { v -= flux[k]; if (fixflag[k]) v = ufix[k] - fixval[k]; }  // :1449-1461
+        // FixSystem / FixFunction act once on the element sums; with the passes in separate launches the interior
+        // pass carries the constant parts (flux, fixed value) and a boundary pass only drops its fixed rows
+        if (op == OP_SYSTEM) { if (!bpass) v += flux[k]; if (fixflag[k]) v = bpass ? 0.0 : fixval[k]; }                                         // src/petigaelem.c:1371-1387
+        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { if (!bpass) v -= flux[k]; if (fixflag[k]) v = bpass ? 0.0 : ufix[k] - fixval[k]; }  // :1449-1461
         out.vec[row * DOF + i] += v;
       }
     }

@@ -22,6 +22,8 @@ struct PtView {
   const double *G;     // IGAPointFormInvGradGeomMap [DIM][DIM] (src/petigapoint.c:269-294)
   const double *prm;   // form parameters (replaces ctx)
   double shift, t;
+  const double *normal;  // unit outward normal [DIM] at a boundary-form point (p->normal), else null
+  int atboundary, boundary_id;   // IGAPoint::atboundary / boundary_id (include/petiga.h:650-652)
 };
 
 // demo/Poisson{1,2,3}D.c System (demo/Poisson3D.c:3-23)
@@ -239,6 +241,48 @@ struct FormNSVMS {
   }
 };
 
+
+// ---- forms with a boundary branch (`if (p->atboundary)` in the reference's callback): bmat / bvec are the
+// un-weighted integrands at a point of a visited face; JW there is detJac * weight * detS.
+template <class F, class = void> struct has_boundary_of { static constexpr bool v = false; };
+template <class F> struct has_boundary_of<F, decltype((void)F::HAS_BOUNDARY)> { static constexpr bool v = F::HAS_BOUNDARY; };
+
+// demo/BoundaryIntegral.c:26-56: Laplace inside (F = 0), Neumann data 1 on the visited faces
+template <int DIM> struct FormBoundaryIntegral {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr bool HAS_BOUNDARY = true;
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormPoisson<DIM>::mat(p, Na, Nb, T); }
+  static __device__ __forceinline__ void vec(const PtView &, const double *, double *R) { R[0] = 0.0; }
+  static __device__ __forceinline__ void bmat(const PtView &, const double *, const double *, double *T) { T[0] = 0.0; }
+  static __device__ __forceinline__ void bvec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * 1.0; }
+};
+
+// demo/NitscheMethod.c:69-110: Poisson with u = sum x_i^2 imposed weakly on the visited faces; params {k = max degree}
+template <int DIM> struct FormNitsche {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X | NEED_G;
+  static constexpr bool HAS_BOUNDARY = true;
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { FormPoisson<DIM>::mat(p, Na, Nb, T); }
+  static __device__ __forceinline__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * (-2.0 * DIM); }
+  static __device__ __forceinline__ double alpha(const PtView &p) {   // C/h, h = NormalMeshSize (:57-66)
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { double Ni = 0; for (int j = 0; j < DIM; ++j) Ni += p.G[i * DIM + j] * p.normal[j]; s += Ni * Ni; }
+    const double h = 2 / sqrt(s), C = 5 * (p.prm[0] + 1);
+    return C / h;
+  }
+  static __device__ __forceinline__ void bmat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double dna = 0, dnb = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { dna += Na[1 + i] * p.normal[i]; dnb += Nb[1 + i] * p.normal[i]; }
+    T[0] = -Na[0] * dnb - Nb[0] * dna + alpha(p) * Na[0] * Nb[0];
+  }
+  static __device__ __forceinline__ void bvec(const PtView &p, const double *Na, double *R) {
+    double g = 0, dna = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) { g += p.x[i] * p.x[i]; dna += Na[1 + i] * p.normal[i]; }
+    R[0] = -dna * g + alpha(p) * Na[0] * g;
+  }
+};
 
 // ---- scalar functionals: the point callbacks handed to IGAComputeScalar (src/petigacomp.c:35-98).  scalar() returns
 // the integrand values S[NSCALAR] at one point; the kernel multiplies by JW and sums (IGAPointAddArray, petigapoint.c:461).

@@ -807,6 +807,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return no("only System / Matrix drivers");
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
   if (s.nsd) return no("mapped geometry");
+  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
   if (S.fixtable) return no("fix table");
   const int deg = s.axis[0].p;
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");

@@ -174,6 +174,13 @@ int basis_init(Basis1D &b, const Axis &ax, int nqp, std::string &err) {
       bspline_ders(k, u, p, d, ax.U.data(), &b.value[((size_t)e * nqp + q) * nen * 5]);
     }
   }
+  {   // basis at the two ends of the axis for boundary-form passes (src/petigabasis.c:196-216)
+    const int k0 = ax.span[0], k1 = ax.span[nel - 1];
+    b.bnd_point[0] = ax.U[k0]; b.bnd_point[1] = ax.U[k1 + 1];
+    for (int sd = 0; sd < 2; ++sd) b.bnd_value[sd].assign((size_t)nen * 5, 0.0);
+    bspline_ders(k0, b.bnd_point[0], p, d, ax.U.data(), b.bnd_value[0].data());
+    bspline_ders(k1, b.bnd_point[1], p, d, ax.U.data(), b.bnd_value[1].data());
+  }
   return 0;
 }
 

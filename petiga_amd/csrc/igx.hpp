@@ -19,6 +19,8 @@ struct Basis1D {              // struct _n_IGABasis, include/petiga.h:122-141
   int nel = 0, nqp = 0, nen = 0;
   std::vector<int> offset;
   std::vector<double> detJac, weight, point, value;   // value: [nel][nqp][nen][5]
+  std::vector<double> bnd_value[2];                   // [nen][5] at the first / last knot (bnd_value, include/petiga.h:136)
+  double bnd_point[2] = {0, 0};
 };
 
 struct BC {                   // struct _IGAFormBC, include/petiga.h:220-225
@@ -70,6 +72,7 @@ struct Space {
   std::vector<double> netX, netW;         // global control net (geometry grid, natural order) kept for IGXWrite / re-partitioning
   int net_nsd = 0;
   BC value[3][2], load[3][2];
+  bool visit[3][2] = {{false, false}, {false, false}, {false, false}};   // IGAFormSetBoundaryForm, src/petigaform.c:134
   IGXFormKind form = IGX_FORM_NONE;
   std::vector<double> params;
   bool setup = false;
@@ -93,6 +96,8 @@ struct AxisDev {
   const double *w;     // [nel][nqp]
   const double *J;     // [nel]
   const double *pt;    // [nel][nqp]
+  const double *bnd;   // [2 sides][nen][NDER] basis at the first / last knot of the axis
+  double bndpt[2];
   const int *off;      // [nel]  ghost-local index of the element's first basis function
   const int *rowmap;   // [gwidth]
   const int *rcnt;     // [nrow]
@@ -122,6 +127,7 @@ struct OutDev {
   double shift, t;
   int op;
   int *errflag;
+  int bid;                 // boundary-form pass: 2*axis+side (IGAElementNextForm, src/petigaelem.c:427); -1 = interior pass
   int debug;               // experiment switches (IGX_DEBUG_FEATURE): 1 no scatter, 2 atomic scatter, 4 no MFMA phase
   long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
