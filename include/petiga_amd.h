@@ -194,7 +194,8 @@ int IGXComputeIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXMat J);  
 /* Functionals of a discrete field: S[k] = sum over this rank's elements and points of JW * scalar_k(point)
  * (IGAComputeScalar, src/petigacomp.c:35-98, before its MPI_Allreduce: with several ranks the caller sums S over the
  * ranks, and U must hold the ghost rows' values).  The point callbacks are the ones the reference's tests use:
- *   IGX_SCALAR_VOLUME  n=1  test/IGAGeometryMap.c:383 (interior pass): volume of the mapped domain; U may be NULL
+ *   IGX_SCALAR_VOLUME  n=2  test/IGAGeometryMap.c:383: S[0] volume of the mapped domain, S[1] area of the faces marked with
+ *                           IGXSetBoundaryForm (boundary passes: normals, detS); U may be NULL
  *   IGX_SCALAR_X2ERR   n=1  src/petigacomp.c:102 (ErrorSqr) with Exact = sum x_i^2 (test/IGAFixTable.c:66), dof 1
  *   IGX_SCALAR_ERRNORM n=4  ErrorSqr with test/IGAErrNorm.c:26 as Exact, dof 4; params {k}: k=0 values, 1 gradients,
  *                           2 Hessians; U NULL gives the norms of the exact fields (squared, like IGAComputeErrorNorm

@@ -282,7 +282,7 @@ class IGX:
     def compute_scalar(self, kind, U=None, params=()):
         """IGAComputeScalar for one of the built-in functionals; returns the rank-local sums."""
         k = SCALARS[kind] if isinstance(kind, str) else kind
-        n = 4 if k == SCALARS["errnorm"] else 1
+        n = 4 if k == SCALARS["errnorm"] else (2 if k == SCALARS["volume"] else 1)
         out = np.zeros(n)
         p = np.ascontiguousarray(params, dtype=np.float64)
         _ck(lib().IGXComputeScalar(self.h, U.h if U is not None else None, k, p.ctypes.data_as(_dp) if p.size else None, p.size, n, out.ctypes.data_as(_dp)))

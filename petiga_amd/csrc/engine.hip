@@ -449,6 +449,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
   constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
   constexpr int NTA = (TA == 4) ? 16 / NW : 1;
+  constexpr int SCALN = nscalar_of<Form>::v;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
@@ -477,7 +478,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0);
       cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
       cv.hpart = 0;
-      cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
+      cv.lift = take(SCALN > 0 ? QC * SCALN : (out.op == OP_SYSTEM ? QC * DOF * NFS : 0));
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
       cv.phi = take(NFS * QC * NEP);
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
@@ -489,7 +490,10 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   ParamsDev prm; memset(&prm, 0, sizeof(prm));
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
   int launches = 0; bool first = true;
-  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  constexpr bool SCAL = nscalar_of<Form>::v > 0;     // nothing is scattered: every element in one sweep, one partial row each
+  int64_t elem_base = 0;
+  int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  if (SCAL) nc[0] = nc[1] = nc[2] = 1;
   for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
     const int cc[3] = {c0, c1, c2};
     ColorRange cr; bool empty = false;
@@ -497,8 +501,9 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
       int firstel = -1, count = 0;
       for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+      if (SCAL) { firstel = 0; count = nel; }
       if (count == 0) { empty = true; break; }
-      cr.start[d] = firstel; cr.step[d] = stride; cr.count[d] = count;
+      cr.start[d] = firstel; cr.step[d] = SCAL ? 1 : stride; cr.count[d] = count;
     }
     if (empty) continue;
     const size_t per2 = (size_t)cr.count[0] * cr.count[1];
@@ -506,7 +511,8 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
     for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
       ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
       const size_t nblocks = per2 * sub.count[2];
-      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, out, sub, cv, nblocks, lds_bytes, first, launches);
+      OutDev o2 = out; o2.elem_base = elem_base; elem_base += (int64_t)nblocks;
+      launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, o2, sub, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
   }
@@ -527,11 +533,13 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
         const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
         int firstel = -1, count = 0;
         for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+        if (SCAL) { firstel = 0; count = nel; }
         if (count == 0) { empty = true; break; }
-        cr.start[d] = firstel; cr.step[d] = stride; cr.count[d] = count;
+        cr.start[d] = firstel; cr.step[d] = SCAL ? 1 : stride; cr.count[d] = count;
       }
       if (empty) continue;
       const size_t nblocks = (size_t)cr.count[0] * cr.count[1] * cr.count[2];
+      ob.elem_base = elem_base; elem_base += (int64_t)nblocks;
       launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, ob, cr, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
@@ -548,26 +556,27 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
 template <class Form, int DIM, int TA>
 static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   constexpr int DOF = Form::DOF;
+  constexpr int NW = (TA == 4) ? 8 : 4;
   // 4x4 tiles: 8 waves, <= 144 accumulator VGPRs per wave (dof 4: two launches of two row fields).  Measured on
   // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s; three launches of one row
   // field with 4 waves and two workgroups per CU 1.60 M elements/s (tabulation repeated per launch).
-  const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
-  if (!hasM) {
-    if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, DOF, false>(g, S, out, done);
-    else return launch_feature_plan<Form, DIM, TA, 4, DOF, false>(g, S, out, done);
+  if constexpr (nscalar_of<Form>::v > 0) return launch_feature_plan<Form, DIM, TA, NW, DOF, false>(g, S, out, done);
+  else {
+    const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+    if (!hasM) return launch_feature_plan<Form, DIM, TA, NW, DOF, false>(g, S, out, done);
+    constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
+    return launch_feature_plan<Form, DIM, TA, NW, ((TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF), true>(g, S, out, done);
   }
-  constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
-  if constexpr (TA == 4) return launch_feature_plan<Form, DIM, 4, 8, ((DOF == 4 && !GRAM) ? 2 : DOF), true>(g, S, out, done);
-  else return launch_feature_plan<Form, DIM, TA, 4, DOF, true>(g, S, out, done);
 }
 
 template <class Form, int DIM>
 static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   done = false;
-  if constexpr (DIM < 2 || nscalar_of<Form>::v > 0) return 0;
+  if constexpr (DIM < 2) return 0;
   else {
     const Space &s = g->s;
-    if (s.dof != Form::DOF) return 0;
+    constexpr bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+    if (s.dof != Form::DOF && (nscalar_of<Form>::v == 0 || fields)) return 0;
     int NE = 1; for (int d = 0; d < 3; ++d) NE *= s.basis[d].nen;
     if (NE > 64) return 0;
     if (NE <= 16) return launch_feature_ta<Form, DIM, 1>(g, S, out, done);
@@ -590,7 +599,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
   }
-  if (NS == 0) for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd)
+  for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd)
     if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes need the feature kernel (dim >= 2, nen <= 64, IGXSetKernel 0 or 3)");
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
@@ -766,17 +775,22 @@ extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[]
   Space &s = g->s;
   if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
   if (!S || n < 1) return fail(IGX_ERR_ARG_WRONG, "null result array");
-  const int ns = (kind == IGX_SCALAR_ERRNORM) ? 4 : 1;
+  const int ns = (kind == IGX_SCALAR_ERRNORM) ? 4 : (kind == IGX_SCALAR_VOLUME ? 2 : 1);
   if (n != ns) return fail(IGX_ERR_ARG_WRONG, "this functional returns " + std::to_string(ns) + " scalars");
   if (nparams < 0 || nparams > MAXPARAM || (nparams && !params)) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad parameter list");
   const int order = (kind == IGX_SCALAR_ERRNORM && nparams > 0) ? (int)params[0] : 0;
   if (order < 0 || order > 2) return fail(IGX_ERR_ARG_OUTOFRANGE, "derivative order must be in range [0,2]");
-  const int64_t nel = (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+  int64_t nel = (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+  for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd) {   // one more partial row per element of a visited face
+    const int eface = sd ? s.elem_sizes[a] - 1 : 0;
+    if (s.visit[a][sd] && eface >= s.elem_start[a] && eface < s.elem_start[a] + s.elem_width[a]) nel += (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] / s.elem_width[a];
+  }
   const int nblk = (int)std::min<int64_t>(1024, (nel + 255) / 256);
   const int64_t chunk = (nel + nblk - 1) / nblk;
   const size_t need = ((size_t)nel + nblk + 1) * ns * sizeof(double);
   if (g->partials.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->partials.alloc(need)) return fail(IGX_ERR_MEM, "partial-sum buffer allocation failed"); }
   double *part = g->partials.as<double>(), *stage = part + (size_t)nel * ns, *res = stage + (size_t)nblk * ns;
+  HIPCK(hipMemsetAsync(part, 0, (size_t)nel * ns * sizeof(double), g->stream));
   OutDev out; memset(&out, 0, sizeof(out));
   out.op = OP_SCALAR; out.bid = -1; out.errflag = g->errflag.as<int>(); out.vec = part; out.U = U ? U->a.as<double>() : nullptr;
   const SpaceDev Sd = make_spacedev(g);

@@ -132,6 +132,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+  constexpr int NS = nscalar_of<Form>::v;                       // > 0: a functional (IGAComputeScalar), no matrix / vector phases
+  static_assert(NS == 0 || !HASM, "functionals have no matrix part");
   constexpr bool HASB = has_boundary_of<Form>::v;                // the callback has an `atboundary` branch (bmat / bvec)
   static_assert(!(HASB && PAIRS != 0ull), "forms with a boundary branch do not take the Gram path");
   constexpr bool GRAM = PAIRS != 0ull;                          // constant-coefficient form: accumulate feature Gram matrices
@@ -162,7 +164,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
   const int QC = cv.QC, NQP = cv.QC * cv.nchunk;
   const int op = out.op;
-  const bool hasV = (I0 == 0) && (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
+  const bool hasV = (NS == 0) && (I0 == 0) && (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
   const bool geo = S.nsd > 0, rat = S.rational != 0;
 
@@ -227,7 +229,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
     const int aa[3] = {a0, a1, a2};
     for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
-    if (op != OP_MATRIX && op != OP_VECTOR) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283)
+    if (op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283); IGAComputeScalar reads U as it is
       for (int d = 0; d < DIM; ++d) {
         if (S.ax[d].periodic) continue;
         for (int side = 0; side < 2; ++side) {
@@ -509,7 +511,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
     FM_STAMP();
     // ---- phase 5: K_e += A^T B on the matrix cores
-    if (HASM && wave_active && !(out.debug & 4)) {
+    if constexpr (HASM) if (wave_active && !(out.debug & 4)) {
       const int kq = lane >> 4, col = tb * 16 + (lane & 15);
       for (int s = 0; s < QC / 4; ++s) {
         const int ql = 4 * s + kq, q = qc0 + ql;
@@ -565,7 +567,19 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     FM_STAMP();
     // ---- phase 6: F_e (vector part of IGAFormSystem), Dirichlet lifting through linearity of mat in Nb;
     // npv adjacent lanes share one basis function and split the points
-    if (hasV && tid < NE * npv) {
+    if constexpr (NS > 0) {
+      // ---- IGAComputeScalar (src/petigacomp.c:35-98): per point JW * scalar(p), summed per element in a fixed order
+      for (int ql = tid; ql < QC; ql += nthr) {
+        const int q = qc0 + ql;
+        double Sq[NS];
+        if (q < NQ) { const PtView p = point(q, ql); Form::scalar(p, Sq); }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lift[ql * NS + i] = (q < NQ) ? Sq[i] * JW[q] : 0.0;
+      }
+      __syncthreads();
+      if (tid < NS) for (int ql = 0; ql < QC; ++ql) Facc[0] += lift[ql * NS + tid];
+    }
+    if constexpr (NS == 0) if (hasV && tid < NE * npv) {
       const int a = tid / npv, part = tid & (npv - 1);
       const int qn = (qc0 + QC <= NQ) ? QC : (NQ - qc0 > 0 ? NQ - qc0 : 0);
       for (int ql = part; ql < qn; ql += npv) {
@@ -596,7 +610,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free).
   // Per tile the four row groups are read together, then written: 4 x DOFI*DOF loads in flight per lane.
-  if (HASM && wave_active && !(out.debug & 1)) {
+  if constexpr (HASM) if (wave_active && !(out.debug & 1)) {
     const int b = tb * 16 + (lane & 15);
     const int bp = adec[b];
     const int b0 = bp & 255, b1 = (bp >> 8) & 255, b2 = bp >> 16;
@@ -658,6 +672,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     }
   }
   FM_STAMP();
+  if constexpr (NS > 0) { if (tid < NS) out.vec[(out.elem_base + blockIdx.x) * NS + tid] = Facc[0]; }
   if (hasV && tid < NE * npv) {   // IGAElementFixSystem / FixFunction on F_e, IGAElementAssembleVec
     const int a = tid / npv, part = tid & (npv - 1);
 #pragma unroll

@@ -335,10 +335,11 @@ template <int DIM> struct ScalarX2Err {
   }
 };
 
-// test/IGAGeometryMap.c:383-389 (Scalar), interior pass: the volume of the mapped domain; any dof
+// test/IGAGeometryMap.c:383-389 (Scalar): S[0] volume of the mapped domain (interior pass), S[1] area of the visited
+// faces (boundary passes); any dof
 template <int DIM> struct ScalarVolume {
-  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 1; static constexpr unsigned NEED = 0;
-  static __device__ __forceinline__ void scalar(const PtView &, double *S) { S[0] = 1.0; }
+  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 2; static constexpr unsigned NEED = 0;
+  static __device__ __forceinline__ void scalar(const PtView &p, double *S) { S[0] = p.atboundary ? 0.0 : 1.0; S[1] = p.atboundary ? 1.0 : 0.0; }
 };
 
 }  // namespace igx

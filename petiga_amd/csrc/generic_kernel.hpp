@@ -310,7 +310,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     for (int q = tid; q < NQ; q += nthr) {
       PtView p;
       p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
       double Sq[NS];
       Form::scalar(p, Sq);
       const double jw = JW[q];
@@ -339,7 +339,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   auto point = [&](int q) {
     PtView p;
     p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
     return p;
   };
   const int W0s = 2 * S.ax[0].p + 1, W1s = 2 * S.ax[1].p + 1, W2s = 2 * S.ax[2].p + 1;

@@ -68,7 +68,7 @@ def test_volume_of_mapped_domain(dim, dof):
     orc.set_geometry(X, W); eng.set_geometry(X, W)
     So = orc.compute_scalar("orc_scalar_volume", 2)
     S = eng.compute_scalar("volume")
-    assert _rel(S, So[:1]) < TOL
+    assert _rel(S[:1], So[:1]) < TOL
 
 
 def test_scalar_argument_errors():
@@ -81,7 +81,7 @@ def test_scalar_argument_errors():
         eng.compute_scalar(9)
     assert e.value.code == 63
     out = np.zeros(2)
-    assert P.lib().IGXComputeScalar(eng.h, None, 1, None, 0, 2, out.ctypes.data_as(P._dp)) == 62
+    assert P.lib().IGXComputeScalar(eng.h, None, 2, None, 0, 2, out.ctypes.data_as(P._dp)) == 62
 
 
 def test_scalar_full_size():
@@ -91,3 +91,18 @@ def test_scalar_full_size():
     S = eng.compute_scalar("x2err")[0]
     # int_[0,1]^3 (x^2+y^2+z^2)^2 = 3/5 + 6/9 (exact for a 3-point rule: degree 4 per axis)
     assert abs(S - (3 / 5 + 6 / 9)) < 1e-12
+
+
+@pytest.mark.parametrize("dim,p,N", [(2, 3, 6), (3, 2, 4), (3, (3, 2, 3), (3, 4, 2))])
+def test_surface_area_on_warped_geometry(dim, p, N):
+    # boundary passes of IGAComputeScalar (IGAComputeScalarFull of test/IGAGeometryMap.c:391-450): normals, detS
+    orc, eng = make_pair(dim, 1, p, N)
+    X, W = warped_geometry(orc, dim, seed=21, rational=True, amp=0.12)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    faces = [(a, s) for a in range(dim) for s in range(2)][1::2] + [(0, 0)]
+    for a, s in faces:
+        orc.set_boundary_form(a, s, True); eng.set_boundary_form(a, s, True)
+    So = orc.compute_scalar("orc_scalar_volume", 2, full=True)
+    S = eng.compute_scalar("volume")
+    assert _rel(S, So) < TOL, (S, So)
+    assert np.array_equal(S, eng.compute_scalar("volume"))

@@ -59,9 +59,15 @@ def test_annulus_from_file_on_device(tmp_path, dim):
     for i in range(dim):
         eng.set_quadrature(i, d[i] + 3)
     eng.setup()
+    for a in range(dim):
+        for s in range(2):
+            eng.set_boundary_form(a, s, True)
     A = np.pi * (4 - 1) / 4
-    vol = eng.compute_scalar("volume")[0]
-    assert abs(vol - (A if dim == 2 else 2 * A)) < 1e-6       # test/IGAGeometryMap.c:545-556, its tolerance
+    Pm = 2 * (2 - 1) + np.pi * (2 + 1) / 2
+    vol, area = eng.compute_scalar("volume")
+    assert abs(vol - (A if dim == 2 else 2 * A)) < 1e-6       # test/IGAGeometryMap.c:545-568, its tolerance
+    assert abs(area - (Pm if dim == 2 else 2 * A + 2 * Pm)) < 1e-6
+    eng.clear_boundary()
     # the same discretisation in the oracle: Poisson parity on the rational geometry
     orc = O.OracleIGA(dim, 1)
     for i in range(dim):
