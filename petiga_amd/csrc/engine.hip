@@ -468,7 +468,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       const int QC = (((NQ4 + nchunk - 1) / nchunk) + 3) & ~3, NQP = QC * nchunk;
       int pos = 0;
       auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };
-      for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(nq[d]); }
+      for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(2 * nq[d]); }
       cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
       cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
       cv.JW = take(NQP); cv.xq = take(NQP * DIM); cv.E1 = take(s.nsd ? NQP * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQP * DIM * D2 : 0);

@@ -199,32 +199,54 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     const int q0 = q % nq[0], q1 = (q / nq[0]) % nq[1], q2 = q / (nq[0] * nq[1]);
     qdec[q] = (q < NQ) ? (q0 | (q1 << 8) | (q2 << 16)) : 0;
   }
+  // Stage A: every global load that depends on the element position only is issued before anything waits on one
+  // (the loads of a workgroup are latency bound: one round trip instead of one per table).  All tables have at most
+  // 8 * 8 * NDER = 256 <= blockDim entries, so one entry per thread.
+  double tv[3] = {0, 0, 0}, wv[3] = {1, 1, 1}, ptv[3] = {0, 0, 0}, Jax[3]; int pv[3] = {0, 0, 0};
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int n = nq[d] * na[d] * NDER;
     const bool face = (d == baxis);
     const double *src = face ? S.ax[d].bnd + (size_t)bside * n : S.ax[d].tab + (size_t)el[d] * n;
-    for (int i = tid; i < n; i += nthr) t1d[d][i] = src[i];
-    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = face ? 1.0 : S.ax[d].w[el[d] * nq[d] + i];
+    if (tid < n) tv[d] = src[tid];
+    if (tid < nq[d]) { if (face) ptv[d] = S.ax[d].bndpt[bside]; else { wv[d] = S.ax[d].w[el[d] * nq[d] + tid]; ptv[d] = S.ax[d].pt[el[d] * nq[d] + tid]; } }
+    Jax[d] = S.ax[d].J[el[d]];
     const int Wd = 2 * S.ax[d].p + 1;
-    for (int i = tid; i < na[d] * na[d]; i += nthr) {
-      const int ad = i / na[d], bd = i - ad * na[d];
-      pax[d * 64 + ad * 8 + bd] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)];
-    }
+    if (tid < na[d] * na[d]) { const int ad = tid / na[d], bd = tid - ad * na[d]; pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)]; }
   }
   const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
   const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
-  for (int a = tid; a < NE; a += nthr) {
-    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
-    const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
-    const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
-    const int r0 = S.ax[0].rowmap[i0], r1 = S.ax[1].rowmap[i1], r2 = S.ax[2].rowmap[i2];
+  const bool isa = tid < NE;                     // nen <= 64 <= blockDim: one basis function per thread
+  const int a = isa ? tid : 0;
+  const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+  const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
+  const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
+  int r0 = 0, r1 = 0, r2 = 0; double xg[DIM], wg = 1;
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) xg[c] = 0;
+  if (isa) {
+    r0 = S.ax[0].rowmap[i0]; r1 = S.ax[1].rowmap[i1]; r2 = S.ax[2].rowmap[i2];
+    if (geo) for (int c = 0; c < DIM; ++c) xg[c] = S.X[g * DIM + c];
+    if (rat) wg = S.W[g];
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (tid < nq[d] * na[d] * NDER) t1d[d][tid] = tv[d];
+    if (tid < nq[d]) { w1d[d][tid] = wv[d]; w1d[d][nq[d] + tid] = ptv[d]; }   // weights, then point coordinates
+    if (tid < na[d] * na[d]) { const int ad = tid / na[d], bd = tid - ad * na[d]; pax[d * 64 + ad * 8 + bd] = pv[d]; }
+  }
+  FM_STAMP();
+  // Stage B: what depends on the row indices
+  if (isa) {
     const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
     rowid[a] = (long long)row;
-    if (HASM) rowbase[a] = out.browptr[row];
-    cc[a] = S.ax[0].rcnt[r0]; cc[NE + a] = S.ax[1].rcnt[r1];
-    if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
-    if (rat) gW[a] = S.W[g];
+    const int c0r = S.ax[0].rcnt[r0], c1r = S.ax[1].rcnt[r1];
+    // browptr[row] in closed form from the per-axis prefix tables (k_browptr): small, cache-resident tables instead of a
+    // dependent load from the 8-byte-per-row array in HBM
+    if (HASM) rowbase[a] = S.ax[2].prefix[r2] * S.ax[1].tot * S.ax[0].tot + (long long)S.ax[2].rcnt[r2] * (S.ax[1].prefix[r1] * S.ax[0].tot + (long long)c1r * S.ax[0].prefix[r0]);
+    cc[a] = c0r; cc[NE + a] = c1r;
+    if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = xg[c];
+    if (rat) gW[a] = wg;
     if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
     if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
     const int aa[3] = {a0, a1, a2};
@@ -247,7 +269,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           if (bl.count) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132)
             double A = 1;
             if (DIM > 1) {
-              for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
+              for (int i = 0; i < DIM; ++i) if (i != d) A *= Jax[i] / (double)na[i];
               A *= (DIM == 2) ? 2 : 4;
             }
             for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
@@ -256,6 +278,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       }
     }
   }
+  FM_STAMP();
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
   if (anyfix && (useU || useV)) {   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
@@ -269,7 +292,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // split the sum over basis functions; partial sums meet in a fixed butterfly order (repeatable).
   double Jel = 1;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) if (d != baxis) Jel *= S.ax[d].J[el[d]];   // bnd_detJac = 1
+  for (int d = 0; d < 3; ++d) if (d != baxis) Jel *= Jax[d];   // bnd_detJac = 1
   {
     int np1 = pow2_floor(nthr / NQP); if (np1 > 16) np1 = 16;
     if (!geo && !rat) np1 = 1;
@@ -284,7 +307,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
       double x0[3], X1[9], X2[27];
 #pragma unroll
-      for (int d = 0; d < DIM; ++d) x0[d] = (d == baxis) ? S.ax[d].bndpt[bside] : S.ax[d].pt[el[d] * nq[d] + qq[d]];
+      for (int d = 0; d < DIM; ++d) x0[d] = w1d[d][nq[d] + qq[d]];
       if (rat) {
         w0 = 0;
         if (valid) for (int a = part; a < NE; a += np1) {
