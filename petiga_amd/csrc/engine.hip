@@ -453,7 +453,9 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
-  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  const bool vec_op = (out.op == OP_SYSTEM || out.op == OP_VECTOR || out.op == OP_FUNCTION || out.op == OP_IFUNCTION);
+  const unsigned need = (vec_op || SCALN > 0) ? Form::NEED : mat_need_of<Form>::v;   // as in the kernel: matrix-only drivers skip residual-only point data
+  const bool fields = (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   const size_t lds_limit = 160 * 1024 - 512;
   // Fewest chunks of points wins almost everywhere (measured: CahnHilliard p=2 tangent 12.5 vs 9.9 M elements/s,
   // NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 for one chunk vs a 78 KiB cap).  The exception is a scalar form at
@@ -475,8 +477,8 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.W0 = take(s.rational ? NQP : 0); cv.W1 = take(s.rational ? NQP * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQP * D2 : 0);
       cv.G = take((Form::NEED & NEED_G) ? NQP * D2 : 0);
       cv.u = take(fields ? QC * DOF : 0); cv.ut = take(fields ? QC * DOF : 0);
-      cv.gu = take((Form::NEED & NEED_GU) ? QC * DOF * DIM : 0);
-      cv.hu = take((Form::NEED & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
+      cv.gu = take((need & NEED_GU) ? QC * DOF * DIM : 0);
+      cv.hu = take((need & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
       cv.hpart = 0;
       cv.lift = take(SCALN > 0 ? QC * SCALN : (out.op == OP_SYSTEM ? QC * DOF * NFS : 0));
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);

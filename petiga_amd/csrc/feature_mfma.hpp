@@ -43,6 +43,11 @@ template <class F> struct mat_pair_mask_of<F, decltype((void)F::MAT_PAIR_MASK)> 
 constexpr int fm_popcount(unsigned long long m) { int n = 0; while (m) { n += (int)(m & 1ull); m >>= 1; } return n; }
 constexpr int fm_pair_index(unsigned long long mask, int f, int g) { return fm_popcount(mask & ((1ull << (f * 8 + g)) - 1ull)); }
 
+// point data the MATRIX callback reads (default: everything the form reads anywhere); matrix-only drivers
+// (Jacobian / IJacobian / Matrix) skip the rest, e.g. the field Hessians NS-VMS needs for its residual alone
+template <class F, class = void> struct mat_need_of { static constexpr unsigned v = F::NEED; };
+template <class F> struct mat_need_of<F, decltype((void)F::MAT_NEED)> { static constexpr unsigned v = F::MAT_NEED; };
+
 struct FCarve {            // offsets in doubles into the dynamic LDS block
   int t1d[3], w1d[3];
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
@@ -65,13 +70,13 @@ __device__ __forceinline__ void shape_features(const double *const t1d[3], const
   double b0, b1[3], b2[9];
   tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
   if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
-    const double w = gW[a], w0 = W0[q];
-    const double r0 = w * b0 / w0;
+    const double w = gW[a], iw0 = 1.0 / W0[q];   // one reciprocal instead of 1 + DIM (+ DIM^2) divisions
+    const double r0 = w * b0 * iw0;
     double r1[3];
-    for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[q * DIM + i]) / w0;
+    for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[q * DIM + i]) * iw0;
     if (SECOND)
       for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-        b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[q * D2 + i * DIM + j] - r1[i] * W1[q * DIM + j] - r1[j] * W1[q * DIM + i]) / w0;
+        b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[q * D2 + i * DIM + j] - r1[i] * W1[q * DIM + j] - r1[j] * W1[q * DIM + i]) * iw0;
     b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
   }
   o[0] = b0;
@@ -167,6 +172,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool hasV = (NS == 0) && (I0 == 0) && (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
   const bool geo = S.nsd > 0, rat = S.rational != 0;
+  const unsigned need = (hasV || NS > 0) ? Form::NEED : mat_need_of<Form>::v;
 
   double *t1d[3] = {smem + cv.t1d[0], smem + cv.t1d[1], smem + cv.t1d[2]};
   double *w1d[3] = {smem + cv.w1d[0], smem + cv.w1d[1], smem + cv.w1d[2]};
@@ -324,6 +330,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         if (SECOND) for (int i = 0; i < D2; ++i) w2[i] = group_sum(w2[i], np1);
         if (!valid) w0 = 1;
       }
+      const double iw0 = 1.0 / w0;
       if (geo) {
         for (int i = 0; i < DIM; ++i) x0[i] = 0;
         for (int i = 0; i < D2; ++i) X1[i] = 0;
@@ -334,12 +341,12 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
           if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
             const double w = gW[a];
-            const double r0 = w * b0 / w0;
+            const double r0 = w * b0 * iw0;
             double r1[3];
-            for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
+            for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) * iw0;
             if (SECOND)
               for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-                b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
+                b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) * iw0;
             b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
           }
           for (int i = 0; i < DIM; ++i) {
@@ -410,7 +417,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   }
   __syncthreads();
 
-  if (HU_FLY) {
+  if (HU_FLY && (need & NEED_HU)) {
     // Hessians of the fields when the form itself never reads second derivatives of N: the second-derivative
     // features are formed on the fly (never stored), nph lanes per point; done for all points before the
     // accumulators become live
@@ -484,7 +491,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
     FM_STAMP();
     // ---- phase 3: field values at the chunk's points (src/petigaval.F90:182-232); np3 lanes per (point, field)
-    if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
+    if (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
       {
         int np3 = pow2_floor(nthr / (QC * DOF)); if (np3 > 16) np3 = 16;
         const int istep = nthr / np3;
@@ -499,16 +506,16 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             const double f0 = phi[(0 * QC + ql) * NEP + a];
             u += f0 * Ua;
             if (useV) ut += f0 * Ve[a * DOF + c];
-            if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
-            if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
+            if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
+            if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
           }
           u = group_sum(u, np3); ut = group_sum(ut, np3);
-          if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] = group_sum(g[i], np3);
-          if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] = group_sum(h[i], np3);
+          if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) g[i] = group_sum(g[i], np3);
+          if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] = group_sum(h[i], np3);
           if (valid && part == 0) {
             fu[idx] = u; fut[idx] = ut;
-            if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
-            if (SECOND_S && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
+            if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];   // regions exist only when needed
+            if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
           }
         }
       }

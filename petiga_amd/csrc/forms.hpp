@@ -164,6 +164,7 @@ template <int DIM> struct FormCahnHilliard {
 // demo/NavierStokesVMS.c:9-244 (Tau, FineScale, Residual, Tangent); params {nu, fx, fy, fz, dt}
 struct FormNSVMS {
   static constexpr int SHAPE_ORDER = 1;   // Residual/Tangent read N and grad N only; Hessians are needed of U alone
+  static constexpr unsigned MAT_NEED = NEED_U | NEED_G;   // Tangent (:166-244) reads u and the metric tensor only
   static constexpr int DOF = 4, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_G;
   static __device__ __forceinline__ void tau(const PtView &p, double &tauM, double &tauC) {
     const double *J = p.G; const double nu = p.prm[0], dt = p.prm[4], C_I = 1.0 / 12.0;
