@@ -43,6 +43,11 @@ template <class F> struct mat_pair_mask_of<F, decltype((void)F::MAT_PAIR_MASK)> 
 constexpr int fm_popcount(unsigned long long m) { int n = 0; while (m) { n += (int)(m & 1ull); m >>= 1; } return n; }
 constexpr int fm_pair_index(unsigned long long mask, int f, int g) { return fm_popcount(mask & ((1ull << (f * 8 + g)) - 1ull)); }
 
+// optional per-block refinement of MAT_TEST_MASK: Form::block_mask(i,j) = test features block (i,j) of mat() reads
+template <class F, class = void> struct has_block_mask { static constexpr bool v = false; };
+template <class F> struct has_block_mask<F, decltype((void)F::block_mask(0, 0))> { static constexpr bool v = true; };
+template <class F> constexpr unsigned fm_block_mask(int i, int j) { if constexpr (has_block_mask<F>::v) return F::block_mask(i, j); else return 0xffffffffu; }
+
 // point data the MATRIX callback reads (default: everything the form reads anywhere); matrix-only drivers
 // (Jacobian / IJacobian / Matrix) skip the rest, e.g. the field Hessians NS-VMS needs for its residual alone
 template <class F, class = void> struct mat_need_of { static constexpr unsigned v = F::NEED; };
@@ -584,6 +589,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           for (int i = 0; i < DOFI; ++i)
 #pragma unroll
             for (int j = 0; j < DOF; ++j) {
+              if (!((fm_block_mask<Form>(I0 + i, j) >> f) & 1u) && !(HASB && bpass)) continue;   // structurally zero for this block
               const double B = live ? T[(I0 + i) * DOF + j] * jw : 0.0;
 #pragma unroll
               for (int t = 0; t < NTA; ++t)

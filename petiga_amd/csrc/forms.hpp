@@ -165,6 +165,14 @@ template <int DIM> struct FormCahnHilliard {
 struct FormNSVMS {
   static constexpr int SHAPE_ORDER = 1;   // Residual/Tangent read N and grad N only; Hessians are needed of U alone
   static constexpr unsigned MAT_NEED = NEED_U | NEED_G;   // Tangent (:166-244) reads u and the metric tensor only
+  // test-function features (bit 0 = N, bits 1..3 = grad N) each (i,j) block of the Tangent reads: 42 of the 64
+  // (block, feature) combinations are non-zero, the others never reach the matrix cores
+  static constexpr unsigned block_mask(int i, int j) {
+    if (i < 3 && j < 3) return (i == j) ? 0xFu : ((1u << (1 + i)) | (1u << (1 + j)));   // Tii: all; nu Na_j Nb_i + tauC Na_i Nb_j
+    if (i < 3 && j == 3) return 0xEu;            // -Na_i Nb + tauM adv(a) Nb_i
+    if (i == 3 && j < 3) return 0x1u | (1u << (1 + j));   // Na Nb_j + tauM Na_j (...)
+    return 0xEu;                                 // tauM grad Na . grad Nb
+  }
   static constexpr int DOF = 4, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_G;
   static __device__ __forceinline__ void tau(const PtView &p, double &tauM, double &tauC) {
     const double *J = p.G; const double nu = p.prm[0], dt = p.prm[4], C_I = 1.0 / 12.0;
