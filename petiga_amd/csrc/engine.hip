@@ -725,7 +725,9 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   out.U = U ? U->a.as<double>() : nullptr; out.V = V ? V->a.as<double>() : nullptr;
   if (g->timing) HIPCK(hipEventRecord(g->ev[0], g->stream));
   // MatZeroEntries / VecZeroEntries (src/petigaksp.c:166-167)
-  if (hasM) HIPCK(hipMemsetAsync(A->val.p, 0, A->val.bytes, g->stream));
+  // (the matrix is zeroed lazily: the axis-0 pencil walk stores first touches and needs no MatZeroEntries at all)
+  bool zeroed = !hasM;
+  auto zero_matrix = [&]() { if (!zeroed) { (void)hipMemsetAsync(A->val.p, 0, A->val.bytes, g->stream); zeroed = true; } };
   if (hasV) HIPCK(hipMemsetAsync(b->a.p, 0, b->a.bytes, g->stream));
   if (g->timing) HIPCK(hipEventRecord(g->ev[1], g->stream));
   const SpaceDev S = make_spacedev(g);
@@ -733,10 +735,11 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   bool done = false;
   if (g->kernel_choice != 1 && g->kernel_choice != 3) {
     g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
-    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom);
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix);
     if (rc) return rc;
   }
   if (!done) {
+    zero_matrix();
     switch (s.dim) {
     case 1: rc = dispatch_dim<1>(g, S, out); break;
     case 2: rc = dispatch_dim<2>(g, S, out); break;

@@ -12,6 +12,7 @@
 // so a k-step costs ~11 v_mul_f64 for 16 MFMAs.  Result layout (measured, scripts/mfma_probe.hip):
 // lane l, reg r of tile (ta,tb) holds K_e[a=(l>>4, r, ta)][b=(l&3, (l>>2)&3, tb)].
 #pragma once
+#include <functional>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -245,6 +246,8 @@ struct PencilArgs {
   int seg_len, nseg;
   int blocks_per_seg;      // ceil(pencils / 8): a workgroup (8 wavefronts = 8 pencils) never straddles segments
   int ne_max;              // LDS capacity: elements (seg_len + 3 halo) ; layers = ne_max + 3
+  int first_touch;         // 1: the matrix was NOT zeroed; the first colour that reaches an entry stores it (walk axis 0 only)
+  int nelx, nely;          // local element counts on the two non-walked axes (for the first-touch rule)
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
   long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
 };
@@ -257,6 +260,7 @@ struct PencilLane {        // per-lane constants of a pencil
   double sxy;              // forcing * sum_q wx Nx[fx] * sum_q wy Ny[fy] for the F lane
   long long frowxy;        // F row without the walk-axis part
   int fslot;
+  unsigned stmask;         // bit r: this lane's entries of register r are stored without a read (first touch)
 };
 
 // LDS-staged axis-0 data of one segment (the knot-span tables of the walk): per element the 1-D basis rows
@@ -394,6 +398,20 @@ __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, in
 
 typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 
+// First touch.  An entry (row slot a, column slot b of element e on one axis) receives contributions from the elements
+// [e + max(a,b) - P, e + min(a,b)] (clipped to the rank's elements); colours are e mod (P+1) and launch in ascending
+// order, so the first launch to reach the entry is colour 0 if the range holds a multiple of P+1, else the colour of
+// its lowest element.  Along the walk axis a pencil combines everything in registers: one write per entry and pencil.
+template <int P>
+__device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel) {
+  constexpr int NB = P + 1;
+  int lo = e + (a > b ? a : b) - P, hi = e + (a < b ? a : b);
+  if (lo < 0) lo = 0;
+  if (hi > nel - 1) hi = nel - 1;
+  const int c0 = ((lo + NB - 1) / NB) * NB;       // smallest multiple of NB >= lo
+  return (c0 <= hi) ? (e % NB == 0) : (e == lo);
+}
+
 // Dirichlet data seen by one pencil of the axis-0 walk (all wave-uniform).  A node is fixed by position only:
 // first / last basis function of the first / last element of a non-periodic axis with boundary values
 // (IGAElementBuildFix, src/petigaelem.c:1214-1283); later faces override earlier ones (axis 0, 1, 2; side 0, 1).
@@ -490,6 +508,11 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       if (lane_ok) {
 #pragma unroll
         for (int r = 0; r < NB; ++r) {
+          if ((L.stmask >> r) & 1u) {   // first touch: nothing to read
+#pragma unroll
+            for (int k = 0; k < BW; ++k) o[r][k] = 0.0;
+            continue;
+          }
           const double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
 #pragma unroll
           for (int k = 0; k < BW / 2; ++k) { const d2u_t x = *reinterpret_cast<const d2u_t *>(p + 2 * k); o[r][2 * k] = x[0]; o[r][2 * k + 1] = x[1]; }
@@ -512,7 +535,10 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
 #pragma unroll
         for (int r = 0; r < NB; ++r)
 #pragma unroll
-          for (int d = 0; d < BW; ++d) if (p0[d] >= 0) out.val[pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10)] += v[r][d];
+          for (int d = 0; d < BW; ++d) if (p0[d] >= 0) {
+            double *q = out.val + pencil_pos<0>(L, r, ps0, c0, p0[d], T0, T10);
+            *q = ((L.stmask >> r) & 1u) ? v[r][d] : *q + v[r][d];
+          }
       }
     }
   }
@@ -639,6 +665,12 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     L.sxy = pa.forcing * (sx * sy) * (AX.J[elx] * AY.J[ely]);
     L.frowxy = rs[X] * AX.rowmap[offx + (fx < NB ? fx : 0)] + rs[Y] * AY.rowmap[offy + (fy < NB ? fy : 0)];
     L.fslot = lane >> 4;
+    L.stmask = 0;
+    if (W == 0 && pa.first_touch) {
+      const bool fx1 = first_touch_axis<P>(elx, a < NB ? a : 0, b1 < NB ? b1 : 0, pa.nelx);
+#pragma unroll
+      for (int r = 0; r < NB; ++r) if (fx1 && first_touch_axis<P>(ely, r, b2 < NB ? b2 : 0, pa.nely)) L.stmask |= 1u << r;
+    }
   }
 
   d4_t acc[4][4];
@@ -742,12 +774,13 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 }
 
 template <bool SYSTEM, int W, int P>
-static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches) {
+static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
   const int nw = bx.hi[W] - bx.lo[W];
   for (int cy = 0; cy < s.lay[Y].ncolors; ++cy) for (int cx = 0; cx < s.lay[X].ncolors; ++cx) {
     PencilArgs pa; pa.forcing = forcing;
+    pa.first_touch = (W == 0 && first_touch) ? 1 : 0; pa.nelx = s.elem_width[X]; pa.nely = s.elem_width[Y];
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
@@ -799,8 +832,18 @@ static bool axis_walkable(const Space &s, int d) {   // one new node layer per e
   return true;
 }
 
+// true when every element pair on axis d follows the e mod (p+1) colouring with one new node layer per element
+static bool axis_first_touch_ok(const Space &s, int d) {
+  if (s.lay[d].alias) return false;
+  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
+    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
+  for (int e = 0; e < s.elem_width[d]; ++e) if (s.lay[d].color[e] != e % (s.axis[d].p + 1)) return false;
+  return true;
+}
+
+// zero_matrix: MatZeroEntries of the caller; called before the first launch unless the axis-0 walk stores first touches
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
-                         std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom) {
+                         std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix) {
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
   if (s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
@@ -826,6 +869,11 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
+  static const bool ft_off = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
+  // (a rank with neighbours keeps columns of nodes it holds no element of -- filled by the ghost-row exchange -- so
+  // its matrix still needs zeroing; first touch is for the single-rank matrix)
+  const bool first_touch = walk_axis == 0 && !ft_off && out.val && s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] == 1 && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
+  if (!first_touch) zero_matrix();
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
@@ -844,10 +892,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (deg == 2) {
-      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches);
+      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {
-    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches); break;
-    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches); break;
+    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
     case 2: launch_pencils<false, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 3: launch_pencils<true, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 4: launch_pencils<false, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;

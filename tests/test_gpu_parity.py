@@ -592,3 +592,43 @@ def test_feature_mfma_kernel_is_selected_and_matches(case):
     else:
         eng.compute_ijacobian(2.5, V, 0.1, U, A2)
     assert np.array_equal(A2.host(True), out[0][0])
+
+
+def _poison(mat):
+    """Overwrite the device values with NaN bit patterns: a first-touch store that misses an entry shows up."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    _, _, val = mat.device_ptrs()
+    assert hip.hipMemset(val, 0xFF, mat.nblocks * mat.bs * mat.bs * 8) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("p,N,size", [(3, (9, 10, 11), 1), (3, (16, 5, 4), 1), (2, (8, 9, 10), 1), (3, (12, 9, 10), 2), (3, (16, 9, 20), 2), (3, (16, 16, 16), 8), (2, (9, 3, 1), 1)])
+def test_pencil_first_touch_needs_no_zeroing(p, N, size):
+    """The axis-0 pencil walk stores the first contribution of every entry (no MatZeroEntries): poisoned matrices
+    must come out identical to freshly zeroed ones, on every rank of a partition."""
+    import petiga_amd as P
+    for r in range(size):
+        g = P.IGX(3, 1)
+        for i in range(3):
+            g.axis_uniform(i, p, N[i])
+        g.set_comm(size, r)
+        g.setup()
+        g.set_boundary_value(0, 0, 0, 1.0); g.set_boundary_value(1, 1, 0, -2.0); g.set_boundary_value(2, 0, 0, 0.5)
+        g.set_form("poisson")
+        g.set_kernel(2)
+        A, b = g.create_mat(), g.create_vec()
+        g.compute_system(A, b); g.synchronize()
+        assert "mfma" in g.kernel_name() and (size > 1 or "walk=0" in g.kernel_name())   # other walks zero the matrix first
+        ref = A.host(True)
+        assert np.all(np.isfinite(ref))
+        _poison(A)
+        g.compute_system(A, b); g.synchronize()
+        assert np.array_equal(A.host(True), ref)
+        _poison(A)
+        g.compute_matrix(A); g.synchronize()
+        assert np.all(np.isfinite(A.host(True)))
+        g.set_kernel(1)                      # and the zeroed read-modify-write path of the generic kernel agrees
+        A2, b2 = g.create_mat(), g.create_vec()
+        g.compute_system(A2, b2); g.synchronize()
+        assert np.abs(A2.host(True) - ref).max() <= TOL * np.abs(ref).max()
