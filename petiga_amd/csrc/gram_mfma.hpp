@@ -832,6 +832,32 @@ static bool axis_walkable(const Space &s, int d) {   // one new node layer per e
   return true;
 }
 
+// zero the values of the rows of a box of row indices (rows near a face shared with another rank: they keep columns
+// of nodes this rank holds no element of, which only the ghost-row exchange fills)
+__global__ void k_zero_row_box(int s0, int s1, int s2, int c0, int c1, int nr0, int nr1, const int64_t *browptr, double *val, int bs2) {
+  const int64_t r = blockIdx.x;
+  const int k0 = (int)(r % c0), k1 = (int)((r / c0) % c1), k2 = (int)(r / ((int64_t)c0 * c1));
+  const int64_t row = (int64_t)(s0 + k0) + (int64_t)nr0 * ((int64_t)(s1 + k1) + (int64_t)nr1 * (s2 + k2));
+  double *p = val + browptr[row] * bs2; const int64_t n = (browptr[row + 1] - browptr[row]) * bs2;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
+}
+
+// rows with stencil columns outside the rank's element box: within p node layers of a face that has a neighbour rank
+static void zero_neighbour_rows(const Space &s, const OutDev &out, hipStream_t stream) {
+  for (int d = 0; d < s.dim; ++d) {
+    const bool per = s.axis[d].periodic != 0;
+    const bool lower = s.proc_sizes[d] > 1 && (s.proc_ranks[d] > 0 || per), upper = s.proc_sizes[d] > 1 && (s.proc_ranks[d] < s.proc_sizes[d] - 1 || per);
+    const int nr = s.lay[d].nrow, p = s.axis[d].p;
+    for (int side = 0; side < 2; ++side) {
+      if (!(side ? upper : lower)) continue;
+      int st[3] = {0, 0, 0}, ct[3] = {s.lay[0].nrow, s.lay[1].nrow, s.lay[2].nrow};
+      ct[d] = std::min(p, nr); st[d] = side ? nr - ct[d] : 0;
+      const int64_t rows = (int64_t)ct[0] * ct[1] * ct[2];
+      if (rows > 0) hipLaunchKernelGGL(k_zero_row_box, dim3((unsigned)rows), dim3(256), 0, stream, st[0], st[1], st[2], ct[0], ct[1], s.lay[0].nrow, s.lay[1].nrow, out.browptr, out.val, s.dof * s.dof);
+    }
+  }
+}
+
 // true when every element pair on axis d follows the e mod (p+1) colouring with one new node layer per element
 static bool axis_first_touch_ok(const Space &s, int d) {
   if (s.lay[d].alias) return false;
@@ -870,10 +896,9 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   static const bool ft_off = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
-  // (a rank with neighbours keeps columns of nodes it holds no element of -- filled by the ghost-row exchange -- so
-  // its matrix still needs zeroing; first touch is for the single-rank matrix)
-  const bool first_touch = walk_axis == 0 && !ft_off && out.val && s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] == 1 && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
+  const bool first_touch = walk_axis == 0 && !ft_off && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
   if (!first_touch) zero_matrix();
+  else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);   // the only entries no local element reaches
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
