@@ -43,7 +43,11 @@ def cpu_baseline(degree, seconds_target=20.0):
         res = pool.map(_cpu_worker, [(degree, n, cores, r) for r in range(cores)])
     wall = max(r[1] for r in res)
     elems = sum(r[0] for r in res)
-    return dict(value=elems / wall, unit="elements/s", cores=cores, kind="port",
+    # one core alone (the reference is single-threaded per rank; SURVEY 8d asks for both figures)
+    n1 = 16 if degree == 3 else 32
+    e1, t1 = _cpu_worker((degree, n1, 1, 0))
+    return dict(value=elems / wall, unit="elements/s", cores=cores, kind="port", single_core_value=e1 / t1,
+                single_core_sample="%d^3 elements on one core, %.1f s" % (n1, t1),
                 sample="3-D p=%d Poisson, %d^3 elements, %d ranks (one per core), oracle/igaoracle.c; slowest rank %.1f s, pool wall %.1f s"
                        % (degree, n, cores, wall, time.time() - t0))
 
