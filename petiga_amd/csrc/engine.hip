@@ -482,7 +482,9 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.hpart = 0;
       cv.lift = take(SCALN > 0 ? QC * SCALN : (out.op == OP_SYSTEM ? QC * DOF * NFS : 0));
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
-      cv.phi = take(NFS * QC * NEP);
+      // the sum-factorised geometry sums of phase 1 borrow the Phi region before Phi exists
+      const int sf_need = (!SECOND && (s.nsd || s.rational)) ? (DIM + 1) * (2 * nq[0] * na[1] * na[2] + 3 * nq[0] * nq[1] * na[2] + 4 * NQ) : 0;
+      cv.phi = take(std::max(NFS * QC * NEP, sf_need));
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
       if (lds_bytes <= cap) fits = true;

@@ -304,9 +304,49 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   double Jel = 1;
 #pragma unroll
   for (int d = 0; d < 3; ++d) if (d != baxis) Jel *= Jax[d];   // bnd_detJac = 1
+  // First-order tabulation on a mapped geometry: the sums over the nen control points factorise over the axes
+  // (sum factorisation, three short contractions through LDS instead of nqp * nen * 16 products per element).  They
+  // run on homogeneous coordinates: A_c = sum_a (w_a X_a[c]) N_a and W = sum_a w_a N_a with their first derivatives;
+  // x = A / W and dx/du = (dA - x dW) / W reproduce Rationalize + GeometryMap (src/petigarat.f90.in, petigamapgeo.f90.in).
+  const bool sumfact = !SECOND && (geo || rat);
+  double *SF = phi;                                   // [NC][4][NQ], in the (not yet used) Phi region
+  if (sumfact) {
+    constexpr int NC = DIM + 1;                       // components: X (times w) and w
+    const int n1 = NC * 2 * nq[0] * na[1] * na[2], n2 = NC * 3 * nq[0] * nq[1] * na[2], n3 = NC * 4 * NQ;
+    double *T1 = phi + n3, *T2 = T1 + n1;
+    for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v]
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r & 1, c = r >> 1;
+      double sm = 0;
+      for (int a0 = 0; a0 < na[0]; ++a0) {
+        const int a = a0 + na[0] * (a1 + na[1] * a2);
+        const double w = rat ? gW[a] : 1.0;
+        const double cv = (c < DIM) ? (geo ? gX[a * DIM + c] * w : 0.0) : w;
+        sm += cv * t1d[0][(q0 * na[0] + a0) * NDER + v];
+      }
+      T1[i] = sm;
+    }
+    __syncthreads();
+    for (int i = tid; i < n2; i += nthr) {            // T2[c][m][q0][q1][a2], m: 0 (val,val) 1 (der,val) 2 (val,der)
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % 3, c = r / 3;
+      const int v0 = (m == 1), v1 = (m == 2);
+      double sm = 0;
+      for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * 2 + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1];
+      T2[i] = sm;
+    }
+    __syncthreads();
+    for (int i = tid; i < n3; i += nthr) {            // SF[c][k][q], k: 0 value, 1..3 d/du_0..2
+      const int q = i % NQ, k = (i / NQ) & 3, c = i / (4 * NQ);
+      const int qp = qdec[q]; const int q0 = qp & 255, q1 = (qp >> 8) & 255, q2 = qp >> 16;
+      const int m = (k == 1) ? 1 : (k == 2 ? 2 : 0), v2 = (k == 3);
+      double sm = 0;
+      for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * 3 + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2];
+      SF[i] = sm;
+    }
+    __syncthreads();
+  }
   {
     int np1 = pow2_floor(nthr / NQP); if (np1 > 16) np1 = 16;
-    if (!geo && !rat) np1 = 1;
+    if ((!geo && !rat) || sumfact) np1 = 1;
     const int qstep = nthr / np1;
     for (int qb = 0; qb < NQP; qb += qstep) {
       const int q = qb + tid / np1, part = tid & (np1 - 1);
@@ -319,6 +359,18 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       double x0[3], X1[9], X2[27];
 #pragma unroll
       for (int d = 0; d < DIM; ++d) x0[d] = w1d[d][nq[d] + qq[d]];
+      if (sumfact) {
+        if (valid) {
+          if (rat) { w0 = SF[(DIM * 4 + 0) * NQ + q]; for (int i = 0; i < DIM; ++i) w1[i] = SF[(DIM * 4 + 1 + i) * NQ + q]; }
+          if (geo) {
+            const double iw = 1.0 / w0;
+            for (int c = 0; c < DIM; ++c) {
+              x0[c] = SF[(c * 4 + 0) * NQ + q] * iw;
+              for (int al = 0; al < DIM; ++al) X1[c * DIM + al] = (SF[(c * 4 + 1 + al) * NQ + q] - x0[c] * w1[al]) * iw;
+            }
+          }
+        }
+      } else {
       if (rat) {
         w0 = 0;
         if (valid) for (int a = part; a < NE; a += np1) {
@@ -364,6 +416,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         for (int i = 0; i < DIM; ++i) x0[i] = group_sum(x0[i], np1);
         for (int i = 0; i < D2; ++i) X1[i] = group_sum(X1[i], np1);
         if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = group_sum(X2[i], np1);
+      }
       }
       if (part != 0 || q >= NQP) continue;
       if (!valid) { JW[q] = 0; for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = 0; continue; }   // padded point
