@@ -239,6 +239,11 @@ int IGXGetNeighborCount(IGX iga,int *nsend,int *nrecv);
 int IGXGetNeighborInfo(IGX iga,int send /*1=send list,0=recv list*/,int k,int *rank,int64_t *mat_doubles,int64_t *vec_doubles);
 int IGXPackGhostRows  (IGX iga,IGXMat A,IGXVec b,int k,double *devbuf);   /* A or b may be NULL */
 int IGXUnpackGhostRows(IGX iga,IGXMat A,IGXVec b,int k,const double *devbuf);
+/* Reverse direction, before a nonlinear assembly (IGAGetLocalVecArray / DMGlobalToLocal, src/petigavec.c:256-269): the
+ * owner's values of a state vector travel to the ranks holding the node as a ghost.  Pack entry k of the RECEIVE list
+ * (vec_doubles of that entry), send it to that rank, which unpacks it as entry k' of its SEND list (assignment). */
+int IGXPackOwnerValues  (IGX iga,IGXVec v,int k,double *devbuf);
+int IGXUnpackGhostValues(IGX iga,IGXVec v,int k,const double *devbuf);
 /* 1 if this rank owns the node of local row (r0,r1,r2): after the exchange only owned rows are final */
 int IGXRowOwned(IGX iga,int r0,int r1,int r2);
 

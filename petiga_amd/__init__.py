@@ -87,6 +87,7 @@ def lib(build_if_needed=False):
         "IGXGetColoring": [V, _ip], "IGXGetElementColor": [V, C.c_int, C.c_int],
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
+        "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
@@ -334,6 +335,8 @@ class IGX:
 
     def pack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXPackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))
     def unpack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXUnpackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))
+    def pack_owner_values(self, v, k, devptr): _ck(lib().IGXPackOwnerValues(self.h, v.h, k, devptr))
+    def unpack_ghost_values(self, v, k, devptr): _ck(lib().IGXUnpackGhostValues(self.h, v.h, k, devptr))
     def row_owned(self, r0, r1=0, r2=0): return bool(lib().IGXRowOwned(self.h, r0, r1, r2))
 
     def coloring(self):

@@ -73,8 +73,9 @@ static std::vector<NbrPlan> neighbour_plans(const Space &s, bool send) {
 
 struct PackDev { int start[3], count[3], nrow[3]; const int *rcnt[3]; const int64_t *prefix[3]; int64_t tot[3], sub0[3]; int bs2, dof; };
 
-// one workgroup per row of the sub-box: copy (PACK) or add (UNPACK) the row's blocks / vector entries
-template <bool PACK>
+// one workgroup per row of the sub-box.  MODE 0: copy the row's blocks / vector entries into the message; 1: add the
+// message to them (ghost-row reduction); 2: overwrite them with the message (ghost-value refresh, vectors)
+template <int MODE>
 __global__ void k_ghost_rows(PackDev P, const int64_t *browptr, double *val, double *vec, double *buf, int64_t mat_doubles) {
   const int64_t r = blockIdx.x;
   const int k0 = (int)(r % P.count[0]), k1 = (int)((r / P.count[0]) % P.count[1]), k2 = (int)(r / ((int64_t)P.count[0] * P.count[1]));
@@ -87,19 +88,20 @@ __global__ void k_ghost_rows(PackDev P, const int64_t *browptr, double *val, dou
     const int64_t off = (p2 * P.tot[1] * P.tot[0] + c2 * (p1 * P.tot[0] + c1 * p0)) * P.bs2;
     const int64_t n = c0 * c1 * c2 * P.bs2;
     double *m = val + browptr[row] * P.bs2, *b = buf + off;
-    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { if (PACK) b[i] = m[i]; else m[i] += b[i]; }
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { if (MODE == 0) b[i] = m[i]; else if (MODE == 1) m[i] += b[i]; else m[i] = b[i]; }
   }
   if (vec && threadIdx.x < P.dof) {
     double *v = vec + row * P.dof + threadIdx.x, *b = buf + mat_doubles + r * P.dof + threadIdx.x;
-    if (PACK) *b = *v; else *v += *b;
+    if (MODE == 0) *b = *v; else if (MODE == 1) *v += *b; else *v = *b;
   }
 }
 
-static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool pack) {
+// plan list `send_list` (true: upper neighbours / my ghost part, false: lower neighbours / my first owned nodes), entry k
+static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool send_list, int mode) {
   NEEDIGA(g);
   if (int rc = ensure_device(g)) return rc;
   const Space &s = g->s;
-  const std::vector<NbrPlan> plans = neighbour_plans(s, pack);
+  const std::vector<NbrPlan> plans = neighbour_plans(s, send_list);
   if (k < 0 || k >= (int)plans.size()) return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour");
   if (!devbuf) return fail(IGX_ERR_ARG_WRONG, "null buffer");
   if (A && A->iga != g) return fail(IGX_ERR_ARG_WRONG, "matrix created by another IGX");
@@ -117,8 +119,10 @@ static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool pac
   const int64_t nrows = (int64_t)pl.count[0] * pl.count[1] * pl.count[2];
   if (nrows == 0) return 0;
   const int64_t matd = A ? pl.mat_doubles : 0;
-  if (pack) hipLaunchKernelGGL(k_ghost_rows<true>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, A ? A->browptr.as<int64_t>() : nullptr, A ? A->val.as<double>() : nullptr, b ? b->a.as<double>() : nullptr, devbuf, matd);
-  else hipLaunchKernelGGL(k_ghost_rows<false>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, A ? A->browptr.as<int64_t>() : nullptr, A ? A->val.as<double>() : nullptr, b ? b->a.as<double>() : nullptr, devbuf, matd);
+  const int64_t *bp = A ? A->browptr.as<int64_t>() : nullptr; double *vp = A ? A->val.as<double>() : nullptr, *xp = b ? b->a.as<double>() : nullptr;
+  if (mode == 0) hipLaunchKernelGGL(k_ghost_rows<0>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
+  else if (mode == 1) hipLaunchKernelGGL(k_ghost_rows<1>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
+  else hipLaunchKernelGGL(k_ghost_rows<2>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
   HIPCK(hipGetLastError());
   return 0;
 }
@@ -137,8 +141,13 @@ extern "C" int IGXGetNeighborInfo(IGX g, int send, int k, int *rank, int64_t *ma
   if (rank) *rank = plans[k].rank; if (mat_doubles) *mat_doubles = plans[k].mat_doubles; if (vec_doubles) *vec_doubles = plans[k].vec_doubles;
   return 0;
 }
-extern "C" int IGXPackGhostRows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf) { return ghost_rows(g, A, b, k, devbuf, true); }
-extern "C" int IGXUnpackGhostRows(IGX g, IGXMat A, IGXVec b, int k, const double *devbuf) { return ghost_rows(g, A, b, k, const_cast<double *>(devbuf), false); }
+extern "C" int IGXPackGhostRows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf) { return ghost_rows(g, A, b, k, devbuf, true, 0); }
+extern "C" int IGXUnpackGhostRows(IGX g, IGXMat A, IGXVec b, int k, const double *devbuf) { return ghost_rows(g, A, b, k, const_cast<double *>(devbuf), false, 1); }
+// the reverse direction, before a nonlinear assembly: the owner's values travel to the ranks that hold the node as a ghost
+// (IGAGetLocalVecArray = DMGlobalToLocal, src/petigavec.c:256-269).  Pack: entry k of the RECEIVE list (a lower neighbour,
+// whose ghosts are my first owned nodes); unpack: entry k of the SEND list (an upper neighbour, owner of my ghost part).
+extern "C" int IGXPackOwnerValues(IGX g, IGXVec v, int k, double *devbuf) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); return ghost_rows(g, nullptr, v, k, devbuf, false, 0); }
+extern "C" int IGXUnpackGhostValues(IGX g, IGXVec v, int k, const double *devbuf) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); return ghost_rows(g, nullptr, v, k, const_cast<double *>(devbuf), true, 2); }
 // 1 if this rank owns the row node with local row indices (r0,r1,r2) -- after the exchange only owned rows are final
 extern "C" int IGXRowOwned(IGX g, int r0, int r1, int r2) {
   if (!g || !g->s.setup) return 0;

@@ -54,3 +54,26 @@ class GhostExchange:
         torch.cuda.synchronize()
         for k, buf in enumerate(self.recv_bufs):
             self.iga.unpack_ghost_rows(self.A, self.b, k, buf.data_ptr())
+
+
+class GhostRefresh:
+    """Owner -> ghost copies of a state vector before a nonlinear assembly (the reverse of GhostExchange.reduce):
+    replaces DMGlobalToLocal of IGAGetLocalVecArray (src/petigavec.c:256-269)."""
+
+    def __init__(self, iga, device="cuda"):
+        self.iga = iga
+        s, r = plan(iga, with_mat=False, with_vec=True)
+        # messages flow against the reduction: I send to my lower neighbours (receive list), receive from the upper ones
+        self.send_peers = [p for p, _ in r]
+        self.recv_peers = [p for p, _ in s]
+        self.send_bufs = [torch.empty(max(n, 1), dtype=torch.float64, device=device) for _, n in r]
+        self.recv_bufs = [torch.empty(max(n, 1), dtype=torch.float64, device=device) for _, n in s]
+
+    def refresh(self, vec):
+        for k, buf in enumerate(self.send_bufs):
+            self.iga.pack_owner_values(vec, k, buf.data_ptr())
+        self.iga.synchronize()
+        p2p_exchange(self.send_bufs, self.send_peers, self.recv_bufs, self.recv_peers)
+        torch.cuda.synchronize()
+        for k, buf in enumerate(self.recv_bufs):
+            self.iga.unpack_ghost_values(vec, k, buf.data_ptr())

@@ -632,3 +632,90 @@ def test_pencil_first_touch_needs_no_zeroing(p, N, size):
         A2, b2 = g.create_mat(), g.create_vec()
         g.compute_system(A2, b2); g.synchronize()
         assert np.abs(A2.host(True) - ref).max() <= TOL * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("size,form,N,periodic", [(4, "ch", (6, 7, 8), (0, 0, 0)), (8, "ch", (8, 8, 8), (0, 0, 0)), (2, "ns", (9, 3, 8), (1, 0, 1)), (4, "ns", (9, 4, 8), (1, 0, 1))])
+def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic):
+    """Nonlinear drivers on a partition (configs 4 and 5 are multi-GPU): every rank knows the state only on the nodes
+    it owns, the owner -> ghost refresh (IGXPackOwnerValues / IGXUnpackGhostValues, the reverse of the ghost-row
+    reduction) fills its ghost rows, then IFunction / IJacobian + ghost-row reduction reproduce the single-rank oracle."""
+    import torch
+    import scipy.sparse as sp
+    import petiga_amd as P
+    periodic = [bool(x) for x in periodic]
+    dof, p = (1, 2) if form == "ch" else (4, 2)
+    orc, _ = make_pair(3, dof, p, list(N), periodic=periodic, order=2, engine=False)
+    if form == "ns":
+        for s_ in range(2):
+            for f in range(3):
+                orc.set_boundary_value(1, s_, f, 0.0)
+    n = orc.global_size()
+    rng = np.random.default_rng(11)
+    Ug, Vg = (0.63 + 0.05 * (2 * rng.random(n) - 1), 0.1 * rng.standard_normal(n)) if form == "ch" else (0.3 * rng.standard_normal(n), 0.1 * rng.standard_normal(n))
+    if form == "ch":
+        ctx, prm, fres, ftan, ename = O.CahnHilliardCtx(1.5, 200.0, 0.63, 1.0, 1e-3, 1.0), (1.5, 200.0, 0.63, 1.0, 1e-3, 1.0), "orc_form_ch_residual", "orc_form_ch_tangent", "cahnhilliard"
+    else:
+        ctx, prm, fres, ftan, ename = O.NSVMSCtx(1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), "orc_form_ns_residual", "orc_form_ns_tangent", "nsvms"
+    F_o = orc.compute_ifunction(fres, ctx, 2.0, Vg, 0.1, Ug)
+    J_o = orc.compute_ijacobian(ftan, ctx, 2.0, Vg, 0.1, Ug)
+    engs, Us, Vs, grows, owns = [], [], [], [], []
+    for r in range(size):
+        g = P.IGX(3, dof)
+        for i in range(3):
+            g.axis_uniform(i, p, N[i], periodic=periodic[i])
+        g.set_order(2); g.set_comm(size, r); g.setup()
+        if form == "ns":
+            for s_ in range(2):
+                for f in range(3):
+                    g.set_boundary_value(1, s_, f, 0.0)
+        g.set_form(ename, prm)
+        A = g.create_mat()
+        nrow, _, maps = A.layout()
+        ns = g.sizes()["node_sizes"]
+        rr = np.arange(A.nbrows)
+        grow = maps[0][0][rr % nrow[0]].astype(np.int64) + ns[0] * (maps[1][0][(rr // nrow[0]) % nrow[1]].astype(np.int64) + ns[1] * maps[2][0][rr // (nrow[0] * nrow[1])].astype(np.int64))
+        own = np.array([g.row_owned(int(a), int(b_), int(c)) for a, b_, c in zip(rr % nrow[0], (rr // nrow[0]) % nrow[1], rr // (nrow[0] * nrow[1]))])
+        def local(vg):
+            v = np.full((A.nbrows, dof), np.nan)
+            v[own] = vg.reshape(-1, dof)[grow[own]]
+            return g.create_vec().set(v.reshape(-1))
+        engs.append(g); Us.append(local(Ug)); Vs.append(local(Vg)); grows.append(grow); owns.append(own)
+    # owner -> ghost refresh, both state vectors
+    for vecs in (Us, Vs):
+        msgs = {}
+        for r, g in enumerate(engs):
+            for k, (peer, _, v) in enumerate(g.neighbors(False)):
+                buf = torch.empty(max(v, 1), dtype=torch.float64, device="cuda")
+                g.pack_owner_values(vecs[r], k, buf.data_ptr()); g.synchronize()
+                assert (r, peer) not in msgs
+                msgs[(r, peer)] = buf
+        for r, g in enumerate(engs):
+            for k, (peer, _, v) in enumerate(g.neighbors(True)):
+                assert msgs[(peer, r)].numel() == max(v, 1)
+                g.unpack_ghost_values(vecs[r], k, msgs[(peer, r)].data_ptr())
+            g.synchronize()
+    for r in range(size):
+        assert np.array_equal(Us[r].get().reshape(-1, dof), Ug.reshape(-1, dof)[grows[r]])      # every ghost row holds its owner's value
+    # assemble, reduce ghost rows, compare the owned rows with the single-rank oracle
+    M = sp.csr_matrix((n, n)); F = np.zeros(n)
+    mats, vecsF, send = [], [], {}
+    for r, g in enumerate(engs):
+        A, b = g.create_mat(), g.create_vec()
+        g.compute_ifunction(2.0, Vs[r], 0.1, Us[r], b)
+        g.compute_ijacobian(2.0, Vs[r], 0.1, Us[r], A)
+        for k, (peer, m, v) in enumerate(g.neighbors(True)):
+            buf = torch.empty(m + v, dtype=torch.float64, device="cuda")
+            g.pack_ghost_rows(A, b, k, buf.data_ptr()); send[(r, peer)] = buf
+        g.synchronize(); mats.append(A); vecsF.append(b)
+    for r, g in enumerate(engs):
+        for k, (peer, m, v) in enumerate(g.neighbors(False)):
+            g.unpack_ghost_rows(mats[r], vecsF[r], k, send[(peer, r)].data_ptr())
+        g.synchronize()
+        rows, cols, vals, own_e, own = _rank_matrix_rows(g, mats[r], vecsF[r])
+        M = M + sp.coo_matrix((vals[own_e], (rows[own_e], cols[own_e])), shape=(n, n)).tocsr()
+        bv = vecsF[r].get().reshape(-1, dof)
+        for c in range(dof):
+            F[grows[r][own] * dof + c] = bv[own, c]
+    Mo = J_o.scipy()
+    assert abs(M - Mo).max() <= 1e-11 * abs(Mo).max()
+    assert np.abs(F - F_o).max() <= 1e-11 * np.abs(F_o).max()
