@@ -773,6 +773,8 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
   }
 }
 
+static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
+
 template <bool SYSTEM, int W, int P>
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
@@ -787,8 +789,22 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     // Segments: as few as possible (every segment re-computes P halo elements).  Bounds: the LDS tables hold
     // <= 160 elements, and a launch should fill the 256 CUs (one 8-pencil workgroup each) at least twice.
     const long long bps = (pencils + 7) / 8;
+    // one 8-pencil workgroup per CU at a time (LDS), so a launch takes ceil(workgroups / CUs) rounds of
+    // (segment length + P halo elements): pick the segment count with the least rounds x length
+    static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
     int nseg = std::max(1, (nw + 159) / 160);
-    while (bps * nseg < 512 && nw / (nseg + 1) >= 32) nseg++;
+    {
+      long long best = -1; int best_n = nseg;
+      for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
+        const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
+        const size_t lds_n = pencil_lds_bytes(len + 3) + (W == 0 ? pencil_hold_bytes(P) : 0);
+        const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
+        const long long cost = ((bps * ns + slots - 1) / slots) * (len + (ns > 1 ? P : 0));
+        if (best < 0 || cost < best) { best = cost; best_n = n; }
+      }
+      nseg = best_n;
+    }
+    { const char *e = getenv("IGX_NSEG"); if (e && atoi(e) > 0) nseg = std::max(nseg_min_lds(nw), std::min(atoi(e), std::max(1, nw / 4))); }   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
     pa.blocks_per_seg = (int)((pencils + 7) / 8);
