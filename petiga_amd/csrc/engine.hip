@@ -300,14 +300,19 @@ __global__ void k_browptr(PatDev P, int64_t nbrows, int64_t *browptr) {
   const int64_t c1 = P.rcnt[1][r1], c2 = P.rcnt[2][r2];
   browptr[r] = P.prefix[2][r2] * P.tot[1] * P.tot[0] + c2 * (P.prefix[1][r1] * P.tot[0] + c1 * P.prefix[0][r0]);
 }
+// one wavefront per row, lanes stride over the row's entries: coalesced 256-byte stores
 __global__ void k_bcolidx(PatDev P, int64_t nbrows, const int64_t *browptr, int32_t *bcolidx) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= nbrows) return;
+  const int lane = threadIdx.x & 63;
   const int r0 = (int)(r % P.nrow[0]), r1 = (int)((r / P.nrow[0]) % P.nrow[1]), r2 = (int)(r / ((int64_t)P.nrow[0] * P.nrow[1]));
   const int c0 = P.rcnt[0][r0], c1 = P.rcnt[1][r1], c2 = P.rcnt[2][r2];
   int32_t *dst = bcolidx + browptr[r];
-  for (int k2 = 0; k2 < c2; ++k2) for (int k1 = 0; k1 < c1; ++k1) for (int k0 = 0; k0 < c0; ++k0)
-    *dst++ = P.rcol[0][r0 * P.W[0] + k0] + P.ncol[0] * (P.rcol[1][r1 * P.W[1] + k1] + P.ncol[1] * P.rcol[2][r2 * P.W[2] + k2]);
+  const int n = c0 * c1 * c2;
+  for (int k = lane; k < n; k += 64) {
+    const int k0 = k % c0, k1 = (k / c0) % c1, k2 = k / (c0 * c1);
+    dst[k] = P.rcol[0][r0 * P.W[0] + k0] + P.ncol[0] * (P.rcol[1][r1 * P.W[1] + k1] + P.ncol[1] * P.rcol[2][r2 * P.W[2] + k2]);
+  }
 }
 
 extern "C" int IGXCreateMat(IGX g, IGXMat *mat) {
@@ -328,7 +333,7 @@ extern "C" int IGXCreateMat(IGX g, IGXMat *mat) {
   }
   const int64_t n1 = A->nbrows + 1;
   hipLaunchKernelGGL(k_browptr, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, g->stream, P, A->nbrows, A->browptr.as<int64_t>());
-  hipLaunchKernelGGL(k_bcolidx, dim3((unsigned)((A->nbrows + 255) / 256)), dim3(256), 0, g->stream, P, A->nbrows, A->browptr.as<int64_t>(), A->bcolidx.as<int32_t>());
+  hipLaunchKernelGGL(k_bcolidx, dim3((unsigned)((A->nbrows + 3) / 4)), dim3(256), 0, g->stream, P, A->nbrows, A->browptr.as<int64_t>(), A->bcolidx.as<int32_t>());
   HIPCK(hipMemsetAsync(A->val.p, 0, A->val.bytes, g->stream));
   HIPCK(hipGetLastError());
   HIPCK(hipStreamSynchronize(g->stream));
