@@ -462,12 +462,13 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   const unsigned need = (vec_op || SCALN > 0) ? Form::NEED : mat_need_of<Form>::v;   // as in the kernel: matrix-only drivers skip residual-only point data
   const bool fields = (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   const size_t lds_limit = 160 * 1024 - 512;
-  // Fewest chunks of points wins almost everywhere (measured: CahnHilliard p=2 tangent 12.5 vs 9.9 M elements/s,
-  // NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 for one chunk vs a 78 KiB cap).  The exception is a scalar form at
-  // nen = 64, whose 16 accumulator VGPRs leave room for two workgroups per CU: there half of the LDS is better
-  // (Poisson p=3 on a NURBS geometry: 8.2 vs 6.4 M elements/s).
+  // LDS budget per workgroup.  4-wave kernels (nen <= 32) are compiled for two waves per SIMD (<= 256 VGPRs), so two
+  // workgroups fit a CU when each stays below half of the LDS: their latency-bound tabulation phases then overlap
+  // (CahnHilliard p=2 tangent 12.8 -> 17.6 M elements/s, residual 16.7 -> 23.5).  8-wave kernels (nen = 64) hold one
+  // workgroup per CU unless the form is scalar (16 accumulator VGPRs: Poisson p=3 on a NURBS geometry 8.2 vs 6.4 M/s);
+  // for the others the fewest chunks of points win (NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 M/s).
   static const int lds_kb_env = [] { const char *e = getenv("IGX_FEATURE_LDS_KB"); return e ? atoi(e) : 0; }();   // experiment switch
-  const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit);
+  const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : ((NW == 4 || (HASM && TA == 4 && DOF == 1)) ? (size_t)78 * 1024 : lds_limit);
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
   for (int pass = 0; pass < 2 && !fits; ++pass) {
     const size_t cap = pass == 0 ? lds_target : lds_limit;

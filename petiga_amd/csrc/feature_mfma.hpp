@@ -128,7 +128,7 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 // NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
 // HASM = false: vector-only operations (Vector / Function / IFunction) -- same tabulation, no matrix phases.
 template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM>
-__global__ void __launch_bounds__(64 * NW)
+__global__ void __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1)
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
