@@ -462,13 +462,15 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   const unsigned need = (vec_op || SCALN > 0) ? Form::NEED : mat_need_of<Form>::v;   // as in the kernel: matrix-only drivers skip residual-only point data
   const bool fields = (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   const size_t lds_limit = 160 * 1024 - 512;
-  // LDS budget per workgroup.  4-wave kernels (nen <= 32) are compiled for two waves per SIMD (<= 256 VGPRs), so two
-  // workgroups fit a CU when each stays below half of the LDS: their latency-bound tabulation phases then overlap
-  // (CahnHilliard p=2 tangent 12.8 -> 17.6 M elements/s, residual 16.7 -> 23.5).  8-wave kernels (nen = 64) hold one
-  // workgroup per CU unless the form is scalar (16 accumulator VGPRs: Poisson p=3 on a NURBS geometry 8.2 vs 6.4 M/s);
-  // for the others the fewest chunks of points win (NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 M/s).
+  // LDS budget per workgroup.  4-wave kernels (nen <= 32) are compiled for 2-4 waves per SIMD (fm_min_waves) and sized
+  // so that as many workgroups fit a CU: their latency-bound tabulation phases then overlap (CahnHilliard p=2 tangent
+  // 12.8 -> 21.6 M elements/s, residual 16.7 -> 28.9).  8-wave kernels (nen = 64) hold one workgroup per CU unless the
+  // form is scalar (16 accumulator VGPRs: Poisson p=3 on a NURBS geometry 8.2 vs 6.4 M/s); for the others the fewest
+  // chunks of points win (NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 M/s).
   static const int lds_kb_env = [] { const char *e = getenv("IGX_FEATURE_LDS_KB"); return e ? atoi(e) : 0; }();   // experiment switch
-  const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : ((NW == 4 || (HASM && TA == 4 && DOF == 1)) ? (size_t)78 * 1024 : lds_limit);
+  constexpr int WGS = fm_min_waves<Form, TA, NW, DOFI, HASM>();
+  const size_t lds_auto = (NW == 4) ? (size_t)(160 * 1024 / WGS - 1024) : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit);
+  const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : lds_auto;
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
   for (int pass = 0; pass < 2 && !fits; ++pass) {
     const size_t cap = pass == 0 ? lds_target : lds_limit;

@@ -125,10 +125,21 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 
 // TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
 
+// Waves per SIMD a 4-wave kernel is compiled for (= workgroups per CU it is sized for): the tabulation phases are latency
+// bound, so more resident workgroups win as long as the accumulators leave registers to work with
+// (CahnHilliard p=2 tangent: 12.8 / 17.6 / 19.7 / 21.6 M elements/s at 1 / 2 / 3 / 4; NS-VMS p=2 with 16 tiles loses at 4).
+template <class Form, int TA, int NW, int DOFI, bool HASM>
+constexpr int fm_min_waves() {
+  if (NW != 4) return 1;
+  const unsigned long long pairs = mat_pair_mask_of<Form>::v;
+  const int nacc = !HASM ? 0 : (pairs ? fm_popcount(pairs) : DOFI * Form::DOF);   // 16x16 tiles per wave (NTA = 1)
+  return nacc <= 4 ? 4 : (nacc <= 9 ? 3 : 2);
+}
+
 // NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
 // HASM = false: vector-only operations (Vector / Function / IFunction) -- same tabulation, no matrix phases.
 template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM>
-__global__ void __launch_bounds__(64 * NW, (NW == 4) ? 2 : 1)
+__global__ void __launch_bounds__(64 * NW, (fm_min_waves<Form, TA, NW, DOFI, HASM>()))
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)

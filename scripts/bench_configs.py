@@ -107,3 +107,9 @@ if "c5r" in which:
             for f in range(3):
                 g.set_boundary_value(1, s, f, 0.0)
     run("NavierStokesVMS p=3 48^3 residual", 3, 4, 3, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ifunction", bc=bc5r)
+if "e2" in which:
+    run("Elasticity3D p=2 96^3", 3, 3, 2, (96,) * 3, "elasticity", (1.0, 1.0), bc=lambda g: [g.set_boundary_value(0, 0, f, 0.0) for f in range(3)])
+if "n2" in which:
+    run("NavierStokesVMS p=2 48^3 tangent", 3, 4, 2, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian")
+if "m4" in which:
+    run("mass dof=4 p=2 64^3", 3, 4, 2, (64,) * 3, "mass")
