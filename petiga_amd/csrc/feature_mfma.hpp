@@ -130,9 +130,10 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 // (CahnHilliard p=2 tangent: 12.8 / 17.6 / 19.7 / 21.6 M elements/s at 1 / 2 / 3 / 4; NS-VMS p=2 with 16 tiles loses at 4).
 template <class Form, int TA, int NW, int DOFI, bool HASM>
 constexpr int fm_min_waves() {
-  if (NW != 4) return 1;
   const unsigned long long pairs = mat_pair_mask_of<Form>::v;
-  const int nacc = !HASM ? 0 : (pairs ? fm_popcount(pairs) : DOFI * Form::DOF);   // 16x16 tiles per wave (NTA = 1)
+  const int nacc = !HASM ? 0 : (pairs ? fm_popcount(pairs) : DOFI * Form::DOF);   // accumulator sets per wave
+  if (NW != 4) return 1;      // 8 waves per workgroup: 256 VGPRs each (measured: a 128-VGPR cap gains nothing for scalar
+                              // forms and costs the NS-VMS residual 20 % in spills)
   return nacc <= 4 ? 4 : (nacc <= 9 ? 3 : 2);
 }
 
