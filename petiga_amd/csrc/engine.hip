@@ -570,8 +570,8 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
   constexpr int DOF = Form::DOF;
   constexpr int NW = (TA == 4) ? 8 : 4;
   // 4x4 tiles: 8 waves, <= 144 accumulator VGPRs per wave (dof 4: two launches of two row fields).  Measured on
-  // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s; three launches of one row
-  // field with 4 waves and two workgroups per CU 1.60 M elements/s (tabulation repeated per launch).
+  // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s (3.2 with Gram accumulators); three
+  // launches of one row field with 4-wave workgroups, two per CU, 1.63 M elements/s (tabulation repeated per launch).
   if constexpr (nscalar_of<Form>::v > 0) return launch_feature_plan<Form, DIM, TA, NW, DOF, false>(g, S, out, done);
   else {
     const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);

@@ -134,7 +134,8 @@ constexpr int fm_min_waves() {
   const int nacc = !HASM ? 0 : (pairs ? fm_popcount(pairs) : DOFI * Form::DOF);   // accumulator sets per wave
   if (NW != 4) return 1;      // 8 waves per workgroup: 256 VGPRs each (measured: a 128-VGPR cap gains nothing for scalar
                               // forms and costs the NS-VMS residual 20 % in spills)
-  return nacc <= 4 ? 4 : (nacc <= 9 ? 3 : 2);
+  const int tiles = nacc * ((TA == 4) ? 4 : 1);   // 16x16 accumulator tiles per wave, 8 VGPRs each
+  return tiles <= 4 ? 4 : (tiles <= 9 ? 3 : 2);
 }
 
 // NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
