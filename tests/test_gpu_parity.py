@@ -719,3 +719,27 @@ def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic
     Mo = J_o.scipy()
     assert abs(M - Mo).max() <= 1e-11 * abs(Mo).max()
     assert np.abs(F - F_o).max() <= 1e-11 * np.abs(F_o).max()
+
+
+def test_user_stream_and_event_timing(kernel_family):
+    """IGXSetStream: the assembly runs on a caller-provided HIP stream (torch's), results unchanged; the HIP-event
+    timings bench.py reads are positive and the dominant kernel is reported."""
+    import torch
+    orc, eng = make_pair(3, 1, 3, [9, 8, 8])
+    dirichlet_all((orc, eng), 3)
+    eng.set_form("poisson")
+    A0, b0 = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A0, b0); eng.synchronize()
+    st = torch.cuda.Stream()
+    eng.set_stream(st.cuda_stream)
+    eng.set_timing(True)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    st.synchronize()
+    assert np.array_equal(A.host(True), A0.host(True)) and np.array_equal(b.get(), b0.get())
+    total_ms, kernel_ms, launches = eng.last_timing()
+    assert total_ms > 0 and kernel_ms > 0 and launches >= 1
+    if kernel_family == "auto":
+        d = eng.dominant_kernel()
+        assert d["launches"] >= 1 and d["ms"] > 0 and d["elements"] == 9 * 8 * 8
+    eng.set_stream(None)
