@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <memory>
 #include <string>
 #include <vector>
@@ -46,6 +47,7 @@ struct _p_IGX {
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
+  std::function<void()> zero_matrix;   // MatZeroEntries of the running IGXCompute*, called by the kernel path that needs it
   DevBuf partials, dbgbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
@@ -502,7 +504,17 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   ParamsDev prm; memset(&prm, 0, sizeof(prm));
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
   int launches = 0; bool first = true;
-  constexpr bool SCAL = nscalar_of<Form>::v > 0;     // nothing is scattered: every element in one sweep, one partial row each
+  constexpr bool SCAL = nscalar_of<Form>::v > 0;
+  // first-touch stores instead of MatZeroEntries + read (same rule as the pencil kernel): regular e mod (p+1) colours on
+  // every axis; a rank with neighbours zeroes only the rows that keep neighbour-owned columns
+  static const bool ft_off = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
+  bool first_touch = HASM && !ft_off;
+  for (int d = 0; d < DIM && first_touch; ++d) first_touch = axis_first_touch_ok(s, d);
+  OutDev out_ft = out; out_ft.first_touch = first_touch ? 1 : 0;
+  if (HASM) {
+    if (!first_touch) { if (g->zero_matrix) g->zero_matrix(); }
+    else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, g->stream);
+  }     // nothing is scattered: every element in one sweep, one partial row each
   int64_t elem_base = 0;
   int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
   if (SCAL) nc[0] = nc[1] = nc[2] = 1;
@@ -523,7 +535,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
     for (int k0 = 0; k0 < cr.count[2]; k0 += chunk2) {
       ColorRange sub = cr; sub.start[2] = cr.start[2] + k0 * cr.step[2]; sub.count[2] = std::min(chunk2, cr.count[2] - k0);
       const size_t nblocks = per2 * sub.count[2];
-      OutDev o2 = out; o2.elem_base = elem_base; elem_base += (int64_t)nblocks;
+      OutDev o2 = out_ft; o2.elem_base = elem_base; elem_base += (int64_t)nblocks;
       launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM>(g, S, prm, o2, sub, cv, nblocks, lds_bytes, first, launches);
       first = false;
     }
@@ -615,6 +627,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
   }
+  if (g->zero_matrix) g->zero_matrix();
   for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd)
     if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes need the feature kernel (dim >= 2, nen <= 64, IGXSetKernel 0 or 3)");
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
@@ -753,12 +766,13 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
     if (rc) return rc;
   }
   if (!done) {
-    zero_matrix();
+    g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
     switch (s.dim) {
     case 1: rc = dispatch_dim<1>(g, S, out); break;
     case 2: rc = dispatch_dim<2>(g, S, out); break;
     default: rc = dispatch_dim<3>(g, S, out); break;
     }
+    g->zero_matrix = nullptr;
     if (rc) return rc;
   }
   if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }

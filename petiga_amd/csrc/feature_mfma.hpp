@@ -105,6 +105,17 @@ __device__ __forceinline__ void shape_features(const double *const t1d[3], const
   }
 }
 
+// First touch (as in the pencil kernel, gram_mfma.hpp): along one axis the entry (row slot a, column slot b) of element e
+// is shared by the elements [e + max(a,b) - p, e + min(a,b)]; colours are e mod (p+1), launched in ascending order.
+__device__ __forceinline__ bool fm_first_touch_axis(int e, int a, int b, int nel, int p) {
+  const int nb = p + 1;
+  int lo = e + (a > b ? a : b) - p, hi = e + (a < b ? a : b);
+  if (lo < 0) lo = 0;
+  if (hi > nel - 1) hi = nel - 1;
+  const int c0 = ((lo + nb - 1) / nb) * nb;
+  return (c0 <= hi) ? (e % nb == 0) : (e == lo);
+}
+
 typedef double fm_d2u_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access at 8-byte alignment
 template <int N> __device__ __forceinline__ void load_run(const double *p, double *v) {
 #pragma unroll
@@ -236,7 +247,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     if (tid < nq[d]) { if (face) ptv[d] = S.ax[d].bndpt[bside]; else { wv[d] = S.ax[d].w[el[d] * nq[d] + tid]; ptv[d] = S.ax[d].pt[el[d] * nq[d] + tid]; } }
     Jax[d] = S.ax[d].J[el[d]];
     const int Wd = 2 * S.ax[d].p + 1;
-    if (tid < na[d] * na[d]) { const int ad = tid / na[d], bd = tid - ad * na[d]; pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)]; }
+    if (tid < na[d] * na[d]) {   // column position, with the first-touch flag of the slot pair in bit 30
+      const int ad = tid / na[d], bd = tid - ad * na[d];
+      pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)] | ((out.first_touch && fm_first_touch_axis(el[d], ad, bd, S.ax[d].nel, S.ax[d].p)) ? (1 << 30) : 0);
+    }
   }
   const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
   const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
@@ -726,10 +740,13 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const int as = ok[r] ? a : 0;
         const int ap = adec[as];
         const int a0 = ap & 255, a1 = (ap >> 8) & 255, a2 = ap >> 16;
-        const int P0 = pax[0 * 64 + a0 * 8 + b0], P1 = pax[1 * 64 + a1 * 8 + b1], P2 = pax[2 * 64 + a2 * 8 + b2];
+        const int v0 = pax[0 * 64 + a0 * 8 + b0], v1 = pax[1 * 64 + a1 * 8 + b1], v2 = pax[2 * 64 + a2 * 8 + b2];
+        const int P0 = v0 & 0x3fffffff, P1 = v1 & 0x3fffffff, P2 = v2 & 0x3fffffff;
         const size_t pos = (size_t)rowbase[as] + ((size_t)P2 * cc[NE + as] + P1) * cc[as] + P0;
         dst[r] = out.val + pos * (DOF * DOF) + I0 * DOF;
-        if (ok[r] && !(out.debug & 16)) load_run<DOFI * DOF>(dst[r], v[r]);
+        // the first colour to reach a block stores it (no MatZeroEntries, no read)
+        const bool first = ((v0 & v1 & v2) >> 30) & 1;
+        if (ok[r] && !first && !(out.debug & 16)) load_run<DOFI * DOF>(dst[r], v[r]);
         else { for (int k = 0; k < DOFI * DOF; ++k) v[r][k] = 0; }
       }
       double kij[GRAM ? 4 : 1][GRAM ? DOF * DOF : 1];

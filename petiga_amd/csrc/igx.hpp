@@ -128,6 +128,7 @@ struct OutDev {
   int op;
   int *errflag;
   int bid;                 // boundary-form pass: 2*axis+side (IGAElementNextForm, src/petigaelem.c:427); -1 = interior pass
+  int first_touch;         // 1: the matrix was not zeroed: the first colour that reaches an entry stores it (feature kernel)
   int debug;               // experiment switches (IGX_DEBUG_FEATURE): 1 no scatter, 2 atomic scatter, 4 no MFMA phase
   long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
