@@ -436,6 +436,7 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
             dirichlet_all((g,), dim, 1.0)
         g.set_form(form, prm)
         A, b = g.create_mat(), g.create_vec()
+        _poison(A)                       # stale values must not survive (first-touch stores + neighbour-row zeroing)
         g.compute_system(A, b)
         for k, (peer, m, v) in enumerate(g.neighbors(True)):
             buf = torch.empty(m + v, dtype=torch.float64, device="cuda")
@@ -702,6 +703,7 @@ def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic
     mats, vecsF, send = [], [], {}
     for r, g in enumerate(engs):
         A, b = g.create_mat(), g.create_vec()
+        _poison(A)
         g.compute_ifunction(2.0, Vs[r], 0.1, Us[r], b)
         g.compute_ijacobian(2.0, Vs[r], 0.1, Us[r], A)
         for k, (peer, m, v) in enumerate(g.neighbors(True)):
