@@ -6,16 +6,28 @@
 #include <functional>
 #include <memory>
 #include <string>
+#include <type_traits>
 #include <vector>
 #include "igx.hpp"
 #include "generic_kernel.hpp"
 #include "feature_mfma.hpp"
+#include "first_touch.hpp"
+#ifndef IGX_TU_DISPATCH
 #include "gram_mfma.hpp"
+#endif
 
 using namespace igx;
 
-static thread_local std::string g_err;
+// The library is built from several translation units of this one source (see petiga_amd/build.py): the main unit
+// (C ABI, set-up, drivers) and, compiled with -DIGX_TU_DISPATCH -DIGX_TU_DIM=d -DIGX_TU_GROUP=g, units that hold only
+// the kernel instantiations of one dimension / form group.  The last-error text is one object for all of them.
+inline std::string &igx_err_slot() { static thread_local std::string e; return e; }
+#define g_err igx_err_slot()
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+constexpr int IGX_NOT_MINE = -12345;    // a dispatch unit's answer for a form of another group
+#ifndef IGX_TU_GROUP
+#define IGX_TU_GROUP -1
+#endif
 #define HIPCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(IGX_ERR_LIB, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
 
 // ------------------------------------------------------------------ objects
@@ -59,8 +71,11 @@ struct _p_IGXMat {
 };
 struct _p_IGXVec { IGX iga; int64_t n; DevBuf a; };
 
+#ifndef IGX_TU_DISPATCH
 extern "C" const char *IGXGetLastError(void) { return g_err.c_str(); }
+#endif
 
+#ifndef IGX_TU_DISPATCH
 // ------------------------------------------------------------------ set-up mirror
 extern "C" int IGXCreate(IGX *iga) { if (!iga) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *iga = new _p_IGX(); return 0; }
 extern "C" int IGXDestroy(IGX *iga) {
@@ -437,6 +452,9 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
   return 0;
 }
 
+#endif   // !IGX_TU_DISPATCH
+
+#ifdef IGX_TU_DISPATCH
 // ------------------------------------------------------------------ feature-GEMM kernel dispatch (feature_mfma.hpp)
 // one launch per group of DOFI row fields: I0 = 0, DOFI, 2*DOFI, ...
 template <class Form, int DIM, int TA, int NW, int DOFI, int I0, bool HASM>
@@ -698,34 +716,92 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   return 0;
 }
 
-template <int DIM>
+// GROUP < 0: every form; else only the forms of that group (0 scalar second-order-free forms, 1 multi-field
+// constant-coefficient forms, 2 the nonlinear demos), IGX_NOT_MINE for the others
+template <int DIM, int GROUP>
 static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
   const Space &s = g->s;
+#define IGX_GROUP(gid, call) do { if constexpr (GROUP < 0 || GROUP == (gid)) return call; else return IGX_NOT_MINE; } while (0)
   switch (s.form) {
-  case IGX_FORM_POISSON:   return launch_generic<FormPoisson<DIM>, DIM>(g, S, out);
-  case IGX_FORM_POISSON_F: return launch_generic<FormPoissonF<DIM>, DIM>(g, S, out);
-  case IGX_FORM_L2PROJ_X2: return launch_generic<FormL2ProjX2<DIM>, DIM>(g, S, out);
-  case IGX_FORM_ERRNORM:   return launch_generic<FormErrNorm<DIM>, DIM>(g, S, out);
+  case IGX_FORM_POISSON:   IGX_GROUP(0, (launch_generic<FormPoisson<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_POISSON_F: IGX_GROUP(0, (launch_generic<FormPoissonF<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_L2PROJ_X2: IGX_GROUP(0, (launch_generic<FormL2ProjX2<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_BOUNDARYINTEGRAL: IGX_GROUP(0, (launch_generic<FormBoundaryIntegral<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_NITSCHE:          IGX_GROUP(0, (launch_generic<FormNitsche<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_ERRNORM:   IGX_GROUP(1, (launch_generic<FormErrNorm<DIM>, DIM>(g, S, out)));
   case IGX_FORM_MASS:
-    switch (s.dof) {
-    case 1: return launch_generic<FormMass<DIM, 1>, DIM>(g, S, out);
-    case 2: return launch_generic<FormMass<DIM, 2>, DIM>(g, S, out);
-    case 3: return launch_generic<FormMass<DIM, 3>, DIM>(g, S, out);
-    case 4: return launch_generic<FormMass<DIM, 4>, DIM>(g, S, out);
-    default: return fail(IGX_ERR_SUP, "mass form is instantiated for dof 1..4");
-    }
+    if constexpr (GROUP < 0 || GROUP == 1) {
+      switch (s.dof) {
+      case 1: return launch_generic<FormMass<DIM, 1>, DIM>(g, S, out);
+      case 2: return launch_generic<FormMass<DIM, 2>, DIM>(g, S, out);
+      case 3: return launch_generic<FormMass<DIM, 3>, DIM>(g, S, out);
+      case 4: return launch_generic<FormMass<DIM, 4>, DIM>(g, S, out);
+      default: return fail(IGX_ERR_SUP, "mass form is instantiated for dof 1..4");
+      }
+    } else return IGX_NOT_MINE;
   case IGX_FORM_ELASTICITY:
-    if constexpr (DIM == 3) return launch_generic<FormElasticity, 3>(g, S, out);
-    else return fail(IGX_ERR_ARG_WRONG, "Elasticity3D form needs dim = 3");
+    if constexpr (GROUP < 0 || GROUP == 1) {
+      if constexpr (DIM == 3) return launch_generic<FormElasticity, 3>(g, S, out);
+      else return fail(IGX_ERR_ARG_WRONG, "Elasticity3D form needs dim = 3");
+    } else return IGX_NOT_MINE;
   case IGX_FORM_CAHNHILLIARD:
-    if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);
-    else return fail(IGX_ERR_ARG_WRONG, "Cahn-Hilliard form needs dim = 2 or 3");
-  case IGX_FORM_BOUNDARYINTEGRAL: return launch_generic<FormBoundaryIntegral<DIM>, DIM>(g, S, out);
-  case IGX_FORM_NITSCHE:          return launch_generic<FormNitsche<DIM>, DIM>(g, S, out);
+    if constexpr (GROUP < 0 || GROUP == 2) {
+      if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);
+      else return fail(IGX_ERR_ARG_WRONG, "Cahn-Hilliard form needs dim = 2 or 3");
+    } else return IGX_NOT_MINE;
   case IGX_FORM_NSVMS:
-    if constexpr (DIM == 3) return launch_generic<FormNSVMS, 3>(g, S, out);
-    else return fail(IGX_ERR_ARG_WRONG, "NavierStokesVMS form needs dim = 3");
+    if constexpr (GROUP < 0 || GROUP == 2) {
+      if constexpr (DIM == 3) return launch_generic<FormNSVMS, 3>(g, S, out);
+      else return fail(IGX_ERR_ARG_WRONG, "NavierStokesVMS form needs dim = 3");
+    } else return IGX_NOT_MINE;
   default: return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetForm...() first");   // IGACheckFormOp, include/petiga.h:925-936
+  }
+#undef IGX_GROUP
+}
+
+// IGAComputeScalar (src/petigacomp.c:35-98): the functionals of one dimension
+template <int DIM>
+static int dispatch_scalar(IGX g, int kind, const SpaceDev &S, const OutDev &out, int order) {
+  switch (kind) {
+  case IGX_SCALAR_VOLUME:  return launch_generic<ScalarVolume<DIM>, DIM>(g, S, out);
+  case IGX_SCALAR_X2ERR:   return launch_generic<ScalarX2Err<DIM>, DIM>(g, S, out);
+  case IGX_SCALAR_ERRNORM: return order >= 2 ? launch_generic<ScalarErrNorm<DIM, true>, DIM>(g, S, out) : launch_generic<ScalarErrNorm<DIM, false>, DIM>(g, S, out);
+  default: return fail(IGX_ERR_ARG_OUTOFRANGE, "unknown scalar functional");
+  }
+}
+
+// the entry points of this unit
+int igx_tu_dispatch(std::integral_constant<int, IGX_TU_DIM>, std::integral_constant<int, IGX_TU_GROUP>, IGX g, const SpaceDev &S, const OutDev &out) {
+  return dispatch_dim<IGX_TU_DIM, IGX_TU_GROUP>(g, S, out);
+}
+#if IGX_TU_GROUP < 0 || IGX_TU_GROUP == 2
+int igx_tu_scalar(std::integral_constant<int, IGX_TU_DIM>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order) {
+  return dispatch_scalar<IGX_TU_DIM>(g, kind, S, out, order);
+}
+#endif
+#endif   // IGX_TU_DISPATCH
+
+#ifndef IGX_TU_DISPATCH
+// kernel instantiations live in the dispatch units (one per dimension; three form groups for dim 3)
+int igx_tu_dispatch(std::integral_constant<int, 1>, std::integral_constant<int, -1>, IGX g, const SpaceDev &S, const OutDev &out);
+int igx_tu_dispatch(std::integral_constant<int, 2>, std::integral_constant<int, -1>, IGX g, const SpaceDev &S, const OutDev &out);
+int igx_tu_dispatch(std::integral_constant<int, 3>, std::integral_constant<int, 0>, IGX g, const SpaceDev &S, const OutDev &out);
+int igx_tu_dispatch(std::integral_constant<int, 3>, std::integral_constant<int, 1>, IGX g, const SpaceDev &S, const OutDev &out);
+int igx_tu_dispatch(std::integral_constant<int, 3>, std::integral_constant<int, 2>, IGX g, const SpaceDev &S, const OutDev &out);
+int igx_tu_scalar(std::integral_constant<int, 1>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
+int igx_tu_scalar(std::integral_constant<int, 2>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
+int igx_tu_scalar(std::integral_constant<int, 3>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
+static int dispatch_by_dim(IGX g, const SpaceDev &S, const OutDev &out) {
+  using std::integral_constant;
+  switch (g->s.dim) {
+  case 1: return igx_tu_dispatch(integral_constant<int, 1>(), integral_constant<int, -1>(), g, S, out);
+  case 2: return igx_tu_dispatch(integral_constant<int, 2>(), integral_constant<int, -1>(), g, S, out);
+  default: {
+    int rc = igx_tu_dispatch(integral_constant<int, 3>(), integral_constant<int, 0>(), g, S, out);
+    if (rc == IGX_NOT_MINE) rc = igx_tu_dispatch(integral_constant<int, 3>(), integral_constant<int, 1>(), g, S, out);
+    if (rc == IGX_NOT_MINE) rc = igx_tu_dispatch(integral_constant<int, 3>(), integral_constant<int, 2>(), g, S, out);
+    return rc;
+  }
   }
 }
 
@@ -767,11 +843,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   }
   if (!done) {
     g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
-    switch (s.dim) {
-    case 1: rc = dispatch_dim<1>(g, S, out); break;
-    case 2: rc = dispatch_dim<2>(g, S, out); break;
-    default: rc = dispatch_dim<3>(g, S, out); break;
-    }
+    rc = dispatch_by_dim(g, S, out);
     g->zero_matrix = nullptr;
     if (rc) return rc;
   }
@@ -792,16 +864,6 @@ extern "C" int IGXComputeIFunction(IGX g, double a, IGXVec V, double t, IGXVec U
 extern "C" int IGXComputeIJacobian(IGX g, double a, IGXVec V, double t, IGXVec U, IGXMat J) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IJACOBIAN, J, nullptr, U, V, a, t); }
 
 // ------------------------------------------------------------------ IGAComputeScalar (src/petigacomp.c:35-98)
-template <int DIM>
-static int dispatch_scalar(IGX g, int kind, const SpaceDev &S, const OutDev &out, int order) {
-  switch (kind) {
-  case IGX_SCALAR_VOLUME:  return launch_generic<ScalarVolume<DIM>, DIM>(g, S, out);
-  case IGX_SCALAR_X2ERR:   return launch_generic<ScalarX2Err<DIM>, DIM>(g, S, out);
-  case IGX_SCALAR_ERRNORM: return order >= 2 ? launch_generic<ScalarErrNorm<DIM, true>, DIM>(g, S, out) : launch_generic<ScalarErrNorm<DIM, false>, DIM>(g, S, out);
-  default: return fail(IGX_ERR_ARG_OUTOFRANGE, "unknown scalar functional");
-  }
-}
-
 extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[], int nparams, int n, double S[]) {
   NEEDIGA(g);
   if (int rc = ensure_device(g)) return rc;
@@ -831,9 +893,9 @@ extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[]
   s.params.assign(params, params + nparams);
   int rc;
   switch (s.dim) {
-  case 1: rc = dispatch_scalar<1>(g, kind, Sd, out, order); break;
-  case 2: rc = dispatch_scalar<2>(g, kind, Sd, out, order); break;
-  default: rc = dispatch_scalar<3>(g, kind, Sd, out, order); break;
+  case 1: rc = igx_tu_scalar(std::integral_constant<int, 1>(), g, kind, Sd, out, order); break;
+  case 2: rc = igx_tu_scalar(std::integral_constant<int, 2>(), g, kind, Sd, out, order); break;
+  default: rc = igx_tu_scalar(std::integral_constant<int, 3>(), g, kind, Sd, out, order); break;
   }
   s.params = keep;
   if (rc) return rc;
@@ -850,3 +912,4 @@ extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[]
 // ------------------------------------------------------------------ multi-GPU ghost rows (filled in by exchange.hpp)
 #include "exchange.hpp"
 #include "fileio.hpp"
+#endif   // !IGX_TU_DISPATCH

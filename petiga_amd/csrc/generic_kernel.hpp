@@ -438,7 +438,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
 }
 
 // deterministic two-stage sum of the per-element partial rows part[n][NS] -> res[NS]
-__global__ void __launch_bounds__(256) k_sum_partials(const double *part, int64_t n, int ns, double *res, int64_t chunk) {
+static __global__ void __launch_bounds__(256) k_sum_partials(const double *part, int64_t n, int ns, double *res, int64_t chunk) {
   __shared__ double red[256];
   const int64_t lo = (int64_t)blockIdx.x * chunk, hi = (lo + chunk < n) ? lo + chunk : n;
   for (int c = 0; c < ns; ++c) {

@@ -13,6 +13,7 @@
 // lane l, reg r of tile (ta,tb) holds K_e[a=(l>>4, r, ta)][b=(l&3, (l>>2)&3, tb)].
 #pragma once
 #include <functional>
+#include "first_touch.hpp"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,11 +27,6 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int HOLD_LD = 66;   // padded row stride (doubles) of the pencil kernel's per-wavefront hold area [6 slots][4 r][HOLD_LD]
 
 // the launches of the dominant kernel of one assembly, for the roofline line of bench.py
-struct DomInfo {
-  std::string name = "none"; int launches = 0; long long elements = 0; double flop_per_element = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // recorded around those launches when timing is on
-};
-
 struct GramArgs {
   double forcing;      // F_a = forcing * int N_a   (1.0 for Poisson3D, -2*dim for IGAFixTable System2)
   int nwaves;          // elements in this launch
@@ -845,41 +841,6 @@ static bool axis_walkable(const Space &s, int d) {   // one new node layer per e
   if (s.lay[d].alias || s.elem_width[d] < 8) return false;
   for (int e = 0; e + 1 < s.elem_width[d]; ++e)
     if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
-  return true;
-}
-
-// zero the values of the rows of a box of row indices (rows near a face shared with another rank: they keep columns
-// of nodes this rank holds no element of, which only the ghost-row exchange fills)
-__global__ void k_zero_row_box(int s0, int s1, int s2, int c0, int c1, int nr0, int nr1, const int64_t *browptr, double *val, int bs2) {
-  const int64_t r = blockIdx.x;
-  const int k0 = (int)(r % c0), k1 = (int)((r / c0) % c1), k2 = (int)(r / ((int64_t)c0 * c1));
-  const int64_t row = (int64_t)(s0 + k0) + (int64_t)nr0 * ((int64_t)(s1 + k1) + (int64_t)nr1 * (s2 + k2));
-  double *p = val + browptr[row] * bs2; const int64_t n = (browptr[row + 1] - browptr[row]) * bs2;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.0;
-}
-
-// rows with stencil columns outside the rank's element box: within p node layers of a face that has a neighbour rank
-static void zero_neighbour_rows(const Space &s, const OutDev &out, hipStream_t stream) {
-  for (int d = 0; d < s.dim; ++d) {
-    const bool per = s.axis[d].periodic != 0;
-    const bool lower = s.proc_sizes[d] > 1 && (s.proc_ranks[d] > 0 || per), upper = s.proc_sizes[d] > 1 && (s.proc_ranks[d] < s.proc_sizes[d] - 1 || per);
-    const int nr = s.lay[d].nrow, p = s.axis[d].p;
-    for (int side = 0; side < 2; ++side) {
-      if (!(side ? upper : lower)) continue;
-      int st[3] = {0, 0, 0}, ct[3] = {s.lay[0].nrow, s.lay[1].nrow, s.lay[2].nrow};
-      ct[d] = std::min(p, nr); st[d] = side ? nr - ct[d] : 0;
-      const int64_t rows = (int64_t)ct[0] * ct[1] * ct[2];
-      if (rows > 0) hipLaunchKernelGGL(k_zero_row_box, dim3((unsigned)rows), dim3(256), 0, stream, st[0], st[1], st[2], ct[0], ct[1], s.lay[0].nrow, s.lay[1].nrow, out.browptr, out.val, s.dof * s.dof);
-    }
-  }
-}
-
-// true when every element pair on axis d follows the e mod (p+1) colouring with one new node layer per element
-static bool axis_first_touch_ok(const Space &s, int d) {
-  if (s.lay[d].alias) return false;
-  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
-    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
-  for (int e = 0; e < s.elem_width[d]; ++e) if (s.lay[d].color[e] != e % (s.axis[d].p + 1)) return false;
   return true;
 }
 
