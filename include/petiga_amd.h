@@ -70,8 +70,9 @@ typedef enum {
   IGX_FORM_NSVMS       = 8, /* IFunction/IJacobian: demo/NavierStokesVMS.c:78-244 (dof=4)
                                params: {nu, fx, fy, fz, dt}  (dt: the reference reads TSGetTimeStep at :85,:173) */
   IGX_FORM_BOUNDARYINTEGRAL = 9, /* System: demo/BoundaryIntegral.c:26-56  interior Laplace, F=N*1 on visited faces (Neumann) */
-  IGX_FORM_NITSCHE     = 10 /* System: demo/NitscheMethod.c:69-110  Poisson with Nitsche terms on visited faces (normals,
+  IGX_FORM_NITSCHE     = 10,/* System: demo/NitscheMethod.c:69-110  Poisson with Nitsche terms on visited faces (normals,
                                normal mesh size through IGAPointFormInvGradGeomMap); params: {max degree k} */
+  IGX_FORM_BRATU       = 11 /* Function/Jacobian and IFunction/IJacobian: demo/Bratu.c, demo/BratuFJ.F90:23-176  params: {lambda} */
 } IGXFormKind;
 
 /* ------------------------------------------------------------------------------------------

@@ -379,3 +379,61 @@ int orc_form_ns_tangent(OrcPoint *pnt,double shift,const double *V,double t,cons
   }
   return 0;
 }
+
+/* demo/BratuFJ.F90:23-58 (Bratu_Function, Galerkin branch): F_a = grad N_a . grad u - N_a lambda exp(u); ctx = double* lambda */
+int orc_form_bratu_function(OrcPoint *p,const double *U,double *F,void *ctx)
+{
+  int a,i,nen=p->nen,dim=p->dim; double u,gu[3],lambda = *(const double*)ctx;
+  const double *N0=p->shape[0],*N1=p->shape[1];
+  orc_point_value(p,U,&u); orc_point_grad(p,U,gu);
+  for (a=0; a<nen; a++) {
+    double s = 0;
+    for (i=0;i<dim;i++) s += N1[a*dim+i]*gu[i];
+    F[a] = + s - N0[a]*lambda*exp(u);
+  }
+  return 0;
+}
+
+/* demo/BratuFJ.F90:60-107 (Bratu_Jacobian, Galerkin branch): J(b,a) = grad N_a . grad N_b - N_a N_b lambda exp(u) */
+int orc_form_bratu_jacobian(OrcPoint *p,const double *U,double *J,void *ctx)
+{
+  int a,b,i,nen=p->nen,dim=p->dim; double u,lambda = *(const double*)ctx;
+  const double *N0=p->shape[0],*N1=p->shape[1];
+  orc_point_value(p,U,&u);
+  for (a=0; a<nen; a++) for (b=0; b<nen; b++) {
+    double s = 0;
+    for (i=0;i<dim;i++) s += N1[a*dim+i]*N1[b*dim+i];
+    J[a*nen+b] = + s - N0[a]*N0[b]*lambda*exp(u);
+  }
+  return 0;
+}
+
+/* demo/BratuFJ.F90:111-141 (Bratu_IFunction): F_a = N_a v + grad N_a . grad u - N_a lambda exp(u) */
+int orc_form_bratu_ifunction(OrcPoint *p,double shift,const double *V,double t,const double *U,double *F,void *ctx)
+{
+  int a,i,nen=p->nen,dim=p->dim; double v,u,gu[3],lambda = *(const double*)ctx;
+  const double *N0=p->shape[0],*N1=p->shape[1];
+  (void)shift; (void)t;
+  orc_point_value(p,V,&v); orc_point_value(p,U,&u); orc_point_grad(p,U,gu);
+  for (a=0; a<nen; a++) {
+    double s = 0;
+    for (i=0;i<dim;i++) s += N1[a*dim+i]*gu[i];
+    F[a] = + N0[a]*v + s - N0[a]*lambda*exp(u);
+  }
+  return 0;
+}
+
+/* demo/BratuFJ.F90:143-176 (Bratu_IJacobian): J(b,a) = shift N_a N_b + grad N_a . grad N_b - N_a N_b lambda exp(u) */
+int orc_form_bratu_ijacobian(OrcPoint *p,double shift,const double *V,double t,const double *U,double *J,void *ctx)
+{
+  int a,b,i,nen=p->nen,dim=p->dim; double u,lambda = *(const double*)ctx;
+  const double *N0=p->shape[0],*N1=p->shape[1];
+  (void)V; (void)t;
+  orc_point_value(p,U,&u);
+  for (a=0; a<nen; a++) for (b=0; b<nen; b++) {
+    double s = 0;
+    for (i=0;i<dim;i++) s += N1[a*dim+i]*N1[b*dim+i];
+    J[a*nen+b] = + shift*N0[a]*N0[b] + s - N0[a]*N0[b]*lambda*exp(u);
+  }
+  return 0;
+}

@@ -957,15 +957,62 @@ static int elem_tabulate(Elem *e)
 /* Iteration: elements, forms, points                                  */
 /* ------------------------------------------------------------------ */
 
-/* src/petigaelem.c:1118-1164 (BoundaryArea) -- only the no-geometry branch is restated;
- * boundary loads on mapped geometries are outside the hot path. */
-static int boundary_area(const Elem *e,int dir,double *A)
+/* src/petiga2d.F90:276-346 / src/petiga3d.F90:379-464 (IGA_BoundaryArea_2D/3D): dS = sum_q w_q sqrt|det(F F^T)| over the
+ * face of the element, F = d(face map)/d(knot coordinates) from the first / last layer of the element's control points,
+ * raw Gauss weights (sum 2 per axis), basis derivatives w.r.t. the knot coordinate, local Rationalize. */
+static double boundary_area_dS(const Elem *e,int dir,int side)
+{
+  const OrcIGA *iga = e->iga; int dim=e->dim, nsd=e->nsd, fd=dim-1;
+  int ax[2]={0,0}, nq[2]={1,1}, na[2]={1,1}, m[3]={1,1,1}, i,k,q0,q1,a0,a1,c,r,s2;
+  const double *W[2]={NULL,NULL}, *N[2]={NULL,NULL}; double dS=0;
+  for (i=0; i<dim; i++) m[i] = iga->basis[i].nen;
+  for (k=0,i=0; i<dim; i++) { if (i==dir) continue; ax[k]=i; nq[k]=iga->basis[i].nqp; na[k]=iga->basis[i].nen;
+    W[k] = iga->basis[i].weight + (size_t)e->ID[i]*iga->basis[i].nqp; N[k] = iga->basis[i].value + (size_t)e->ID[i]*iga->basis[i].nqp*na[k]*5; k++; }
+  for (q1=0; q1<nq[1]; q1++) for (q0=0; q0<nq[0]; q0++) {
+    double N0[64], N1[2][64], Xw[64], F[2][3], M[2][2]={{0,0},{0,0}}, detJ=1, W0=0, S1[2]={0,0}; int nen = na[0]*na[1];
+    for (a1=0; a1<na[1]; a1++) for (a0=0; a0<na[0]; a0++) {
+      int a = a0 + na[0]*a1, loc[3], la; double n0 = N[0][(q0*na[0]+a0)*5+0], d0 = N[0][(q0*na[0]+a0)*5+1], n1 = 1, d1 = 0;
+      if (fd == 2) { n1 = N[1][(q1*na[1]+a1)*5+0]; d1 = N[1][(q1*na[1]+a1)*5+1]; }
+      N0[a] = n0*n1; N1[0][a] = d0*n1; N1[1][a] = n0*d1;
+      loc[0]=loc[1]=loc[2]=0; loc[dir] = side ? m[dir]-1 : 0; loc[ax[0]] = a0; if (fd == 2) loc[ax[1]] = a1;
+      la = loc[0] + m[0]*(loc[1] + m[1]*loc[2]);
+      Xw[a] = iga->rational ? e->rationalW[la] : 1.0;
+      (void)la;
+    }
+    if (iga->rational) {   /* local Rationalize */
+      for (k=0; k<nen; k++) { N0[k] *= Xw[k]; W0 += N0[k]; }
+      for (k=0; k<nen; k++) N0[k] /= W0;
+      for (r=0; r<fd; r++) { for (k=0; k<nen; k++) S1[r] += Xw[k]*N1[r][k]; for (k=0; k<nen; k++) N1[r][k] = (Xw[k]*N1[r][k] - N0[k]*S1[r])/W0; }
+    }
+    if (iga->nsd) {        /* local Jacobian: F = N1 X^T, M = F F^T, J = sqrt|det M| */
+      for (r=0; r<fd; r++) for (c=0; c<nsd; c++) F[r][c] = 0;
+      for (a1=0; a1<na[1]; a1++) for (a0=0; a0<na[0]; a0++) {
+        int a = a0 + na[0]*a1, loc[3]={0,0,0}, la;
+        loc[dir] = side ? m[dir]-1 : 0; loc[ax[0]] = a0; if (fd == 2) loc[ax[1]] = a1;
+        la = loc[0] + m[0]*(loc[1] + m[1]*loc[2]);
+        for (r=0; r<fd; r++) for (c=0; c<nsd; c++) F[r][c] += N1[r][a]*e->geometryX[(size_t)la*nsd+c];
+      }
+      for (r=0; r<fd; r++) for (s2=0; s2<fd; s2++) { M[r][s2]=0; for (c=0; c<nsd; c++) M[r][s2] += F[r][c]*F[s2][c]; }
+      detJ = (fd == 1) ? M[0][0] : M[0][0]*M[1][1]-M[0][1]*M[1][0];
+      detJ = sqrt(fabs(detJ));
+    }
+    dS += detJ * W[0][q0]*(fd == 2 ? W[1][q1] : 1.0);
+  }
+  return dS;
+}
+
+/* src/petigaelem.c:1118-1164 (BoundaryArea) */
+static int boundary_area(const Elem *e,int dir,int side,double *A)
 {
   int i,dim=e->dim; double a=1;
   if (dim == 1) { *A = 1; return 0; }
   for (i=0; i<dim; i++) if (i != dir) a *= e->iga->basis[i].detJac[e->ID[i]]/(double)e->iga->basis[i].nen;
-  if (e->iga->nsd) ORC_ERR("boundary load with geometry not restated");
-  a *= (dim==2) ? 2 : 4;
+  if (!e->iga->nsd) a *= (dim==2) ? 2 : 4;   /* sum(W) = 2 */
+  else {
+    if (e->nen > 64*8) ORC_ERR("boundary_area: element too large");
+    for (i=0; i<dim; i++) if (i != dir && e->iga->basis[i].nen > 8) ORC_ERR("boundary_area: degree too large");
+    a *= boundary_area_dS(e,dir,side);
+  }
   *A = a;
   return 0;
 }
@@ -1010,7 +1057,7 @@ static int elem_buildfix(Elem *e)
       int S[3]={0,0,0},E[3]={1,1,1},ia,ja,ka,d; double Area = 1;
       if (e->ID[i] != (side ? last : 0)) continue;
       if (!bcv->count && !bcl->count) continue;
-      if (bcl->count && boundary_area(e,i,&Area)) return 1;
+      if (bcl->count && boundary_area(e,i,side,&Area)) return 1;
       for (d=0; d<dim; d++) E[d] = iga->basis[d].nen;
       { int jstride = E[0], kstride = E[0]*E[1];
         if (side) S[i] = E[i]-1; else E[i] = S[i]+1;

@@ -173,6 +173,10 @@ int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,dou
 int orc_form_ch_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ns_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ns_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
+int orc_form_bratu_function (OrcPoint*,const double*,double*,void*);   /* demo/BratuFJ.F90 Bratu_Function; ctx = double* lambda */
+int orc_form_bratu_jacobian (OrcPoint*,const double*,double*,void*);   /* demo/BratuFJ.F90 Bratu_Jacobian */
+int orc_form_bratu_ifunction(OrcPoint*,double,const double*,double,const double*,double*,void*);
+int orc_form_bratu_ijacobian(OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_scalar_errnorm  (OrcPoint*,const double*,int,double*,void*); /* ctx = int* order; test/IGAErrNorm.c Exact */
 int orc_scalar_x2err    (OrcPoint*,const double*,int,double*,void*); /* test/IGAFixTable.c Exact, L2 */
 int orc_scalar_volume   (OrcPoint*,const double*,int,double*,void*); /* test/IGAGeometryMap.c Scalar */

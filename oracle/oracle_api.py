@@ -313,6 +313,18 @@ class OracleIGA:
         self._ck(self.L.orc_compute_system(self.p, _fn(form), C.cast(C.byref(ctx), C.c_void_p) if ctx is not None else None, A.ptr, _dp(B)))
         return A, B
 
+    def compute_function(self, form, ctx, U):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        F = np.zeros(self.global_size())
+        self._ck(self.L.orc_compute_function(self.p, _fn(form), C.cast(C.byref(ctx), C.c_void_p), _dp(U), _dp(F)))
+        return F
+
+    def compute_jacobian(self, form, ctx, U, A=None):
+        U = np.ascontiguousarray(U, dtype=np.float64)
+        A = A or self.create_mat()
+        self._ck(self.L.orc_compute_jacobian(self.p, _fn(form), C.cast(C.byref(ctx), C.c_void_p), _dp(U), A.ptr))
+        return A
+
     def compute_ifunction(self, form, ctx, a, V, t, U):
         V = np.ascontiguousarray(V, dtype=np.float64)
         U = np.ascontiguousarray(U, dtype=np.float64)

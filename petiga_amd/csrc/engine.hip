@@ -45,8 +45,6 @@ struct DevBuf {
 
 struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix, bnd; };
 
-// IGX_KERNEL=0..3 presets IGXSetKernel for every new IGX (test / experiment switch)
-static int default_kernel_choice() { const char *e = getenv("IGX_KERNEL"); const int k = e ? atoi(e) : 0; return (k >= 0 && k <= 3) ? k : 0; }
 
 struct _p_IGX {
   Space s;
@@ -54,7 +52,8 @@ struct _p_IGX {
   AxisBufs ab[3];
   DevBuf X, W, fixtable, errflag, scratch;
   hipStream_t stream = nullptr;
-  int kernel_choice = default_kernel_choice();
+  int kernel_choice = 0;
+  _p_IGX() { s.env = read_env_switches(); kernel_choice = s.env.kernel; }   // environment switches are read here, once per IGX
   std::string last_kernel = "none";
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
@@ -487,7 +486,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   // 12.8 -> 21.6 M elements/s, residual 16.7 -> 28.9).  8-wave kernels (nen = 64) hold one workgroup per CU unless the
   // form is scalar (16 accumulator VGPRs: Poisson p=3 on a NURBS geometry 8.2 vs 6.4 M/s); for the others the fewest
   // chunks of points win (NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 M/s).
-  static const int lds_kb_env = [] { const char *e = getenv("IGX_FEATURE_LDS_KB"); return e ? atoi(e) : 0; }();   // experiment switch
+  const int lds_kb_env = s.env.feature_lds_kb;   // experiment switch
   constexpr int WGS = fm_min_waves<Form, TA, NW, DOFI, HASM>();
   const size_t lds_auto = (NW == 4) ? (size_t)(160 * 1024 / WGS - 1024) : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit);
   const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : lds_auto;
@@ -525,8 +524,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   constexpr bool SCAL = nscalar_of<Form>::v > 0;
   // first-touch stores instead of MatZeroEntries + read (same rule as the pencil kernel): regular e mod (p+1) colours on
   // every axis; a rank with neighbours zeroes only the rows that keep neighbour-owned columns
-  static const bool ft_off = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
-  bool first_touch = HASM && !ft_off;
+  bool first_touch = HASM && !s.env.no_first_touch;
   for (int d = 0; d < DIM && first_touch; ++d) first_touch = axis_first_touch_ok(s, d);
   OutDev out_ft = out; out_ft.first_touch = first_touch ? 1 : 0;
   if (HASM) {
@@ -749,6 +747,7 @@ static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
       if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);
       else return fail(IGX_ERR_ARG_WRONG, "Cahn-Hilliard form needs dim = 2 or 3");
     } else return IGX_NOT_MINE;
+  case IGX_FORM_BRATU:     IGX_GROUP(2, (launch_generic<FormBratu<DIM>, DIM>(g, S, out)));
   case IGX_FORM_NSVMS:
     if constexpr (GROUP < 0 || GROUP == 2) {
       if constexpr (DIM == 3) return launch_generic<FormNSVMS, 3>(g, S, out);
@@ -817,12 +816,10 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   if (hasV && (!b || b->iga != g)) return fail(IGX_ERR_ARG_WRONG, "vector missing or created by another IGX");
   if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
   if (V && V->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
-  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd)
-    if (s.load[a][sd].count && s.nsd) return fail(IGX_ERR_SUP, "boundary loads on mapped geometries are not supported on the device path");
   OutDev out; memset(&out, 0, sizeof(out));
   out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>(); out.bid = -1;
-  { const char *e = getenv("IGX_DEBUG_FEATURE"); out.debug = e ? atoi(e) : 0; }
-  if (out.debug & 8) { if (!g->dbgbuf.p) g->dbgbuf.alloc(32 * sizeof(long long)); HIPCK(hipMemsetAsync(g->dbgbuf.p, 0, 32 * sizeof(long long), g->stream)); out.dbg = g->dbgbuf.as<long long>(); }
+  out.debug = s.env.debug_feature;
+  if (kDebug && (out.debug & 8)) { if (!g->dbgbuf.p) g->dbgbuf.alloc(32 * sizeof(long long)); HIPCK(hipMemsetAsync(g->dbgbuf.p, 0, 32 * sizeof(long long), g->stream)); out.dbg = g->dbgbuf.as<long long>(); }
   if (hasM) { out.browptr = A->browptr.as<int64_t>(); out.val = A->val.as<double>(); }
   if (hasV) out.vec = b->a.as<double>();
   out.U = U ? U->a.as<double>() : nullptr; out.V = V ? V->a.as<double>() : nullptr;
@@ -848,7 +845,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
     if (rc) return rc;
   }
   if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }
-  if (out.dbg) {
+  if (kDebug && out.dbg) {
     long long h[32]; HIPCK(hipStreamSynchronize(g->stream)); HIPCK(hipMemcpy(h, g->dbgbuf.p, sizeof(h), hipMemcpyDeviceToHost));
     fprintf(stderr, "[feature stamps]"); for (int i = 1; i < (int)h[31] && i < 31; ++i) fprintf(stderr, " %lld", h[i] - h[i - 1]); fprintf(stderr, "\n");
   }

@@ -101,6 +101,7 @@ static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool sen
   NEEDIGA(g);
   if (int rc = ensure_device(g)) return rc;
   const Space &s = g->s;
+  { std::string e; if (int rc = exchange_supported(s, e)) return fail(rc, e); }
   const std::vector<NbrPlan> plans = neighbour_plans(s, send_list);
   if (k < 0 || k >= (int)plans.size()) return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour");
   if (!devbuf) return fail(IGX_ERR_ARG_WRONG, "null buffer");
@@ -130,12 +131,14 @@ static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool sen
 extern "C" int IGXGetNeighborCount(IGX g, int *nsend, int *nrecv) {
   NEEDIGA(g);
   if (!g->s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  { std::string e; if (int rc = exchange_supported(g->s, e)) return fail(rc, e); }
   if (nsend) *nsend = (int)neighbour_plans(g->s, true).size();
   if (nrecv) *nrecv = (int)neighbour_plans(g->s, false).size();
   return 0;
 }
 extern "C" int IGXGetNeighborInfo(IGX g, int send, int k, int *rank, int64_t *mat_doubles, int64_t *vec_doubles) {
   NEEDIGA(g);
+  { std::string e; if (int rc = exchange_supported(g->s, e)) return fail(rc, e); }
   const std::vector<NbrPlan> plans = neighbour_plans(g->s, send != 0);
   if (k < 0 || k >= (int)plans.size()) return fail(IGX_ERR_ARG_OUTOFRANGE, "no such neighbour");
   if (rank) *rank = plans[k].rank; if (mat_doubles) *mat_doubles = plans[k].mat_doubles; if (vec_doubles) *vec_doubles = plans[k].vec_doubles;

@@ -220,7 +220,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   int *qdec = reinterpret_cast<int *>(smem + cv.qdec);          // [NQP] q -> q0 | q1<<8 | q2<<16
   __shared__ int s_anyfix;
   if (tid == 0) s_anyfix = 0;
-  const bool stamp = out.dbg && blockIdx.x == 7 && tid == 0;
+  const bool stamp = kDebug && out.dbg && blockIdx.x == 7 && tid == 0;
   int nst = 0;
 #define FM_STAMP() do { if (stamp) out.dbg[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
   FM_STAMP();
@@ -304,7 +304,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             s_anyfix = 1;
           }
           const BCDev &bl = S.bcl[d][side];
-          if (bl.count) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132)
+          if (bl.count && !geo) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132); mapped: add_mapped_flux below
             double A = 1;
             if (DIM > 1) {
               for (int i = 0; i < DIM; ++i) if (i != d) A *= Jax[i] / (double)na[i];
@@ -319,6 +319,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
+  if (geo && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
   if (anyfix && (useU || useV)) {   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
     for (int k = tid; k < NE * DOF; k += nthr)
       if (fixflag[k]) { if (useU) { ufix[k] = Ue[k]; Ue[k] = fixval[k]; } if (useV) Ve[k] = 0.0; }
@@ -626,7 +627,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
     FM_STAMP();
     // ---- phase 5: K_e += A^T B on the matrix cores
-    if constexpr (HASM) if (wave_active && !(out.debug & 4)) {
+    if constexpr (HASM) if (wave_active && !(kDebug && (out.debug & 4))) {
       const int kq = lane >> 4, col = tb * 16 + (lane & 15);
       for (int s = 0; s < QC / 4; ++s) {
         const int ql = 4 * s + kq, q = qc0 + ql;
@@ -726,7 +727,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free).
   // Per tile the four row groups are read together, then written: 4 x DOFI*DOF loads in flight per lane.
-  if constexpr (HASM) if (wave_active && !(out.debug & 1)) {
+  if constexpr (HASM) if (wave_active && !(kDebug && (out.debug & 1))) {
     const int b = tb * 16 + (lane & 15);
     const int bp = adec[b];
     const int b0 = bp & 255, b1 = (bp >> 8) & 255, b2 = bp >> 16;
@@ -746,7 +747,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         dst[r] = out.val + pos * (DOF * DOF) + I0 * DOF;
         // the first colour to reach a block stores it (no MatZeroEntries, no read)
         const bool first = ((v0 & v1 & v2) >> 30) & 1;
-        if (ok[r] && !first && !(out.debug & 16)) load_run<DOFI * DOF>(dst[r], v[r]);
+        if (ok[r] && !first && !(kDebug && (out.debug & 16))) load_run<DOFI * DOF>(dst[r], v[r]);
         else { for (int k = 0; k < DOFI * DOF; ++k) v[r][k] = 0; }
       }
       double kij[GRAM ? 4 : 1][GRAM ? DOF * DOF : 1];
@@ -785,8 +786,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
             v[r][i * DOF + j] += x;
           }
-        if (!(out.debug & 32)) store_run<DOFI * DOF>(dst[r], v[r]);
-        else if (v[r][0] == 1.2345e300) dst[r][0] = 0;
+        if (!(kDebug && (out.debug & 32))) store_run<DOFI * DOF>(dst[r], v[r]);
       }
     }
   }

@@ -161,6 +161,25 @@ template <int DIM> struct FormCahnHilliard {
   }
 };
 
+// demo/Bratu.c + demo/BratuFJ.F90:23-176 (Function / Jacobian and IFunction / IJacobian, Galerkin branches); params {lambda}.
+// Function / Jacobian are the IFunction / IJacobian with V absent (ut = 0) and shift = 0.
+template <int DIM> struct FormBratu {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU;
+  static constexpr unsigned MAT_NEED = NEED_U;
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += Na[1 + i] * p.gu[i];
+    R[0] = Na[0] * p.ut[0] + s - Na[0] * p.prm[0] * exp(p.u[0]);
+  }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i];
+    T[0] = p.shift * Na[0] * Nb[0] + s - Na[0] * Nb[0] * p.prm[0] * exp(p.u[0]);
+  }
+};
+
 // demo/NavierStokesVMS.c:9-244 (Tau, FineScale, Residual, Tangent); params {nu, fx, fy, fz, dt}
 struct FormNSVMS {
   static constexpr int SHAPE_ORDER = 1;   // Residual/Tangent read N and grad N only; Hessians are needed of U alone

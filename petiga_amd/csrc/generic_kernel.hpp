@@ -63,6 +63,72 @@ __device__ __forceinline__ void tensor_basis(const double *const t[3], const int
   }
 }
 
+
+// BoundaryArea, geometry branch (src/petigaelem.c:1133-1160 -> IGA_BoundaryArea_2D/3D, src/petiga2d.F90:276-346,
+// src/petiga3d.F90:379-464): dS = sum over the Gauss points of the element's face of w * sqrt|det(F F^T)|, F = d(face map)/du
+// from the first / last layer of the element's control points; raw Gauss weights (sum 2 per axis), derivatives w.r.t. the
+// knot coordinate, the routine's own Rationalize.  Called by the few threads of a face element that carry a load.
+template <int DIM>
+__device__ inline double face_dS(const double *const t1d[3], const double *const w1d[3], const int nq[3], const int na[3],
+                                 const double *gX, const double *gW, bool rat, int dir, int side) {
+  if constexpr (DIM == 1) return 1.0;
+  else {
+    constexpr int FD = DIM - 1;
+    int ax[2] = {0, 0};
+    { int k = 0; for (int i = 0; i < DIM; ++i) if (i != dir) ax[k++] = i; }
+    const int n0 = na[ax[0]], n1 = (FD == 2) ? na[ax[1]] : 1, q0n = nq[ax[0]], q1n = (FD == 2) ? nq[ax[1]] : 1;
+    auto ctrl = [&](int a0, int a1) { int loc[3] = {0, 0, 0}; loc[dir] = side ? na[dir] - 1 : 0; loc[ax[0]] = a0; if (FD == 2) loc[ax[1]] = a1; return loc[0] + na[0] * (loc[1] + na[1] * loc[2]); };
+    double dS = 0;
+    for (int q1 = 0; q1 < q1n; ++q1) for (int q0 = 0; q0 < q0n; ++q0) {
+      double W0 = 1, S1[2] = {0, 0};
+      if (rat) {
+        W0 = 0;
+        for (int a1 = 0; a1 < n1; ++a1) for (int a0 = 0; a0 < n0; ++a0) {
+          const double *r0 = t1d[ax[0]] + (q0 * n0 + a0) * NDER; const double v1 = (FD == 2) ? t1d[ax[1]][(q1 * n1 + a1) * NDER] : 1.0, d1 = (FD == 2) ? t1d[ax[1]][(q1 * n1 + a1) * NDER + 1] : 0.0;
+          const double w = gW[ctrl(a0, a1)];
+          W0 += w * r0[0] * v1; S1[0] += w * r0[1] * v1; S1[1] += w * r0[0] * d1;
+        }
+      }
+      double F[2][3] = {{0, 0, 0}, {0, 0, 0}};
+      for (int a1 = 0; a1 < n1; ++a1) for (int a0 = 0; a0 < n0; ++a0) {
+        const double *r0 = t1d[ax[0]] + (q0 * n0 + a0) * NDER; const double v1 = (FD == 2) ? t1d[ax[1]][(q1 * n1 + a1) * NDER] : 1.0, d1 = (FD == 2) ? t1d[ax[1]][(q1 * n1 + a1) * NDER + 1] : 0.0;
+        const int la = ctrl(a0, a1);
+        double N0 = r0[0] * v1, N1[2] = {r0[1] * v1, r0[0] * d1};
+        if (rat) { const double w = gW[la]; N0 = w * N0 / W0; for (int r = 0; r < FD; ++r) N1[r] = (w * N1[r] - N0 * S1[r]) / W0; }
+        for (int r = 0; r < FD; ++r) for (int c = 0; c < DIM; ++c) F[r][c] += N1[r] * gX[la * DIM + c];
+      }
+      double M[2][2] = {{0, 0}, {0, 0}};
+      for (int r = 0; r < FD; ++r) for (int s = 0; s < FD; ++s) for (int c = 0; c < DIM; ++c) M[r][s] += F[r][c] * F[s][c];
+      const double det = (FD == 1) ? M[0][0] : M[0][0] * M[1][1] - M[0][1] * M[1][0];
+      dS += sqrt(fabs(det)) * w1d[ax[0]][q0] * ((FD == 2) ? w1d[ax[1]][q1] : 1.0);
+    }
+    return dS;
+  }
+}
+
+// IGAElementBuildFix's flux part on a mapped geometry (AddFlux with BoundaryArea's geometry branch): run after the closure
+// gathers are visible.  aa-decoding as in the kernels: a = a0 + na0*(a1 + na1*a2).
+template <int DIM, int DOF>
+__device__ inline void add_mapped_flux(const SpaceDev &S, const int ID[3], const int el[3], const double *const t1d[3], const double *const w1d[3],
+                                       const int nq[3], const int na[3], const double *gX, const double *gW, bool rat, double *flux, int tid, int nthr) {
+  const int NE = na[0] * na[1] * na[2];
+  for (int d = 0; d < DIM; ++d) {
+    if (S.ax[d].periodic) continue;
+    for (int side = 0; side < 2; ++side) {
+      const BCDev &bl = S.bcl[d][side];
+      if (!bl.count || ID[d] != (side ? S.ax[d].esizes - 1 : 0)) continue;
+      for (int a = tid; a < NE; a += nthr) {
+        const int aa[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        if (aa[d] != (side ? na[d] - 1 : 0)) continue;
+        double A = 1;
+        for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
+        A *= face_dS<DIM>(t1d, w1d, nq, na, gX, gW, rat, d, side);
+        for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
+      }
+    }
+  }
+}
+
 template <class Form, int DIM>
 __global__ void __launch_bounds__(256)
 generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv, double *phi_global, size_t phi_stride) {
@@ -146,7 +212,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
             s_anyfix = 1;
           }
           const BCDev &bl = S.bcl[d][side];
-          if (bl.count) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132)
+          if (bl.count && !(geo && DIM > 1)) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132); mapped: add_mapped_flux below
             double A = 1;
             if (DIM > 1) {
               for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
@@ -160,6 +226,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   }
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
+  if (geo && DIM > 1 && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
   if (anyfix && (useU || useV)) {
     for (int k = tid; k < NE * DOF; k += nthr)

@@ -616,7 +616,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
   int own_lo = (seg == 0) ? -1 : AW.off[ws];
   int own_hi = (seg == pa.nseg - 1) ? (1 << 30) : AW.off[we];
-  if (pa.debug_noflush == 1 || !valid) { own_lo = 1 << 30; own_hi = 1 << 30; }
+  if ((kDebug && pa.debug_noflush == 1) || !valid) { own_lo = 1 << 30; own_hi = 1 << 30; }
   const int offx = AX.off[elx], offy = AY.off[ely];
   const long long T0 = S.ax[0].tot, T10 = S.ax[1].tot * S.ax[0].tot;
   // row index = rho0 + nrow0*(rho1 + nrow1*rho2): stride of each axis' rho
@@ -707,9 +707,9 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
-    if (pa.debug_buf) tq0 = __builtin_readcyclecounter();
+    if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
     pencil_mfma<W, W == 0, NB>(acc, L, zt);
-    if (pa.debug_buf) tq1 = __builtin_readcyclecounter();
+    if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
       const int fs = L.fslot < NB ? L.fslot : 0;
@@ -718,7 +718,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
       if (L.fslot < NB) Facc += L.sxy * sw;
     }
     __builtin_amdgcn_s_barrier();
-    if (pa.debug_buf) tq2 = __builtin_readcyclecounter();
+    if (kDebug && pa.debug_buf) tq2 = __builtin_readcyclecounter();
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
@@ -730,7 +730,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
     held[NB - 1] = 0;
     __builtin_amdgcn_s_setprio(0);
-    if (pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
+    if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -800,15 +800,15 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       }
       nseg = best_n;
     }
-    { const char *e = getenv("IGX_NSEG"); if (e && atoi(e) > 0) nseg = std::max(nseg_min_lds(nw), std::min(atoi(e), std::max(1, nw / 4))); }   // experiment switch
+    if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
     pa.blocks_per_seg = (int)((pencils + 7) / 8);
     pa.ne_max = pa.seg_len + 3;
-    { const char *dbg = getenv("IGX_DEBUG_NOFLUSH"); pa.debug_noflush = dbg ? atoi(dbg) : 0; }
+    pa.debug_noflush = s.env.debug_noflush;
     pa.debug_buf = nullptr;
     static int dbg_done = 0;
-    const bool dbg_t = getenv("IGX_DEBUG_TIMING") && !dbg_done;
+    const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes(P) : 0);
@@ -866,14 +866,13 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool sys = out.op == OP_SYSTEM;
   // walk axis: the slowest-varying mesh axis that qualifies keeps axis 0 (contiguous CSR columns) on the lanes
   int walk_axis = -1;
-  { const char *wa = getenv("IGX_WALK_AXIS"); const int pref[3] = {wa ? atoi(wa) : 0, 2, 1};
+  { const int pref[3] = {s.env.walk_axis, 2, 1};
     for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
-  static const bool ft_off = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
-  const bool first_touch = walk_axis == 0 && !ft_off && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
+  const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
   if (!first_touch) zero_matrix();
   else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);   // the only entries no local element reaches
   if (!walk) {

@@ -6,8 +6,23 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <string>
+#include <cstdlib>
 
 namespace igx {
+
+EnvSwitches read_env_switches() {
+  EnvSwitches e;
+  auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+  e.kernel = num("IGX_KERNEL", 0); if (e.kernel < 0 || e.kernel > 3) e.kernel = 0;
+  e.walk_axis = num("IGX_WALK_AXIS", 0);
+  e.nseg = num("IGX_NSEG", 0);
+  e.no_first_touch = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
+  e.feature_lds_kb = num("IGX_FEATURE_LDS_KB", 0);
+  e.combine = num("IGX_COMBINE", -1);
+  if (kDebug) { e.debug_feature = num("IGX_DEBUG_FEATURE", 0); e.debug_noflush = num("IGX_DEBUG_NOFLUSH", 0); e.debug_timing = getenv("IGX_DEBUG_TIMING") != nullptr; }
+  return e;
+}
 
 // ------------------------------------------------------------------ Gauss-Legendre
 // The reference tabulates q = 1..10 (src/petigarule.c:182-319).  Nodes are the roots of P_q, found by
@@ -296,6 +311,33 @@ void stencil(const Axis &ax, int i, int *first, int *last) {
 }
 
 // ------------------------------------------------------------------ IGASetUp
+// The ghost-row exchange (exchange.hpp) moves a rank's ghost rows to its +1 neighbour on each axis.  That is every owner
+// only while no rank's ghost layer reaches past its neighbour's owned nodes, i.e. while every rank of a split axis owns at
+// least as many nodes as its lower neighbour has ghosts (fewer than p elements per rank breaks it: the reference's PETSc
+// stash would route such rows two ranks up).  Refused by the exchange entry points rather than summed into the wrong rows.
+int exchange_supported(const Space &s, std::string &err) {
+  for (int i = 0; i < s.dim; ++i) {
+    const Axis &ax = s.axis[i];
+    const int np = s.proc_sizes[i], nel = s.elem_sizes[i], p = ax.p;
+    if (np == 1) continue;
+    auto ranges = [&](int c, int &lw, int &gw) {   // node ranges of the rank with coordinate c on this axis (space_setup)
+      const int q = nel / np, r = nel % np, ew = q + (r > c ? 1 : 0), es = c * q + std::min(c, r), el = es + ew - 1;
+      const int lstart = ax.span[es] - p, gend = ax.span[el] + 1;
+      const int lend = (el < nel - 1) ? ax.span[el + 1] - p : ax.span[el] + 1;
+      lw = (c == np - 1) ? ax.nnp - lstart : lend - lstart; gw = gend - lstart;
+    };
+    for (int c = 0; c < np; ++c) {
+      if (c == np - 1 && !ax.periodic) continue;
+      int lw, gw, lwn, gwn; ranges(c, lw, gw); ranges((c + 1) % np, lwn, gwn);
+      if (gw - lw > lwn) {
+        err = "axis " + std::to_string(i) + ": a rank owns fewer nodes than its neighbour's ghost layer (fewer than p elements per rank); use fewer processors on this axis";
+        return IGX_ERR_SUP;
+      }
+    }
+  }
+  return 0;
+}
+
 int space_setup(Space &s, std::string &err) {
   const int dim = s.dim;
   if (dim < 1 || dim > 3) { err = "Must call IGASetDim() first"; return IGX_ERR_ARG_WRONGSTATE; }

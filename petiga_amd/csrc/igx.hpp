@@ -8,6 +8,25 @@
 
 namespace igx {
 
+// Experiment hooks (cycle stamps, scatter / MFMA phase switches) are compiled into the kernels only with -DIGX_DEBUG.
+#ifdef IGX_DEBUG
+constexpr bool kDebug = true;
+#else
+constexpr bool kDebug = false;
+#endif
+
+// Environment switches, read once when an IGX is created (IGXCreate / IGXCreateFromTables)
+struct EnvSwitches {
+  int kernel = 0;            // IGX_KERNEL=0..3 presets IGXSetKernel (the parity suite runs every case under two kernel families)
+  int walk_axis = 0;         // IGX_WALK_AXIS: preferred walk axis of the pencil kernel
+  int nseg = 0;              // IGX_NSEG: segments per pencil (0 = model)
+  int no_first_touch = 0;    // IGX_NO_FIRST_TOUCH: MatZeroEntries + read-modify-write everywhere
+  int feature_lds_kb = 0;    // IGX_FEATURE_LDS_KB: LDS target of the feature kernel
+  int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)
+  int debug_feature = 0, debug_noflush = 0, debug_timing = 0;   // only honoured by -DIGX_DEBUG builds
+};
+EnvSwitches read_env_switches();
+
 // ------------------------------------------------------------------ host discretisation
 struct Axis {                 // struct _n_IGAAxis, include/petiga.h:80-96
   int p = 0, m = 0, periodic = 0, nel = 0, nnp = 0;
@@ -77,10 +96,12 @@ struct Space {
   std::vector<double> params;
   bool setup = false;
   AxisLayout lay[3];
+  EnvSwitches env;
 };
 
 int  space_setup(Space &s, std::string &err);          // IGASetUp stages 1+3 (src/petiga.c:1111-1310,1450-1493)
 int  space_layout(Space &s, std::string &err);         // AxisLayout for the three axes
+int  exchange_supported(const Space &s, std::string &err);   // 0, or IGX_ERR_SUP when ghost rows would need a two-rank hop
 
 // ------------------------------------------------------------------ device descriptors (POD, passed by value)
 constexpr int MAXBC = 8;      // fields per face the device tables hold (dof <= 8 on the device path)

@@ -27,6 +27,16 @@ def make_rank(dim, dof, p, N, periodic, size, rank):
                                                    (3, 1, 2, (8, 8, 8), (1, 0, 1)), (1, 3, 3, (16,), (0,))])
 @pytest.mark.parametrize("size", [2, 4, 8])
 def test_exchange_plan_is_consistent(dim, dof, p, N, periodic, size):
+    if dim == 1 and size == 8:
+        # 16 elements of degree 3 on 8 ranks: 2 elements per rank, a rank's 3 ghost nodes reach past its neighbour's 2 owned
+        # ones.  The +1-neighbour exchange would add such a row into a rank that does not own it: the set-up refuses
+        # (PETSC_ERR_SUP) instead.
+        import petiga_amd as P
+        g = make_rank(dim, dof, p, N, [bool(x) for x in periodic], size, 3)
+        with pytest.raises(P.IGXError) as e:
+            g.neighbors(True)
+        assert e.value.code == 56
+        return
     ranks = [make_rank(dim, dof, p, N, [bool(x) for x in periodic], size, r) for r in range(size)]
     sends = {(r, peer): (m, v) for r, g in enumerate(ranks) for peer, m, v in g.neighbors(True)}
     recvs = {(peer, r): (m, v) for r, g in enumerate(ranks) for peer, m, v in g.neighbors(False)}
@@ -103,3 +113,22 @@ def test_p2p_pattern_on_gloo(world, tmp_path):
     outs = [p.communicate(timeout=300)[0].decode() for p in procs]
     for p, o in zip(procs, outs):
         assert p.returncode == 0, o
+
+
+@pytest.mark.parametrize("p,N,size,ok", [(3, 16, 4, True), (3, 16, 5, True), (3, 16, 6, False), (2, 8, 4, True), (2, 9, 8, False), (1, 8, 8, True)])
+def test_exchange_refuses_ranks_thinner_than_a_ghost_layer(p, N, size, ok):
+    """A rank of a split axis must own at least as many nodes as its lower neighbour has ghosts (with fewer than p
+    elements per rank the ghost rows belong to rank+2 and the neighbour exchange would lose them).  The partition itself
+    stays the reference's (tests/test_host_setup.py); only the exchange entry points refuse."""
+    import petiga_amd as P
+    for rank in range(size):
+        g = P.IGX(1, 1)
+        g.set_comm(size, rank)
+        g.axis_uniform(0, p, N)
+        g.setup()
+        if ok:
+            g.neighbors(True), g.neighbors(False)
+        else:
+            with pytest.raises(P.IGXError) as e:
+                g.neighbors(rank % 2 == 0)
+            assert e.value.code == 56
