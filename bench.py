@@ -25,40 +25,71 @@ FLOP_PER_ELEM = {3: 1572864, 2: 118098}        # 2*nen^2*nqp*dim (SURVEY 8d / BA
 BYTES_PER_ELEM = {3: 2785, 2: 1019}            # compulsory CSR bytes per element
 FP64_PEAK_TFLOPS = 78.6                        # MI355X fp64 vector = matrix peak (256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+KERNEL_TAG = "r02"                             # profiles/traffic.json must describe this round's kernel to be quoted
 
 
-def cpu_baseline(degree, seconds_target=20.0):
-    """Times the CPU oracle (port of the reference loop) on this box's host cores on a bounded sample
-    of the same workload: same discretisation, a smaller cube, every core assembling its own block
-    of elements (emulates mpiexec -n cores; src/petigapart.c partition)."""
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs; SMT siblings count once)."""
+    seen = set()
+    try:
+        pkg = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pkg = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pkg is not None and core is not None:
+                    seen.add((pkg, core))
+                pkg = core = None
+        if pkg is not None and core is not None:
+            seen.add((pkg, core))
+    except OSError:
+        pass
+    n = len(seen) or (os.cpu_count() or 1)
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(degree, seconds_target=15.0):
+    """Times the CPU oracle (port of the reference loop) on this box's host cores on a bounded sample of the same
+    workload.  One worker per PHYSICAL core; every worker assembles its own box of m^3 elements into its own local
+    matrix -- what a rank of `mpiexec -n cores` does with its ghosted box (the reference's MatSetValuesLocal works on the
+    rank-local rows) -- so no worker pays for a global pattern.  Reported: the measured all-core rate, the single-core
+    rate and cores x single-core (the no-loss bound); the speed-up quoted next to it uses the larger of the two."""
     import multiprocessing as mp
-    cores = max(1, min(os.cpu_count() or 1, 64))
-    while cores > 1 and cores not in (2, 4, 8, 16, 32, 64):
-        cores -= 1
-    rate1 = 550.0 if degree == 3 else 6000.0          # rough single-core guess, only to size the sample
-    n = int(round((rate1 * cores * seconds_target) ** (1.0 / 3.0)))
-    n = max(8, min(n, 64))
+    cores = physical_cores()
+    rate1 = 900.0 if degree == 3 else 9000.0          # rough single-core rate, only to size the sample
+    m = int(round((rate1 * seconds_target) ** (1.0 / 3.0)))
+    m = max(8, min(m, 40))
+    # one core alone first (also warms the page cache / builds nothing: the .so is prebuilt)
+    e1, t1 = _cpu_worker((degree, m))
     t0 = time.time()
-    with mp.get_context("spawn").Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(degree, n, cores, r) for r in range(cores)])
+    if cores > 1:
+        with mp.get_context("spawn").Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(degree, m)] * cores)
+    else:
+        res = [(e1, t1)]
     wall = max(r[1] for r in res)
     elems = sum(r[0] for r in res)
-    # one core alone (the reference is single-threaded per rank; SURVEY 8d asks for both figures)
-    n1 = 16 if degree == 3 else 32
-    e1, t1 = _cpu_worker((degree, n1, 1, 0))
-    return dict(value=elems / wall, unit="elements/s", cores=cores, kind="port", single_core_value=e1 / t1,
-                single_core_sample="%d^3 elements on one core, %.1f s" % (n1, t1),
-                sample="3-D p=%d Poisson, %d^3 elements, %d ranks (one per core), oracle/igaoracle.c; slowest rank %.1f s, pool wall %.1f s"
-                       % (degree, n, cores, wall, time.time() - t0))
+    single = e1 / t1
+    return dict(value=elems / wall, unit="elements/s", cores=cores, kind="port", single_core_value=single,
+                cores_x_single_core=cores * single,
+                logical_cpus=os.cpu_count(),
+                sample="3-D p=%d Poisson System (Dirichlet on 6 faces), %d^3 elements per core into a core-local matrix, %d physical cores at once "
+                       "(oracle/igaoracle.c, the reference's loop: order-%d tabulation, scalar callback, search-insert); slowest core %.1f s, "
+                       "one core alone %.1f s, pool wall %.1f s" % (degree, m, cores, degree, wall, t1, time.time() - t0))
 
 
 def _cpu_worker(args):
-    degree, n, size, rank = args
+    degree, m = args
     import oracle_api as O
     g = O.OracleIGA(3, 1)
     for i in range(3):
-        g.axis_uniform(i, degree, n)
-    g.set_partition(size, rank)
+        g.axis_uniform(i, degree, m)
     g.setup()
     for d in range(3):
         for s in range(2):
@@ -67,8 +98,7 @@ def _cpu_worker(args):
     t = time.time()
     g.compute_system("orc_form_poisson", A=A)
     dt = time.time() - t
-    w = g.ranges()["elem_width"]
-    return w[0] * w[1] * w[2], dt
+    return m ** 3, dt
 
 
 def main():
@@ -149,13 +179,17 @@ def main():
         elems_per_launch = dom_elems / max(dom_launches, 1)
         achieved = flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         executed = dom_flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")      # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc passes
+        # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes of this same command
+        # (scripts/profile_round.sh), committed as profiles/traffic.json: they are NOT measured inside this run, so the
+        # line names the file and the commit that last touched it; null when the file does not describe this configuration.
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("size") == args.size and tj.get("degree") == args.degree and tj.get("n_gpus") == world:
+                if tj.get("size") == args.size and tj.get("degree") == args.degree and tj.get("n_gpus") == world and tj.get("kernel_tag") == KERNEL_TAG:
                     traffic = tj.get("bytes_per_launch")
+                    traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % tj.get("round")
             except Exception:
                 traffic = None
         line = {
@@ -166,21 +200,24 @@ def main():
             "config": {"workload": "IGAComputeSystem demo/Poisson3D.c: p=%d C%d, %d^3 elements, dof=1, Dirichlet u=1 on 6 faces, Gauss %d^3"
                                    % (args.degree, args.degree - 1, args.size, args.degree + 1),
                        "kernels": g.kernel_name(), "partition": g.sizes()["proc_sizes"]},
-            # dominant kernel; achieved = ALGORITHMIC flops (2*nen^2*nqp*dim per element) / measured launch time.
-            # The kernel exploits the symmetry of K_e (10 of 16 MFMA tiles), so it EXECUTES executed_flop_per_element < flop_per_element
-            # and `frac` may exceed 1; mfma_busy_frac is the executed-flop fraction of the fp64 MFMA peak.
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
+            # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (it skips the 6
+            # mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
+            # (2*nen^2*nqp*dim flop per element, SURVEY 8d / BASELINE.md 3) is kept next to it.
+            "roofline": {"bound": "mfma", "achieved": executed, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": executed / FP64_PEAK_TFLOPS,
+                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / FP64_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
                          "kernel": dom_name, "launches_per_step": dom_launches // max(args.steps, 1),
                          "avg_launch_ms": avg_launch_s * 1e3, "elements_per_launch": elems_per_launch,
                          "flop_per_element": flop, "executed_flop_per_element": dom_flop,
-                         "mfma_busy_frac": executed / FP64_PEAK_TFLOPS,
                          "algorithmic_bytes_per_element": BYTES_PER_ELEM.get(args.degree)},
             "device": P.device_info(),
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.degree)
-            line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
+            cb = cpu_baseline(args.degree)
+            line["cpu_baseline"] = cb
+            line["speedup_vs_cpu"] = value / max(cb["value"], cb["cores_x_single_core"])
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -248,6 +248,12 @@ int IGXUnpackGhostValues(IGX iga,IGXVec v,int k,const double *devbuf);
 /* 1 if this rank owns the node of local row (r0,r1,r2): after the exchange only owned rows are final */
 int IGXRowOwned(IGX iga,int r0,int r1,int r2);
 
+/* Checksums of an assembled system over the rows this rank OWNS (after the ghost-row reduction only those are final):
+ * S[0] = sum A_ij, S[1] = sum |A_ij|, S[2] = sum b_i, S[3] = sum b_i^2; A or b may be NULL.  Added over the ranks of any
+ * partition they equal the single-rank values up to rounding: bench.py asserts exactly that on its N > 1 path, the PetIGA
+ * adapter can use it as a MatNorm-free sanity check.  Fixed summation order (bitwise repeatable). */
+int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
+
 /* library / device info for logs */
 int IGXGetDeviceInfo(char *buf,int len);
 

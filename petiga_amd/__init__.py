@@ -47,7 +47,7 @@ def lib(build_if_needed=False):
     global _LIB
     if _LIB is not None:
         return _LIB
-    so = os.path.join(_HERE, "libpetiga_amd.so")
+    so = os.path.join(_HERE, "libpetiga_amd_debug.so" if os.environ.get("IGX_USE_DEBUG_LIB") else "libpetiga_amd.so")   # the -DIGX_DEBUG experiment build
     if build_if_needed:
         so = _build.build()
     if not os.path.exists(so):
@@ -88,6 +88,7 @@ def lib(build_if_needed=False):
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
+        "IGXChecksum": [V, V, V, _dp],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
@@ -338,6 +339,12 @@ class IGX:
     def pack_owner_values(self, v, k, devptr): _ck(lib().IGXPackOwnerValues(self.h, v.h, k, devptr))
     def unpack_ghost_values(self, v, k, devptr): _ck(lib().IGXUnpackGhostValues(self.h, v.h, k, devptr))
     def row_owned(self, r0, r1=0, r2=0): return bool(lib().IGXRowOwned(self.h, r0, r1, r2))
+
+    def checksum(self, A=None, b=None):
+        """[sum A, sum |A|, sum b, sum b^2] over the rows this rank owns."""
+        out = np.zeros(4)
+        _ck(lib().IGXChecksum(self.h, A.h if A is not None else None, b.h if b is not None else None, out.ctypes.data_as(_dp)))
+        return out
 
     def coloring(self):
         nc = (C.c_int * 3)()

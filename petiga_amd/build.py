@@ -10,7 +10,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_build")
-SO = os.path.join(HERE, "libpetiga_amd.so")
+# IGX_BUILD_DEBUG=1: the experiment build (-DIGX_DEBUG: cycle stamps, phase switches) into its own objects / library
+DEBUG = os.environ.get("IGX_BUILD_DEBUG", "") not in ("", "0")
+OBJ = os.path.join(HERE, "_build_debug" if DEBUG else "_build")
+SO = os.path.join(HERE, "libpetiga_amd_debug.so" if DEBUG else "libpetiga_amd.so")
 HEADERS = ["igx.hpp", "forms.hpp", "generic_kernel.hpp", "feature_mfma.hpp", "first_touch.hpp", "gram_mfma.hpp", "exchange.hpp", "fileio.hpp",
            os.path.join("..", "..", "include", "petiga_amd.h")]
 # (object name, source, extra flags)
@@ -21,7 +24,7 @@ UNITS = [("engine_main.o", "engine.hip", []),
          ("engine_d3g1.o", "engine.hip", ["-DIGX_TU_DISPATCH", "-DIGX_TU_DIM=3", "-DIGX_TU_GROUP=1"]),
          ("engine_d3g2.o", "engine.hip", ["-DIGX_TU_DISPATCH", "-DIGX_TU_DIM=3", "-DIGX_TU_GROUP=2"]),
          ("host.o", "host.cpp", [])]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics"] + (["-DIGX_DEBUG"] if DEBUG else [])
 
 
 def stale():

@@ -456,17 +456,47 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
 #ifdef IGX_TU_DISPATCH
 // ------------------------------------------------------------------ feature-GEMM kernel dispatch (feature_mfma.hpp)
 // one launch per group of DOFI row fields: I0 = 0, DOFI, 2*DOFI, ...
-template <class Form, int DIM, int TA, int NW, int DOFI, int I0, bool HASM>
+template <class Form, int DIM, int TA, int NW, int DOFI, int I0, bool HASM, bool PENCIL = false>
 static void launch_feature_passes(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first, int &launches) {
-  auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI, HASM>;
+  auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI, HASM, PENCIL>;
   if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * NW), lds_bytes, g->stream, S, prm, out, cr, cv);
   launches++;
-  if constexpr (HASM && I0 + DOFI < Form::DOF) launch_feature_passes<Form, DIM, TA, NW, DOFI, I0 + DOFI, HASM>(g, S, prm, out, cr, cv, nblocks, lds_bytes, first, launches);
+  if constexpr (HASM && I0 + DOFI < Form::DOF) launch_feature_passes<Form, DIM, TA, NW, DOFI, I0 + DOFI, HASM, PENCIL>(g, S, prm, out, cr, cv, nblocks, lds_bytes, first, launches);
+}
+
+// executed v_mfma_f64_16x16x4 flops per element of the feature kernel's matrix phase (roofline accounting)
+template <class Form, int TA>
+static double feature_mfma_flop(int nq_padded) {
+  constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+  constexpr int DOF = Form::DOF, NFS = (shape_order_of<Form>::v >= 2) ? 13 : 4;
+  int per_kstep = 0;
+  if (PAIRS) per_kstep = fm_popcount(PAIRS);
+  else for (int f = 0; f < NFS; ++f) { if (!((mat_test_mask_of<Form>::v >> f) & 1u)) continue; for (int i = 0; i < DOF; ++i) for (int j = 0; j < DOF; ++j) if ((fm_block_mask<Form>(i, j) >> f) & 1u) per_kstep++; }
+  return 2048.0 * per_kstep * TA * TA * (nq_padded / 4);
+}
+
+// Pencil mode of the feature kernel (combine before write along axis 0): 4x4x4 basis functions, one new node layer per element
+// on axis 0 (a periodic axis 0 wrapped inside the rank is walked too: the last elements add to the rows the first ones wrote,
+// inside the same workgroup; such an axis never has first-touch stores), no boundary-form passes, and enough pencils per
+// colour of axes 1, 2 to fill the CUs (a workgroup walks the whole local axis-0 range).  IGX_COMBINE=0 / 1 overrides the count.
+static bool feature_pencil_wanted(IGX g, int wgs_per_cu, bool pays) {
+  const Space &s = g->s;
+  if (s.dim != 3 || s.env.combine == 0) return false;
+  for (int d = 0; d < 3; ++d) if (s.basis[d].nen != 4) return false;
+  if (s.elem_width[0] < 4) return false;
+  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return false;
+  for (int e = 0; e + 1 < s.elem_width[0]; ++e) if (s.basis[0].offset[s.elem_start[0] + e + 1] != s.basis[0].offset[s.elem_start[0] + e] + 1) return false;
+  if (s.env.combine > 0) return true;
+  if (!pays) return false;
+  static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  const int nc1 = std::max(1, s.lay[1].ncolors), nc2 = std::max(1, s.lay[2].ncolors);
+  const long long per_colour = (long long)((s.elem_width[1] + nc1 - 1) / nc1) * ((s.elem_width[2] + nc2 - 1) / nc2);
+  return per_colour * 2 >= (long long)ncu * wgs_per_cu;   // too few pencils: one element per workgroup fills the chip better
 }
 
 // returns 0 and sets done when the feature kernel ran; done stays false when the case is not covered
-template <class Form, int DIM, int TA, int NW, int DOFI, bool HASM>
+template <class Form, int DIM, int TA, int NW, int DOFI, bool HASM, bool PEN = false>
 static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   const Space &s = g->s;
   constexpr int DOF = Form::DOF;
@@ -487,7 +517,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   // form is scalar (16 accumulator VGPRs: Poisson p=3 on a NURBS geometry 8.2 vs 6.4 M/s); for the others the fewest
   // chunks of points win (NS-VMS 0.92 vs 0.84, Elasticity 2.67 vs 2.24 M/s).
   const int lds_kb_env = s.env.feature_lds_kb;   // experiment switch
-  constexpr int WGS = fm_min_waves<Form, TA, NW, DOFI, HASM>();
+  constexpr int WGS = fm_min_waves<Form, TA, NW, DOFI, HASM, PEN>();
   const size_t lds_auto = (NW == 4) ? (size_t)(160 * 1024 / WGS - 1024) : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit);
   const size_t lds_target = lds_kb_env > 0 ? (size_t)lds_kb_env * 1024 : lds_auto;
   FCarve cv; size_t lds_bytes = 0; bool fits = false;
@@ -511,7 +541,10 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
       // the sum-factorised geometry sums of phase 1 borrow the Phi region before Phi exists
       const int sf_need = (!SECOND && (s.nsd || s.rational)) ? (DIM + 1) * (2 * nq[0] * na[1] * na[2] + 3 * nq[0] * nq[1] * na[2] + 4 * NQ) : 0;
-      cv.phi = take(std::max(NFS * QC * NEP, sf_need));
+      // pencil mode parks the 7 leaving tiles of every (i,j) block of a launch in the Phi region before they are written out
+      constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
+      const int stage_need = PEN ? 7 * 16 * 17 * (PR ? fm_popcount(fm_pairs_upper(PR)) : DOFI * DOF) : 0;   // the leaving tiles (feature_mfma.hpp)
+      cv.phi = take(std::max(std::max(NFS * QC * NEP, sf_need), stage_need));
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
       if (lds_bytes <= cap) fits = true;
@@ -534,7 +567,29 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   int64_t elem_base = 0;
   int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
   if (SCAL) nc[0] = nc[1] = nc[2] = 1;
-  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+  if (g->timing && g->dom.ev0 && g->dom.launches == 0) (void)hipEventRecord(g->dom.ev0, g->stream);
+  constexpr bool pencil = PEN;
+  if constexpr (PEN) {
+    {
+      for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) {
+        const int cc[3] = {0, c1, c2};
+        ColorRange cr; bool empty = false;
+        cr.start[0] = 0; cr.step[0] = 1; cr.count[0] = s.elem_width[0];
+        for (int d = 1; d < 3; ++d) {
+          const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+          int firstel = -1, count = 0;
+          for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+          if (count == 0) { empty = true; break; }
+          cr.start[d] = firstel; cr.step[d] = L.p + 1; cr.count[d] = count;
+        }
+        if (empty) continue;
+        const size_t nblocks = (size_t)cr.count[1] * cr.count[2];
+        launch_feature_passes<Form, DIM, TA, NW, DOFI, 0, HASM, true>(g, S, prm, out_ft, cr, cv, nblocks, lds_bytes, first, launches);
+        first = false;
+      }
+    }
+  }
+  if constexpr (!PEN) for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
     const int cc[3] = {c0, c1, c2};
     ColorRange cr; bool empty = false;
     for (int d = 0; d < 3; ++d) {
@@ -558,7 +613,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   }
   // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447): the elements of this rank on a visited face,
   // one point layer at the face; their K_e / F_e add to what the interior pass left (stream order)
-  for (int bid = 0; bid < 2 * DIM; ++bid) {
+  if constexpr (!PEN) for (int bid = 0; bid < 2 * DIM; ++bid) {   // (the pencil plan is not chosen when a face is visited)
     const int ax = bid / 2, sd = bid % 2;
     if (!s.visit[ax][sd]) continue;
     const int eface = sd ? s.elem_sizes[ax] - 1 : 0;
@@ -586,8 +641,14 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   }
   HIPCK(hipGetLastError());
   g->last_launches = launches;
+  if (g->dom.launches == 0) {   // dominant kernel of this assembly, for bench.py's roofline block
+    if (g->timing && g->dom.ev1) (void)hipEventRecord(g->dom.ev1, g->stream);
+    g->dom.name = std::string("feature_assemble<") + (pencil ? "pencil" : "element") + ">"; g->dom.launches = launches;
+    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * (HASM ? (DOF / DOFI) : 1);
+    g->dom.flop_per_element = HASM ? feature_mfma_flop<Form, TA>(cv.QC * cv.nchunk) * DOFI / DOF : 0.0;
+  }
   if (HASM) g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
-                   ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+                   ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + (pencil ? ",pencil walk axis 0" : "") + ")";
   else g->last_kernel = std::string("feature_assemble(vector only,waves=") + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
   return 0;
@@ -607,9 +668,24 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
     constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
     // a scalar form at nen = 64 has 4 tiles per wave with 4-wave workgroups: small enough for 4 workgroups per CU
     // (Poisson p=3 on a NURBS geometry: 11.9 vs 10.4 M elements/s with the 8-wave layout)
+    constexpr int DOFI = (TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF;
+    if constexpr (TA == 4 && DIM == 3) {
+      // pencil mode: the same wave layouts as the element mode (scalar forms: 4 waves with 4 tiles each, 4 workgroups per CU)
+      constexpr int NWP = (DOF == 1) ? 4 : 8;
+      constexpr int WG = fm_min_waves<Form, 4, NWP, (DOF == 1 ? 1 : DOFI), true, true>();
+      // Measured (MI355X): Elasticity3D 128^3 3.35 -> 4.8 M elements/s; NavierStokesVMS 96^3 (two launches of 8 accumulator
+      // sets, 128 registers live through a heavy tabulation) 1.41 -> 0.78: the automatic choice keeps the walk for the
+      // constant-coefficient (Gram) multi-field forms.  Scalar forms lose as well (Poisson p=3 on a NURBS geometry, 128^3:
+      // 8.5 vs 12.5 M elements/s: their scatter is small next to the tabulation, and the walk runs fewer workgroups per CU).
+      constexpr bool PAYS = GRAM && DOF > 1;
+      if (feature_pencil_wanted(g, WG, PAYS)) {   // (not covered when the staging buffers do not fit the LDS next to a mapped geometry's arrays)
+        if (int rc = launch_feature_plan<Form, DIM, 4, NWP, (DOF == 1 ? 1 : DOFI), true, true>(g, S, out, done)) return rc;
+        if (done) return 0;
+      }
+    }
     if constexpr (TA == 4 && DOF == 1) return launch_feature_plan<Form, DIM, 4, 4, 1, true>(g, S, out, done);
     else
-    return launch_feature_plan<Form, DIM, TA, NW, ((TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF), true>(g, S, out, done);
+    return launch_feature_plan<Form, DIM, TA, NW, DOFI, true>(g, S, out, done);
   }
 }
 
@@ -833,8 +909,8 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   const SpaceDev S = make_spacedev(g);
   int rc;
   bool done = false;
+  g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
   if (g->kernel_choice != 1 && g->kernel_choice != 3) {
-    g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
     rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix);
     if (rc) return rc;
   }
@@ -903,6 +979,53 @@ extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[]
   HIPCK(hipStreamSynchronize(g->stream));
   int flag = 0; HIPCK(hipMemcpy(&flag, g->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
   if (flag) { HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); return fail(flag, "Non-positive det(Jacobian) of the geometry mapping"); }
+  return 0;
+}
+
+// ------------------------------------------------------------------ checksums over the owned rows
+// one workgroup per stride of rows; fixed grid and a fixed in-block tree: bitwise repeatable
+__global__ void __launch_bounds__(256) k_checksum(int nown0, int nown1, int nown2, int nrow0, int nrow1, int bs, const int64_t *browptr, const double *val, const double *vec, double *part) {
+  __shared__ double red[256];
+  const int64_t nown = (int64_t)nown0 * nown1 * nown2;
+  double s[4] = {0, 0, 0, 0};
+  for (int64_t k = blockIdx.x; k < nown; k += gridDim.x) {
+    const int r0 = (int)(k % nown0), r1 = (int)((k / nown0) % nown1), r2 = (int)(k / ((int64_t)nown0 * nown1));
+    const int64_t row = (int64_t)r0 + (int64_t)nrow0 * ((int64_t)r1 + (int64_t)nrow1 * r2);
+    if (val) {
+      const int64_t lo = browptr[row] * bs * bs, hi = browptr[row + 1] * bs * bs;
+      for (int64_t i = lo + threadIdx.x; i < hi; i += 256) { const double v = val[i]; s[0] += v; s[1] += fabs(v); }
+    }
+    if (vec && (int)threadIdx.x < bs) { const double v = vec[row * bs + threadIdx.x]; s[2] += v; s[3] += v * v; }
+  }
+  for (int c = 0; c < 4; ++c) {
+    red[threadIdx.x] = s[c]; __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) { if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w]; __syncthreads(); }
+    if (threadIdx.x == 0) part[(int64_t)blockIdx.x * 4 + c] = red[0];
+    __syncthreads();
+  }
+}
+
+extern "C" int IGXChecksum(IGX g, IGXMat A, IGXVec b, double S[4]) {
+  NEEDIGA(g);
+  if (int rc = ensure_device(g)) return rc;
+  if (!S) return fail(IGX_ERR_ARG_WRONG, "null result array");
+  if ((A && A->iga != g) || (b && b->iga != g)) return fail(IGX_ERR_ARG_WRONG, "matrix / vector created by another IGX");
+  const Space &s = g->s;
+  int nown[3];
+  for (int d = 0; d < 3; ++d) {   // owned rows are a prefix of the row box on every axis (ghosts sit on the high side, src/petiga.c:1172-1208)
+    const AxisLayout &L = s.lay[d]; nown[d] = 0;
+    for (int r = 0; r < L.nrow; ++r) { if (L.owned[r]) { if (nown[d] != r) return fail(IGX_ERR_PLIB, "owned rows are not a prefix of the row box"); nown[d]++; } }
+  }
+  const int nblk = 2048;
+  const size_t need = ((size_t)nblk + 1) * 4 * sizeof(double);
+  if (g->partials.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->partials.alloc(need)) return fail(IGX_ERR_MEM, "partial-sum buffer allocation failed"); }
+  double *part = g->partials.as<double>(), *res = part + (size_t)nblk * 4;
+  hipLaunchKernelGGL(k_checksum, dim3(nblk), dim3(256), 0, g->stream, nown[0], nown[1], nown[2], s.lay[0].nrow, s.lay[1].nrow, s.dof,
+                     A ? A->browptr.as<int64_t>() : nullptr, A ? A->val.as<double>() : nullptr, b ? b->a.as<double>() : nullptr, part);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, g->stream, part, (int64_t)nblk, 4, res, (int64_t)nblk);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(S, res, 4 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  HIPCK(hipStreamSynchronize(g->stream));
   return 0;
 }
 

@@ -42,6 +42,12 @@ template <class F, class = void> struct mat_pair_mask_of { static constexpr unsi
 template <class F> struct mat_pair_mask_of<F, decltype((void)F::MAT_PAIR_MASK)> { static constexpr unsigned long long v = F::MAT_PAIR_MASK; };
 constexpr int fm_popcount(unsigned long long m) { int n = 0; while (m) { n += (int)(m & 1ull); m >>= 1; } return n; }
 constexpr int fm_pair_index(unsigned long long mask, int f, int g) { return fm_popcount(mask & ((1ull << (f * 8 + g)) - 1ull)); }
+// Gram matrices are transposes of each other, M_gf[a][b] = M_fg[b][a]: the pairs with f <= g carry everything
+constexpr unsigned long long fm_pairs_upper(unsigned long long mask) {
+  unsigned long long u = 0ull;
+  for (int f = 0; f < 8; ++f) for (int g = 0; g < 8; ++g) if ((mask >> (f * 8 + g)) & 1ull) u |= 1ull << ((f < g ? f : g) * 8 + (f < g ? g : f));
+  return u;
+}
 
 // optional per-block refinement of MAT_TEST_MASK: Form::block_mask(i,j) = test features block (i,j) of mat() reads
 template <class F, class = void> struct has_block_mask { static constexpr bool v = false; };
@@ -139,21 +145,34 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 // Waves per SIMD a 4-wave kernel is compiled for (= workgroups per CU it is sized for): the tabulation phases are latency
 // bound, so more resident workgroups win as long as the accumulators leave registers to work with
 // (CahnHilliard p=2 tangent: 12.8 / 17.6 / 19.7 / 21.6 M elements/s at 1 / 2 / 3 / 4; NS-VMS p=2 with 16 tiles loses at 4).
-template <class Form, int TA, int NW, int DOFI, bool HASM>
+template <class Form, int TA, int NW, int DOFI, bool HASM, bool PENCIL = false>
 constexpr int fm_min_waves() {
   const unsigned long long pairs = mat_pair_mask_of<Form>::v;
-  const int nacc = !HASM ? 0 : (pairs ? fm_popcount(pairs) : DOFI * Form::DOF);   // accumulator sets per wave
+  const int nacc = !HASM ? 0 : (pairs ? fm_popcount(PENCIL ? fm_pairs_upper(pairs) : pairs) : DOFI * Form::DOF);   // accumulator sets per wave
   if (NW != 4) return 1;      // 8 waves per workgroup: 256 VGPRs each (measured: a 128-VGPR cap gains nothing for scalar
                               // forms and costs the NS-VMS residual 20 % in spills)
   const int tiles = nacc * ((TA == 4) ? 4 : 1);   // 16x16 accumulator tiles per wave, 8 VGPRs each
+  // pencil mode keeps the tiles live through every phase of an element: above 16 tiles (128 registers) a wave gets a SIMD
+  // to itself, i.e. the unified 512-entry file with the accumulators in AGPRs
+  if (PENCIL) return tiles > 16 ? 1 : (tiles <= 4 ? 3 : 2);   // (a scalar form's 4 tiles stay live next to ~110 registers of tabulation: 3 waves)
   return tiles <= 4 ? 4 : (tiles <= 9 ? 3 : 2);
 }
 
 // NW wavefronts per workgroup: 4, or 8 (TA == 4 only: two waves per SIMD share the tile column work).
 // HASM = false: vector-only operations (Vector / Function / IFunction) -- same tabulation, no matrix phases.
-template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM>
-__global__ void __launch_bounds__(64 * NW, (fm_min_waves<Form, TA, NW, DOFI, HASM>()))
+//
+// PENCIL (nen = 4x4x4, matrix-producing drivers, interior pass): combine before write.  The workgroup walks a pencil of
+// elements along mesh axis 0 and keeps its accumulator tiles across elements.  Basis functions are numbered a = 16 a0 +
+// a1 + 4 a2, so a 16x16 tile pairs two axis-0 node layers; a layer lives in tile slot (layer mod 4) for as long as the walk
+// holds it, which makes the operand addresses of an element a rotation of the tile index and never moves an accumulator.
+// After an element its first layer is complete for this pencil: the 7 tiles of an (i,j) block that touch that slot are
+// fixed up (IGAElementFixSystem on the combined values: the diagonal of a fixed row is the number of walked elements that
+// hold the node), written and cleared -- 7/16 of the entries per element reach memory, contributions of the elements of a
+// pencil never meet in memory, and only pencils sharing axis-1/2 nodes conflict: 16 colours instead of 64.
+template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM, bool PENCIL = false>
+__global__ void __launch_bounds__(64 * NW, (fm_min_waves<Form, TA, NW, DOFI, HASM, PENCIL>()))
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
+  static_assert(!PENCIL || (TA == 4 && HASM && DIM == 3), "pencil mode: 4x4 tiles, matrix drivers, dim 3");
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
   constexpr bool SECOND_S = shape_order_of<Form>::v >= 2;      // order of the shape-function features mat()/vec() read
@@ -172,7 +191,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   static_assert(!(HASB && PAIRS != 0ull), "forms with a boundary branch do not take the Gram path");
   constexpr bool GRAM = PAIRS != 0ull;                          // constant-coefficient form: accumulate feature Gram matrices
   static_assert(!GRAM || (DOFI == DOF && I0 == 0 && NFS <= 8), "Gram path forms all row fields in one launch");
-  constexpr int NACC = !HASM ? 1 : (GRAM ? fm_popcount(PAIRS) : DOFI * DOF);
+  // pencil mode accumulates the pairs f <= g only: its write-out reads the mirror tile for the others
+  constexpr unsigned long long PACC = PENCIL ? fm_pairs_upper(PAIRS) : PAIRS;
+  constexpr int NACC = !HASM ? 1 : (GRAM ? fm_popcount(PACC) : DOFI * DOF);
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,7 +201,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   int el[3], ID[3], off[3], nq[3], na[3];
   {
     int b = blockIdx.x;
-    const int t0 = b % cr.count[0]; b /= cr.count[0];
+    int t0 = 0;
+    if (!PENCIL) { t0 = b % cr.count[0]; b /= cr.count[0]; }   // PENCIL: the workgroup walks [start0, start0 + count0) itself
     const int t1 = b % cr.count[1]; b /= cr.count[1];
     const int tt[3] = {t0, t1, b};
 #pragma unroll
@@ -220,15 +242,38 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   int *qdec = reinterpret_cast<int *>(smem + cv.qdec);          // [NQP] q -> q0 | q1<<8 | q2<<16
   __shared__ int s_anyfix;
   if (tid == 0) s_anyfix = 0;
+  __syncthreads();
   const bool stamp = kDebug && out.dbg && blockIdx.x == 7 && tid == 0;
   int nst = 0;
-#define FM_STAMP() do { if (stamp) out.dbg[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
+#define FM_STAMP() do { if (stamp && nst < 31) out.dbg[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
   FM_STAMP();
+
+  // ---- accumulators (PENCIL: they live across the elements of the walk)
+  const bool wave_active = (TA >= 2) || (wave == 0);
+  const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
+  const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
+  fm_d4_t acc[NACC][NTA];
+#pragma unroll
+  for (int k = 0; k < NACC; ++k)
+#pragma unroll
+    for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
+
+  const int nwalk = PENCIL ? cr.count[0] : 1;
+  for (int ei = 0; ei < nwalk; ++ei) {
+  if (PENCIL) {
+    el[0] = cr.start[0] + ei; ID[0] = el[0] + S.ax[0].estart; off[0] = S.ax[0].off[el[0]];
+    // Everything that depends on the pencil's position on axes 1, 2 only is invariant in this loop; hoisted, it stays live
+    // across all phases of every element (measured: hundreds of spilled registers).  Hide the invariance from the optimiser.
+    asm volatile("" : "+s"(el[1]), "+s"(el[2]), "+s"(off[1]), "+s"(off[2]), "+s"(ID[1]), "+s"(ID[2]));
+  }
+  // tile slot of a local axis-0 index: the layer's position mod 4 (PENCIL); rslot undoes it for the tile index T
+  const int rot = PENCIL ? (off[0] & 3) : 0;
+  auto rslot = [&](int T) { return PENCIL ? ((T - rot) & 3) : T; };
 
   // ---- phase 0: 1-D rows, index tables, closure gathers, BC flags, CSR position tables
   for (int a = tid; a < NEP; a += nthr) {
-    const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
-    adec[a] = (a < NE) ? (a0 | (a1 << 8) | (a2 << 16)) : 0;
+    int aa[3]; slot_decode<PENCIL>(a, na, aa);
+    adec[a] = (a < NE) ? (aa[0] | (aa[1] << 8) | (aa[2] << 16)) : 0;
   }
   for (int q = tid; q < NQP; q += nthr) {
     const int q0 = q % nq[0], q1 = (q / nq[0]) % nq[1], q2 = q / (nq[0] * nq[1]);
@@ -249,14 +294,16 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     const int Wd = 2 * S.ax[d].p + 1;
     if (tid < na[d] * na[d]) {   // column position, with the first-touch flag of the slot pair in bit 30
       const int ad = tid / na[d], bd = tid - ad * na[d];
-      pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)] | ((out.first_touch && fm_first_touch_axis(el[d], ad, bd, S.ax[d].nel, S.ax[d].p)) ? (1 << 30) : 0);
+      // (PENCIL: along the walk everything is combined on chip, so every entry is written once per pencil)
+      pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)] | ((out.first_touch && ((PENCIL && d == 0) || fm_first_touch_axis(el[d], ad, bd, S.ax[d].nel, S.ax[d].p))) ? (1 << 30) : 0);
     }
   }
   const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
   const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
   const bool isa = tid < NE;                     // nen <= 64 <= blockDim: one basis function per thread
   const int a = isa ? tid : 0;
-  const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
+  int a012[3]; slot_decode<PENCIL>(a, na, a012);
+  const int a0 = a012[0], a1 = a012[1], a2 = a012[2];
   const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
   const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
   int r0 = 0, r1 = 0, r2 = 0; double xg[DIM], wg = 1;
@@ -319,7 +366,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
-  if (geo && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
+  if (geo && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF, PENCIL>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
   if (anyfix && (useU || useV)) {   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
     for (int k = tid; k < NE * DOF; k += nthr)
       if (fixflag[k]) { if (useU) { ufix[k] = Ue[k]; Ue[k] = fixval[k]; } if (useV) Ve[k] = 0.0; }
@@ -346,7 +393,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r & 1, c = r >> 1;
       double sm = 0;
       for (int a0 = 0; a0 < na[0]; ++a0) {
-        const int a = a0 + na[0] * (a1 + na[1] * a2);
+        const int a = slot_of<PENCIL>(a0, a1, a2, na);
         const double w = rat ? gW[a] : 1.0;
         const double cv = (c < DIM) ? (geo ? gX[a * DIM + c] * w : 0.0) : w;
         sm += cv * t1d[0][(q0 * na[0] + a0) * NDER + v];
@@ -542,15 +589,6 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   }
 
   FM_STAMP();
-  // ---- accumulators
-  const bool wave_active = (TA >= 2) || (wave == 0);
-  const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
-  const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
-  fm_d4_t acc[NACC][NTA];
-#pragma unroll
-  for (int k = 0; k < NACC; ++k)
-#pragma unroll
-    for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
   double Facc[DOF];
 #pragma unroll
   for (int i = 0; i < DOF; ++i) Facc[i] = 0;
@@ -628,7 +666,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     FM_STAMP();
     // ---- phase 5: K_e += A^T B on the matrix cores
     if constexpr (HASM) if (wave_active && !(kDebug && (out.debug & 4))) {
-      const int kq = lane >> 4, col = tb * 16 + (lane & 15);
+      const int kq = lane >> 4, col = rslot(tb) * 16 + (lane & 15);
       for (int s = 0; s < QC / 4; ++s) {
         const int ql = 4 * s + kq, q = qc0 + ql;
         const bool live = q < NQ;
@@ -640,17 +678,17 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         if constexpr (GRAM) {
 #pragma unroll
           for (int f = 0; f < NFS; ++f) {
-            if (!((PAIRS >> (f * 8)) & 0xffull)) continue;
+            if (!((PACC >> (f * 8)) & 0xffull)) continue;
             double A[NTA];
 #pragma unroll
-            for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + (ta0 + t) * 16 + (lane & 15)];
+            for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)];
 #pragma unroll
             for (int g = 0; g < NFS; ++g) {
-              if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+              if (!((PACC >> (f * 8 + g)) & 1ull)) continue;
               const double B = live ? nb[g] * jw : 0.0;
 #pragma unroll
               for (int t = 0; t < NTA; ++t)
-                acc[fm_pair_index(PAIRS, f, g)][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[fm_pair_index(PAIRS, f, g)][t], 0, 0, 0);
+                acc[fm_pair_index(PACC, f, g)][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[fm_pair_index(PACC, f, g)][t], 0, 0, 0);
             }
           }
         } else {
@@ -665,7 +703,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           else Form::mat(p, ef, nb, T);
           double A[NTA];
 #pragma unroll
-          for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + (ta0 + t) * 16 + (lane & 15)];
+          for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)];
 #pragma unroll
           for (int i = 0; i < DOFI; ++i)
 #pragma unroll
@@ -727,16 +765,20 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   FM_STAMP();
   // ---- IGAElementFixSystem / FixJacobian on the tiles, then IGAElementAssembleMat (coloured, conflict-free).
   // Per tile the four row groups are read together, then written: 4 x DOFI*DOF loads in flight per lane.
-  if constexpr (HASM) if (wave_active && !(kDebug && (out.debug & 1))) {
+  if constexpr (HASM && !PENCIL) if (wave_active && !(kDebug && (out.debug & 1))) {
     const int b = tb * 16 + (lane & 15);
     const int bp = adec[b];
     const int b0 = bp & 255, b1 = (bp >> 8) & 255, b2 = bp >> 16;
 #pragma unroll
     for (int t = 0; t < NTA; ++t) {
-      double v[4][DOFI * DOF]; double *dst[4]; bool ok[4];
+      const int arow0 = (ta0 + t) * 16;
+      constexpr int RB = 4;   // row groups per batch: their loads are in flight together
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
+      for (int rb = 0; rb < 4; rb += RB) {
+      double v[RB][DOFI * DOF]; double *dst[RB]; bool ok[RB];
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        const int a = arow0 + (lane >> 4) + 4 * (rb + r);
         ok[r] = (a < NE) && (b < NE);
         const int as = ok[r] ? a : 0;
         const int ap = adec[as];
@@ -750,11 +792,11 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         if (ok[r] && !first && !(kDebug && (out.debug & 16))) load_run<DOFI * DOF>(dst[r], v[r]);
         else { for (int k = 0; k < DOFI * DOF; ++k) v[r][k] = 0; }
       }
-      double kij[GRAM ? 4 : 1][GRAM ? DOF * DOF : 1];
+      double kij[GRAM ? RB : 1][GRAM ? DOF * DOF : 1];
       if constexpr (GRAM) {   // K^{ij} = sum_{fg} C^{ij}_{fg} M_fg; C = mat(e_f, e_g) folds to the form's constants
         PtView p0; p0.x = xq; p0.u = fu; p0.ut = fut; p0.gu = fgu; p0.hu = fhu; p0.G = Gq; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t; p0.normal = nullptr; p0.atboundary = 0; p0.boundary_id = -1;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
           for (int k = 0; k < DOF * DOF; ++k) kij[r][k] = 0;
 #pragma unroll
@@ -768,26 +810,27 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             double T[DOF * DOF];
             Form::mat(p0, ef, eg, T);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < RB; ++r)
 #pragma unroll
-              for (int k = 0; k < DOF * DOF; ++k) kij[r][k] += T[k] * acc[fm_pair_index(PAIRS, f, g)][t][r];
+              for (int k = 0; k < DOF * DOF; ++k) kij[r][k] += T[k] * acc[fm_pair_index(PAIRS, f, g)][t][rb + r];
           }
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < RB; ++r) {
         if (!ok[r]) continue;
-        const int a = (ta0 + t) * 16 + (lane >> 4) + 4 * r;
+        const int a = arow0 + (lane >> 4) + 4 * (rb + r);
 #pragma unroll
         for (int i = 0; i < DOFI; ++i)
 #pragma unroll
           for (int j = 0; j < DOF; ++j) {
             double x;
-            if constexpr (GRAM) x = kij[r][i * DOF + j]; else x = acc[i * DOF + j][t][r];
+            if constexpr (GRAM) x = kij[r][i * DOF + j]; else x = acc[i * DOF + j][t][rb + r];
             if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
             v[r][i * DOF + j] += x;
           }
         if (!(kDebug && (out.debug & 32))) store_run<DOFI * DOF>(dst[r], v[r]);
       }
+      }   // row-group batches
     }
   }
   FM_STAMP();
@@ -798,6 +841,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     for (int i = 0; i < DOF; ++i) Facc[i] = group_sum(Facc[i], npv);
     if (part == 0) {
       const size_t row = (size_t)rowid[a];
+      double vold[DOF];
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) vold[i] = out.vec[row * DOF + i];   // one round trip for the row's fields
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
         const int k = a * DOF + i;
@@ -806,11 +852,133 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         // pass carries the constant parts (flux, fixed value) and a boundary pass only drops its fixed rows
         if (op == OP_SYSTEM) { if (!bpass) v += flux[k]; if (fixflag[k]) v = bpass ? 0.0 : fixval[k]; }                                         // src/petigaelem.c:1371-1387
         else if (op == OP_FUNCTION || op == OP_IFUNCTION) { if (!bpass) v -= flux[k]; if (fixflag[k]) v = bpass ? 0.0 : ufix[k] - fixval[k]; }  // :1449-1461
-        out.vec[row * DOF + i] += v;
+        out.vec[row * DOF + i] = vold[i] + v;
+      }
+    }
+  }
+  // ---- PENCIL: the tiles of the leaving layer (local axis-0 index lv = 0; the last element of the walk flushes lv = 0..3 in
+  // turn) are complete for this pencil.  Two steps through LDS (the Phi region is free by now):
+  //   1. every wave copies its leaving accumulator tiles to LDS, [accumulator set][tile slot][16 rows x 17]: tile slots
+  //      0..ncolb-1 = "row part" (row layer lv x column layers lv..3), then the "column part" (row layers lv+1..3 x column
+  //      layer lv);
+  //   2. all threads write them out: one thread per (row slot, column slot) pair and part.  It forms its blocks -- for a
+  //      constant-coefficient form K^{ij} = sum_{fg} C^{ij}_{fg} M_fg with M_fg for f > g read from the mirror tile (also
+  //      leaving) -- applies IGAElementFixSystem / FixJacobian to the combined values and adds them to the block CSR: the
+  //      blocks of a thread in one CSR row are consecutive (the axis-0 neighbours of a row are contiguous), the loads of a
+  //      batch of blocks in flight together.
+  // A wave's own tiles are 2 of the 7 leaving ones at best: writing from the accumulators left most waves idle at the
+  // barrier while two of them paid 4 dependent round trips per tile (measured 45-100k cycles per element, 58 % of the time),
+  // and keeping the coefficient transform with the accumulators cost hundreds of spilled registers.  Measured and rejected:
+  // a third pass that puts the finished blocks back into LDS in memory order for a lane-coalesced streaming read-add-write
+  // (8 dependent round trips per wave instead of 2: 3.9 instead of 4.8 M elements/s on Elasticity3D).
+  if constexpr (HASM && PENCIL) {
+    constexpr int NBK = DOFI * DOF, TS = 16 * 17;
+    double *stage = phi;
+    const bool last = ei == nwalk - 1;
+    const int nlv = last ? 4 : 1;
+    for (int lv = 0; lv < nlv; ++lv) {
+      __syncthreads();                     // Phi (MFMA / vector phases of this element) or the previous pass's staging is free
+      const int ncolb = 4 - lv;            // column layers of the row part = its tile slots
+      if (wave_active && !(kDebug && (out.debug & 1))) {
+        const int lb = rslot(tb);
+#pragma unroll
+        for (int t = 0; t < NTA; ++t) {
+          const int la = rslot(ta0 + t);
+          const bool rowp = (la == lv) && (lb >= lv), colp = (lb == lv) && (la > lv);
+          if (!rowp && !colp) continue;
+          const int ts = rowp ? lb - lv : ncolb + (la - lv - 1);
+          double *sp = stage + ts * TS + (lane >> 4) * 17 + (lane & 15);
+#pragma unroll
+          for (int k = 0; k < NACC; ++k) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sp[k * 7 * TS + 4 * 17 * r] = acc[k][t][r];
+            acc[k][t] = (fm_d4_t){0, 0, 0, 0};   // the slot is re-used by the layer that enters next
+          }
+        }
+      }
+      __syncthreads();
+      if (!(kDebug && (out.debug & 1)))
+      for (int pr = tid; pr < 512; pr += nthr) {
+        const bool rowp = pr < 256;
+        const int u = pr & 255, ra = u >> 4, cb = u & 15;
+        const int nblk = rowp ? ncolb : 3 - lv;
+        const int a1 = ra & 3, a2 = ra >> 2, b1 = cb & 3, b2 = cb >> 2;
+        const int v1 = pax[1 * 64 + a1 * 8 + b1], v2 = pax[2 * 64 + a2 * 8 + b2];
+        constexpr int KB = (NBK > 4) ? 2 : 4;   // blocks of a thread in flight together
+#pragma unroll
+        for (int k0 = 0; k0 < 4; k0 += KB) {
+          double old[KB][NBK]; double *dst[KB];
+#pragma unroll
+          for (int kk = 0; kk < KB; ++kk) {
+            const int kb = k0 + kk;
+            if (kb >= nblk) continue;
+            const int la = rowp ? lv : lv + 1 + kb, lb = rowp ? lv + kb : lv;
+            const int a = la * 16 + ra;
+            const int v0 = pax[0 * 64 + la * 8 + lb];
+            const int P0 = v0 & 0x3fffffff, P1 = v1 & 0x3fffffff, P2 = v2 & 0x3fffffff;
+            const size_t pos = (size_t)rowbase[a] + ((size_t)P2 * cc[NE + a] + P1) * cc[a] + P0;
+            dst[kk] = out.val + pos * (DOF * DOF) + I0 * DOF;
+            const bool first = ((v0 & v1 & v2) >> 30) & 1;   // the first colour to reach a block stores it (no MatZeroEntries, no read)
+            if (!first && !(kDebug && (out.debug & 16))) load_run<NBK>(dst[kk], old[kk]);
+            else { for (int k = 0; k < NBK; ++k) old[kk][k] = 0; }
+          }
+#pragma unroll
+          for (int kk = 0; kk < KB; ++kk) {
+            const int kb = k0 + kk;
+            if (kb >= nblk) continue;
+            const int la = rowp ? lv : lv + 1 + kb, lb = rowp ? lv + kb : lv;
+            const int a = la * 16 + ra, b = lb * 16 + cb;
+            const int ts = rowp ? kb : ncolb + kb;
+            // mirror tile (column layer x row layer): the diagonal tile is its own mirror
+            const int tm = rowp ? (kb == 0 ? 0 : ncolb + kb - 1) : kb + 1;
+            const double *sd = stage + ts * TS + ra * 17 + cb, *sm = stage + tm * TS + cb * 17 + ra;
+            double kx[NBK];
+            if constexpr (GRAM) {   // K^{ij} = sum_{fg} C^{ij}_{fg} M_fg; C = mat(e_f, e_g) folds to the form's constants
+              PtView p0; p0.x = xq; p0.u = fu; p0.ut = fut; p0.gu = fgu; p0.hu = fhu; p0.G = Gq; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t; p0.normal = nullptr; p0.atboundary = 0; p0.boundary_id = -1;
+#pragma unroll
+              for (int k = 0; k < NBK; ++k) kx[k] = 0;
+#pragma unroll
+              for (int f = 0; f < NFS; ++f)
+#pragma unroll
+                for (int g = 0; g < NFS; ++g) {
+                  if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+                  double ef[NFS], eg[NFS];
+#pragma unroll
+                  for (int k = 0; k < NFS; ++k) { ef[k] = (k == f) ? 1.0 : 0.0; eg[k] = (k == g) ? 1.0 : 0.0; }
+                  double T[DOF * DOF];
+                  Form::mat(p0, ef, eg, T);
+                  const double m = (f <= g) ? sd[fm_pair_index(PACC, f, g) * 7 * TS] : sm[fm_pair_index(PACC, g, f) * 7 * TS];
+#pragma unroll
+                  for (int k = 0; k < NBK; ++k) kx[k] += T[I0 * DOF + k] * m;
+                }
+            } else {
+#pragma unroll
+              for (int k = 0; k < NBK; ++k) kx[k] = sd[k * 7 * TS];
+            }
+            // IGAElementFixSystem / FixJacobian on the combined values: the diagonal of a fixed row is the number of walked
+            // elements that hold its node (each sets K_kk = 1)
+            if (anyfix) {
+              const double held = (double)(min(ei, 3 - la) + 1);
+#pragma unroll
+              for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+                for (int j = 0; j < DOF; ++j)
+                  if (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j]) kx[i * DOF + j] = (a == b && I0 + i == j) ? held : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < NBK; ++k) old[kk][k] += kx[k];
+            if (!(kDebug && (out.debug & 32))) store_run<NBK>(dst[kk], old[kk]);
+          }
+        }
       }
     }
   }
   FM_STAMP();
+  if (PENCIL) {   // next element of the walk: LDS is re-used, the vector rows written above are read by other threads
+    if (tid == 0) s_anyfix = 0;
+    __syncthreads();
+  }
+  }   // walk
   if (stamp) out.dbg[31] = nst;
 #undef FM_STAMP
 }

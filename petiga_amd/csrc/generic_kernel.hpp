@@ -64,11 +64,20 @@ __device__ __forceinline__ void tensor_basis(const double *const t[3], const int
 }
 
 
+// Local numbering of an element's basis functions in the kernels' LDS arrays.  Natural: a = a0 + na0*(a1 + na1*a2)
+// (IGAElementBuildClosure, src/petigaelem.c:711-719).  WALK (feature kernel's pencil mode, 4x4x4 functions): the axis-0 index
+// is the 16x16 MFMA tile, a = 16*a0 + a1 + 4*a2, so that a tile pairs two axis-0 node layers.
+template <bool WALK> __device__ __forceinline__ int slot_of(int a0, int a1, int a2, const int na[3]) { return WALK ? (a0 * 16 + a1 + 4 * a2) : (a0 + na[0] * (a1 + na[1] * a2)); }
+template <bool WALK> __device__ __forceinline__ void slot_decode(int a, const int na[3], int aa[3]) {
+  if (WALK) { aa[0] = a >> 4; aa[1] = a & 3; aa[2] = (a >> 2) & 3; }
+  else { aa[0] = a % na[0]; aa[1] = (a / na[0]) % na[1]; aa[2] = a / (na[0] * na[1]); }
+}
+
 // BoundaryArea, geometry branch (src/petigaelem.c:1133-1160 -> IGA_BoundaryArea_2D/3D, src/petiga2d.F90:276-346,
 // src/petiga3d.F90:379-464): dS = sum over the Gauss points of the element's face of w * sqrt|det(F F^T)|, F = d(face map)/du
 // from the first / last layer of the element's control points; raw Gauss weights (sum 2 per axis), derivatives w.r.t. the
 // knot coordinate, the routine's own Rationalize.  Called by the few threads of a face element that carry a load.
-template <int DIM>
+template <int DIM, bool WALK = false>
 __device__ inline double face_dS(const double *const t1d[3], const double *const w1d[3], const int nq[3], const int na[3],
                                  const double *gX, const double *gW, bool rat, int dir, int side) {
   if constexpr (DIM == 1) return 1.0;
@@ -77,7 +86,7 @@ __device__ inline double face_dS(const double *const t1d[3], const double *const
     int ax[2] = {0, 0};
     { int k = 0; for (int i = 0; i < DIM; ++i) if (i != dir) ax[k++] = i; }
     const int n0 = na[ax[0]], n1 = (FD == 2) ? na[ax[1]] : 1, q0n = nq[ax[0]], q1n = (FD == 2) ? nq[ax[1]] : 1;
-    auto ctrl = [&](int a0, int a1) { int loc[3] = {0, 0, 0}; loc[dir] = side ? na[dir] - 1 : 0; loc[ax[0]] = a0; if (FD == 2) loc[ax[1]] = a1; return loc[0] + na[0] * (loc[1] + na[1] * loc[2]); };
+    auto ctrl = [&](int a0, int a1) { int loc[3] = {0, 0, 0}; loc[dir] = side ? na[dir] - 1 : 0; loc[ax[0]] = a0; if (FD == 2) loc[ax[1]] = a1; return slot_of<WALK>(loc[0], loc[1], loc[2], na); };
     double dS = 0;
     for (int q1 = 0; q1 < q1n; ++q1) for (int q0 = 0; q0 < q0n; ++q0) {
       double W0 = 1, S1[2] = {0, 0};
@@ -108,7 +117,7 @@ __device__ inline double face_dS(const double *const t1d[3], const double *const
 
 // IGAElementBuildFix's flux part on a mapped geometry (AddFlux with BoundaryArea's geometry branch): run after the closure
 // gathers are visible.  aa-decoding as in the kernels: a = a0 + na0*(a1 + na1*a2).
-template <int DIM, int DOF>
+template <int DIM, int DOF, bool WALK = false>
 __device__ inline void add_mapped_flux(const SpaceDev &S, const int ID[3], const int el[3], const double *const t1d[3], const double *const w1d[3],
                                        const int nq[3], const int na[3], const double *gX, const double *gW, bool rat, double *flux, int tid, int nthr) {
   const int NE = na[0] * na[1] * na[2];
@@ -118,11 +127,11 @@ __device__ inline void add_mapped_flux(const SpaceDev &S, const int ID[3], const
       const BCDev &bl = S.bcl[d][side];
       if (!bl.count || ID[d] != (side ? S.ax[d].esizes - 1 : 0)) continue;
       for (int a = tid; a < NE; a += nthr) {
-        const int aa[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
+        int aa[3]; slot_decode<WALK>(a, na, aa);
         if (aa[d] != (side ? na[d] - 1 : 0)) continue;
         double A = 1;
         for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
-        A *= face_dS<DIM>(t1d, w1d, nq, na, gX, gW, rat, d, side);
+        A *= face_dS<DIM, WALK>(t1d, w1d, nq, na, gX, gW, rat, d, side);
         for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
       }
     }

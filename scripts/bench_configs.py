@@ -87,6 +87,8 @@ if "c5" in which:
     run("NavierStokesVMS p=3 32^3 tangent (config 5 is 192^3 on 8 GPUs)", 3, 4, 3, (32,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian", bc=bc5)
 if "c6" in which:
     run("Poisson3D p=3 64^3 on a NURBS geometry", 3, 1, 3, (64,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
+if "c6b" in which:
+    run("Poisson3D p=3 128^3 on a NURBS geometry", 3, 1, 3, (128,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "c7" in which:
     run("Poisson3D p=2 96^3 on a NURBS geometry", 3, 1, 2, (96,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "full3" in which:
