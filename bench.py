@@ -51,6 +51,12 @@ def physical_cores():
         n = min(n, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
+    try:                       # a container's CPU quota (cgroup v2 "cpu.max": "<quota> <period>" or "max <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
     return max(1, n)
 
 
@@ -101,16 +107,101 @@ def _cpu_worker(args):
     return m ** 3, dt
 
 
+WORKLOADS = {
+    # name: (dim, dof, p, C, default size at N GPUs, periodic, form, op, description)
+    "poisson": dict(dof=1, p=3, size=256, periodic=(0, 0, 0), form="poisson", op="system",
+                    metric="element stiffness assemblies/sec (3D p=3 Poisson, 256^3 elems)", ref="IGAComputeSystem demo/Poisson3D.c"),
+    "elasticity": dict(dof=3, p=3, size=128, periodic=(0, 0, 0), form="elasticity", op="system",
+                       metric="element stiffness assemblies/sec (3D p=3 Elasticity, 128^3 elems, 3 DOF/node)", ref="IGAComputeSystem demo/Elasticity3D.c"),
+    "cahnhilliard": dict(dof=1, p=2, size=256, periodic=(0, 0, 0), form="cahnhilliard", op="tangent",
+                         metric="element residual+tangent assemblies/sec (3D p=2 CahnHilliard, 256^3 elems)", ref="IGAComputeIFunction + IGAComputeIJacobian demo/CahnHilliard3D.c"),
+    "nsvms": dict(dof=4, p=3, size=192, periodic=(1, 0, 1), form="nsvms", op="tangent",
+                  metric="element residual+tangent assemblies/sec (3D p=3 NavierStokesVMS, 192^3 elems, 4 DOF/node, NURBS geometry)", ref="IGAComputeIFunction + IGAComputeIJacobian demo/NavierStokesVMS.c"),
+}
+
+
+def _state(vec_like_mat, sizes, dof, amp, base):
+    """A partition-independent synthetic state: a hash of the GLOBAL natural node index, laid out in this rank's row box."""
+    import numpy as np
+    nrow, _, maps = vec_like_mat.layout()
+    ns = sizes["node_sizes"]
+    n0 = maps[0][0].astype(np.int64)[None, None, :]
+    n1 = maps[1][0].astype(np.int64)[None, :, None]
+    n2 = maps[2][0].astype(np.int64)[:, None, None]
+    idx = (n0 + ns[0] * (n1 + ns[1] * n2)).reshape(-1)
+    out = np.empty((idx.size, dof))
+    for c in range(dof):
+        x = np.sin((idx * dof + c) * 12.9898 + 78.233) * 43758.5453
+        out[:, c] = base + amp * (2 * (x - np.floor(x)) - 1)
+    return out.reshape(-1)
+
+
+def build_problem(P, name, size, degree, world, rank, kernel, geometry):
+    import numpy as np
+    w = WORKLOADS[name]
+    dof, p = w["dof"], (degree if name == "poisson" else w["p"])
+    g = P.IGX(3, dof)
+    g.set_comm(world, rank)
+    for i in range(3):
+        g.axis_uniform(i, p, size, periodic=bool(w["periodic"][i]))
+    g.setup()
+    params = ()
+    if name == "poisson":
+        for d in range(3):
+            for s in range(2):
+                g.set_boundary_value(d, s, 0, 1.0)
+    elif name == "elasticity":      # demo/Elasticity3D.c:66-71: clamped face (0,0), u_x = 1 on face (0,1); lambda = mu = 1
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(0, 1, 0, 1.0)
+        params = (1.0, 1.0)
+    elif name == "cahnhilliard":    # demo/CahnHilliard3D.c:247-251: theta, alpha, cbar, L0, lambda = tau h^2, tau
+        params = (1.5, 200.0, 0.63, 1.0, 1.0 / (3.0 * size * size), 1.0)
+    elif name == "nsvms":           # demo/NavierStokesVMS.c:362-385: no-slip on axis 1; nu, f, dt
+        for s_ in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s_, f, 0.0)
+        params = (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2)
+    if geometry:                    # a smooth rational map (config 5's premise), the same net on every rank
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from common import greville
+        gv = []
+        for i in range(3):
+            per = bool(w["periodic"][i])
+            U = (np.arange(-p, size + p + 1) / size) if per else np.concatenate([[0.0] * (p + 1), np.arange(1, size) / size, [1.0] * (p + 1)])
+            gv.append(greville(U, p))
+        mesh = np.meshgrid(*gv[::-1], indexing="ij")[::-1]
+        X = np.stack([m.copy() for m in mesh], axis=-1)
+        X[..., 0] += 0.05 * np.sin(2 * np.pi * mesh[1])
+        X[..., 1] += 0.05 * np.sin(2 * np.pi * mesh[2])
+        W = 1.0 + 0.1 * np.cos(2 * np.pi * mesh[0])
+        g.set_geometry(X.reshape(-1, 3), W.reshape(-1))
+    g.set_form(w["form"], params)
+    g.set_kernel(kernel)
+    A, b = g.create_mat(), g.create_vec()
+    U = V = None
+    if w["op"] == "tangent":
+        U = g.create_vec().set(_state(A, g.sizes(), dof, 0.05, 0.63 if name == "cahnhilliard" else 0.1))
+        V = g.create_vec().set(_state(A, g.sizes(), dof, 0.01, 0.0))
+    return g, A, b, U, V, p
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--size", type=int, default=256, help="elements per axis (metric config: 256)")
-    ap.add_argument("--degree", type=int, default=3)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 MFMA")
+    ap.add_argument("--form", default="poisson", choices=sorted(WORKLOADS), help="poisson = the BASELINE metric; the others are BASELINE configs 3, 4, 5")
+    ap.add_argument("--size", type=int, default=0, help="elements per axis (0: the config's own size)")
+    ap.add_argument("--degree", type=int, default=3, help="poisson only")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 MFMA pencil, 3 feature")
+    ap.add_argument("--geometry", action="store_true", help="mapped rational geometry (default for nsvms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
     args = ap.parse_args()
+    wl = WORKLOADS[args.form]
+    size = args.size or wl["size"]
+    geometry = args.geometry or args.form == "nsvms"
 
     import torch
     import torch.distributed as dist
@@ -127,23 +218,22 @@ def main():
 
     import petiga_amd as P
     from petiga_amd import exchange
-    g = P.IGX(3, 1)
-    g.set_comm(world, rank)
-    for i in range(3):
-        g.axis_uniform(i, args.degree, args.size)
-    g.setup()
-    for d in range(3):
-        for s in range(2):
-            g.set_boundary_value(d, s, 0, 1.0)
-    g.set_form("poisson")
-    g.set_kernel(args.kernel)
-    A, b = g.create_mat(), g.create_vec()
-    ex = exchange.GhostExchange(g, A, b) if world > 1 else None
+    g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry)
+    transport = exchange.init_comm(g) if world > 1 else None      # the library's own exchange: RCCL (or the gloo test transport)
+    tangent = wl["op"] == "tangent"
+    shift = 1.0e3
 
     def step():
-        g.compute_system(A, b)
-        if ex is not None:
-            ex.reduce()
+        if tangent:
+            if world > 1:          # DMGlobalToLocal of the state (IGAGetLocalVecArray): owner values to the ghosts
+                g.refresh_ghosts(U)
+                g.refresh_ghosts(V)
+            g.compute_ifunction(shift, V, 0.0, U, b)
+            g.compute_ijacobian(shift, V, 0.0, U, A)
+        else:
+            g.compute_system(A, b)
+        if world > 1:              # MatAssemblyBegin/End + VecAssemblyBegin/End: ghost rows to their owners
+            g.reduce_ghost_rows(A, b)
 
     def fence():
         g.synchronize()
@@ -170,14 +260,38 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    total_elems = args.size ** 3
+    total_elems = size ** 3
     value = total_elems * args.steps / dt
 
+    # checksums over the owned rows: partition-independent up to rounding.  N > 1: rank 0 also assembles the whole mesh as a
+    # single rank (it fits next to its share on a 288 GB GPU for the headline) and the sums must agree: a lost or doubled
+    # ghost row cannot print a rate.
+    cs = g.checksum(A, b)
+    check = None
+    if world > 1:
+        tcs = torch.tensor(cs, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(tcs, op=dist.ReduceOp.SUM)
+        cs = tcs.cpu().numpy()
+        if rank == 0 and not args.no_check:
+            g1, A1, b1, U1, V1, _ = build_problem(P, args.form, size, args.degree, 1, 0, args.kernel, geometry)
+            if tangent:
+                g1.compute_ifunction(shift, V1, 0.0, U1, b1)
+                g1.compute_ijacobian(shift, V1, 0.0, U1, A1)
+            else:
+                g1.compute_system(A1, b1)
+            g1.synchronize()
+            ref = g1.checksum(A1, b1)
+            rel = [abs(float(x) - float(y)) / max(abs(float(y)), 1e-300) for x, y in zip(cs, ref)]
+            check = dict(reference="single-rank assembly of the same mesh on rank 0's GPU", rel_diff=rel)
+            del A1, b1, g1
+            assert max(rel[1], rel[3]) < 1e-9 and rel[0] < 1e-6 and rel[2] < 1e-6, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs), list(ref))
+
     if rank == 0:
-        flop = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3)
+        nen, nqp = (p + 1) ** 3, (p + 1) ** 3
+        flop = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3) if args.form == "poisson" else None
         avg_launch_s = (dom_ms / 1e3) / max(dom_launches, 1)
         elems_per_launch = dom_elems / max(dom_launches, 1)
-        achieved = flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+        achieved = flop * elems_per_launch / avg_launch_s / 1e12 if (avg_launch_s > 0 and flop) else None
         executed = dom_flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
         # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes of this same command
         # (scripts/profile_round.sh), committed as profiles/traffic.json: they are NOT measured inside this run, so the
@@ -187,34 +301,36 @@ def main():
         if os.path.exists(tf):
             try:
                 tj = json.load(open(tf))
-                if tj.get("size") == args.size and tj.get("degree") == args.degree and tj.get("n_gpus") == world and tj.get("kernel_tag") == KERNEL_TAG:
+                if args.form == "poisson" and tj.get("size") == size and tj.get("degree") == args.degree and tj.get("n_gpus") == world and tj.get("kernel_tag") == KERNEL_TAG:
                     traffic = tj.get("bytes_per_launch")
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % tj.get("round")
             except Exception:
                 traffic = None
         line = {
-            "metric": "element stiffness assemblies/sec (3D p=3 Poisson, 256^3 elems)",
+            "metric": wl["metric"],
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "IGAComputeSystem demo/Poisson3D.c: p=%d C%d, %d^3 elements, dof=1, Dirichlet u=1 on 6 faces, Gauss %d^3"
-                                   % (args.degree, args.degree - 1, args.size, args.degree + 1),
-                       "kernels": g.kernel_name(), "partition": g.sizes()["proc_sizes"]},
+            "config": {"workload": "%s: p=%d C%d, %d^3 elements, dof=%d, Gauss %d^3%s%s"
+                                   % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
+                                      ", rational NURBS geometry map" if geometry else ""),
+                       "kernels": g.kernel_name(), "partition": g.sizes()["proc_sizes"],
+                       "transport": transport, "checksum": [float(x) for x in cs], "checksum_check": check},
             # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (it skips the 6
             # mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
             # (2*nen^2*nqp*dim flop per element, SURVEY 8d / BASELINE.md 3) is kept next to it.
             "roofline": {"bound": "mfma", "achieved": executed, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": executed / FP64_PEAK_TFLOPS,
-                         "achieved_algorithmic": achieved, "frac_algorithmic": achieved / FP64_PEAK_TFLOPS,
+                         "achieved_algorithmic": achieved, "frac_algorithmic": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
                          "kernel": dom_name, "launches_per_step": dom_launches // max(args.steps, 1),
                          "avg_launch_ms": avg_launch_s * 1e3, "elements_per_launch": elems_per_launch,
                          "flop_per_element": flop, "executed_flop_per_element": dom_flop,
-                         "algorithmic_bytes_per_element": BYTES_PER_ELEM.get(args.degree)},
+                         "algorithmic_bytes_per_element": BYTES_PER_ELEM.get(args.degree) if args.form == "poisson" else None},
             "device": P.device_info(),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.form == "poisson":
             cb = cpu_baseline(args.degree)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = value / max(cb["value"], cb["cores_x_single_core"])

@@ -233,8 +233,8 @@ int IGXGetElementColor(IGX iga,int axis,int e);
  * holds but does not own) are packed per upper neighbour (send list, k < nsend); the owner adds
  * them (receive list, k < nrecv).  A message is mat_doubles values (if A given) followed by
  * vec_doubles values (if b given).  Replaces the stash traffic of MatAssemblyBegin/End and
- * VecAssemblyBegin/End (src/petigaksp.c:197-200).  The transport (RCCL send/recv over xGMI) is the
- * caller's: torch.distributed in petiga_amd/exchange.py.
+ * VecAssemblyBegin/End (src/petigaksp.c:197-200).  These are the building blocks; IGXReduceGhostRows / IGXRefreshGhosts
+ * below run the whole exchange inside the library (RCCL or a caller-provided transport).
  * ------------------------------------------------------------------------------------------ */
 int IGXGetNeighborCount(IGX iga,int *nsend,int *nrecv);
 int IGXGetNeighborInfo(IGX iga,int send /*1=send list,0=recv list*/,int k,int *rank,int64_t *mat_doubles,int64_t *vec_doubles);
@@ -247,6 +247,47 @@ int IGXPackOwnerValues  (IGX iga,IGXVec v,int k,double *devbuf);
 int IGXUnpackGhostValues(IGX iga,IGXVec v,int k,const double *devbuf);
 /* 1 if this rank owns the node of local row (r0,r1,r2): after the exchange only owned rows are final */
 int IGXRowOwned(IGX iga,int r0,int r1,int r2);
+
+/* The transport, inside the library.  IGXReduceGhostRows = pack every send-list message, move them, add the received ones
+ * (the whole of MatAssemblyBegin/End + VecAssemblyBegin/End, src/petigaksp.c:197-200); IGXRefreshGhosts = the owner's values
+ * of a state vector to the ranks that hold the node as a ghost (DMGlobalToLocal in IGAGetLocalVecArray,
+ * src/petigavec.c:256-269).  Both are enqueued: packs, transfers and unpacks run on the library's exchange stream, which
+ * waits for the engine stream's last launch and is waited for by its next one (events); the host never blocks.
+ *   IGXCommInitRCCL: grouped ncclSend / ncclRecv (RCCL over xGMI).  librccl.so is bound with dlopen (an already loaded copy
+ *     is reused; `librccl_path` or $IGX_RCCL_LIB name another).  Rank 0 calls IGXCommGetUniqueId and the caller broadcasts
+ *     the 128 bytes (MPI_Bcast in PetIGA, torch.distributed in bench.py); size and rank are those of IGXSetComm.
+ *   IGXCommInitTransport: a host callback that moves the packed DEVICE buffers (test transport: gloo; an MPI caller).
+ *     It is called after the exchange stream has been synchronised and must return with the receive buffers filled. */
+typedef struct { char internal[128]; } IGXUniqueId;       /* = ncclUniqueId */
+typedef int (*IGXTransportFn)(void *ctx,int nsend,const int send_peer[],double *const send_buf[],const int64_t send_count[],
+                              int nrecv,const int recv_peer[],double *const recv_buf[],const int64_t recv_count[]);
+int IGXCommGetUniqueId(IGXUniqueId *id,const char *librccl_path /* may be NULL */);
+int IGXCommInitRCCL(IGX iga,const IGXUniqueId *id,const char *librccl_path /* may be NULL */);
+int IGXCommInitTransport(IGX iga,IGXTransportFn fn,void *ctx);
+int IGXCommDestroy(IGX iga);
+int IGXReduceGhostRows(IGX iga,IGXMat A,IGXVec b);        /* A or b may be NULL */
+int IGXRefreshGhosts(IGX iga,IGXVec v);
+int IGXCommGetLastBytes(IGX iga,int64_t *bytes_sent);      /* of the last exchange */
+/* one rank sends n doubles to itself through the RCCL path (binding, communicator, streams and events on a single GPU) */
+int IGXCommLoopbackTest(IGX iga,int64_t n,double *maxdiff);
+
+/* ------------------------------------------------------------------------------------------
+ * Hand-back to PETSc (used by adapter/petiga_amd_petsc.c).  PETSc assembles device matrices from coordinate
+ * lists: MatSetPreallocationCOO(A,n,coo_i,coo_j) once, MatSetValuesCOO(A,v,ADD_VALUES) per assembly with v on the device.
+ * The engine's value array (IGXMatGetDeviceArrays) is that v; IGXMatGetCOO gives the index pair of every stored scalar in
+ * the same order (block by block, row-major inside a block).  numbering 0: natural, node*dof+field with axis 0 fastest
+ * (IGA_Grid_LocalIndices, src/petigagrid.c); 1: PETSc's, i.e. PetIGA's AO (AOCreateMemoryScalable over the ranks' owned boxes,
+ * src/petigagrid.c:185-199).  owned_only: entries of rows this rank does not own get -1, which MatSetPreallocationCOO ignores
+ * (use after IGXReduceGhostRows; without it PETSc itself moves the not-owned rows, as MatAssemblyBegin/End always did).
+ * Arrays have nblocks*bs*bs (matrix) / vector-size entries, on the device (on_device != 0) or on the host.
+ * IGXVecCopyFromGhosted / ToGhosted: the rank's ghosted local array [gw2][gw1][gw0][dof] (IGAGetLocalVecArray,
+ * src/petigavec.c:256-269) to / from an IGXVec: identical unless a periodic axis is wrapped inside the rank.
+ * ------------------------------------------------------------------------------------------ */
+int IGXMatGetCOO(IGXMat A,int numbering,int owned_only,int64_t *coo_i,int64_t *coo_j,int on_device);
+int IGXVecGetIndices(IGXVec v,int numbering,int owned_only,int64_t *idx,int on_device);
+int IGXVecGetGhostedSize(IGXVec v,int64_t *n);
+int IGXVecCopyFromGhosted(IGXVec v,const double *array,int on_device);
+int IGXVecCopyToGhosted(IGXVec v,double *array,int on_device);
 
 /* Checksums of an assembled system over the rows this rank OWNS (after the ghost-row reduction only those are final):
  * S[0] = sum A_ij, S[1] = sum |A_ij|, S[2] = sum b_i, S[3] = sum b_i^2; A or b may be NULL.  Added over the ranks of any

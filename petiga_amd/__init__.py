@@ -36,6 +36,10 @@ class IGXTables(C.Structure):
                 ("nsd", C.c_int), ("rational", C.c_int), ("geometryX", _dp), ("rationalW", _dp)]
 
 
+# IGXTransportFn (include/petiga_amd.h): the host-callback transport of the ghost-row exchange
+TRANSPORT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int, _ip, C.POINTER(C.c_void_p), C.POINTER(C.c_int64))
+
+
 class IGXError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("IGX error %d: %s" % (code, msg))
@@ -89,6 +93,11 @@ def lib(build_if_needed=False):
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
         "IGXChecksum": [V, V, V, _dp],
+        "IGXMatGetCOO": [V, C.c_int, C.c_int, V, V, C.c_int], "IGXVecGetIndices": [V, C.c_int, C.c_int, V, C.c_int],
+        "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
+        "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
+        "IGXCommDestroy": [V], "IGXReduceGhostRows": [V, V, V], "IGXRefreshGhosts": [V, V], "IGXCommGetLastBytes": [V, C.POINTER(C.c_int64)],
+        "IGXCommLoopbackTest": [V, C.c_int64, _dp],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
@@ -135,6 +144,28 @@ class Vec:
         _ck(lib().IGXVecGetDeviceArray(self.h, C.byref(p)))
         return p.value
 
+    def indices(self, numbering=0, owned_only=False):
+        """Global index of every entry (natural or PETSc numbering), -1 for not-owned rows when owned_only."""
+        idx = np.empty(self.n, dtype=np.int64)
+        _ck(lib().IGXVecGetIndices(self.h, numbering, int(owned_only), idx.ctypes.data, 0))
+        return idx
+
+    def ghosted_size(self):
+        n = C.c_int64()
+        _ck(lib().IGXVecGetGhostedSize(self.h, C.byref(n)))
+        return n.value
+
+    def set_from_ghosted(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        assert a.size == self.ghosted_size()
+        _ck(lib().IGXVecCopyFromGhosted(self.h, a.ctypes.data, 0))
+        return self
+
+    def get_ghosted(self):
+        a = np.empty(self.ghosted_size())
+        _ck(lib().IGXVecCopyToGhosted(self.h, a.ctypes.data, 0))
+        return a
+
 
 class Mat:
     def __init__(self, iga):
@@ -165,6 +196,13 @@ class Mat:
         ci = np.empty(self.nblocks, dtype=np.int32)
         _ck(lib().IGXMatCopyToHost(self.h, rp.ctypes.data, ci.ctypes.data, val.ctypes.data))
         return rp, ci, val
+
+    def coo(self, numbering=0, owned_only=False):
+        """(coo_i, coo_j) of every stored scalar in the order of the value array (IGXMatGetCOO)."""
+        n = self.nblocks * self.bs * self.bs
+        ci, cj = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
+        _ck(lib().IGXMatGetCOO(self.h, numbering, int(owned_only), ci.ctypes.data, cj.ctypes.data, 0))
+        return ci, cj
 
     def layout(self):
         nrow, ncol = (C.c_int * 3)(), (C.c_int * 3)()
@@ -333,6 +371,44 @@ class IGX:
             _ck(lib().IGXGetNeighborInfo(self.h, int(send), k, C.byref(r), C.byref(m), C.byref(v)))
             out.append((r.value, m.value, v.value))
         return out
+
+    # -- the exchange inside the library (RCCL, or a host-callback transport)
+    @staticmethod
+    def comm_unique_id(librccl=None):
+        buf = C.create_string_buffer(128)
+        _ck(lib().IGXCommGetUniqueId(buf, librccl.encode() if librccl else None))
+        return buf.raw
+
+    def comm_init_rccl(self, unique_id, librccl=None):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _ck(lib().IGXCommInitRCCL(self.h, buf, librccl.encode() if librccl else None))
+
+    def comm_init_transport(self, pyfn):
+        """pyfn(send=[(peer, devptr, count)], recv=[(peer, devptr, count)]) moves the packed device buffers."""
+        def tramp(ctx, ns, sp, sb, sn, nr, rp, rb, rn):
+            try:
+                pyfn([(sp[i], sb[i], sn[i]) for i in range(ns)], [(rp[i], rb[i], rn[i]) for i in range(nr)])
+                return 0
+            except Exception as e:      # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._transport = TRANSPORT_FN(tramp)     # keep the trampoline alive
+        _ck(lib().IGXCommInitTransport(self.h, self._transport, None))
+
+    def comm_destroy(self): _ck(lib().IGXCommDestroy(self.h))
+    def reduce_ghost_rows(self, A=None, b=None): _ck(lib().IGXReduceGhostRows(self.h, A.h if A is not None else None, b.h if b is not None else None))
+    def refresh_ghosts(self, v): _ck(lib().IGXRefreshGhosts(self.h, v.h))
+
+    def comm_last_bytes(self):
+        n = C.c_int64()
+        _ck(lib().IGXCommGetLastBytes(self.h, C.byref(n)))
+        return n.value
+
+    def comm_loopback_test(self, n=1 << 20):
+        d = C.c_double()
+        _ck(lib().IGXCommLoopbackTest(self.h, n, C.byref(d)))
+        return d.value
 
     def pack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXPackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))
     def unpack_ghost_rows(self, A, b, k, devptr): _ck(lib().IGXUnpackGhostRows(self.h, A.h if A else None, b.h if b else None, k, devptr))

@@ -1,0 +1,195 @@
+// comm.hpp -- the transport of the ghost-row exchange, inside the library (included by engine.hip after exchange.hpp).
+//
+// Reference: the only communication on the assembly path is MatAssemblyBegin/End + VecAssemblyBegin/End
+// (src/petigaksp.c:197-200; PETSc's stash moves the rows of not-owned nodes to their owners) and, before a nonlinear
+// assembly, DMGlobalToLocal of the state vectors (IGAGetLocalVecArray, src/petigavec.c:256-269).  Here a rank's ghost rows
+// go point-to-point to its <= 7 upper neighbours: grouped ncclSend / ncclRecv on RCCL (one xGMI link per neighbour pair of
+// a 2x2x2 grid, all messages concurrent), on the library's own exchange stream.  The engine stream and the exchange stream
+// meet through events only: IGXReduceGhostRows / IGXRefreshGhosts never block the host.
+//
+// RCCL is bound at run time (dlopen): the library has no link-time dependency on it, a copy that is already loaded in the
+// process (e.g. the one PyTorch ships) is reused.  A second transport takes a host callback that is handed the packed device
+// buffers: the test transport (gloo in tests / bench.py with ranks sharing one GPU) and the hook for an MPI-based caller.
+#include <dlfcn.h>
+
+namespace {
+
+struct RcclApi {
+  void *handle = nullptr;
+  int (*GetUniqueId)(void *) = nullptr;                                           // ncclGetUniqueId(ncclUniqueId*)
+  int (*CommInitRank)(void **, int, IGXUniqueId, int) = nullptr;                  // ncclCommInitRank(comm*, nranks, id (by value), rank)
+  int (*CommDestroy)(void *) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;     // ncclSend(buf, count, datatype, peer, comm, stream)
+  int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclDouble = 8;   // ncclFloat64 (rccl.h)
+
+static int load_rccl(RcclApi &api, const char *path, std::string &err) {
+  if (api.handle) return 0;
+  const char *env = getenv("IGX_RCCL_LIB");
+  const char *names[] = {path, env, "librccl.so.1", "librccl.so"};
+  for (int pass = 0; pass < 2 && !api.handle; ++pass)     // first a copy that is already loaded, then a fresh one
+    for (const char *n : names) {
+      if (!n || !*n) continue;
+      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      if (api.handle) break;
+    }
+  if (!api.handle) { err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }
+  auto sym = [&](const char *n) { return dlsym(api.handle, n); };
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
+  api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  if (!api.GetUniqueId || !api.CommInitRank || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv) {
+    err = "librccl.so lacks the point-to-point API (ncclSend / ncclRecv)"; dlclose(api.handle); api = RcclApi(); return IGX_ERR_LIB;
+  }
+  return 0;
+}
+
+static RcclApi &rccl_api() { static RcclApi a; return a; }
+
+}  // namespace
+
+struct IgxComm {
+  int kind = 0;                       // 1 RCCL, 2 host callback
+  void *nccl = nullptr;               // ncclComm_t
+  IGXTransportFn fn = nullptr; void *fnctx = nullptr;
+  hipStream_t xs = nullptr;           // exchange stream
+  hipEvent_t ready = nullptr, done = nullptr;
+  std::vector<DevBuf> sbuf, rbuf;     // one per neighbour of the larger of the two lists
+  int64_t last_bytes = 0;
+  ~IgxComm() {
+    if (nccl && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(nccl);
+    if (ready) (void)hipEventDestroy(ready);
+    if (done) (void)hipEventDestroy(done);
+    if (xs) (void)hipStreamDestroy(xs);
+  }
+};
+
+#define NCCLCK(call) do { int r_ = (call); if (r_ != 0) return fail(IGX_ERR_LIB, std::string(#call) + ": " + (rccl_api().GetErrorString ? rccl_api().GetErrorString(r_) : "RCCL error")); } while (0)
+
+static int comm_common_init(IGX g, std::unique_ptr<IgxComm> &c) {
+  HIPCK(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
+  HIPCK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+  g->comm = std::move(c);
+  return 0;
+}
+
+extern "C" int IGXCommGetUniqueId(IGXUniqueId *id, const char *librccl_path) {
+  if (!id) return fail(IGX_ERR_ARG_WRONG, "null id");
+  std::string e; if (int rc = load_rccl(rccl_api(), librccl_path, e)) return fail(rc, e);
+  NCCLCK(rccl_api().GetUniqueId(id));
+  return 0;
+}
+
+extern "C" int IGXCommInitRCCL(IGX g, const IGXUniqueId *id, const char *librccl_path) {
+  NEEDIGA(g); if (!id) return fail(IGX_ERR_ARG_WRONG, "null id");
+  if (!g->s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  std::string e; if (int rc = load_rccl(rccl_api(), librccl_path, e)) return fail(rc, e);
+  std::unique_ptr<IgxComm> c(new IgxComm());
+  c->kind = 1;
+  NCCLCK(rccl_api().CommInitRank(&c->nccl, g->s.comm_size, *id, g->s.comm_rank));
+  return comm_common_init(g, c);
+}
+
+extern "C" int IGXCommInitTransport(IGX g, IGXTransportFn fn, void *ctx) {
+  NEEDIGA(g); if (!fn) return fail(IGX_ERR_ARG_WRONG, "null transport");
+  std::unique_ptr<IgxComm> c(new IgxComm());
+  c->kind = 2; c->fn = fn; c->fnctx = ctx;
+  return comm_common_init(g, c);
+}
+
+extern "C" int IGXCommDestroy(IGX g) { NEEDIGA(g); if (g->comm) { (void)hipStreamSynchronize(g->comm->xs); g->comm.reset(); } return 0; }
+
+// One exchange: pack `npack` messages (list `pack_send_list`), move them, unpack the `nunp` received ones.  reduce = true:
+// ghost rows to their owners (added); false: owner values to the ghosts (assigned; vectors only).
+static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
+  NEEDIGA(g);
+  if (!g->comm) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXCommInitRCCL() / IGXCommInitTransport() first");
+  if (int rc = ensure_device(g)) return rc;
+  { std::string e; if (int rc = exchange_supported(g->s, e)) return fail(rc, e); }
+  IgxComm &c = *g->comm;
+  // reduce: I pack my SEND list (upper neighbours) and unpack my RECEIVE list; refresh: the other way round
+  const std::vector<NbrPlan> out_plans = neighbour_plans(g->s, reduce), in_plans = neighbour_plans(g->s, !reduce);
+  auto doubles = [&](const NbrPlan &p) { return (A ? p.mat_doubles : 0) + (b ? p.vec_doubles : 0); };
+  if (c.sbuf.size() < out_plans.size()) c.sbuf.resize(out_plans.size());
+  if (c.rbuf.size() < in_plans.size()) c.rbuf.resize(in_plans.size());
+  bool grew = false;
+  for (size_t k = 0; k < out_plans.size(); ++k) if (c.sbuf[k].bytes < (size_t)doubles(out_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.sbuf[k].alloc((size_t)doubles(out_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
+  for (size_t k = 0; k < in_plans.size(); ++k) if (c.rbuf[k].bytes < (size_t)doubles(in_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.rbuf[k].alloc((size_t)doubles(in_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
+  // the exchange stream picks up where the engine stream stands (the assembly's last launch)
+  HIPCK(hipEventRecord(c.ready, g->stream));
+  HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
+  c.last_bytes = 0;
+  for (size_t k = 0; k < out_plans.size(); ++k) {
+    if (doubles(out_plans[k]) == 0) continue;
+    if (int rc = ghost_rows(g, A, b, (int)k, c.sbuf[k].as<double>(), reduce, 0, c.xs)) return rc;
+    c.last_bytes += doubles(out_plans[k]) * 8;
+  }
+  if (c.kind == 1) {
+    NCCLCK(rccl_api().GroupStart());
+    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k])) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
+    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k])) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
+    NCCLCK(rccl_api().GroupEnd());
+  } else {
+    std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
+    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k])) { sp.push_back(out_plans[k].rank); sb.push_back(c.sbuf[k].as<double>()); sn.push_back(doubles(out_plans[k])); }
+    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k])) { rp.push_back(in_plans[k].rank); rb.push_back(c.rbuf[k].as<double>()); rn.push_back(doubles(in_plans[k])); }
+    HIPCK(hipStreamSynchronize(c.xs));      // a host transport reads the packed buffers
+    if (int rc = c.fn(c.fnctx, (int)sp.size(), sp.data(), sb.data(), sn.data(), (int)rp.size(), rp.data(), rb.data(), rn.data())) return fail(IGX_ERR_LIB, "transport callback failed with code " + std::to_string(rc));
+  }
+  for (size_t k = 0; k < in_plans.size(); ++k) {
+    if (doubles(in_plans[k]) == 0) continue;
+    if (int rc = ghost_rows(g, A, b, (int)k, c.rbuf[k].as<double>(), !reduce, reduce ? 1 : 2, c.xs)) return rc;
+  }
+  // whatever the engine stream does next sees the exchanged rows
+  HIPCK(hipEventRecord(c.done, c.xs));
+  HIPCK(hipStreamWaitEvent(g->stream, c.done, 0));
+  return 0;
+}
+
+extern "C" int IGXReduceGhostRows(IGX g, IGXMat A, IGXVec b) {
+  if (!A && !b) return fail(IGX_ERR_ARG_WRONG, "nothing to reduce");
+  if ((A && A->iga != g) || (b && b->iga != g)) return fail(IGX_ERR_ARG_WRONG, "matrix / vector created by another IGX");
+  return comm_exchange(g, A, b, true);
+}
+extern "C" int IGXRefreshGhosts(IGX g, IGXVec v) {
+  if (!v || v->iga != g) return fail(IGX_ERR_ARG_WRONG, "vector missing or created by another IGX");
+  return comm_exchange(g, nullptr, v, false);
+}
+extern "C" int IGXCommGetLastBytes(IGX g, int64_t *bytes) { NEEDIGA(g); if (bytes) *bytes = g->comm ? g->comm->last_bytes : 0; return 0; }
+
+// RCCL on one rank: n doubles travel to this rank itself through a grouped ncclSend / ncclRecv on the exchange stream
+// (binding, communicator, stream and event plumbing on a single-GPU box); returns the largest difference
+extern "C" int IGXCommLoopbackTest(IGX g, int64_t n, double *maxdiff) {
+  NEEDIGA(g);
+  if (!g->comm || g->comm->kind != 1) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXCommInitRCCL() first");
+  if (n < 1 || !maxdiff) return fail(IGX_ERR_ARG_WRONG, "bad arguments");
+  IgxComm &c = *g->comm;
+  DevBuf a, r; std::vector<double> h((size_t)n), back((size_t)n, -1.0);
+  for (int64_t i = 0; i < n; ++i) h[(size_t)i] = 0.5 * (double)i - 3.0;
+  if (a.upload(h) || r.alloc((size_t)n * 8)) return fail(IGX_ERR_MEM, "device allocation failed");
+  HIPCK(hipMemset(r.p, 0, (size_t)n * 8));
+  HIPCK(hipEventRecord(c.ready, g->stream));
+  HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
+  NCCLCK(rccl_api().GroupStart());
+  NCCLCK(rccl_api().Recv(r.p, (size_t)n, kNcclDouble, g->s.comm_rank, c.nccl, c.xs));
+  NCCLCK(rccl_api().Send(a.p, (size_t)n, kNcclDouble, g->s.comm_rank, c.nccl, c.xs));
+  NCCLCK(rccl_api().GroupEnd());
+  HIPCK(hipEventRecord(c.done, c.xs));
+  HIPCK(hipStreamWaitEvent(g->stream, c.done, 0));
+  HIPCK(hipStreamSynchronize(g->stream));
+  HIPCK(hipStreamSynchronize(c.xs));
+  HIPCK(hipMemcpy(back.data(), r.p, (size_t)n * 8, hipMemcpyDeviceToHost));
+  double d = 0; for (int64_t i = 0; i < n; ++i) d = std::max(d, std::fabs(back[(size_t)i] - h[(size_t)i]));
+  *maxdiff = d;
+  return 0;
+}

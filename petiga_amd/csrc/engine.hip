@@ -2,6 +2,7 @@
 // Reference citations are file:line of dalcinl/PetIGA @ 2025-04-04.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <memory>
@@ -46,6 +47,7 @@ struct DevBuf {
 struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix, bnd; };
 
 
+struct IgxComm;
 struct _p_IGX {
   Space s;
   bool on_device = false;
@@ -62,6 +64,7 @@ struct _p_IGX {
   DevBuf partials, dbgbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
+  std::shared_ptr<IgxComm> comm;   // transport of the ghost-row exchange (comm.hpp)
 };
 
 struct _p_IGXMat {
@@ -1031,5 +1034,7 @@ extern "C" int IGXChecksum(IGX g, IGXMat A, IGXVec b, double S[4]) {
 
 // ------------------------------------------------------------------ multi-GPU ghost rows (filled in by exchange.hpp)
 #include "exchange.hpp"
+#include "comm.hpp"
+#include "coo.hpp"
 #include "fileio.hpp"
 #endif   // !IGX_TU_DISPATCH

@@ -97,7 +97,7 @@ __global__ void k_ghost_rows(PackDev P, const int64_t *browptr, double *val, dou
 }
 
 // plan list `send_list` (true: upper neighbours / my ghost part, false: lower neighbours / my first owned nodes), entry k
-static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool send_list, int mode) {
+static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool send_list, int mode, hipStream_t stream_or_null = nullptr) {
   NEEDIGA(g);
   if (int rc = ensure_device(g)) return rc;
   const Space &s = g->s;
@@ -120,10 +120,11 @@ static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool sen
   const int64_t nrows = (int64_t)pl.count[0] * pl.count[1] * pl.count[2];
   if (nrows == 0) return 0;
   const int64_t matd = A ? pl.mat_doubles : 0;
+  const hipStream_t st = stream_or_null ? stream_or_null : g->stream;
   const int64_t *bp = A ? A->browptr.as<int64_t>() : nullptr; double *vp = A ? A->val.as<double>() : nullptr, *xp = b ? b->a.as<double>() : nullptr;
-  if (mode == 0) hipLaunchKernelGGL(k_ghost_rows<0>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
-  else if (mode == 1) hipLaunchKernelGGL(k_ghost_rows<1>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
-  else hipLaunchKernelGGL(k_ghost_rows<2>, dim3((unsigned)nrows), dim3(256), 0, g->stream, P, bp, vp, xp, devbuf, matd);
+  if (mode == 0) hipLaunchKernelGGL(k_ghost_rows<0>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
+  else if (mode == 1) hipLaunchKernelGGL(k_ghost_rows<1>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
+  else hipLaunchKernelGGL(k_ghost_rows<2>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
   HIPCK(hipGetLastError());
   return 0;
 }

@@ -1,5 +1,9 @@
 """Ghost-row reduction between ranks (one process per GPU).
 
+The product path is inside the library: init_comm(iga) + iga.reduce_ghost_rows(A, b) / iga.refresh_ghosts(v)
+(include/petiga_amd.h: IGXCommInitRCCL, IGXReduceGhostRows, IGXRefreshGhosts).  GhostExchange / GhostRefresh below drive the
+same pack / unpack kernels from Python with torch.distributed as the transport; the tests use them as an independent check.
+
 Each rank packs the rows of nodes it holds but does not own, one message per upper neighbour
 (IGXPackGhostRows), the messages travel point-to-point (RCCL over xGMI: every neighbour pair of a
 2x2x2 grid has its own link, so the <=7 messages of a rank move concurrently), and the owner adds them to
@@ -32,6 +36,34 @@ def p2p_exchange(send_bufs, send_peers, recv_bufs, recv_peers):
     if staged:
         for d, h in zip(dev_recv, recv_bufs):
             d.copy_(h)
+
+
+def _device_view(ptr, count):
+    """float64 torch view of `count` doubles of device memory at `ptr` (no copy)."""
+    class _A:
+        pass
+    a = _A()
+    a.__cuda_array_interface__ = dict(shape=(int(count),), typestr="<f8", data=(int(ptr), False), version=3)
+    return torch.as_tensor(a, device="cuda")
+
+
+def init_comm(iga, transport=None):
+    """Binds the library's own exchange (IGXReduceGhostRows / IGXRefreshGhosts) for this rank of the default process
+    group.  transport "rccl": the library's grouped ncclSend / ncclRecv (the product path; the unique id is broadcast
+    through torch.distributed).  transport "host": torch.distributed moves the packed device buffers (test transport:
+    gloo stages through the host, so ranks may share one GPU)."""
+    transport = transport or ("rccl" if dist.get_backend() == "nccl" else "host")
+    if transport == "rccl":
+        ids = [iga.comm_unique_id() if dist.get_rank() == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        iga.comm_init_rccl(ids[0])
+    else:
+        def move(send, recv):
+            p2p_exchange([_device_view(p, n) for _, p, n in send], [r for r, _, _ in send],
+                         [_device_view(p, n) for _, p, n in recv], [r for r, _, _ in recv])
+            torch.cuda.synchronize()
+        iga.comm_init_transport(move)
+    return transport
 
 
 class GhostExchange:
