@@ -281,10 +281,13 @@ def main():
                 g1.compute_system(A1, b1)
             g1.synchronize()
             ref = g1.checksum(A1, b1)
-            rel = [abs(float(x) - float(y)) / max(abs(float(y)), 1e-300) for x, y in zip(cs, ref)]
+            # the signed sums may cancel: they are measured against sum|A| and sqrt(n sum b^2) (their natural bounds)
+            nrows = float(b1.n)
+            scale = [max(float(ref[1]), 1e-300), max(float(ref[1]), 1e-300), max((nrows * float(ref[3])) ** 0.5, 1e-300), max(float(ref[3]), 1e-300)]
+            rel = [abs(float(x) - float(y)) / sc for x, y, sc in zip(cs, ref, scale)]
             check = dict(reference="single-rank assembly of the same mesh on rank 0's GPU", rel_diff=rel)
             del A1, b1, g1
-            assert max(rel[1], rel[3]) < 1e-9 and rel[0] < 1e-6 and rel[2] < 1e-6, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs), list(ref))
+            assert max(rel) < 1e-9, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs), list(ref))
 
     if rank == 0:
         nen, nqp = (p + 1) ** 3, (p + 1) ** 3

@@ -72,7 +72,8 @@ typedef enum {
   IGX_FORM_BOUNDARYINTEGRAL = 9, /* System: demo/BoundaryIntegral.c:26-56  interior Laplace, F=N*1 on visited faces (Neumann) */
   IGX_FORM_NITSCHE     = 10,/* System: demo/NitscheMethod.c:69-110  Poisson with Nitsche terms on visited faces (normals,
                                normal mesh size through IGAPointFormInvGradGeomMap); params: {max degree k} */
-  IGX_FORM_BRATU       = 11 /* Function/Jacobian and IFunction/IJacobian: demo/Bratu.c, demo/BratuFJ.F90:23-176  params: {lambda} */
+  IGX_FORM_BRATU       = 11,/* Function/Jacobian and IFunction/IJacobian: demo/Bratu.c, demo/BratuFJ.F90:23-176  params: {lambda} */
+  IGX_FORM_SOURCE      = 100 /* a user form compiled at run time: IGXSetFormSource */
 } IGXFormKind;
 
 /* ------------------------------------------------------------------------------------------
@@ -108,6 +109,22 @@ int IGXSetFixTable(IGX iga,IGXVec U);                                      /* IG
 /* IGASetFormSystem / IGASetFormMatrix / ... (src/petigaform.c:388-833): kind + params replace (fn,ctx).
  * The one kind serves System/Matrix/Vector or Function/Jacobian/IFunction/IJacobian as the reference demo does. */
 int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
+
+/* The open end of the plugin API (IGASetFormSystem(iga,fn,ctx) with an arbitrary user fn, src/petigaform.c:388-833): a point
+ * form given as HIP source and compiled at run time (hiprtc) into the general element kernel.  `source` defines a struct
+ * `struct_name` with the contract of the built-in forms (petiga_amd/csrc/forms.hpp, the device restatement of
+ * include/petiga.h:153-197 + src/petigapoint.c:427-462):
+ *     struct MyForm {
+ *       static constexpr int DOF = 1, ORDER = 1;          // fields per node; 2 if second derivatives of N or of U are read
+ *       static constexpr unsigned NEED = NEED_X | NEED_U; // point data read: NEED_X x, NEED_U u, NEED_UT du/dt, NEED_GU grad u,
+ *                                                         // NEED_HU hess u, NEED_G IGAPointFormInvGradGeomMap
+ *       static __device__ void mat(const PtView &p,const double *Na,const double *Nb,double *T); // T[i*DOF+j]: K block of (a,b)
+ *       static __device__ void vec(const PtView &p,const double *Na,double *R);                  // R[i]: F entries of a
+ *     };
+ * Na / Nb: [0] N, [1+i] dN/dx_i, [1+dim+i*dim+j] d2N/dx_i dx_j; p.prm[] = params (the callback's ctx); the integrand is
+ * un-weighted and mat() must be linear in Nb, as every IGAFormSystem/Jacobian is.  Compile errors come back as
+ * PETSC_ERR_USER with the compiler log in IGXGetLastError().  The seven drivers then work as with a built-in form. */
+int IGXSetFormSource(IGX iga,const char *source,const char *struct_name,const double params[],int nparams);
 
 /* On-disk formats (PETSc binary, big-endian): the discretisation + NURBS control net written by IGAWrite / igakit,
  * and a Vec in natural order.  IGXRead replaces dim, axes and geometry of `iga` (dof is kept); call IGXSetUp next. */

@@ -437,3 +437,19 @@ int orc_form_bratu_ijacobian(OrcPoint *p,double shift,const double *V,double t,c
   }
   return 0;
 }
+
+/* demo/AdvectionDiffusion.c:26-47 (System): K = grad Na . grad Nb + Na (w . grad Nb), F = 0; ctx = double wind[3] */
+int orc_form_advection_diffusion(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  const double *w = (const double*)ctx;
+  int a,b,i,nen=p->nen,dim=p->dim; const double *N0=p->shape[0],*N1=p->shape[1];
+  for (a=0; a<nen; a++) {
+    for (b=0; b<nen; b++) {
+      double diffusion = 0, advection = 0;
+      for (i=0;i<dim;i++) { diffusion += N1[a*dim+i]*N1[b*dim+i]; advection += w[i]*N1[b*dim+i]; }
+      K[a*nen+b] = diffusion + N0[a]*advection;
+    }
+    F[a] = 0.0;
+  }
+  return 0;
+}

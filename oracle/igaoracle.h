@@ -173,6 +173,7 @@ int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,dou
 int orc_form_ch_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ns_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ns_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
+int orc_form_advection_diffusion(OrcPoint*,double*,double*,void*);     /* demo/AdvectionDiffusion.c System; ctx = double wind[3] */
 int orc_form_bratu_function (OrcPoint*,const double*,double*,void*);   /* demo/BratuFJ.F90 Bratu_Function; ctx = double* lambda */
 int orc_form_bratu_jacobian (OrcPoint*,const double*,double*,void*);   /* demo/BratuFJ.F90 Bratu_Jacobian */
 int orc_form_bratu_ifunction(OrcPoint*,double,const double*,double,const double*,double*,void*);

@@ -92,7 +92,7 @@ def lib(build_if_needed=False):
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
-        "IGXChecksum": [V, V, V, _dp],
+        "IGXChecksum": [V, V, V, _dp], "IGXSetFormSource": [V, C.c_char_p, C.c_char_p, _dp, C.c_int],
         "IGXMatGetCOO": [V, C.c_int, C.c_int, V, V, C.c_int], "IGXVecGetIndices": [V, C.c_int, C.c_int, V, C.c_int],
         "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
@@ -308,6 +308,11 @@ class IGX:
     def set_form(self, kind, params=()):
         p = np.ascontiguousarray(params, dtype=np.float64)
         _ck(lib().IGXSetForm(self.h, FORMS[kind] if isinstance(kind, str) else kind, p.ctypes.data_as(_dp) if p.size else None, p.size))
+
+    def set_form_source(self, source, struct_name, params=()):
+        """A user point form as HIP source (the contract of petiga_amd/csrc/forms.hpp), compiled at run time with hiprtc."""
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _ck(lib().IGXSetFormSource(self.h, source.encode(), struct_name.encode(), p.ctypes.data_as(_dp) if p.size else None, p.size))
 
     def sizes(self):
         arrs = [(C.c_int * 3)() for _ in range(8)]

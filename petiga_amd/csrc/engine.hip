@@ -48,6 +48,7 @@ struct AxisBufs { DevBuf tab, w, J, pt, off, rowmap, rcnt, P, rcol, prefix, bnd;
 
 
 struct IgxComm;
+struct RtcForm;
 struct _p_IGX {
   Space s;
   bool on_device = false;
@@ -65,6 +66,7 @@ struct _p_IGX {
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
   std::shared_ptr<IgxComm> comm;   // transport of the ghost-row exchange (comm.hpp)
+  std::shared_ptr<RtcForm> rtc; std::string rtc_source, rtc_name;   // run-time compiled user form (rtc.hpp)
 };
 
 struct _p_IGXMat {
@@ -869,6 +871,7 @@ int igx_tu_dispatch(std::integral_constant<int, 3>, std::integral_constant<int, 
 int igx_tu_scalar(std::integral_constant<int, 1>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
 int igx_tu_scalar(std::integral_constant<int, 2>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
 int igx_tu_scalar(std::integral_constant<int, 3>, IGX g, int kind, const SpaceDev &S, const OutDev &out, int order);
+static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out);
 static int dispatch_by_dim(IGX g, const SpaceDev &S, const OutDev &out) {
   using std::integral_constant;
   switch (g->s.dim) {
@@ -919,7 +922,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   }
   if (!done) {
     g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
-    rc = dispatch_by_dim(g, S, out);
+    rc = (s.form == IGX_FORM_SOURCE) ? launch_generic_rtc(g, S, out) : dispatch_by_dim(g, S, out);
     g->zero_matrix = nullptr;
     if (rc) return rc;
   }
@@ -1037,4 +1040,5 @@ extern "C" int IGXChecksum(IGX g, IGXMat A, IGXVec b, double S[4]) {
 #include "comm.hpp"
 #include "coo.hpp"
 #include "fileio.hpp"
+#include "rtc.hpp"
 #endif   // !IGX_TU_DISPATCH

@@ -1,10 +1,19 @@
 // igx.hpp -- internal types of libpetiga_amd (host discretisation + device descriptors).
 // Reference citations are file:line of dalcinl/PetIGA @ 2025-04-04.
 #pragma once
+// IGX_RTC: this header is also the prelude of run-time compiled user forms (rtc.hpp): hiprtc has no standard library and no
+// hip_runtime.h to include, so the host part is skipped and the few fixed-width types are spelled out.
+#ifndef IGX_RTC
 #include <cstdint>
 #include <string>
 #include <vector>
 #include "../../include/petiga_amd.h"
+#else
+typedef long long int64_t;
+typedef int int32_t;
+typedef unsigned long size_t;
+#define IGX_ERR_USER 83
+#endif
 
 namespace igx {
 
@@ -15,6 +24,7 @@ constexpr bool kDebug = true;
 constexpr bool kDebug = false;
 #endif
 
+#ifndef IGX_RTC
 // Environment switches, read once when an IGX is created (IGXCreate / IGXCreateFromTables)
 struct EnvSwitches {
   int kernel = 0;            // IGX_KERNEL=0..3 presets IGXSetKernel (the parity suite runs every case under two kernel families)
@@ -102,6 +112,8 @@ struct Space {
 int  space_setup(Space &s, std::string &err);          // IGASetUp stages 1+3 (src/petiga.c:1111-1310,1450-1493)
 int  space_layout(Space &s, std::string &err);         // AxisLayout for the three axes
 int  exchange_supported(const Space &s, std::string &err);   // 0, or IGX_ERR_SUP when ghost rows would need a two-rank hop
+
+#endif   // !IGX_RTC
 
 // ------------------------------------------------------------------ device descriptors (POD, passed by value)
 constexpr int MAXBC = 8;      // fields per face the device tables hold (dof <= 8 on the device path)
