@@ -549,6 +549,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       // pencil mode parks the 7 leaving tiles of every (i,j) block of a launch in the Phi region before they are written out
       constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
       const int stage_need = PEN ? 7 * 16 * 17 * (PR ? fm_popcount(fm_pairs_upper(PR)) : DOFI * DOF) : 0;   // the leaving tiles (feature_mfma.hpp)
+      cv.boff = 0;
       cv.phi = take(std::max(std::max(NFS * QC * NEP, sf_need), stage_need));
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);

@@ -64,7 +64,7 @@ struct FCarve {            // offsets in doubles into the dynamic LDS block
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, hpart, lift, phi;
-  int rowbase, rowid, cc, pax, adec, qdec, nrm;
+  int rowbase, rowid, cc, pax, adec, qdec, nrm, boff;
   int total;
   int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
 };
@@ -195,10 +195,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr unsigned long long PACC = PENCIL ? fm_pairs_upper(PAIRS) : PAIRS;
   constexpr int NACC = !HASM ? 1 : (GRAM ? fm_popcount(PACC) : DOFI * DOF);
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid_ = threadIdx.x, nthr_ = blockDim.x;
+  const int wave_ = __builtin_amdgcn_readfirstlane(tid_ >> 6);
 
-  int el[3], ID[3], off[3], nq[3], na[3];
+  int el[3], ID[3], off[3], nq_[3], na_[3];
   {
     int b = blockIdx.x;
     int t0 = 0;
@@ -210,14 +210,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       el[d] = cr.start[d] + tt[d] * cr.step[d];
       ID[d] = el[d] + S.ax[d].estart;
       off[d] = S.ax[d].off[el[d]];
-      nq[d] = S.ax[d].nqp; na[d] = S.ax[d].nen;
+      nq_[d] = S.ax[d].nqp; na_[d] = S.ax[d].nen;
     }
   }
   // boundary-form pass: one point on the face axis, basis from the end-of-axis table (src/petigaelem.c:796-823)
   const int bid = out.bid; const bool bpass = bid >= 0;
   const int baxis = bpass ? (bid >> 1) : -1, bside = bid & 1;
-  if (bpass) nq[baxis] = 1;
-  const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
+  if (bpass) nq_[baxis] = 1;
+  const int NQ = nq_[0] * nq_[1] * nq_[2], NE = na_[0] * na_[1] * na_[2];
   const int QC = cv.QC, NQP = cv.QC * cv.nchunk;
   const int op = out.op;
   const bool hasV = (NS == 0) && (I0 == 0) && (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
@@ -241,17 +241,17 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   int *adec = reinterpret_cast<int *>(smem + cv.adec);          // [NEP] a -> a0 | a1<<8 | a2<<16
   int *qdec = reinterpret_cast<int *>(smem + cv.qdec);          // [NQP] q -> q0 | q1<<8 | q2<<16
   __shared__ int s_anyfix;
-  if (tid == 0) s_anyfix = 0;
+  if (tid_ == 0) s_anyfix = 0;
   __syncthreads();
-  const bool stamp = kDebug && out.dbg && blockIdx.x == 7 && tid == 0;
+  const bool stamp = kDebug && out.dbg && blockIdx.x == 7 && tid_ == 0;
   int nst = 0;
 #define FM_STAMP() do { if (stamp && nst < 31) out.dbg[nst++] = (long long)__builtin_readcyclecounter(); } while (0)
   FM_STAMP();
 
   // ---- accumulators (PENCIL: they live across the elements of the walk)
-  const bool wave_active = (TA >= 2) || (wave == 0);
-  const int tb = (TA == 4) ? (wave & 3) : (TA == 2 ? (wave & 1) : 0);
-  const int ta0 = (TA == 4) ? NTA * (wave >> 2) : (TA == 2 ? (wave >> 1) : 0);   // first row tile of this wave
+  const bool wave_active = (TA >= 2) || (wave_ == 0);
+  const int tb = (TA == 4) ? (wave_ & 3) : (TA == 2 ? (wave_ & 1) : 0);
+  const int ta0 = (TA == 4) ? NTA * (wave_ >> 2) : (TA == 2 ? (wave_ >> 1) : 0);   // first row tile of this wave
   fm_d4_t acc[NACC][NTA];
 #pragma unroll
   for (int k = 0; k < NACC; ++k)
@@ -266,6 +266,12 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     // across all phases of every element (measured: hundreds of spilled registers).  Hide the invariance from the optimiser.
     asm volatile("" : "+s"(el[1]), "+s"(el[2]), "+s"(off[1]), "+s"(off[2]), "+s"(ID[1]), "+s"(ID[2]));
   }
+  // (likewise for what depends on the thread index and the element shape only: index decodes, division reciprocals, table
+  // addresses.  An opaque zero per iteration keeps them from being hoisted: scratch 892 -> 504 bytes per lane.)
+  int zv_ = 0, zs_ = 0;
+  if (PENCIL) { asm volatile("" : "+v"(zv_)); asm volatile("" : "+s"(zs_)); }
+  const int tid = tid_ + zv_, lane = tid & 63, wave = wave_ + zs_, nthr = nthr_ + zs_;
+  const int nq[3] = {nq_[0] + zs_, nq_[1] + zs_, nq_[2] + zs_}, na[3] = {na_[0] + zs_, na_[1] + zs_, na_[2] + zs_};
   // tile slot of a local axis-0 index: the layer's position mod 4 (PENCIL); rslot undoes it for the tile index T
   const int rot = PENCIL ? (off[0] & 3) : 0;
   auto rslot = [&](int T) { return PENCIL ? ((T - rot) & 3) : T; };
@@ -841,9 +847,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     for (int i = 0; i < DOF; ++i) Facc[i] = group_sum(Facc[i], npv);
     if (part == 0) {
       const size_t row = (size_t)rowid[a];
-      double vold[DOF];
-#pragma unroll
-      for (int i = 0; i < DOF; ++i) vold[i] = out.vec[row * DOF + i];   // one round trip for the row's fields
+      double vnew[DOF]; bool any = false;
 #pragma unroll
       for (int i = 0; i < DOF; ++i) {
         const int k = a * DOF + i;
@@ -852,7 +856,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         // pass carries the constant parts (flux, fixed value) and a boundary pass only drops its fixed rows
         if (op == OP_SYSTEM) { if (!bpass) v += flux[k]; if (fixflag[k]) v = bpass ? 0.0 : fixval[k]; }                                         // src/petigaelem.c:1371-1387
         else if (op == OP_FUNCTION || op == OP_IFUNCTION) { if (!bpass) v -= flux[k]; if (fixflag[k]) v = bpass ? 0.0 : ufix[k] - fixval[k]; }  // :1449-1461
-        out.vec[row * DOF + i] = vold[i] + v;
+        vnew[i] = v; any = any || (v != 0.0);
+      }
+      if (any) {   // (a form without a load term, e.g. Elasticity3D's F = 0, adds nothing away from the Dirichlet faces: no round trip)
+        double vold[DOF];
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) vold[i] = out.vec[row * DOF + i];   // one round trip for the row's fields
+#pragma unroll
+        for (int i = 0; i < DOF; ++i) out.vec[row * DOF + i] = vold[i] + vnew[i];
       }
     }
   }
@@ -870,7 +881,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // barrier while two of them paid 4 dependent round trips per tile (measured 45-100k cycles per element, 58 % of the time),
   // and keeping the coefficient transform with the accumulators cost hundreds of spilled registers.  Measured and rejected:
   // a third pass that puts the finished blocks back into LDS in memory order for a lane-coalesced streaming read-add-write
-  // (8 dependent round trips per wave instead of 2: 3.9 instead of 4.8 M elements/s on Elasticity3D).
+  // (4 loads in flight per lane: 3.9, every load of a part in flight: 4.2 against 5.65 M elements/s on Elasticity3D: more
+  // barriers, more spills, and 36 of 64 lanes active per instruction).
   if constexpr (HASM && PENCIL) {
     constexpr int NBK = DOFI * DOF, TS = 16 * 17;
     double *stage = phi;
@@ -904,7 +916,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const int nblk = rowp ? ncolb : 3 - lv;
         const int a1 = ra & 3, a2 = ra >> 2, b1 = cb & 3, b2 = cb >> 2;
         const int v1 = pax[1 * 64 + a1 * 8 + b1], v2 = pax[2 * 64 + a2 * 8 + b2];
-        constexpr int KB = (NBK > 4) ? 2 : 4;   // blocks of a thread in flight together
+        constexpr int KB = (NBK > 4) ? 2 : 4;   // blocks of a thread in flight together (all four: 5.37 vs 5.65 M elements/s on Elasticity3D, spills)
 #pragma unroll
         for (int k0 = 0; k0 < 4; k0 += KB) {
           double old[KB][NBK]; double *dst[KB];
