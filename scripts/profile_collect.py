@@ -9,7 +9,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC, DST = "gpurun_out/prof", "profiles"
 
 
@@ -43,7 +43,7 @@ if dom:
     mean = lambda c: sum(a[k][c]) / len(a[k][c])
     F, W = mean("FETCH_SIZE"), mean("WRITE_SIZE")
     r = line["roofline"]
-    traffic = dict(round=int(tag[1:]), size=256, degree=3, n_gpus=1, kernel=k.replace("void igx::", ""), launches_per_step=r["launches_per_step"],
+    traffic = dict(round=int(tag[1:]), kernel_tag=tag, size=256, degree=3, n_gpus=1, kernel=k.replace("void igx::", ""), launches_per_step=r["launches_per_step"],
                    FETCH_SIZE_KB_per_launch=F, WRITE_SIZE_KB_per_launch=W, raw_bytes_per_launch=(F + W) * 1024, bytes_per_launch=(2 * F + W) * 1024,
                    mfma_busy_pmc=mean("SQ_VALU_MFMA_BUSY_CYCLES") / mean("GRBM_GUI_ACTIVE") / 128.0,
                    note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_bench256_pmc_summary.csv); "
@@ -53,5 +53,8 @@ if dom:
                         "(GRBM_GUI_ACTIVE * 128)" % tag)
     json.dump(traffic, open(DST + "/traffic.json", "w"), indent=1)
     line["roofline"]["traffic"] = traffic["bytes_per_launch"]
+    line["roofline"]["traffic_source"] = "rocprofv3 --pmc passes of the same command in the same gpurun call (profiles/%s_bench256_pmc_summary.csv)" % tag
+    if r.get("avg_launch_ms"):
+        line["roofline"]["hbm_frac"] = traffic["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
 json.dump(line, open("%s/%s_bench256_line.json" % (DST, tag), "w"), indent=1)
 print(open(DST + "/traffic.json").read())

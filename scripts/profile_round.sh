@@ -16,7 +16,7 @@ done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_SQ -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_LDS -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_LDS.log 2>&1
 # secondary: Elasticity3D p=3 at its full config size (feature-GEMM kernel)
-BENCH_COMPACT=1 python3 scripts/bench_configs.py c2 full3 full4 full5 c5r c6 > $OUT/configs.txt 2> $OUT/configs.err
+BENCH_COMPACT=1 python3 scripts/bench_configs.py c1 c2 full3 full4 full5 c5r c6 c6b > $OUT/configs.txt 2> $OUT/configs.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_elast -o kt -- python3 scripts/bench_configs.py full3 > $OUT/kt_elast.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmce_$c -o p -- python3 scripts/bench_configs.py c3 > $OUT/pmce_$c.log 2>&1
