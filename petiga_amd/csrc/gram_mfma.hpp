@@ -273,18 +273,23 @@ struct PencilLds {
   int lay0;          // first layer held
 };
 
-__device__ __forceinline__ PencilLds pencil_lds_carve(double *sm, int ne_max) {
+// geo: the mapped-geometry variant reads the (unscaled) walk-axis rows from global memory instead: no zt
+__device__ __forceinline__ PencilLds pencil_lds_carve(double *sm, int ne_max, bool geo = false) {
   PencilLds t; const int nl = ne_max + 3;
-  t.zt = sm; t.wq = t.zt + ne_max * 32; t.Jz = t.wq + ne_max * 4;
+  t.zt = sm; t.wq = t.zt + (geo ? 0 : ne_max * 32); t.Jz = t.wq + ne_max * 4;
   t.pre = reinterpret_cast<long long *>(t.Jz + ((ne_max + 1) & ~1));
   t.cnt = reinterpret_cast<int *>(t.pre + nl); t.rho = t.cnt + nl; t.P = t.rho + nl; t.lay0 = 0;
   return t;
 }
-__host__ __device__ static inline size_t pencil_lds_bytes(int ne_max) {
+__host__ __device__ static inline size_t pencil_lds_bytes(int ne_max, bool geo = false) {
   const int nl = ne_max + 3;
-  const size_t tables = (size_t)(ne_max * 32 + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
-  return ((tables + 15) & ~(size_t)15) + 8 * 32 * 8;   // + per-wavefront Y-axis basis rows [8 waves][4 a][4 q][2]
+  const size_t tables = (size_t)((geo ? 0 : ne_max * 32) + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
+  return ((tables + 15) & ~(size_t)15) + (geo ? 2 : 1) * 8 * 32 * 8;   // + per-wavefront Y-axis (geo: and X-axis) basis rows [8 waves][4 a][4 q][2]
 }
+// mapped geometry: per-wavefront [64 points][7] (JW * F^-1 F^-T: 00,01,02,11,12,22; forcing * JW / W) + [64][4] (1/W, dW/W);
+// the element's control points (homogeneous, [aw][ay][ax][4]) are staged at its start and overwritten by the results
+constexpr int GEO_M = 7, GEO_DOUBLES = 64 * GEO_M + 64 * 4;
+__host__ __device__ static inline size_t pencil_geo_bytes() { return (size_t)8 * GEO_DOUBLES * 8; }
 // walk along axis 0 only: per-wavefront hold area for the lower-band entries [P(P+1)/2 slots][4 r][HOLD_LD lanes]
 __host__ __device__ static inline size_t pencil_hold_bytes(int P) { return (size_t)8 * (P * (P + 1) / 2) * 4 * HOLD_LD * 8; }
 
@@ -569,9 +574,174 @@ __device__ __forceinline__ void pencil_leave(d4_t (&acc)[4][4], double &Facc, co
   pencil_shift<false, 4>(acc, Facc, L.fslot);
 }
 
-template <bool SYSTEM, int W, int P>
+// ---- mapped geometry (K3 Rationalize, K4 GeometryMap, K5 InverseMap folded into the contraction).
+// K_e[a][b] = sum_q JW_q grad_x R_a . grad_x R_b = sum_q sum_{beta,gamma} d_beta R_a (JW F^-1 F^-T)_{beta gamma} d_gamma R_b with PARAMETRIC
+// derivatives of R, so the A operand keeps its tensor-product form (three 1-D rows, as on the identity geometry) and the B
+// operand is the same three products combined with the 6 metric coefficients of the lane's Gauss point.  For a NURBS
+// R_a = w_a N_a / W:  d_beta R_a = (w_a / W) (d_beta N_a - N_a W_beta / W): one scale per basis function and four per point.
+// The metric is evaluated per element by the wavefront itself, lane = Gauss point, on homogeneous coordinates
+// (x = A / W, dx/du = (dA - x dW) / W: src/petigarat.f90.in + petigamapgeo.f90.in), closed-form inverse (src/petigainv.f90.in).
+
+// stage the element's 4 x 4 x 4 control points: lane = (aw, ay, ax) = (lane>>4, (lane>>2)&3, lane&3)
+template <int P>
+__device__ __forceinline__ void pencil_geo_ctrl(double *geo, const SpaceDev &S, int lane, int off0, int offx, int offy, double (&wt)[4]) {
+  constexpr int NB = P + 1;
+  const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+  double c[4] = {0, 0, 0, 0};
+  if (aw < NB && ay < NB && ax < NB) {
+    const size_t g = (size_t)(off0 + aw) + (size_t)S.ax[0].gwidth * ((size_t)(offx + ax) + (size_t)S.ax[1].gwidth * (size_t)(offy + ay));
+    const double w = S.W ? S.W[g] : 1.0;
+    c[0] = S.X[g * 3 + 0] * w; c[1] = S.X[g * 3 + 1] * w; c[2] = S.X[g * 3 + 2] * w; c[3] = w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous element's readers of this area are done
+#pragma unroll
+  for (int k = 0; k < 4; ++k) geo[lane * 4 + k] = c[k];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // NURBS weights of the MFMA lane's basis functions (t, ix = lane&3, iy = (lane>>2)&3)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wt[t] = geo[((t * 4 + ((lane >> 2) & 3)) * 4 + (lane & 3)) * 4 + 3];
+}
+
+// lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); uxr [q][a][2], vyr [a][q][2] raw rows in LDS, ztg the
+// element's raw walk-axis rows [q][NB][NDER] in global memory; wj = w_q J of the three axes at this lane's point
+template <int P>
+__device__ __forceinline__ void pencil_geo_eval(double *geo, int lane, const double *uxr, const double *vyr, const double *__restrict__ ztg,
+                                                double wj, double forcing, bool rational, int *errflag) {
+  constexpr int NB = P + 1;
+  const int qx = lane & 3, qy = (lane >> 2) & 3, qw = lane >> 4;
+  const bool valid = qx < NB && qy < NB && qw < NB;
+  double H[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) H[c][k] = 0;
+  if (valid) {
+#pragma unroll
+    for (int aw = 0; aw < NB; ++aw) {
+      const double nw = ztg[(qw * NB + aw) * NDER + 0], dw = ztg[(qw * NB + aw) * NDER + 1];
+#pragma unroll
+      for (int ay = 0; ay < NB; ++ay) {
+        const double ny = vyr[(ay * 4 + qy) * 2 + 0], dy = vyr[(ay * 4 + qy) * 2 + 1];
+        const double b_wy = nw * ny, b_dwy = dw * ny, b_wdy = nw * dy;
+#pragma unroll
+        for (int ax = 0; ax < NB; ++ax) {
+          const double nx = uxr[(qx * 4 + ax) * 2 + 0], dx = uxr[(qx * 4 + ax) * 2 + 1];
+          const double b0 = b_wy * nx, b1 = b_dwy * nx, b2 = b_wy * dx, b3 = b_wdy * nx;   // value, d/du0 (walk), d/du1 (X), d/du2 (Y)
+          const double *cp = geo + ((aw * 4 + ay) * 4 + ax) * 4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { const double C = cp[c]; H[c][0] += C * b0; H[c][1] += C * b1; H[c][2] += C * b2; H[c][3] += C * b3; }
+        }
+      }
+    }
+  }
+  double M[GEO_M] = {0, 0, 0, 0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+  if (valid) {
+    const double iw = 1.0 / H[3][0];
+    double F[3][3];     // F[c][beta] = dx_c / du_beta
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const double x = H[c][0] * iw;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) F[c][b] = (H[c][1 + b] - x * H[3][1 + b]) * iw;
+    }
+    const double det = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) + F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+    if (!(det > 0.0)) atomicExch(errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+    const double id = 1.0 / det;
+    double E[3][3];     // E[beta][c] = du_beta / dx_c
+    E[0][0] = (F[1][1] * F[2][2] - F[1][2] * F[2][1]) * id; E[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id; E[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id;
+    E[1][0] = (F[1][2] * F[2][0] - F[1][0] * F[2][2]) * id; E[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id; E[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
+    E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
+    const double JW = det * wj;
+    int k = 0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int g = b; g < 3; ++g) M[k++] = JW * (E[b][0] * E[g][0] + E[b][1] * E[g][1] + E[b][2] * E[g][2]);
+    M[6] = forcing * JW * (rational ? iw : 1.0);
+    R[0] = iw; R[1] = H[3][1] * iw; R[2] = H[3][2] * iw; R[3] = H[3][3] * iw;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // every lane has read the control points
+#pragma unroll
+  for (int k = 0; k < GEO_M; ++k) geo[lane * GEO_M + k] = M[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) geo[64 * GEO_M + lane * 4 + k] = R[k];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// the MFMAs of one element on a mapped geometry: k-step (qw, qy, beta), k slot = qx (lane>>4); 10 tiles (K_e is symmetric)
+template <int NB>
+__device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *__restrict__ ztg,
+                                                const double *geo, int lane, const double (&wt)[4], bool rational) {
+  const int qx = lane >> 4;
+#pragma unroll
+  for (int qw = 0; qw < NB; ++qw) {
+    double z0[NB], z1[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * NB + t) * NDER + 0]; z1[t] = ztg[(qw * NB + t) * NDER + 1]; }
+#pragma unroll
+    for (int qy = 0; qy < NB; ++qy) {
+      const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
+      const int p = (qw * 4 + qy) * 4 + qx;
+      const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
+      const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
+      const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
+      double g0[NB], g1[NB], g2[NB];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) { g0[t] = a_n * z1[t]; g1[t] = a_x * z0[t]; g2[t] = a_y * z0[t]; }
+      if (rational) {
+        const double rinv = Rp[0], o0 = Rp[1], o1 = Rp[2], o2 = Rp[3];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const double n = a_n * z0[t], sc = wt[t] * rinv;
+          g0[t] = sc * (g0[t] - n * o0); g1[t] = sc * (g1[t] - n * o1); g2[t] = sc * (g2[t] - n * o2);
+        }
+      }
+#pragma unroll
+      for (int be = 0; be < 3; ++be) {
+        const double ma = (be == 0) ? m00 : (be == 1 ? m01 : m02), mb = (be == 0) ? m01 : (be == 1 ? m11 : m12), mc = (be == 0) ? m02 : (be == 1 ? m12 : m22);
+        double B[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) B[t] = ma * g0[t] + mb * g1[t] + mc * g2[t];
+#pragma unroll
+        for (int ta = 0; ta < NB; ++ta) {
+          const double A = (be == 0) ? g0[ta] : (be == 1 ? g1[ta] : g2[ta]);
+#pragma unroll
+          for (int tb = ta; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B[tb], acc[ta][tb], 0, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// F_a += w_a sum_q (forcing JW / W)_q N_a(q) for the F lane (fx, fy, slot): the sum factorises over the axes
+template <int NB>
+__device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, const double *uxr, const double *vyr, const double *__restrict__ ztg) {
+  const int fx = lane & 3, fy = (lane >> 2) & 3, aw = lane >> 4;
+  if (fx >= NB || fy >= NB || aw >= NB) return 0.0;
+  double s = 0;
+#pragma unroll
+  for (int qw = 0; qw < NB; ++qw) {
+    double sy = 0;
+#pragma unroll
+    for (int qy = 0; qy < NB; ++qy) {
+      double sx = 0;
+#pragma unroll
+      for (int qx = 0; qx < NB; ++qx) sx += uxr[(qx * 4 + fx) * 2] * geo[((qw * 4 + qy) * 4 + qx) * GEO_M + 6];
+      sy += vyr[(fy * 4 + qy) * 2] * sx;
+    }
+    s += ztg[(qw * NB + aw) * NDER] * sy;
+  }
+  return s;
+}
+
+template <bool SYSTEM, int W, int P, bool GEO = false>
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+  static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
   constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
@@ -587,16 +757,17 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   const AxisDev &AW = S.ax[W], &AX = S.ax[X], &AY = S.ax[Y];
 
   // ---- stage the segment's walk-axis tables in LDS (all 512 threads); tables are zero padded to 4 x 4
-  PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max);
+  PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max, GEO);
   T.lay0 = AW.off[wh];
   {
     const int tid = threadIdx.x;
     const double *__restrict__ tabw = AW.tab + (size_t)wh * (NB * NB * NDER);
-    for (int i = tid; i < ne * 32; i += 512) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
+    if (!GEO) for (int i = tid; i < ne * 32; i += 512) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
       const int e = i >> 5, j = i & 31, q = j >> 3, aa = (j >> 1) & 3, k = j & 1;
       T.zt[i] = (q < NB && aa < NB) ? tabw[((size_t)e * NB * NB + q * NB + aa) * NDER + k] * sqrt(AW.w[(wh + e) * NB + q] * AW.J[wh + e]) : 0.0;
     }
-    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3; T.wq[i] = (q < NB) ? sqrt(AW.w[(wh + e) * NB + q] * AW.J[wh + e]) : 0.0; }
+    // (GEO: the weight itself, not its root: the metric carries the whole JW)
+    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3; const double wj = (q < NB) ? AW.w[(wh + e) * NB + q] * AW.J[wh + e] : 0.0; T.wq[i] = GEO ? wj : sqrt(wj); }
     for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[wh + i];
     for (int i = tid; i < nl; i += 512) {
       const int lay = T.lay0 + i;
@@ -630,14 +801,18 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *__restrict__ WYq = AY.w + ely * NB;
     const int qx = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
     L.u0 = 0; L.u1 = 0;
-    if (qx < NB && ix < NB) { const double sx = sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * NB + ix) * NDER + 0] * sx; L.u1 = TX[(qx * NB + ix) * NDER + 1] * sx; }
+    if (qx < NB && ix < NB) { const double sx = GEO ? 1.0 : sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * NB + ix) * NDER + 0] * sx; L.u1 = TX[(qx * NB + ix) * NDER + 1] * sx; }
     {   // Y-axis rows of this pencil -> LDS [a][q][2] (zero padded); a lane later reads its own row (a = iy) one q at a time
-      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max) - 8 * 32 * 8))) + wave * 32;
+      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max, GEO) - (GEO ? 2 : 1) * 8 * 32 * 8))) + wave * 32;
       if (lane < 32) {
         const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1;
-        vyw[lane] = (aa < NB && qq < NB) ? TY[(qq * NB + aa) * NDER + kk] * sqrt(WYq[qq] * AY.J[ely]) : 0.0;
+        vyw[lane] = (aa < NB && qq < NB) ? TY[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WYq[qq] * AY.J[ely])) : 0.0;
       }
       L.vy = vyw + iy * 8;
+      if (GEO && lane >= 32) {   // X-axis rows [q][a][2], unscaled, for the geometry evaluation and F
+        const int l2 = lane - 32, qq = l2 >> 3, aa = (l2 >> 1) & 3, kk = l2 & 1;
+        vyw[8 * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] : 0.0;
+      }
     }
     // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
     const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
@@ -678,9 +853,26 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   double *hold = nullptr;
   if (W == 0) {
     constexpr int HS = (P * (P + 1) / 2) * 4 * HOLD_LD;
-    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max)) + wave * HS;
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO)) + wave * HS;
     for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
+  // mapped geometry: this wavefront's metric area, the raw basis rows, the Gauss weights of this lane's point on axes X, Y
+  double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
+  const bool rational = GEO && S.W != nullptr;
+  if constexpr (GEO) {
+    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GEO_DOUBLES;
+    vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + 8 * 32;
+    const int gqx = lane & 3, gqy = (lane >> 2) & 3;
+    if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
+  }
+  auto geometry = [&](int ei) {   // control points, NURBS weights of the lane's basis functions and the metric of element wh + ei
+    if constexpr (GEO) {
+      pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
+      const int gqw = lane >> 4;
+      pencil_geo_eval<P>(geo, lane, uxr, vyr, AW.tab + (size_t)(wh + ei) * (NB * NB * NDER), wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
+    }
+  };
+  geometry(0);
 
   PencilBC bc; bc.any = false; bc.xlo = bc.xhi = bc.ylo = bc.yhi = false; bc.wlo = bc.whi = -1000;
   bc.vwlo = bc.vwhi = bc.vxlo = bc.vxhi = bc.vylo = bc.vyhi = 0;
@@ -708,9 +900,16 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    pencil_mfma<W, W == 0, NB>(acc, L, zt);
+    const double *__restrict__ ztg = AW.tab + (size_t)(wh + ei) * (NB * NB * NDER);   // GEO: the element's raw walk-axis rows
+    if constexpr (GEO) pencil_mfma_geo<NB>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt, rational);
+    else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
-    if (SYSTEM) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
+    if (SYSTEM && GEO) {
+      const int fs = lane >> 4;
+      const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
+      Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
+    }
+    if (SYSTEM && !GEO) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
       const int fs = L.fslot < NB ? L.fslot : 0;
 #pragma unroll
@@ -729,6 +928,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
     held[NB - 1] = 0;
+    if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
     __builtin_amdgcn_s_setprio(0);
     if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
@@ -771,7 +971,7 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
-template <bool SYSTEM, int W, int P>
+template <bool SYSTEM, int W, int P, bool GEO = false>
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
@@ -793,7 +993,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       long long best = -1; int best_n = nseg;
       for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
         const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
-        const size_t lds_n = pencil_lds_bytes(len + 3) + (W == 0 ? pencil_hold_bytes(P) : 0);
+        const size_t lds_n = pencil_lds_bytes(len + 3, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
         const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
         const long long cost = ((bps * ns + slots - 1) / slots) * (len + (ns > 1 ? P : 0));
         if (best < 0 || cost < best) { best = cost; best_n = n; }
@@ -811,8 +1011,8 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max) + (W == 0 ? pencil_hold_bytes(P) : 0);
-    auto kern = gram_pencil<SYSTEM, W, P>;
+    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
+    auto kern = gram_pencil<SYSTEM, W, P, GEO>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
     if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
@@ -852,7 +1052,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
   if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return no("only System / Matrix drivers");
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
-  if (s.nsd) return no("mapped geometry");
+  const bool geo = s.nsd != 0;
+  if (geo && s.nsd != 3) return no("mapped geometry of another dimension");
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
   if (S.fixtable) return no("fix table");
   const int deg = s.axis[0].p;
@@ -870,6 +1071,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
+  if (geo && walk_axis != 0) return no("a mapped geometry needs a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
@@ -892,7 +1094,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     }
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
-    if (deg == 2) {
+    if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
+      if (deg == 2) { if (sys) launch_pencils<true, 0, 2, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); }
+      else { if (sys) launch_pencils<true, 0, 3, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 3, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); }
+    } else if (deg == 2) {
       if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {
     case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
@@ -903,7 +1108,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     default: launch_pencils<true, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     }
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
-    dom.name = std::string("gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + ">"; dom.launches = launches - l0;
+    dom.name = std::string("gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
     dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 27 * 6);
@@ -915,7 +1120,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = std::string("gram_pencil(mfma_f64_16x16x4,p=") + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = std::string("gram_pencil(mfma_f64_16x16x4,p=") + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;
