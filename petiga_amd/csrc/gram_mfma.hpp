@@ -288,7 +288,7 @@ __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max, bool geo =
 }
 // mapped geometry: per-wavefront [64 points][7] (JW * F^-1 F^-T: 00,01,02,11,12,22; forcing * JW / W) + [64][4] (1/W, dW/W);
 // the element's control points (homogeneous, [aw][ay][ax][4]) are staged at its start and overwritten by the results
-constexpr int GEO_M = 7, GEO_DOUBLES = 64 * GEO_M + 64 * 4;
+constexpr int GEO_M = 7, GEO_Z = 64 * GEO_M + 64 * 4, GEO_DOUBLES = GEO_Z + 32;   // + the element's walk-axis rows [q][a][2] (zero padded)
 __host__ __device__ static inline size_t pencil_geo_bytes() { return (size_t)8 * GEO_DOUBLES * 8; }
 // walk along axis 0 only: per-wavefront hold area for the lower-band entries [P(P+1)/2 slots][4 r][HOLD_LD lanes]
 __host__ __device__ static inline size_t pencil_hold_bytes(int P) { return (size_t)8 * (P * (P + 1) / 2) * 4 * HOLD_LD * 8; }
@@ -604,37 +604,56 @@ __device__ __forceinline__ void pencil_geo_ctrl(double *geo, const SpaceDev &S, 
   for (int t = 0; t < 4; ++t) wt[t] = geo[((t * 4 + ((lane >> 2) & 3)) * 4 + (lane & 3)) * 4 + 3];
 }
 
-// lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); uxr [q][a][2], vyr [a][q][2] raw rows in LDS, ztg the
-// element's raw walk-axis rows [q][NB][NDER] in global memory; wj = w_q J of the three axes at this lane's point
+// lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); uxr [q][a][2], vyr [a][q][2], ztg [q][a][2] (walk axis) raw
+// rows in LDS; wj = w_q J of the three axes at this lane's point
 template <int P>
-__device__ __forceinline__ void pencil_geo_eval(double *geo, int lane, const double *uxr, const double *vyr, const double *__restrict__ ztg,
+__device__ __forceinline__ void pencil_geo_eval(double *geo, int lane, const double *uxr, const double *vyr, const double *ztg,
                                                 double wj, double forcing, bool rational, int *errflag) {
   constexpr int NB = P + 1;
   const int qx = lane & 3, qy = (lane >> 2) & 3, qw = lane >> 4;
   const bool valid = qx < NB && qy < NB && qw < NB;
+  // H[c][k] = sum_a C_a[c] D_k N_a(q), c = (wX, wY, wZ, w), k = (value, d/du0, d/du1, d/du2), by sum factorisation shared across
+  // the wavefront (one component at a time; scratch behind the control points): lanes (qx, ay, aw) contract axis X, lanes
+  // (qx, qy, aw) axis Y, lanes (qx, qy, qw) the walk axis: 36 fused multiply-adds per lane and component instead of 64 x 22.
+  // (fp64 VALU work shares the pipe with the partner wavefront's MFMAs: the straightforward loop took 36k cycles per element.)
   double H[4][4];
+  double *T1 = geo + 256, *T2 = geo + 384;
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  double zv[4] = {0, 0, 0, 0}, zd[4] = {0, 0, 0, 0};
+  if (i2 < NB) {
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+    for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[(i2 * 4 + aw) * 2 + 0]; zd[aw] = ztg[(i2 * 4 + aw) * 2 + 1]; }
+  }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) H[c][k] = 0;
-  if (valid) {
+  for (int c = 0; c < 4; ++c) {
+    {   // axis X: lane (qx = i0, ay = i1, aw = i2)
+      double tv = 0, td = 0;
 #pragma unroll
-    for (int aw = 0; aw < NB; ++aw) {
-      const double nw = ztg[(qw * NB + aw) * NDER + 0], dw = ztg[(qw * NB + aw) * NDER + 1];
-#pragma unroll
-      for (int ay = 0; ay < NB; ++ay) {
-        const double ny = vyr[(ay * 4 + qy) * 2 + 0], dy = vyr[(ay * 4 + qy) * 2 + 1];
-        const double b_wy = nw * ny, b_dwy = dw * ny, b_wdy = nw * dy;
-#pragma unroll
-        for (int ax = 0; ax < NB; ++ax) {
-          const double nx = uxr[(qx * 4 + ax) * 2 + 0], dx = uxr[(qx * 4 + ax) * 2 + 1];
-          const double b0 = b_wy * nx, b1 = b_dwy * nx, b2 = b_wy * dx, b3 = b_wdy * nx;   // value, d/du0 (walk), d/du1 (X), d/du2 (Y)
-          const double *cp = geo + ((aw * 4 + ay) * 4 + ax) * 4;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) { const double C = cp[c]; H[c][0] += C * b0; H[c][1] += C * b1; H[c][2] += C * b2; H[c][3] += C * b3; }
-        }
-      }
+      for (int ax = 0; ax < 4; ++ax) { const double C = geo[((i2 * 4 + i1) * 4 + ax) * 4 + c]; tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1]; }
+      T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td;
     }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {   // axis Y: lane (qx = i0, qy = i1, aw = i2); m = 0 (value, value), 1 (d/dX, value), 2 (value, d/dY)
+      double m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+      for (int ay = 0; ay < 4; ++ay) {
+        const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0];
+        const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1];
+        m0 += a * yv; m1 += d * yv; m2 += a * yd;
+      }
+      T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {   // walk axis: lane = point (qx = i0, qy = i1, qw = i2)
+      double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+      for (int aw = 0; aw < 4; ++aw) {
+        const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
+        h0 += t0 * zv[aw]; h1 += t0 * zd[aw]; h2 += t1 * zv[aw]; h3 += t2 * zv[aw];
+      }
+      H[c][0] = h0; H[c][1] = h1; H[c][2] = h2; H[c][3] = h3;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
   double M[GEO_M] = {0, 0, 0, 0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
   if (valid) {
@@ -673,15 +692,17 @@ __device__ __forceinline__ void pencil_geo_eval(double *geo, int lane, const dou
 }
 
 // the MFMAs of one element on a mapped geometry: k-step (qw, qy, beta), k slot = qx (lane>>4); 10 tiles (K_e is symmetric)
-template <int NB>
-__device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *__restrict__ ztg,
-                                                const double *geo, int lane, const double (&wt)[4], bool rational) {
+// (the walk-axis point loop stays rolled and the rational branch is a template parameter: fully unrolled with both branches
+// the kernel was 60 KB of code and its MFMA phase took 55k cycles against 31k of MFMA issue: instruction-cache bound)
+template <int NB, bool RAT>
+__device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *ztg,
+                                                const double *geo, int lane, const double (&wt)[4]) {
   const int qx = lane >> 4;
-#pragma unroll
+#pragma unroll 1
   for (int qw = 0; qw < NB; ++qw) {
     double z0[NB], z1[NB];
 #pragma unroll
-    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * NB + t) * NDER + 0]; z1[t] = ztg[(qw * NB + t) * NDER + 1]; }
+    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * 4 + t) * 2 + 0]; z1[t] = ztg[(qw * 4 + t) * 2 + 1]; }
 #pragma unroll
     for (int qy = 0; qy < NB; ++qy) {
       const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
@@ -692,7 +713,7 @@ __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, do
       double g0[NB], g1[NB], g2[NB];
 #pragma unroll
       for (int t = 0; t < NB; ++t) { g0[t] = a_n * z1[t]; g1[t] = a_x * z0[t]; g2[t] = a_y * z0[t]; }
-      if (rational) {
+      if (RAT) {
         const double rinv = Rp[0], o0 = Rp[1], o1 = Rp[2], o2 = Rp[3];
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
@@ -719,26 +740,26 @@ __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, do
 
 // F_a += w_a sum_q (forcing JW / W)_q N_a(q) for the F lane (fx, fy, slot): the sum factorises over the axes
 template <int NB>
-__device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, const double *uxr, const double *vyr, const double *__restrict__ ztg) {
+__device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, const double *uxr, const double *vyr, const double *ztg) {
   const int fx = lane & 3, fy = (lane >> 2) & 3, aw = lane >> 4;
   if (fx >= NB || fy >= NB || aw >= NB) return 0.0;
   double s = 0;
-#pragma unroll
-  for (int qw = 0; qw < NB; ++qw) {
+#pragma unroll 1
+  for (int qw = 0; qw < NB; ++qw) {      // (rolled: unrolled, the 64 point values stay live and spill)
     double sy = 0;
-#pragma unroll
+#pragma unroll 1
     for (int qy = 0; qy < NB; ++qy) {
       double sx = 0;
 #pragma unroll
       for (int qx = 0; qx < NB; ++qx) sx += uxr[(qx * 4 + fx) * 2] * geo[((qw * 4 + qy) * 4 + qx) * GEO_M + 6];
       sy += vyr[(fy * 4 + qy) * 2] * sx;
     }
-    s += ztg[(qw * NB + aw) * NDER] * sy;
+    s += ztg[(qw * 4 + aw) * 2] * sy;
   }
   return s;
 }
 
-template <bool SYSTEM, int W, int P, bool GEO = false>
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false>
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
@@ -858,7 +879,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   }
   // mapped geometry: this wavefront's metric area, the raw basis rows, the Gauss weights of this lane's point on axes X, Y
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
-  const bool rational = GEO && S.W != nullptr;
+  constexpr bool rational = GEO && RAT;
   if constexpr (GEO) {
     geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GEO_DOUBLES;
     vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + 8 * 32;
@@ -867,9 +888,12 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   }
   auto geometry = [&](int ei) {   // control points, NURBS weights of the lane's basis functions and the metric of element wh + ei
     if constexpr (GEO) {
+      // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
+      // there stalls the in-order MFMA issue for its whole latency)
+      if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
       pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
       const int gqw = lane >> 4;
-      pencil_geo_eval<P>(geo, lane, uxr, vyr, AW.tab + (size_t)(wh + ei) * (NB * NB * NDER), wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
+      pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
     }
   };
   geometry(0);
@@ -900,15 +924,10 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    const double *__restrict__ ztg = AW.tab + (size_t)(wh + ei) * (NB * NB * NDER);   // GEO: the element's raw walk-axis rows
-    if constexpr (GEO) pencil_mfma_geo<NB>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt, rational);
+    const double *ztg = geo + GEO_Z;   // GEO: the element's raw walk-axis rows [q][a][2] (staged with its metric)
+    if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
-    if (SYSTEM && GEO) {
-      const int fs = lane >> 4;
-      const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
-      Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
-    }
     if (SYSTEM && !GEO) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
       double sw = 0;
       const int fs = L.fslot < NB ? L.fslot : 0;
@@ -921,6 +940,11 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
+    if (SYSTEM && GEO) {   // F of this element (its point values are still in the metric area), outside the MFMA phase
+      const int fs = lane >> 4;
+      const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
+      Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
+    }
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
     if constexpr (W == 0) pencil0_leave<SYSTEM, P>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0]);
@@ -971,7 +995,7 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
-template <bool SYSTEM, int W, int P, bool GEO = false>
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false>
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
@@ -1012,7 +1036,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
-    auto kern = gram_pencil<SYSTEM, W, P, GEO>;
+    auto kern = gram_pencil<SYSTEM, W, P, GEO, RAT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
     if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
@@ -1095,8 +1119,17 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
-      if (deg == 2) { if (sys) launch_pencils<true, 0, 2, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); }
-      else { if (sys) launch_pencils<true, 0, 3, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 3, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); }
+      const int v = (deg == 2 ? 0 : 4) + (sys ? 2 : 0) + (s.rational ? 1 : 0);
+      switch (v) {
+      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      }
     } else if (deg == 2) {
       if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {

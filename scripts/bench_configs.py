@@ -28,8 +28,8 @@ def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=No
         X = _np.stack([m.copy() for m in mesh], axis=-1)
         X[..., 0] += 0.05 * _np.sin(2 * _np.pi * mesh[1]); X[..., 1] += 0.05 * _np.sin(2 * _np.pi * mesh[dim - 1])
         W = 1.0 + 0.1 * _np.cos(2 * _np.pi * mesh[0])
-        g.set_geometry(X.reshape(-1, dim), W.reshape(-1))
-    A = g.create_mat() if op in ("system", "ijacobian") else None
+        g.set_geometry(X.reshape(-1, dim), None if geo == "poly" else W.reshape(-1))
+    A = g.create_mat() if op in ("system", "ijacobian", "matrix") else None
     b = g.create_vec()
     U = V = None
     if op in ("ifunction", "ijacobian"):
@@ -42,6 +42,8 @@ def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=No
         t = time.perf_counter()
         if op == "system":
             g.compute_system(A, b)
+        elif op == "matrix":
+            g.compute_matrix(A)
         elif op == "ijacobian":
             g.compute_ijacobian(1e3, V, 0.0, U, A)
         else:
@@ -89,6 +91,10 @@ if "c6" in which:
     run("Poisson3D p=3 64^3 on a NURBS geometry", 3, 1, 3, (64,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "c6b" in which:
     run("Poisson3D p=3 128^3 on a NURBS geometry", 3, 1, 3, (128,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
+if "c6m" in which:
+    run("Poisson3D p=3 128^3 on a NURBS geometry, Matrix driver", 3, 1, 3, (128,) * 3, "poisson", op="matrix", geo=True)
+if "c6p" in which:
+    run("Poisson3D p=3 128^3 on a polynomial geometry", 3, 1, 3, (128,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo="poly")
 if "c7" in which:
     run("Poisson3D p=2 96^3 on a NURBS geometry", 3, 1, 2, (96,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "full3" in which:
