@@ -54,10 +54,29 @@ def init_comm(iga, transport=None):
     gloo stages through the host, so ranks may share one GPU)."""
     transport = transport or ("rccl" if dist.get_backend() == "nccl" else "host")
     if transport == "rccl":
-        ids = [iga.comm_unique_id() if dist.get_rank() == 0 else None]
+        # every rank must end up on the same transport: the outcome of the binding is agreed on before anything is sent
+        err = None
+        try:
+            ids = [iga.comm_unique_id() if dist.get_rank() == 0 else None]
+        except Exception as e:          # librccl.so could not be bound on rank 0
+            ids, err = [None], e
         dist.broadcast_object_list(ids, src=0)
-        iga.comm_init_rccl(ids[0])
-    else:
+        ok = ids[0] is not None
+        if ok:
+            try:
+                iga.comm_init_rccl(ids[0])
+            except Exception as e:
+                ok, err = False, e
+        flags = [None] * dist.get_world_size()
+        dist.all_gather_object(flags, bool(ok))
+        if not all(flags):
+            import sys
+            if dist.get_rank() == 0:
+                print("petiga_amd.exchange: the library's RCCL binding failed (%s); falling back to torch.distributed point-to-point" % (err,), file=sys.stderr)
+            if ok:
+                iga.comm_destroy()
+            transport = "host"
+    if transport != "rccl":
         def move(send, recv):
             p2p_exchange([_device_view(p, n) for _, p, n in send], [r for r, _, _ in send],
                          [_device_view(p, n) for _, p, n in recv], [r for r, _, _ in recv])

@@ -405,7 +405,9 @@ def _rank_matrix_rows(eng, A, b):
                                                              (4, 2, 2, 2, (9, 10), (0, 0), "mass"), (4, 3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson"),
                                                              (8, 3, 1, 3, (20, 18, 16), (0, 0, 0), "poisson"),
                                                              (4, 3, 3, 2, (6, 7, 5), (0, 0, 0), "elasticity+nurbs"), (8, 3, 1, 3, (7, 8, 9), (0, 0, 0), "poisson+nurbs"),
-                                                             (3, 2, 1, 3, (11, 4), (0, 0), "poisson+nurbs")])
+                                                             (3, 2, 1, 3, (11, 4), (0, 0), "poisson+nurbs"),
+                                                             # axis 0 long enough for the pencil kernel's mapped-geometry variant on every rank
+                                                             (2, 3, 1, 3, (9, 4, 8), (0, 0, 0), "poisson+nurbs"), (4, 3, 1, 2, (10, 6, 8), (0, 0, 0), "poisson+nurbs")])
 def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     """Every rank assembles its own element box, ghost rows are packed / added through the C ABI exactly as
     petiga_amd/exchange.py does between processes; the owned rows of all ranks together must be the
