@@ -726,8 +726,6 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
   }
   if (g->zero_matrix) g->zero_matrix();
-  for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd)
-    if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes need the feature kernel (dim >= 2, nen <= 64, IGXSetKernel 0 or 3)");
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   int nq[3], na[3]; int NQ = 1, NE = 1;
@@ -743,6 +741,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((Form::NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
+  cv.nrm = take(NQ * DIM);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   const size_t lds_limit = 160 * 1024 - 512;
   bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;
@@ -787,6 +786,39 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
       }
       OutDev o2 = out; o2.elem_base = elem_base; elem_base += (int64_t)nblocks;
       hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, o2, sub, cv, g->scratch.as<double>(), phi_doubles);
+      launches++;
+    }
+  }
+  // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447): the elements of this rank on a visited face, one point
+  // layer at the face; their K_e / F_e add to what the interior pass left (stream order)
+  for (int bid = 0; bid < 2 * DIM; ++bid) {
+    const int ax = bid / 2, sd = bid % 2;
+    if (!s.visit[ax][sd]) continue;
+    const int eface = sd ? s.elem_sizes[ax] - 1 : 0;
+    if (eface < s.elem_start[ax] || eface >= s.elem_start[ax] + s.elem_width[ax]) continue;   // the face is on another rank
+    OutDev ob = out; ob.bid = bid;
+    int nc2[3] = {nc[0], nc[1], nc[2]}; nc2[ax] = 1;
+    for (int c2 = 0; c2 < nc2[2]; ++c2) for (int c1 = 0; c1 < nc2[1]; ++c1) for (int c0 = 0; c0 < nc2[0]; ++c0) {
+      const int cc[3] = {c0, c1, c2};
+      ColorRange cr; bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        if (d == ax) { cr.start[d] = eface - s.elem_start[ax]; cr.step[d] = 1; cr.count[d] = 1; continue; }
+        const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
+        int first = -1, count = 0;
+        for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+        if (NS > 0) { first = 0; count = nel; }
+        if (count == 0) { empty = true; break; }
+        cr.start[d] = first; cr.step[d] = (NS > 0) ? 1 : stride; cr.count[d] = count;
+      }
+      if (empty) continue;
+      const size_t nblocks = (size_t)cr.count[0] * cr.count[1] * cr.count[2];
+      if (!phi_in_lds) {
+        const size_t need = nblocks * phi_doubles * sizeof(double);
+        if (nblocks > max_blocks) return fail(IGX_ERR_SUP, "scratch too small for one face layer");
+        if (g->scratch.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->scratch.alloc(need)) return fail(IGX_ERR_MEM, "scratch allocation failed"); }
+      }
+      ob.elem_base = elem_base; elem_base += (int64_t)nblocks;
+      hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(256), lds_bytes, g->stream, S, prm, ob, cr, cv, g->scratch.as<double>(), phi_doubles);
       launches++;
     }
   }

@@ -20,6 +20,7 @@ struct Carve {          // offsets (in doubles) into the dynamic LDS block; -1 =
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, lift, phi;
+  int nrm;              // [nqp][DIM] outward unit normals of a boundary-form pass
   int total;            // doubles
 };
 
@@ -164,6 +165,12 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
       nq[d] = S.ax[d].nqp; na[d] = S.ax[d].nen;
     }
   }
+  // boundary-form pass (IGAElementNextForm, src/petigaelem.c:427-447): one point on the face axis, basis from the end-of-axis
+  // table (src/petigaelem.c:796-823), weight 1, bnd_detJac 1
+  const int bid = out.bid; const bool bpass = bid >= 0;
+  const int baxis = bpass ? (bid >> 1) : -1, bside = bid & 1;
+  if (bpass) nq[baxis] = 1;
+  constexpr bool HASB = has_boundary_of<Form>::v;
   const int NQ = nq[0] * nq[1] * nq[2], NE = na[0] * na[1] * na[2];
   const int op = out.op;
   const bool hasM = (op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN);
@@ -178,7 +185,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
   double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
   double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
-  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift;
+  double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift, *nrm = smem + cv.nrm;
   double *phi = (cv.phi >= 0) ? smem + cv.phi : phi_global + (size_t)blockIdx.x * phi_stride;
   __shared__ int s_anyfix;
   if (tid == 0) s_anyfix = 0;
@@ -188,9 +195,10 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const int n = nq[d] * na[d] * NDER;
-    const double *src = S.ax[d].tab + (size_t)el[d] * n;
+    const bool face = (d == baxis);
+    const double *src = face ? S.ax[d].bnd + (size_t)bside * n : S.ax[d].tab + (size_t)el[d] * n;
     for (int i = tid; i < n; i += nthr) t1d[d][i] = src[i];
-    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = S.ax[d].w[el[d] * nq[d] + i];
+    for (int i = tid; i < nq[d]; i += nthr) w1d[d][i] = face ? 1.0 : S.ax[d].w[el[d] * nq[d] + i];
   }
   const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;
   const int nr0 = S.ax[0].nrow, nr1 = S.ax[1].nrow;
@@ -221,7 +229,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
             s_anyfix = 1;
           }
           const BCDev &bl = S.bcl[d][side];
-          if (bl.count && !(geo && DIM > 1)) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132); mapped: add_mapped_flux below
+          if (bl.count && !(geo && DIM > 1) && !bpass) {   // BoundaryArea, no-geometry branch (src/petigaelem.c:1118-1132); mapped: add_mapped_flux below
             double A = 1;
             if (DIM > 1) {
               for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
@@ -235,7 +243,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   }
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
-  if (geo && DIM > 1 && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
+  if (geo && DIM > 1 && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
   if (anyfix && (useU || useV)) {
     for (int k = tid; k < NE * DOF; k += nthr)
@@ -246,14 +254,14 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   // ---- phase 1: per-point geometry (K1, K3 sums, K4, K5)
   double Jel = 1;
 #pragma unroll
-  for (int d = 0; d < 3; ++d) Jel *= S.ax[d].J[el[d]];
+  for (int d = 0; d < 3; ++d) if (d != baxis) Jel *= S.ax[d].J[el[d]];
   for (int q = tid; q < NQ; q += nthr) {
     const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
     double detX = 1.0;
     double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
     double x0[3], X1[9], X2[27];
 #pragma unroll
-    for (int d = 0; d < DIM; ++d) x0[d] = S.ax[d].pt[el[d] * nq[d] + qq[d]];
+    for (int d = 0; d < DIM; ++d) x0[d] = (d == baxis) ? S.ax[d].bndpt[bside] : S.ax[d].pt[el[d] * nq[d] + qq[d]];
     if (rat) {
       w0 = 0;
       for (int a = 0; a < NE; ++a) {
@@ -307,6 +315,26 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         }
       }
       if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+    }
+    if (bpass) {   // K7: IGA_GetNormal, src/petigaval.F90:45-99; detJac *= detS instead of detX (src/petigaelem.c:1012-1029)
+      double n[3] = {0, 0, 0}, dS = 1;
+      if (!geo || DIM == 1) n[baxis] = 1.0;
+      else if (DIM == 3) {
+        const int r1 = (baxis + 1) % 3, r2 = (baxis + 2) % 3;
+        const double s0 = X1[0 * DIM + r1], s1 = X1[1 * DIM + r1], s2 = X1[2 * DIM + r1];
+        const double t0 = X1[0 * DIM + r2], t1 = X1[1 * DIM + r2], t2 = X1[2 * DIM + r2];
+        n[0] = s1 * t2 - s2 * t1; n[1] = s2 * t0 - s0 * t2; n[2] = s0 * t1 - s1 * t0;
+        dS = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        n[0] /= dS; n[1] /= dS; n[2] /= dS;
+      } else {
+        double t0, t1;
+        if (baxis == 0) { t0 = +X1[0 * DIM + 1]; t1 = +X1[1 * DIM + 1]; } else { t0 = -X1[0 * DIM + 0]; t1 = -X1[1 * DIM + 0]; }
+        n[0] = +t1; n[1] = -t0;
+        dS = sqrt(n[0] * n[0] + n[1] * n[1]);
+        n[0] /= dS; n[1] /= dS;
+      }
+      for (int i = 0; i < DIM; ++i) nrm[q * DIM + i] = bside ? n[i] : -n[i];
+      detX = dS;
     }
     double w = 1;
 #pragma unroll
@@ -386,7 +414,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     for (int q = tid; q < NQ; q += nthr) {
       PtView p;
       p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
       double Sq[NS];
       Form::scalar(p, Sq);
       const double jw = JW[q];
@@ -415,7 +443,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   auto point = [&](int q) {
     PtView p;
     p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
     return p;
   };
   const int W0s = 2 * S.ax[0].p + 1, W1s = 2 * S.ax[1].p + 1, W2s = 2 * S.ax[2].p + 1;
@@ -439,7 +467,8 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
           if (pr < npairs) {
             const int a = pr / NE, b = pr - a * NE;
             double T[DOF * DOF];
-            Form::mat(p, phi + ((size_t)q * NE + a) * NF, phi + ((size_t)q * NE + b) * NF, T);
+            if constexpr (HASB) { if (bpass) Form::bmat(p, phi + ((size_t)q * NE + a) * NF, phi + ((size_t)q * NE + b) * NF, T); else Form::mat(p, phi + ((size_t)q * NE + a) * NF, phi + ((size_t)q * NE + b) * NF, T); }
+            else Form::mat(p, phi + ((size_t)q * NE + a) * NF, phi + ((size_t)q * NE + b) * NF, T);
 #pragma unroll
             for (int i = 0; i < DOF * DOF; ++i) acc[s][i] += T[i] * jw;
           }
@@ -455,7 +484,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
           for (int i = 0; i < DOF; ++i)
 #pragma unroll
             for (int j = 0; j < DOF; ++j)
-              if (fixflag[a * DOF + i] || fixflag[b * DOF + j]) acc[s][i * DOF + j] = (a == b && i == j) ? 1.0 : 0.0;
+              if (fixflag[a * DOF + i] || fixflag[b * DOF + j]) acc[s][i * DOF + j] = (a == b && i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
         }
         const int a0 = a % na[0], a1 = (a / na[0]) % na[1], a2 = a / (na[0] * na[1]);
         const int b0 = b % na[0], b1 = (b / na[0]) % na[1], b2 = b / (na[0] * na[1]);
@@ -484,12 +513,14 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         const PtView p = point(q);
         const double *Na = phi + ((size_t)q * NE + a) * NF;
         double R[DOF];
-        Form::vec(p, Na, R);
+        if constexpr (HASB) { if (bpass) Form::bvec(p, Na, R); else Form::vec(p, Na, R); }
+        else Form::vec(p, Na, R);
         if (dolift) {   // F[i] -= K[i][k] v_k, summed through the lifting features (mat is linear in Nb)
 #pragma unroll
           for (int j = 0; j < DOF; ++j) {
             double T[DOF * DOF];
-            Form::mat(p, Na, lift + ((size_t)q * DOF + j) * NF, T);
+            if constexpr (HASB) { if (bpass) Form::bmat(p, Na, lift + ((size_t)q * DOF + j) * NF, T); else Form::mat(p, Na, lift + ((size_t)q * DOF + j) * NF, T); }
+            else Form::mat(p, Na, lift + ((size_t)q * DOF + j) * NF, T);
 #pragma unroll
             for (int i = 0; i < DOF; ++i) R[i] -= T[i * DOF + j];
           }
@@ -504,8 +535,10 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
       for (int i = 0; i < DOF; ++i) {
         const int k = a * DOF + i;
         double v = F[i];
-        if (op == OP_SYSTEM) { v += flux[k]; if (fixflag[k]) v = fixval[k]; }                        // src/petigaelem.c:1371-1387
-        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { v -= flux[k]; if (fixflag[k]) v = ufix[k] - fixval[k]; }   // :1449-1461
+        // FixSystem / FixFunction act once on the sum of the passes; in separate launches the interior pass carries the constant
+        // parts (flux, fixed value) and a boundary pass only drops its fixed rows
+        if (op == OP_SYSTEM) { if (!bpass) v += flux[k]; if (fixflag[k]) v = bpass ? 0.0 : fixval[k]; }                        // src/petigaelem.c:1371-1387
+        else if (op == OP_FUNCTION || op == OP_IFUNCTION) { if (!bpass) v -= flux[k]; if (fixflag[k]) v = bpass ? 0.0 : ufix[k] - fixval[k]; }   // :1449-1461
         out.vec[row * DOF + i] += v;
       }
     }

@@ -140,6 +140,7 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(out.op == OP_SYSTEM ? NQ * DOF * NF : 0);
+  cv.nrm = take(NQ * DIM);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   const size_t lds_limit = 64 * 1024;      // module kernels keep to the default dynamic-LDS limit; Phi spills to HBM beyond it
   const bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;

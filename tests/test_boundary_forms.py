@@ -95,11 +95,45 @@ def test_boundary_integral_on_device(dim, axis, side, geo):
 
 
 @pytest.mark.gpu
-def test_boundary_forms_refused_where_not_covered():
-    import petiga_amd as P
+@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 16, None), (1, 3, 7, None), (2, 2, 6, "nurbs"), (3, 2, 3, "poly"), (3, 4, 2, None), (3, 4, 2, "nurbs")])
+def test_boundary_passes_on_the_generic_kernel(dim, p, N, geo):
+    """dim 1 and nen > 64 (p = 4 in 3-D: 125 functions) have no MFMA kernel: the point-form kernel makes the boundary passes
+    itself (IGAElementNextForm, src/petigaelem.c:427-447); the other cases run it by choice (IGXSetKernel 1)."""
+    orc, eng = _nitsche_pair(dim, p, N, geo)
+    Ao, bo = orc.compute_system("orc_form_nitsche", C.c_int(p))
+    eng.set_form("nitsche", (float(p),))
+    eng.set_kernel(1)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    assert "generic_assemble" in eng.kernel_name()
+    tol = 1e-12 if geo is None else 2e-11
+    compare_mats(A, Ao, tol)
+    assert rel_err(b.get(), bo) < tol
+    if dim == 1 and p == 2:      # demo/makefile:218: -iga_dim 1 -iga_degree 2 -check_error 1e-6
+        x = sla.spsolve(A.to_scipy_global().tocsc(), b.get())
+        assert np.sqrt(eng.compute_scalar("x2err", eng.create_vec().set(x))[0]) < 1e-6
+    # a Dirichlet face next to a visited one, and a form without a boundary branch integrated over the face
+    orc2, eng2 = make_pair(dim, 1, p, N)
+    for g in (orc2, eng2):
+        g.set_boundary_value(0, 0, 0, 1.0)
+        g.set_boundary_form(0, 1, True)
+        if dim > 1:
+            g.set_boundary_value(1, 0, 0, -0.5)
+    for oform, eform in (("orc_form_boundary_integral", "boundary_integral"), ("orc_form_mass", "mass")):
+        Ao, bo = orc2.compute_system(oform)
+        eng2.set_form(eform)
+        eng2.set_kernel(1)
+        A, b = eng2.create_mat(), eng2.create_vec()
+        eng2.compute_system(A, b)
+        compare_mats(A, Ao, 1e-12)
+        assert np.abs(b.get() - bo).max() <= 1e-12 * max(np.abs(bo).max(), 1.0)
+
+
+@pytest.mark.gpu
+def test_boundary_functional_in_one_dimension():
+    # IGAComputeScalarFull (test/IGAGeometryMap.c:391-450) in 1-D: length of the interval and one unit "area" per visited end
     _, eng = make_pair(1, 1, 2, 6)
+    eng.set_boundary_form(0, 0, True)
     eng.set_boundary_form(0, 1, True)
-    eng.set_form("poisson")
-    with pytest.raises(P.IGXError) as e:
-        eng.compute_system(eng.create_mat(), eng.create_vec())
-    assert e.value.code == 56
+    S = eng.compute_scalar("volume")
+    assert abs(S[0] - 1.0) < 1e-14 and abs(S[1] - 2.0) < 1e-14
