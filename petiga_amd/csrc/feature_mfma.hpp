@@ -389,14 +389,18 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // (sum factorisation, three short contractions through LDS instead of nqp * nen * 16 products per element).  They
   // run on homogeneous coordinates: A_c = sum_a (w_a X_a[c]) N_a and W = sum_a w_a N_a with their first derivatives;
   // x = A / W and dx/du = (dA - x dW) / W reproduce Rationalize + GeometryMap (src/petigarat.f90.in, petigamapgeo.f90.in).
-  const bool sumfact = !SECOND && (geo || rat);
-  double *SF = phi;                                   // [NC][4][NQ], in the (not yet used) Phi region
+  // Second-order tabulations (Cahn-Hilliard, NS-VMS) take the same route with the second derivatives: 3 derivative orders per
+  // axis, 6 pairs after two axes, 10 sums per component and point; x, dx/du, d2x/du2 follow by the quotient rule.  The
+  // per-point loop over the 64 basis functions with its 39 accumulators cost 540k cycles per element of NS-VMS on a NURBS.
+  const bool sumfact = geo || rat;
+  constexpr int SF_NV = SECOND ? 3 : 2, SF_NM = SECOND ? 6 : 3, SF_NK = SECOND ? 10 : 4;
+  double *SF = phi;                                   // [NC][SF_NK][NQ], in the (not yet used) Phi region
   if (sumfact) {
     constexpr int NC = DIM + 1;                       // components: X (times w) and w
-    const int n1 = NC * 2 * nq[0] * na[1] * na[2], n2 = NC * 3 * nq[0] * nq[1] * na[2], n3 = NC * 4 * NQ;
+    const int n1 = NC * SF_NV * nq[0] * na[1] * na[2], n2 = NC * SF_NM * nq[0] * nq[1] * na[2], n3 = NC * SF_NK * NQ;
     double *T1 = phi + n3, *T2 = T1 + n1;
-    for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v]
-      int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r & 1, c = r >> 1;
+    for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v], v = derivative order on axis 0
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r % SF_NV, c = r / SF_NV;
       double sm = 0;
       for (int a0 = 0; a0 < na[0]; ++a0) {
         const int a = slot_of<PENCIL>(a0, a1, a2, na);
@@ -407,27 +411,28 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       T1[i] = sm;
     }
     __syncthreads();
-    for (int i = tid; i < n2; i += nthr) {            // T2[c][m][q0][q1][a2], m: 0 (val,val) 1 (der,val) 2 (val,der)
-      int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % 3, c = r / 3;
-      const int v0 = (m == 1), v1 = (m == 2);
+    for (int i = tid; i < n2; i += nthr) {            // T2[c][m][q0][q1][a2], m -> orders (v0, v1): (0,0) (1,0) (0,1) | (2,0) (1,1) (0,2)
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % SF_NM, c = r / SF_NM;
+      const int v0 = (m == 1 || m == 4) ? 1 : (m == 3 ? 2 : 0), v1 = (m == 2 || m == 4) ? 1 : (m == 5 ? 2 : 0);
       double sm = 0;
-      for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * 2 + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1];
+      for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * SF_NV + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1];
       T2[i] = sm;
     }
     __syncthreads();
-    for (int i = tid; i < n3; i += nthr) {            // SF[c][k][q], k: 0 value, 1..3 d/du_0..2
-      const int q = i % NQ, k = (i / NQ) & 3, c = i / (4 * NQ);
+    for (int i = tid; i < n3; i += nthr) {            // SF[c][k][q], k: 0 value, 1..3 d/du_i, 4..9 d2/du_i du_j for (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+      const int q = i % NQ, k = (i / NQ) % SF_NK, c = i / (SF_NK * NQ);
       const int qp = qdec[q]; const int q0 = qp & 255, q1 = (qp >> 8) & 255, q2 = qp >> 16;
-      const int m = (k == 1) ? 1 : (k == 2 ? 2 : 0), v2 = (k == 3);
+      // (m, v2) of k: value (0,0); d0 (1,0) d1 (2,0) d2 (0,1); d00 (3,0) d01 (4,0) d02 (1,1) d11 (5,0) d12 (2,1) d22 (0,2)
+      const int m = (k == 1 || k == 6) ? 1 : ((k == 2 || k == 8) ? 2 : (k == 4 ? 3 : (k == 5 ? 4 : (k == 7 ? 5 : 0))));
+      const int v2 = (k == 3 || k == 6 || k == 8) ? 1 : (k == 9 ? 2 : 0);
       double sm = 0;
-      for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * 3 + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2];
+      for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * SF_NM + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2];
       SF[i] = sm;
     }
     __syncthreads();
   }
   {
-    int np1 = pow2_floor(nthr / NQP); if (np1 > 16) np1 = 16;
-    if ((!geo && !rat) || sumfact) np1 = 1;
+    const int np1 = 1;                 // one lane per point: the sums over the basis functions are done (sum factorisation above)
     const int qstep = nthr / np1;
     for (int qb = 0; qb < NQP; qb += qstep) {
       const int q = qb + tid / np1, part = tid & (np1 - 1);
@@ -442,62 +447,23 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       for (int d = 0; d < DIM; ++d) x0[d] = w1d[d][nq[d] + qq[d]];
       if (sumfact) {
         if (valid) {
-          if (rat) { w0 = SF[(DIM * 4 + 0) * NQ + q]; for (int i = 0; i < DIM; ++i) w1[i] = SF[(DIM * 4 + 1 + i) * NQ + q]; }
-          if (geo) {
+          // index of the second derivative (i, j) among the 10 sums
+          auto k2 = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
+          if (rat) {
+            w0 = SF[(DIM * SF_NK + 0) * NQ + q];
+            for (int i = 0; i < DIM; ++i) w1[i] = SF[(DIM * SF_NK + 1 + i) * NQ + q];
+            if (SECOND) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) w2[i * DIM + j] = SF[(DIM * SF_NK + k2(i, j)) * NQ + q];
+          }
+          if (geo) {   // quotient rule on the homogeneous sums A = sum w X N, W = sum w N
             const double iw = 1.0 / w0;
             for (int c = 0; c < DIM; ++c) {
-              x0[c] = SF[(c * 4 + 0) * NQ + q] * iw;
-              for (int al = 0; al < DIM; ++al) X1[c * DIM + al] = (SF[(c * 4 + 1 + al) * NQ + q] - x0[c] * w1[al]) * iw;
+              x0[c] = SF[(c * SF_NK + 0) * NQ + q] * iw;
+              for (int al = 0; al < DIM; ++al) X1[c * DIM + al] = (SF[(c * SF_NK + 1 + al) * NQ + q] - x0[c] * w1[al]) * iw;
+              if (SECOND) for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be)
+                X2[c * D2 + al * DIM + be] = (SF[(c * SF_NK + k2(al, be)) * NQ + q] - x0[c] * w2[al * DIM + be] - X1[c * DIM + al] * w1[be] - X1[c * DIM + be] * w1[al]) * iw;
             }
           }
         }
-      } else {
-      if (rat) {
-        w0 = 0;
-        if (valid) for (int a = part; a < NE; a += np1) {
-          const int ap = adec[a]; const int aq[3] = {ap & 255, (ap >> 8) & 255, ap >> 16};
-          double b0, b1[3], b2[9];
-          tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-          const double w = gW[a];
-          w0 += w * b0;
-          for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
-          if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
-        }
-        w0 = group_sum(w0, np1);
-        for (int i = 0; i < DIM; ++i) w1[i] = group_sum(w1[i], np1);
-        if (SECOND) for (int i = 0; i < D2; ++i) w2[i] = group_sum(w2[i], np1);
-        if (!valid) w0 = 1;
-      }
-      const double iw0 = 1.0 / w0;
-      if (geo) {
-        for (int i = 0; i < DIM; ++i) x0[i] = 0;
-        for (int i = 0; i < D2; ++i) X1[i] = 0;
-        if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
-        if (valid) for (int a = part; a < NE; a += np1) {
-          const int ap = adec[a]; const int aq[3] = {ap & 255, (ap >> 8) & 255, ap >> 16};
-          double b0, b1[3], b2[9];
-          tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-          if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
-            const double w = gW[a];
-            const double r0 = w * b0 * iw0;
-            double r1[3];
-            for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) * iw0;
-            if (SECOND)
-              for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-                b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) * iw0;
-            b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
-          }
-          for (int i = 0; i < DIM; ++i) {
-            const double x = gX[a * DIM + i];
-            x0[i] += x * b0;
-            for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
-            if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
-          }
-        }
-        for (int i = 0; i < DIM; ++i) x0[i] = group_sum(x0[i], np1);
-        for (int i = 0; i < D2; ++i) X1[i] = group_sum(X1[i], np1);
-        if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = group_sum(X2[i], np1);
-      }
       }
       if (part != 0 || q >= NQP) continue;
       if (!valid) { JW[q] = 0; for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = 0; continue; }   // padded point
@@ -511,13 +477,16 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         double e1[9];
         inv3(X1, DIM, detX, e1);
         for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
-        if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45
-          for (int c = 0; c < DIM; ++c) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) {
-            double sm = 0;
-            for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
-              sm -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
-            E2[(q * DIM + c) * D2 + i * DIM + j] = sm;
+        if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45: E2[c][i][j] = -X2[k][a][b] e1[a][i] e1[b][j] e1[c][k],
+          double e2[27];  // contracted one index at a time (3 x 81 products instead of 729)
+          for (int i = 0; i < D2 * DIM; ++i) e2[i] = 0;
+          for (int k = 0; k < DIM; ++k) {
+            double U[9], T[9];
+            for (int a = 0; a < DIM; ++a) for (int j = 0; j < DIM; ++j) { double sm = 0; for (int b = 0; b < DIM; ++b) sm += X2[k * D2 + a * DIM + b] * e1[b * DIM + j]; U[a * DIM + j] = sm; }
+            for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) { double sm = 0; for (int a = 0; a < DIM; ++a) sm += U[a * DIM + j] * e1[a * DIM + i]; T[i * DIM + j] = sm; }
+            for (int c = 0; c < DIM; ++c) for (int i = 0; i < D2; ++i) e2[c * D2 + i] -= T[i] * e1[c * DIM + k];
           }
+          for (int i = 0; i < D2 * DIM; ++i) E2[(size_t)q * DIM * D2 + i] = e2[i];
         }
         if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
       }

@@ -87,6 +87,14 @@ if "c5" in which:
             for f in range(3):
                 g.set_boundary_value(1, s, f, 0.0)
     run("NavierStokesVMS p=3 32^3 tangent (config 5 is 192^3 on 8 GPUs)", 3, 4, 3, (32,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian", bc=bc5)
+if "c5g" in which:
+    def bc5g(g):
+        for s in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s, f, 0.0)
+    run("NavierStokesVMS p=3 48^3 tangent on a NURBS geometry", 3, 4, 3, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), op="ijacobian", bc=bc5g, geo=True)
+    run("NavierStokesVMS p=3 48^3 residual on a NURBS geometry", 3, 4, 3, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), op="ifunction", bc=bc5g, geo=True)
+    run("NavierStokesVMS p=3 48^3 tangent, no geometry", 3, 4, 3, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), op="ijacobian", bc=bc5g)
 if "c6" in which:
     run("Poisson3D p=3 64^3 on a NURBS geometry", 3, 1, 3, (64,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "c6b" in which:
