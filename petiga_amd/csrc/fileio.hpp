@@ -7,6 +7,7 @@
 // IGAWriteVec/IGAReadVec (src/petigaio.c:640-736): one PETSc Vec in natural order.
 #include <cfloat>
 #include <cstdio>
+#include <exception>
 
 namespace {
 const int IGA_FILE_CLASSID_ = 1211299, VEC_FILE_CLASSID_ = 1211214;
@@ -19,40 +20,44 @@ bool wr_dbl(FILE *f, const double *a, size_t n) { for (size_t i = 0; i < n; ++i)
 struct FileCloser { FILE *f; ~FileCloser() { if (f) fclose(f); } };
 }  // namespace
 
-extern "C" int IGXRead(IGX g, const char filename[]) {   // IGARead -> IGALoad, src/petigaio.c:141,11
-  NEEDIGA(g); if (!filename) return fail(IGX_ERR_ARG_WRONG, "null file name");
-  FileCloser fc{fopen(filename, "rb")};
-  if (!fc.f) return fail(65 /*PETSC_ERR_FILE_OPEN*/, std::string("cannot open ") + filename);
+// bytes left in the file from the current position (record sizes in a header are checked against it before anything is
+// allocated: a corrupt or hostile header must come back as PETSC_ERR_FILE_READ, not as std::bad_alloc through the C ABI)
+static long long bytes_left(FILE *f) {
+  const long pos = ftell(f);
+  if (pos < 0 || fseek(f, 0, SEEK_END) != 0) return -1;
+  const long end = ftell(f);
+  if (fseek(f, pos, SEEK_SET) != 0) return -1;
+  return (long long)end - pos;
+}
+
+static int igx_read_into(Space &s, FILE *f, const Space &keep) {
   int classid = 0, info = 0, dim = 0;
-  if (!rd_int(fc.f, classid) || classid != IGA_FILE_CLASSID_) return fail(IGX_ERR_ARG_WRONG, "Not an IGA in file");
-  if (!rd_int(fc.f, info) || !rd_int(fc.f, dim) || dim < 1 || dim > 3) return fail(66 /*PETSC_ERR_FILE_READ*/, "bad IGA header");
-  Space &s = g->s;
-  {   // IGAReset (src/petiga.c:225) drops the discretisation, not the options the caller set
-    Space fresh;
-    fresh.dof = s.dof; fresh.order = s.order; fresh.comm_size = s.comm_size; fresh.comm_rank = s.comm_rank;
-    for (int i = 0; i < 3; ++i) { fresh.proc_req[i] = s.proc_req[i]; fresh.rule_nqp[i] = s.rule_nqp[i]; fresh.axis[i].periodic = 0; }
-    fresh.form = s.form; fresh.params = s.params; fresh.dim = dim;
-    s = fresh;
-  }
+  if (!rd_int(f, classid) || classid != IGA_FILE_CLASSID_) return fail(IGX_ERR_ARG_WRONG, "Not an IGA in file");
+  if (!rd_int(f, info) || !rd_int(f, dim) || dim < 1 || dim > 3) return fail(66 /*PETSC_ERR_FILE_READ*/, "bad IGA header");
+  // IGAReset (src/petiga.c:225) drops the discretisation, not the options the caller set
+  s.dof = keep.dof; s.order = keep.order; s.comm_size = keep.comm_size; s.comm_rank = keep.comm_rank; s.env = keep.env;
+  for (int i = 0; i < 3; ++i) { s.proc_req[i] = keep.proc_req[i]; s.rule_nqp[i] = keep.rule_nqp[i]; s.axis[i].periodic = 0; }
+  s.form = keep.form; s.params = keep.params; s.dim = dim;
   for (int i = 0; i < dim; ++i) {
     int p = 0, nk = 0;
-    if (!rd_int(fc.f, p) || !rd_int(fc.f, nk) || p < 1 || p > 7 || nk < 2 * (p + 1)) return fail(66, "bad axis record");
+    if (!rd_int(f, p) || !rd_int(f, nk) || p < 1 || p > 7 || nk < 2 * (p + 1)) return fail(66, "bad axis record");
+    if ((long long)nk * 8 > bytes_left(f)) return fail(66, "truncated knot vector");
     std::vector<double> U((size_t)nk);
-    if (!rd_dbl(fc.f, U.data(), U.size())) return fail(66, "truncated knot vector");
+    if (!rd_dbl(f, U.data(), U.size())) return fail(66, "truncated knot vector");
     s.axis[i].p = p;
     std::string e;
     if (int rc = axis_set_knots(s.axis[i], nk - 1, U.data(), e)) return fail(rc, e);   // IGAAxisInit, src/petigaaxis.c:314
   }
-  touch(g);
   if (info & 0x1) {
     int nsd = 0, vid = 0, n = 0;
-    if (!rd_int(fc.f, nsd) || nsd < 1 || nsd > 3) return fail(66, "bad geometry dimension");
-    if (!rd_int(fc.f, vid) || vid != VEC_FILE_CLASSID_ || !rd_int(fc.f, n)) return fail(66, "bad geometry Vec header");
+    if (!rd_int(f, nsd) || nsd < 1 || nsd > 3) return fail(66, "bad geometry dimension");
+    if (!rd_int(f, vid) || vid != VEC_FILE_CLASSID_ || !rd_int(f, n) || n < 0) return fail(66, "bad geometry Vec header");
     size_t nnet = 1;
     for (int i = 0; i < dim; ++i) nnet *= (size_t)(s.axis[i].m - s.axis[i].p);   // n_i + 1 control points
     if ((size_t)n != nnet * (nsd + 1)) return fail(IGX_ERR_ARG_WRONG, "geometry Vec size does not match the knot vectors");
+    if ((long long)n * 8 > bytes_left(f)) return fail(66, "truncated geometry");
     std::vector<double> xw((size_t)n);
-    if (!rd_dbl(fc.f, xw.data(), xw.size())) return fail(66, "truncated geometry");
+    if (!rd_dbl(f, xw.data(), xw.size())) return fail(66, "truncated geometry");
     s.netX.assign(nnet * nsd, 0.0); s.netW.assign(nnet, 1.0);
     double wmin = DBL_MAX, wmax = -DBL_MAX;
     for (size_t a = 0; a < nnet; ++a) {
@@ -64,6 +69,21 @@ extern "C" int IGXRead(IGX g, const char filename[]) {   // IGARead -> IGALoad, 
     s.net_nsd = nsd;
   }
   // property arrays (info & 2) are not on the assembly path: ignored
+  return 0;
+}
+
+extern "C" int IGXRead(IGX g, const char filename[]) {   // IGARead -> IGALoad, src/petigaio.c:141,11
+  NEEDIGA(g); if (!filename) return fail(IGX_ERR_ARG_WRONG, "null file name");
+  FileCloser fc{fopen(filename, "rb")};
+  if (!fc.f) return fail(65 /*PETSC_ERR_FILE_OPEN*/, std::string("cannot open ") + filename);
+  try {
+    Space fresh;                       // parsed aside: a failed read leaves the IGX as it was
+    if (int rc = igx_read_into(fresh, fc.f, g->s)) return rc;
+    g->s = fresh;
+  } catch (const std::exception &e) {  // nothing may unwind through the C boundary
+    return fail(66, std::string("reading the IGA file failed: ") + e.what());
+  }
+  touch(g);
   return 0;
 }
 
@@ -107,6 +127,7 @@ extern "C" int IGXReadVec(IGX g, IGXVec v, const char filename[]) {
   int vid = 0, n = 0;
   if (!rd_int(fc.f, vid) || vid != VEC_FILE_CLASSID_ || !rd_int(fc.f, n)) return fail(66, "not a PETSc Vec file");
   if (n != v->n) return fail(IGX_ERR_ARG_WRONG, "Vec size in file does not match");
+  if ((long long)n * 8 > bytes_left(fc.f)) return fail(66, "truncated Vec");
   std::vector<double> h((size_t)n);
   if (!rd_dbl(fc.f, h.data(), h.size())) return fail(66, "truncated Vec");
   return IGXVecCopyFromHost(v, h.data());

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import petiga_amd as P
-from common import iga_file_bytes, make_pair, rel_err, vec_file_bytes, warped_geometry, compare_mats
+from common import IGA_FILE_CLASSID, VEC_FILE_CLASSID, iga_file_bytes, make_pair, rel_err, vec_file_bytes, warped_geometry, compare_mats
 
 
 def _case(dim, p, N, rational, seed=1):
@@ -100,3 +100,36 @@ def test_vec_file_round_trip(tmp_path):
     with pytest.raises(P.IGXError) as e:
         other.read_vec(other.create_vec(), f)
     assert e.value.code == 62
+
+
+def test_corrupt_headers_are_errors_and_leave_the_iga_untouched(tmp_path):
+    """A hostile or truncated file comes back as PETSC_ERR_FILE_READ (66) / ARG_WRONG, never as an exception through the C ABI,
+    and a failed read leaves the discretisation as it was."""
+    import struct
+    import petiga_amd as P
+    g = P.IGX(2, 1)
+    for i in range(2):
+        g.axis_uniform(i, 2, 5)
+    g.setup()
+    before = g.sizes()
+    U = np.array([0, 0, 0, 0.5, 1, 1, 1.0])
+    good = iga_file_bytes([2, 2], [U, U])
+    cases = {
+        "huge-knot-count": struct.pack(">iii", IGA_FILE_CLASSID, 0, 2) + struct.pack(">ii", 2, 2 ** 30),
+        "truncated-knots": good[:len(good) - 20],
+        "huge-geometry": good[:4] + struct.pack(">i", 1) + good[8:] + struct.pack(">iii", 2, VEC_FILE_CLASSID, 2 ** 30),
+        "negative-geometry": good[:4] + struct.pack(">i", 1) + good[8:] + struct.pack(">iii", 2, VEC_FILE_CLASSID, -5),
+        "bad-dim": struct.pack(">iii", IGA_FILE_CLASSID, 0, 7),
+    }
+    for name, blob in cases.items():
+        f = tmp_path / (name + ".dat")
+        f.write_bytes(blob)
+        with pytest.raises(P.IGXError) as e:
+            g.read(f)
+        assert e.value.code in (62, 66), (name, e.value.code)
+        assert g.sizes() == before, name          # still set up, unchanged
+    f = tmp_path / "good.dat"
+    f.write_bytes(good)
+    g.read(f)
+    g.setup()
+    assert g.sizes()["elem_sizes"][:2] == [2, 2]
