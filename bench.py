@@ -23,6 +23,7 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 FLOP_PER_ELEM = {3: 1572864, 2: 118098}        # 2*nen^2*nqp*dim (SURVEY 8d / BASELINE.md 3)
 BYTES_PER_ELEM = {3: 2785, 2: 1019}            # compulsory CSR bytes per element
+NOMINAL_MHZ = 2400.0
 FP64_PEAK_TFLOPS = 78.6                        # MI355X fp64 vector = matrix peak (256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
 KERNEL_TAG = "r02"                             # profiles/traffic.json must describe this round's kernel to be quoted
@@ -205,6 +206,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    os.environ.setdefault("IGX_CLOCK_PROBE", "1")   # read at IGXCreate: three stores by one lane per launch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,6 +246,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    try:
+        g.clock_probe()            # clears the sums: the figure below covers the timed steps only
+    except Exception:
+        pass
     g.set_timing(True)
     fence()
     t0 = time.perf_counter()
@@ -290,6 +296,12 @@ def main():
             assert max(rel) < 1e-9, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs), list(ref))
 
     if rank == 0:
+        # shader clock the chip sustained while the pencil kernel ran (s_memtime ticks per 100 MHz s_memrealtime tick of the first
+        # and last workgroup of every timed launch, IGXGetClockProbe): `peak` stays the nominal 2.4 GHz figure, this says how much of the gap is clock
+        try:
+            clock_mhz = g.clock_probe()[0]
+        except Exception:
+            clock_mhz = None
         nen, nqp = (p + 1) ** 3, (p + 1) ** 3
         flop = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3) if args.form == "poisson" else None
         avg_launch_s = (dom_ms / 1e3) / max(dom_launches, 1)
@@ -327,6 +339,8 @@ def main():
                          "achieved_algorithmic": achieved, "frac_algorithmic": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
+                         "shader_clock_mhz": clock_mhz, "nominal_clock_mhz": NOMINAL_MHZ,
+                         "frac_at_measured_clock": (executed / (FP64_PEAK_TFLOPS * clock_mhz / NOMINAL_MHZ)) if clock_mhz else None,
                          "kernel": dom_name, "launches_per_step": dom_launches // max(args.steps, 1),
                          "avg_launch_ms": avg_launch_s * 1e3, "elements_per_launch": elems_per_launch,
                          "flop_per_element": flop, "executed_flop_per_element": dom_flop,

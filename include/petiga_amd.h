@@ -312,6 +312,12 @@ int IGXVecCopyToGhosted(IGXVec v,double *array,int on_device);
  * adapter can use it as a MatNorm-free sanity check.  Fixed summation order (bitwise repeatable). */
 int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
 
+/* Shader clock under load.  With IGX_CLOCK_PROBE=1 in the environment at IGXCreate, the first and the last workgroup of every
+ * pencil-kernel launch add their s_memtime ticks and the ticks of the constant 100 MHz s_memrealtime counter over their walk to
+ * two sums; this returns the ratio (MHz) and the elements those wavefronts walked since the previous call, and clears the sums.  The MFMA roofline in bench.py is quoted against the
+ * nominal 2400 MHz peak; this figure says what the chip actually sustained while the kernel ran. */
+int IGXGetClockProbe(IGX iga,double *shader_mhz,int64_t *elements);
+
 /* library / device info for logs */
 int IGXGetDeviceInfo(char *buf,int len);
 

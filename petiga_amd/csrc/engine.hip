@@ -62,7 +62,7 @@ struct _p_IGX {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
   std::function<void()> zero_matrix;   // MatZeroEntries of the running IGXCompute*, called by the kernel path that needs it
-  DevBuf partials, dbgbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
+  DevBuf partials, dbgbuf, clkbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
   std::shared_ptr<IgxComm> comm;   // transport of the ghost-row exchange (comm.hpp)
@@ -935,6 +935,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   out.op = op; out.shift = shift; out.t = t; out.errflag = g->errflag.as<int>(); out.bid = -1;
   out.debug = s.env.debug_feature;
   if (kDebug && (out.debug & 8)) { if (!g->dbgbuf.p) g->dbgbuf.alloc(32 * sizeof(long long)); HIPCK(hipMemsetAsync(g->dbgbuf.p, 0, 32 * sizeof(long long), g->stream)); out.dbg = g->dbgbuf.as<long long>(); }
+  if (s.env.clock_probe) { if (!g->clkbuf.p) { if (g->clkbuf.alloc(4 * sizeof(long long))) return fail(IGX_ERR_MEM, "clock probe buffer"); HIPCK(hipMemsetAsync(g->clkbuf.p, 0, 4 * sizeof(long long), g->stream)); } out.clk = g->clkbuf.as<long long>(); }
   if (hasM) { out.browptr = A->browptr.as<int64_t>(); out.val = A->val.as<double>(); }
   if (hasV) out.vec = b->a.as<double>();
   out.U = U ? U->a.as<double>() : nullptr; out.V = V ? V->a.as<double>() : nullptr;
@@ -1065,6 +1066,20 @@ extern "C" int IGXChecksum(IGX g, IGXMat A, IGXVec b, double S[4]) {
   HIPCK(hipGetLastError());
   HIPCK(hipMemcpyAsync(S, res, 4 * sizeof(double), hipMemcpyDeviceToHost, g->stream));
   HIPCK(hipStreamSynchronize(g->stream));
+  return 0;
+}
+
+extern "C" int IGXGetClockProbe(IGX g, double *shader_mhz, int64_t *elements) {
+  NEEDIGA(g);
+  if (!shader_mhz) return fail(IGX_ERR_ARG_WRONG, "null result");
+  if (!g->s.env.clock_probe || !g->clkbuf.p) return fail(IGX_ERR_ARG_WRONGSTATE, "set IGX_CLOCK_PROBE=1 before IGXCreate and run an assembly on the pencil kernel first");
+  long long h[4];
+  HIPCK(hipStreamSynchronize(g->stream));
+  HIPCK(hipMemcpy(h, g->clkbuf.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (h[1] <= 0) return fail(IGX_ERR_ARG_WRONGSTATE, "no pencil-kernel launch since the last call");
+  *shader_mhz = 100.0 * (double)h[0] / (double)h[1];
+  if (elements) *elements = h[2];
+  HIPCK(hipMemsetAsync(g->clkbuf.p, 0, 4 * sizeof(long long), g->stream));   // the sums start again
   return 0;
 }
 

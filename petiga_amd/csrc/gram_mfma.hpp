@@ -917,6 +917,8 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   //   group 0:  mfma(0) | flush(0) | mfma(1) | flush(1) | ...
   //   group 1:          | mfma(0)  | flush(0)| mfma(1)  | ...
   const int grp = wave >> 2;
+  long long tk0 = 0, tw0 = 0;
+  if (out.clk) { tk0 = __builtin_readcyclecounter(); tw0 = wall_clock64(); }
   if (grp == 1) __builtin_amdgcn_s_barrier();
   int lay = T.lay0;
   for (int ei = 0; ei < ne; ++ei) {
@@ -956,6 +958,12 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     __builtin_amdgcn_s_setprio(0);
     if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     __builtin_amdgcn_s_barrier();
+  }
+  if (out.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && wave == 0 && lane == 0) {
+    // IGX_CLOCK_PROBE: s_memtime against the 100 MHz s_memrealtime over the walk, first and last workgroup of every launch
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk), (unsigned long long)(__builtin_readcyclecounter() - tk0));
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 1, (unsigned long long)(wall_clock64() - tw0));
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 2, (unsigned long long)ne);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window

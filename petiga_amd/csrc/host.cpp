@@ -18,6 +18,7 @@ EnvSwitches read_env_switches() {
   e.walk_axis = num("IGX_WALK_AXIS", 0);
   e.nseg = num("IGX_NSEG", 0);
   e.no_first_touch = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
+  e.clock_probe = getenv("IGX_CLOCK_PROBE") != nullptr;
   e.feature_lds_kb = num("IGX_FEATURE_LDS_KB", 0);
   e.combine = num("IGX_COMBINE", -1);
   if (kDebug) { e.debug_feature = num("IGX_DEBUG_FEATURE", 0); e.debug_noflush = num("IGX_DEBUG_NOFLUSH", 0); e.debug_timing = getenv("IGX_DEBUG_TIMING") != nullptr; }

@@ -30,6 +30,7 @@ struct EnvSwitches {
   int kernel = 0;            // IGX_KERNEL=0..3 presets IGXSetKernel (the parity suite runs every case under two kernel families)
   int walk_axis = 0;         // IGX_WALK_AXIS: preferred walk axis of the pencil kernel
   int nseg = 0;              // IGX_NSEG: segments per pencil (0 = model)
+  int clock_probe = 0;       // IGX_CLOCK_PROBE: the pencil kernel records shader-clock ticks against the 100 MHz wall clock (IGXGetClockProbe)
   int no_first_touch = 0;    // IGX_NO_FIRST_TOUCH: MatZeroEntries + read-modify-write everywhere
   int feature_lds_kb = 0;    // IGX_FEATURE_LDS_KB: LDS target of the feature kernel
   int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)
@@ -163,6 +164,7 @@ struct OutDev {
   int bid;                 // boundary-form pass: 2*axis+side (IGAElementNextForm, src/petigaelem.c:427); -1 = interior pass
   int first_touch;         // 1: the matrix was not zeroed: the first colour that reaches an entry stores it (feature kernel)
   int debug;               // experiment switches (IGX_DEBUG_FEATURE): 1 no scatter, 2 atomic scatter, 4 no MFMA phase
+  long long *clk;          // IGX_CLOCK_PROBE: [ticks, wall ticks, elements] of workgroup 0 of the last pencil launch, or null
   long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
 };

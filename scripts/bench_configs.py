@@ -103,6 +103,8 @@ if "c6m" in which:
     run("Poisson3D p=3 128^3 on a NURBS geometry, Matrix driver", 3, 1, 3, (128,) * 3, "poisson", op="matrix", geo=True)
 if "c6p" in which:
     run("Poisson3D p=3 128^3 on a polynomial geometry", 3, 1, 3, (128,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo="poly")
+if "metric" in which:
+    run("Poisson3D p=3 256^3 (the metric config)", 3, 1, 3, (256,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3))
 if "c7" in which:
     run("Poisson3D p=2 96^3 on a NURBS geometry", 3, 1, 2, (96,) * 3, "poisson", bc=lambda g: dirichlet_all(g, 3), geo=True)
 if "full3" in which:

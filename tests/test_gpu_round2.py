@@ -196,3 +196,4 @@ def test_boundary_loads_function_driver(dim, geo):
     eng.compute_function(Uv, F)
     eng.synchronize()
     _vec_close(F.get(), F_o, 1e-11)
+
