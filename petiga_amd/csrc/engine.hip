@@ -550,7 +550,8 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
       const int stage_need = PEN ? 7 * 16 * 17 * (PR ? fm_popcount(fm_pairs_upper(PR)) : DOFI * DOF) : 0;   // the leaving tiles (feature_mfma.hpp)
       cv.boff = 0;
-      cv.phi = take(std::max(std::max(NFS * QC * NEP, sf_need), stage_need));
+      constexpr int NPS = fm_popcount((unsigned long long)(phi_mask_of<Form>::v & ((1u << NFS) - 1u)));   // features kept in LDS
+      cv.phi = take(std::max(std::max(NPS * QC * NEP, sf_need), stage_need));
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
       lds_bytes = (size_t)pos * sizeof(double);
       if (lds_bytes <= cap) fits = true;

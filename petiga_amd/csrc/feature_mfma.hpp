@@ -33,6 +33,12 @@ template <class F> struct shape_order_of<F, decltype((void)F::SHAPE_ORDER)> { st
 template <class F, class = void> struct mat_test_mask_of { static constexpr unsigned v = 0xffffffffu; };
 template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> { static constexpr unsigned v = F::MAT_TEST_MASK; };
 
+// bit f set: feature f of Phi is read by the form at all (by mat / vec on either side or through the field values); the others are
+// neither tabulated into LDS nor summed into field Hessians.  Cahn-Hilliard reads the Laplacian only: 7 of 13 features, half the
+// chunks of points at the same LDS footprint.
+template <class F, class = void> struct phi_mask_of { static constexpr unsigned v = 0xffffffffu; };
+template <class F> struct phi_mask_of<F, decltype((void)F::PHI_MASK)> { static constexpr unsigned v = F::PHI_MASK; };
+
 // Forms whose matrix integrand has point-independent coefficients in the physical-space features (Poisson, mass,
 // linear elasticity): K_e[(a,i),(b,j)] = sum_{f,g} C^{ij}_{fg} M_fg[a][b] with the feature Gram matrices
 // M_fg = sum_q JW Phi_f(a,q) Phi_g(b,q).  Only the M_fg go through the matrix cores (K dimension nqp instead of
@@ -41,6 +47,7 @@ template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> 
 template <class F, class = void> struct mat_pair_mask_of { static constexpr unsigned long long v = 0ull; };
 template <class F> struct mat_pair_mask_of<F, decltype((void)F::MAT_PAIR_MASK)> { static constexpr unsigned long long v = F::MAT_PAIR_MASK; };
 constexpr int fm_popcount(unsigned long long m) { int n = 0; while (m) { n += (int)(m & 1ull); m >>= 1; } return n; }
+constexpr int fm_phi_slot(unsigned mask, int f) { return fm_popcount((unsigned long long)(mask & ((1u << f) - 1u))); }
 constexpr int fm_pair_index(unsigned long long mask, int f, int g) { return fm_popcount(mask & ((1ull << (f * 8 + g)) - 1ull)); }
 // Gram matrices are transposes of each other, M_gf[a][b] = M_fg[b][a]: the pairs with f <= g carry everything
 constexpr unsigned long long fm_pairs_upper(unsigned long long mask) {
@@ -178,7 +185,11 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   constexpr bool SECOND_S = shape_order_of<Form>::v >= 2;      // order of the shape-function features mat()/vec() read
   constexpr int D2 = DIM * DIM;
   constexpr int NF = SECOND ? 1 + DIM + D2 : 1 + DIM;
-  constexpr int NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;       // features kept in LDS
+  constexpr int NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;       // features of a basis function
+  constexpr unsigned PM = phi_mask_of<Form>::v & ((1u << NFS) - 1u);   // those kept in LDS: feature f lives in slot PS(f)
+  static_assert(PM & 1u, "the value feature is always kept");
+#define PS(f) fm_phi_slot(PM, (f))
+#define PHAS(f) (((PM >> (f)) & 1u) != 0)
   constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
   static_assert(NW == 4 || (NW == 8 && TA == 4), "wave layout");
   constexpr int NTA = (TA == 4) ? 16 / NW : 1;                 // tiles per wave and (i,j) block
@@ -584,7 +595,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         for (int f = 0; f < NFS; ++f) o[f] = 0;
       }
 #pragma unroll
-      for (int f = 0; f < NFS; ++f) phi[(f * QC + ql) * NEP + a] = o[f];
+      for (int f = 0; f < NFS; ++f) if (PHAS(f)) phi[(PS(f) * QC + ql) * NEP + a] = o[f];
     }
     __syncthreads();
 
@@ -605,12 +616,12 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
             const double f0 = phi[(0 * QC + ql) * NEP + a];
             u += f0 * Ua;
             if (useV) ut += f0 * Ve[a * DOF + c];
-            if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) g[i] += phi[((1 + i) * QC + ql) * NEP + a] * Ua;
-            if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += phi[((1 + DIM + i) * QC + ql) * NEP + a] * Ua;
+            if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) if (PHAS(1 + i)) g[i] += phi[(PS(1 + i) * QC + ql) * NEP + a] * Ua;
+            if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) if (PHAS(1 + DIM + i)) h[i] += phi[(PS(1 + DIM + i) * QC + ql) * NEP + a] * Ua;
           }
           u = group_sum(u, np3); ut = group_sum(ut, np3);
-          if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) g[i] = group_sum(g[i], np3);
-          if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] = group_sum(h[i], np3);
+          if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) if (PHAS(1 + i)) g[i] = group_sum(g[i], np3);
+          if (SECOND_S && (Form::NEED & NEED_HU) && (need & NEED_HU)) for (int i = 0; i < D2; ++i) if (PHAS(1 + DIM + i)) h[i] = group_sum(h[i], np3);
           if (valid && part == 0) {
             fu[idx] = u; fut[idx] = ut;
             if ((Form::NEED & NEED_GU) && (need & NEED_GU)) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];   // regions exist only when needed
@@ -624,7 +635,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       for (int idx = tid; idx < QC * DOF * NFS; idx += nthr) {
         const int f = idx % NFS, j = (idx / NFS) % DOF, ql = idx / (NFS * DOF);
         double sm = 0;
-        for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) sm += fixval[b * DOF + j] * phi[(f * QC + ql) * NEP + b];
+        const int fs = __popc(PM & ((1u << f) - 1u));
+        if ((PM >> f) & 1u) for (int b = 0; b < NE; ++b) if (fixflag[b * DOF + j]) sm += fixval[b * DOF + j] * phi[(fs * QC + ql) * NEP + b];
         lift[idx] = sm;
       }
     }
@@ -649,14 +661,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const double jw = JW[q];
         double nb[NFS];
 #pragma unroll
-        for (int g = 0; g < NFS; ++g) nb[g] = phi[(g * QC + ql) * NEP + col];
+        for (int g = 0; g < NFS; ++g) nb[g] = PHAS(g) ? phi[(PS(g) * QC + ql) * NEP + col] : 0.0;
         if constexpr (GRAM) {
 #pragma unroll
           for (int f = 0; f < NFS; ++f) {
             if (!((PACC >> (f * 8)) & 0xffull)) continue;
             double A[NTA];
 #pragma unroll
-            for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)];
+            for (int t = 0; t < NTA; ++t) A[t] = PHAS(f) ? phi[(PS(f) * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)] : 0.0;
 #pragma unroll
             for (int g = 0; g < NFS; ++g) {
               if (!((PACC >> (f * 8 + g)) & 1ull)) continue;
@@ -678,7 +690,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           else Form::mat(p, ef, nb, T);
           double A[NTA];
 #pragma unroll
-          for (int t = 0; t < NTA; ++t) A[t] = phi[(f * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)];
+          for (int t = 0; t < NTA; ++t) A[t] = PHAS(f) ? phi[(PS(f) * QC + ql) * NEP + rslot(ta0 + t) * 16 + (lane & 15)] : 0.0;
 #pragma unroll
           for (int i = 0; i < DOFI; ++i)
 #pragma unroll
@@ -716,7 +728,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const PtView p = point(qc0 + ql, ql);
         double Na[NFS];
 #pragma unroll
-        for (int f = 0; f < NFS; ++f) Na[f] = phi[(f * QC + ql) * NEP + a];
+        for (int f = 0; f < NFS; ++f) Na[f] = PHAS(f) ? phi[(PS(f) * QC + ql) * NEP + a] : 0.0;
         double R[DOF];
         if constexpr (HASB) { if (bpass) Form::bvec(p, Na, R); else Form::vec(p, Na, R); }
         else Form::vec(p, Na, R);
@@ -962,6 +974,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   }   // walk
   if (stamp) out.dbg[31] = nst;
 #undef FM_STAMP
+#undef PS
+#undef PHAS
 }
 
 }  // namespace igx
