@@ -270,6 +270,10 @@ static int ensure_device(IGX g) {
       }
       for (int a = 0; a < na; ++a) for (int k = 0; k < NDER; ++k) bnd[((size_t)sd * na + a) * NDER + k] = bv[(size_t)a * 5 + k];
     }
+    {   // the element kernels take rowmap in closed form (AxisDev::rwrap): i, or i - nnp past the wrap of a rank-local periodic axis
+      const int rw = L.alias ? s.axis[d].nnp : 0x7fffffff;
+      for (int i = 0; i < L.gwidth; ++i) if (L.rowmap[i] != (i < rw ? i : i - rw)) return fail(IGX_ERR_PLIB, "row map of an axis is not of the closed form the kernels assume");
+    }
     if (B.bnd.upload(bnd) || B.tab.upload(tab) || B.w.upload(w) || B.J.upload(J) || B.pt.upload(pt) || B.off.upload(off) || B.rowmap.upload(L.rowmap) ||
         B.rcnt.upload(L.rcnt) || B.P.upload(L.P) || B.rcol.upload(L.rcol) || B.prefix.upload(prefix))
       return fail(IGX_ERR_MEM, "device allocation of axis tables failed");
@@ -298,7 +302,7 @@ static SpaceDev make_spacedev(IGX g) {
     A.tab = B.tab.as<double>(); A.w = B.w.as<double>(); A.J = B.J.as<double>(); A.pt = B.pt.as<double>();
     A.bnd = B.bnd.as<double>();
     if (d < s.dim && !s.axis[d].U.empty() && !s.axis[d].span.empty()) { const Axis &ax = s.axis[d]; A.bndpt[0] = ax.U[ax.span[0]]; A.bndpt[1] = ax.U[ax.span[ax.nel - 1] + 1]; }
-    A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
+    A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rwrap = L.alias ? s.axis[d].nnp : 0x7fffffff; A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
     A.prefix = B.prefix.as<int64_t>(); A.tot = 0; for (int r = 0; r < L.nrow; ++r) A.tot += L.rcnt[r];
   }
   S.X = s.nsd ? g->X.as<double>() : nullptr; S.W = s.rational ? g->W.as<double>() : nullptr;

@@ -323,13 +323,22 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const int a0 = a012[0], a1 = a012[1], a2 = a012[2];
   const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
   const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
-  int r0 = 0, r1 = 0, r2 = 0; double xg[DIM], wg = 1;
+  // rows in closed form (no dependent load): what hangs on the row index joins the same round trip
+  const int r0 = i0 < S.ax[0].rwrap ? i0 : i0 - S.ax[0].rwrap, r1 = i1 < S.ax[1].rwrap ? i1 : i1 - S.ax[1].rwrap, r2 = i2 < S.ax[2].rwrap ? i2 : i2 - S.ax[2].rwrap;
+  const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
+  double xg[DIM], wg = 1, Uv[DOF], Vv[DOF];
+  int c0r = 0, c1r = 0, c2r = 0; long long pre0 = 0, pre1 = 0, pre2 = 0;
 #pragma unroll
   for (int c = 0; c < DIM; ++c) xg[c] = 0;
+#pragma unroll
+  for (int c = 0; c < DOF; ++c) { Uv[c] = 0; Vv[c] = 0; }
   if (isa) {
-    r0 = S.ax[0].rowmap[i0]; r1 = S.ax[1].rowmap[i1]; r2 = S.ax[2].rowmap[i2];
     if (geo) for (int c = 0; c < DIM; ++c) xg[c] = S.X[g * DIM + c];
     if (rat) wg = S.W[g];
+    c0r = S.ax[0].rcnt[r0]; c1r = S.ax[1].rcnt[r1];
+    if (HASM) { c2r = S.ax[2].rcnt[r2]; pre0 = S.ax[0].prefix[r0]; pre1 = S.ax[1].prefix[r1]; pre2 = S.ax[2].prefix[r2]; }
+    if (useU) for (int c = 0; c < DOF; ++c) Uv[c] = out.U[row * DOF + c];
+    if (useV) for (int c = 0; c < DOF; ++c) Vv[c] = out.V[row * DOF + c];
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -338,19 +347,17 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     if (tid < na[d] * na[d]) { const int ad = tid / na[d], bd = tid - ad * na[d]; pax[d * 64 + ad * 8 + bd] = pv[d]; }
   }
   FM_STAMP();
-  // Stage B: what depends on the row indices
+  // Stage B: the row tables and the closure values into LDS, BC flags
   if (isa) {
-    const size_t row = (size_t)r0 + (size_t)nr0 * ((size_t)r1 + (size_t)nr1 * (size_t)r2);
     rowid[a] = (long long)row;
-    const int c0r = S.ax[0].rcnt[r0], c1r = S.ax[1].rcnt[r1];
     // browptr[row] in closed form from the per-axis prefix tables (k_browptr): small, cache-resident tables instead of a
     // dependent load from the 8-byte-per-row array in HBM
-    if (HASM) rowbase[a] = S.ax[2].prefix[r2] * S.ax[1].tot * S.ax[0].tot + (long long)S.ax[2].rcnt[r2] * (S.ax[1].prefix[r1] * S.ax[0].tot + (long long)c1r * S.ax[0].prefix[r0]);
+    if (HASM) rowbase[a] = pre2 * S.ax[1].tot * S.ax[0].tot + (long long)c2r * (pre1 * S.ax[0].tot + (long long)c1r * pre0);
     cc[a] = c0r; cc[NE + a] = c1r;
     if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = xg[c];
     if (rat) gW[a] = wg;
-    if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
-    if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
+    if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = Uv[c];
+    if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = Vv[c];
     const int aa[3] = {a0, a1, a2};
     for (int c = 0; c < DOF; ++c) { fixflag[a * DOF + c] = 0; fixval[a * DOF + c] = 0; flux[a * DOF + c] = 0; }
     if (op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) {   // IGAElementBuildFix (src/petigaelem.c:1214-1283); IGAComputeScalar reads U as it is

@@ -134,6 +134,7 @@ struct AxisDev {
   double bndpt[2];
   const int *off;      // [nel]  ghost-local index of the element's first basis function
   const int *rowmap;   // [gwidth]
+  int rwrap;           // rowmap in closed form: rowmap[i] = i < rwrap ? i : i - rwrap (a periodic axis wrapped inside the rank: nnp)
   const int *rcnt;     // [nrow]
   const int *P;        // [gwidth][2p+1]
   const int64_t *prefix;  // [nrow+1] exclusive prefix sums of rcnt
