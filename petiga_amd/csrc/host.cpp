@@ -405,7 +405,12 @@ int space_layout(Space &s, std::string &err) {
     const int p = ax.p, nnp = ax.nnp, W = 2 * p + 1;
     L.p = p; L.gstart = s.node_gstart[d]; L.gwidth = s.node_gwidth[d];
     L.alias = (ax.periodic && s.proc_sizes[d] == 1) ? 1 : 0;
-    if (ax.periodic && nnp < W) { err = "periodic axis needs at least 2p+1 basis functions"; return IGX_ERR_SUP; }
+    // A periodic axis with fewer than 2p+1 basis functions: the stencil of a row wraps onto itself and the reference's Mat adds
+    // the duplicate columns (ghost indices through the LGMap, src/petigamat.c:243-267).  Held by one rank the row keeps its
+    // distinct columns and P sends every duplicate to the same position; the elements of such an axis get one colour each
+    // (below).  Still refused: fewer than p+1 functions (an element's own basis functions would alias each other) and the
+    // axis split over ranks (a rank could not even hold its ghost layer, exchange_supported()).
+    if (ax.periodic && nnp < (L.alias ? p + 1 : W)) { err = L.alias ? "periodic axis needs at least p+1 basis functions" : "periodic axis split over ranks needs at least 2p+1 basis functions"; return IGX_ERR_SUP; }
     auto wrapn = [&](int i) { int r = i % nnp; return r < 0 ? r + nnp : r; };
     auto st = [&](int I, int &f, int &l) {   // stencil of the (possibly unwrapped) node I, unwrapped
       if (!ax.periodic) { stencil(ax, I, &f, &l); return; }
@@ -437,6 +442,7 @@ int space_layout(Space &s, std::string &err) {
       for (int Jn = f; Jn <= l; ++Jn) cols.push_back(L.alias ? wrapn(Jn) : Jn - L.cstart);
       std::vector<int> sorted = cols;
       std::sort(sorted.begin(), sorted.end());
+      sorted.erase(std::unique(sorted.begin(), sorted.end()), sorted.end());
       L.rcnt[r] = (int)sorted.size();
       for (size_t k = 0; k < sorted.size(); ++k) L.rcol[(size_t)r * W + k] = sorted[k];
       for (int dlt = 0; dlt < W; ++dlt) {
