@@ -312,6 +312,12 @@ int IGXVecCopyToGhosted(IGXVec v,double *array,int on_device);
  * adapter can use it as a MatNorm-free sanity check.  Fixed summation order (bitwise repeatable). */
 int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
 
+/* Compile-only check of a run-time form (no GPU needed): IGXSetFormSource compiles the point-form kernel; this compiles the
+ * matrix-core kernel the drivers would launch for the degrees set so far (dim >= 2, (p+1)^dim <= 64), for the matrix drivers
+ * (with_matrix != 0) or the vector-only ones.  gram != 0 when the struct declares MAT_PAIR_MASK (it decides the wave layout at
+ * dof = 4; on a GPU the flag is read from the compiled module).  Returns 0 or IGX_ERR_USER with the compiler's log. */
+int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
+
 /* Shader clock under load.  With IGX_CLOCK_PROBE=1 in the environment at IGXCreate, the first and the last workgroup of every
  * pencil-kernel launch add their s_memtime ticks and the ticks of the constant 100 MHz s_memrealtime counter over their walk to
  * two sums; this returns the ratio (MHz) and the elements those wavefronts walked since the previous call, and clears the sums.  The MFMA roofline in bench.py is quoted against the

@@ -477,12 +477,8 @@ static void launch_feature_passes(IGX g, const SpaceDev &S, const ParamsDev &prm
 // executed v_mfma_f64_16x16x4 flops per element of the feature kernel's matrix phase (roofline accounting)
 template <class Form, int TA>
 static double feature_mfma_flop(int nq_padded) {
-  constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
-  constexpr int DOF = Form::DOF, NFS = (shape_order_of<Form>::v >= 2) ? 13 : 4;
-  int per_kstep = 0;
-  if (PAIRS) per_kstep = fm_popcount(PAIRS);
-  else for (int f = 0; f < NFS; ++f) { if (!((mat_test_mask_of<Form>::v >> f) & 1u)) continue; for (int i = 0; i < DOF; ++i) for (int j = 0; j < DOF; ++j) if ((fm_block_mask<Form>(i, j) >> f) & 1u) per_kstep++; }
-  return 2048.0 * per_kstep * TA * TA * (nq_padded / 4);
+  constexpr int NFS = (shape_order_of<Form>::v >= 2) ? 13 : 4;
+  return 2048.0 * fm_mfma_per_kstep<Form>(NFS) * TA * TA * (nq_padded / 4);
 }
 
 // Pencil mode of the feature kernel (combine before write along axis 0): 4x4x4 basis functions, one new node layer per element
@@ -748,8 +744,10 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
   cv.nrm = take(NQ * DIM);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
-  const size_t lds_limit = 160 * 1024 - 512;
-  bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;
+  // Phi in LDS up to 64 KiB per workgroup, in an HBM slice beyond: a 131 KiB Phi (p = 3) in LDS leaves one workgroup per CU and
+  // measured slower than the HBM slice with two (Poisson p=3 48^3: 0.91 vs 1.71 M elements/s, Elasticity 0.80 vs 1.28)
+  const size_t lds_limit = 160 * 1024 - 512, phi_limit = 64 * 1024;
+  bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= phi_limit;
   if (phi_in_lds) cv.phi = take((int)phi_doubles); else cv.phi = -1;
   cv.total = pos;
   const size_t lds_bytes = (size_t)pos * sizeof(double);

@@ -149,6 +149,18 @@ __device__ __forceinline__ double group_sum(double v, int np) {
 
 // TA: tiles per side of an (i,j) block (1, 2 or 4).  Row fields [I0, I0+DOFI) are formed by this launch.
 
+// executed v_mfma_f64_16x16x4 instructions per k-step and tile of the matrix phase (roofline accounting of the launchers)
+template <class Form> constexpr int fm_mfma_per_kstep(int nfs) {
+  const unsigned long long pairs = mat_pair_mask_of<Form>::v;
+  if (pairs) return fm_popcount(pairs);
+  int n = 0;
+  for (int f = 0; f < nfs; ++f) {
+    if (!((mat_test_mask_of<Form>::v >> f) & 1u)) continue;
+    for (int i = 0; i < Form::DOF; ++i) for (int j = 0; j < Form::DOF; ++j) if ((fm_block_mask<Form>(i, j) >> f) & 1u) n++;
+  }
+  return n;
+}
+
 // Waves per SIMD a 4-wave kernel is compiled for (= workgroups per CU it is sized for): the tabulation phases are latency
 // bound, so more resident workgroups win as long as the accumulators leave registers to work with
 // (CahnHilliard p=2 tangent: 12.8 / 17.6 / 19.7 / 21.6 M elements/s at 1 / 2 / 3 / 4; NS-VMS p=2 with 16 tiles loses at 4).

@@ -53,31 +53,43 @@ static int load_hiprtc(std::string &err) {
 
 }  // namespace
 
+// feature_assemble<UserForm, dim, TA, NW, I0, DOFI, HASM> for one wave layout: one function per group of row fields
+struct RtcFeature {
+  std::vector<char> code;
+  std::vector<std::string> lowered;
+  hipModule_t module = nullptr; std::vector<hipFunction_t> func;
+  int meta[4] = {0, 0, 0, 0};          // workgroups per CU the kernel is compiled for, features kept in LDS, executed MFMAs per k-step, 0
+  ~RtcFeature() { if (module) (void)hipModuleUnload(module); }
+};
+
 // one compiled user form for one dimension: code object + what the host-side launcher must know about the struct
 struct RtcForm {
   std::string name, source, lowered;
   int dim = 0;
   std::vector<char> code;
-  int meta[4] = {0, 0, 0, 0};          // DOF, ORDER, NEED, NSCALAR (read from the module)
+  int meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch (read from the module)
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
+  std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
-static int rtc_compile(IGX g, const std::string &source, const std::string &name, int dim, std::shared_ptr<RtcForm> &out) {
+// compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
+static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
+                     std::vector<char> &code, std::vector<std::string> &lowered) {
   std::string e; if (int rc = load_hiprtc(e)) return fail(rc, e);
   HiprtcApi &a = hiprtc_api();
   std::string src;
-  src.reserve(source.size() + 200000);
+  src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
   src += kRtcSrc_igx; src += "\n"; src += kRtcSrc_forms; src += "\n"; src += kRtcSrc_generic; src += "\n";
+  if (with_feature) { src += kRtcSrc_feature; src += "\n"; }
   src += "using namespace igx;\n#line 1 \"user_form.hip\"\n";
   src += source;
-  src += "\n// what the host-side launcher reads back\n__device__ int igx_user_meta[4] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name + ">::v};\n";
-  const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
-  src += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
+  src += "\n";
+  src += tail;
   void *prog = nullptr;
   if (a.Create(&prog, src.c_str(), "igx_user_form.hip", 0, nullptr, nullptr) != 0) return fail(IGX_ERR_LIB, "hiprtcCreateProgram failed");
-  (void)a.AddName(prog, expr.c_str());
+  for (const std::string &x : exprs) (void)a.AddName(prog, x.c_str());
   const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
   const int rc = a.Compile(prog, 4, opts);
   if (rc != 0) {
@@ -85,12 +97,26 @@ static int rtc_compile(IGX g, const std::string &source, const std::string &name
     (void)a.Destroy(&prog);
     return fail(IGX_ERR_USER, "the form source does not compile:\n" + log);
   }
-  std::shared_ptr<RtcForm> f(new RtcForm());
-  const char *low = nullptr;
-  if (a.Lowered(prog, expr.c_str(), &low) != 0 || !low) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetLoweredName failed"); }
-  f->lowered = low;
-  size_t cs = 0; (void)a.CodeSize(prog, &cs); f->code.resize(cs); (void)a.Code(prog, f->code.data());
+  lowered.clear();
+  for (const std::string &x : exprs) {
+    const char *low = nullptr;
+    if (a.Lowered(prog, x.c_str(), &low) != 0 || !low) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetLoweredName failed"); }
+    lowered.push_back(low);
+  }
+  size_t cs = 0; (void)a.CodeSize(prog, &cs); code.resize(cs); (void)a.Code(prog, code.data());
   (void)a.Destroy(&prog);
+  return 0;
+}
+
+static int rtc_compile(IGX g, const std::string &source, const std::string &name, int dim, std::shared_ptr<RtcForm> &out) {
+  const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
+  std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[8] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
+                     ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v};\n";
+  tail += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
+  std::shared_ptr<RtcForm> f(new RtcForm());
+  std::vector<std::string> low;
+  if (int rc = rtc_build(source, true, tail, {expr}, f->code, low)) return rc;
+  f->lowered = low[0];
   f->name = name; f->source = source; f->dim = dim;
   out = f;
   return 0;
@@ -110,6 +136,148 @@ static int rtc_load(IGX g, RtcForm &f) {
 // the kernel arguments of generic_assemble, laid out as the kernarg segment is (natural alignment, in order)
 struct RtcArgs { SpaceDev S; ParamsDev prm; OutDev out; ColorRange cr; Carve cv; double *phi_global; size_t phi_stride; };
 
+
+// ---- the feature-GEMM kernel (feature_mfma.hpp) for a run-time form: launch_feature / launch_feature_ta / launch_feature_plan of
+// engine.hip with the form's constants read from the module.  Element mode only (no pencil walk), matrix / vector drivers.
+struct RtcFeatArgs { SpaceDev S; ParamsDev prm; OutDev out; ColorRange cr; FCarve cv; };
+
+// (DOF is passed in: it is read from the module on a GPU, and given by the caller for the compile-only check)
+static int rtc_feature_module(IGX g, RtcForm &F, int DIM, int DOF, int TA, int NW, int DOFI, bool HASM, bool load, std::shared_ptr<RtcFeature> &out) {
+  const int key = TA | (NW << 4) | (DOFI << 8) | ((HASM ? 1 : 0) << 12);
+  auto it = F.feature.find(key);
+  if (it != F.feature.end() && (it->second->module || !load)) { out = it->second; return 0; }
+  std::shared_ptr<RtcFeature> f(new RtcFeature());
+  std::vector<std::string> exprs;
+  const std::string common = F.name + ", " + std::to_string(DIM) + ", " + std::to_string(TA) + ", " + std::to_string(NW) + ", ";
+  std::string tail;
+  for (int I0 = 0; I0 < (HASM ? DOF : 1); I0 += DOFI) {
+    const std::string x = "igx::feature_assemble<" + common + std::to_string(I0) + ", " + std::to_string(DOFI) + ", " + (HASM ? "true" : "false") + ", false>";
+    exprs.push_back(x);
+    tail += "template __global__ void " + x + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::FCarve);\n";
+  }
+  const std::string nfs = "((igx::shape_order_of<" + F.name + ">::v >= 2) ? 1 + " + std::to_string(DIM) + " + " + std::to_string(DIM * DIM) + " : 1 + " + std::to_string(DIM) + ")";
+  tail += "__device__ int igx_feature_meta[4] = {igx::fm_min_waves<" + F.name + ", " + std::to_string(TA) + ", " + std::to_string(NW) + ", " + std::to_string(DOFI) + ", " + (HASM ? "true" : "false") +
+          ", false>(), igx::fm_popcount((unsigned long long)(igx::phi_mask_of<" + F.name + ">::v & ((1u << " + nfs + ") - 1u))), igx::fm_mfma_per_kstep<" + F.name + ">(" + nfs + "), 0};\n";
+  if (int rc = rtc_build(F.source, true, tail, exprs, f->code, f->lowered)) return rc;
+  if (!load) { F.feature[key] = f; out = f; return 0; }
+  HIPCK(hipModuleLoadData(&f->module, f->code.data()));
+  for (const std::string &l : f->lowered) { hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, f->module, l.c_str())); f->func.push_back(fn); }
+  hipDeviceptr_t p = nullptr; size_t n = 0;
+  HIPCK(hipModuleGetGlobal(&p, &n, f->module, "igx_feature_meta"));
+  if (n != sizeof(f->meta)) return fail(IGX_ERR_LIB, "unexpected igx_feature_meta size");
+  HIPCK(hipMemcpy(f->meta, p, sizeof(f->meta), hipMemcpyDeviceToHost));
+  F.feature[key] = f; out = f;
+  return 0;
+}
+
+// wave layouts of launch_feature_ta (engine.hip): 8 waves at 4x4 tiles, except scalar matrix forms (4 waves with 4 tiles each);
+// dof 4 at 4x4 tiles takes two launches of two row fields
+static void rtc_feature_layout(int NE, int DOF, bool GRAM, bool HASM, int &TA, int &NW, int &DOFI) {
+  TA = NE <= 16 ? 1 : (NE <= 32 ? 2 : 4);
+  NW = (TA == 4) ? 8 : 4; DOFI = DOF;
+  if (HASM) { if (TA == 4 && DOF == 4 && !GRAM) DOFI = 2; if (TA == 4 && DOF == 1) NW = 4; }
+}
+
+static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done) {
+  done = false;
+  const Space &s = g->s;
+  const int DIM = s.dim, DOF = F.meta[0];
+  if (DIM < 2 || DOF > 4) return 0;
+  int nq[3], na[3]; int NQ = 1, NE = 1;
+  for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
+  if (NE > 64) return 0;
+  const bool SECOND = F.meta[1] >= 2, SECOND_S = F.meta[4] >= 2, GRAM = F.meta[6] != 0;
+  if (GRAM && DOF * DOF > 16) return 0;
+  const bool HASM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+  int TA, NW, DOFI; rtc_feature_layout(NE, DOF, GRAM, HASM, TA, NW, DOFI);
+  std::shared_ptr<RtcFeature> K;
+  if (int rc = rtc_feature_module(g, F, DIM, DOF, TA, NW, DOFI, HASM, true, K)) return rc;
+  const int WGS = K->meta[0], NPS = K->meta[1];
+  const int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
+  const int NEP = 16 * TA, NQ4 = (NQ + 3) & ~3;
+  const bool vec_op = (out.op == OP_SYSTEM || out.op == OP_VECTOR || out.op == OP_FUNCTION || out.op == OP_IFUNCTION);
+  const unsigned need = vec_op ? (unsigned)F.meta[2] : (unsigned)F.meta[5];
+  const bool fields = (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  // LDS budget as in launch_feature_plan (a module kernel takes more than 64 KiB of dynamic LDS like any other: measured)
+  const size_t lds_limit = 160 * 1024 - 512;
+  const size_t lds_auto = s.env.feature_lds_kb > 0 ? (size_t)s.env.feature_lds_kb * 1024
+                        : ((NW == 4) ? (size_t)(160 * 1024 / std::max(WGS, 1) - 1024) : ((HASM && TA == 4 && DOF == 1) ? (size_t)78 * 1024 : lds_limit));
+  FCarve cv; size_t lds_bytes = 0; bool fits = false;
+  for (int pass = 0; pass < 2 && !fits; ++pass) {
+    const size_t cap = pass == 0 ? lds_auto : lds_limit;
+    for (int nchunk = 1; nchunk <= NQ4 / 4 && !fits; ++nchunk) {
+      const int QC = (((NQ4 + nchunk - 1) / nchunk) + 3) & ~3, NQP = QC * nchunk;
+      int pos = 0;
+      auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };
+      memset(&cv, 0, sizeof(cv));
+      for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(2 * nq[d]); }
+      cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
+      cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
+      cv.JW = take(NQP); cv.xq = take(NQP * DIM); cv.E1 = take(s.nsd ? NQP * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQP * DIM * D2 : 0);
+      cv.W0 = take(s.rational ? NQP : 0); cv.W1 = take(s.rational ? NQP * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQP * D2 : 0);
+      cv.G = take(((unsigned)F.meta[2] & NEED_G) ? NQP * D2 : 0);
+      cv.u = take(fields ? QC * DOF : 0); cv.ut = take(fields ? QC * DOF : 0);
+      cv.gu = take((need & NEED_GU) ? QC * DOF * DIM : 0);
+      cv.hu = take((need & NEED_HU) ? ((SECOND && !SECOND_S) ? NQP : QC) * DOF * D2 : 0);
+      cv.hpart = 0;
+      cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
+      cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
+      const int sf_need = (s.nsd || s.rational) ? (DIM + 1) * ((SECOND ? 3 : 2) * nq[0] * na[1] * na[2] + (SECOND ? 6 : 3) * nq[0] * nq[1] * na[2] + (SECOND ? 10 : 4) * NQ) : 0;
+      cv.boff = 0;
+      cv.phi = take(std::max(NPS * QC * NEP, sf_need));
+      cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
+      lds_bytes = (size_t)pos * sizeof(double);
+      if (lds_bytes <= cap) fits = true;
+    }
+  }
+  if (!fits) return 0;   // the generic kernel takes it
+  RtcFeatArgs args; memset(&args, 0, sizeof(args));
+  args.S = S; args.out = out; args.cv = cv;
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) args.prm.v[i] = s.params[i];
+  bool first_touch = HASM && !s.env.no_first_touch;
+  for (int d = 0; d < DIM && first_touch; ++d) first_touch = axis_first_touch_ok(s, d);
+  args.out.first_touch = first_touch ? 1 : 0;
+  if (HASM) {
+    if (!first_touch) { if (g->zero_matrix) g->zero_matrix(); }
+    else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, g->stream);
+  }
+  int launches = 0;
+  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  if (g->timing && g->dom.ev0 && g->dom.launches == 0) (void)hipEventRecord(g->dom.ev0, g->stream);
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+      int firstel = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = firstel; cr.step[d] = L.p + 1; cr.count[d] = count;
+    }
+    if (empty) continue;
+    const size_t nblocks = (size_t)cr.count[0] * cr.count[1] * cr.count[2];
+    args.cr = cr;
+    for (hipFunction_t fn : K->func) {
+      size_t asz = sizeof(args);
+      void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+      HIPCK(hipModuleLaunchKernel(fn, (unsigned)nblocks, 1, 1, (unsigned)(64 * NW), 1, 1, (unsigned)lds_bytes, g->stream, nullptr, cfg));
+      launches++;
+    }
+  }
+  g->last_launches = launches;
+  if (g->dom.launches == 0) {
+    if (g->timing && g->dom.ev1) (void)hipEventRecord(g->dom.ev1, g->stream);
+    g->dom.name = "feature_assemble<element, hiprtc>"; g->dom.launches = launches;
+    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * (HASM ? (DOF / DOFI) : 1);
+    g->dom.flop_per_element = HASM ? 2048.0 * K->meta[2] * TA * TA * (cv.QC * cv.nchunk / 4) * DOFI / DOF : 0.0;
+  }
+  if (HASM) g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,mfma_f64_16x16x4,tiles=" + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
+                             ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+  else g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,vector only,waves=" + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+  done = true;
+  return 0;
+}
+
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
@@ -124,6 +292,12 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "run-time forms are matrix / vector forms (no scalar functionals)");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes are not available for run-time forms");
+  if (g->kernel_choice != 1) {   // the dense contraction on the matrix cores when the case is covered (as launch_generic does)
+    bool done = false;
+    if (int rc = launch_feature_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
+  }
   const int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   if (g->zero_matrix) g->zero_matrix();
   const bool fields = (NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
@@ -142,7 +316,7 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.lift = take(out.op == OP_SYSTEM ? NQ * DOF * NF : 0);
   cv.nrm = take(NQ * DIM);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
-  const size_t lds_limit = 64 * 1024;      // module kernels keep to the default dynamic-LDS limit; Phi spills to HBM beyond it
+  const size_t lds_limit = 64 * 1024;   // as launch_generic: beyond it Phi goes to an HBM slice and two workgroups share a CU
   const bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;
   if (phi_in_lds) cv.phi = take((int)phi_doubles); else cv.phi = -1;
   cv.total = pos;
@@ -199,4 +373,20 @@ extern "C" int IGXSetFormSource(IGX g, const char *source, const char *struct_na
   g->rtc = f; g->rtc_source = source; g->rtc_name = struct_name;
   g->s.form = IGX_FORM_SOURCE; g->s.params.assign(params ? params : nullptr, params ? params + nparams : nullptr);
   return 0;
+}
+
+// Compile-only check of a run-time form against the kernels the drivers would launch for the axes set so far (no GPU needed):
+// the point-form kernel was compiled by IGXSetFormSource; this adds the matrix-core kernel (feature_mfma.hpp) in the wave
+// layout of the current degree, for the matrix drivers (with_matrix != 0) or the vector-only ones.
+extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
+  NEEDIGA(g);
+  if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
+  const Space &s = g->s;
+  if (s.dim < 2) return 0;   // dim 1: the point-form kernel only
+  int NE = 1;
+  for (int d = 0; d < s.dim; ++d) { if (s.axis[d].p < 1) return fail(IGX_ERR_ARG_WRONGSTATE, "set the axes (degrees) first"); NE *= s.axis[d].p + 1; }
+  if (NE > 64) return 0;
+  int TA, NW, DOFI; rtc_feature_layout(NE, s.dof, gram != 0, with_matrix != 0, TA, NW, DOFI);
+  std::shared_ptr<RtcFeature> K;
+  return rtc_feature_module(g, *g->rtc, s.dim, s.dof, TA, NW, DOFI, with_matrix != 0, false, K);
 }

@@ -39,11 +39,46 @@ struct UserBratu {
 """
 
 
+USER_ELASTICITY = r"""
+// demo/Elasticity3D.c:13-46 given as source (with its :37 quirk); params = {lambda, mu}.  GRAM = 1 adds the declaration that the
+// coefficients are point-independent (MAT_PAIR_MASK): the matrix cores then accumulate the feature Gram matrices only.
+template <int GRAM> struct UserElasticity;
+template <> struct UserElasticity<0> {
+  static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const double l = p.prm[0], m = p.prm[1];
+    const double ax = Na[1], ay = Na[2], az = Na[3], bx = Nb[1], by = Nb[2], bz = Nb[3];
+    T[0] = ax * bx * (l + 2 * m) + m * (ay * by + az * bz); T[1] = ax * by * l + ay * bx * m; T[2] = ax * bz * l + az * bx * m;
+    T[3] = ax * by * m + ay * bx * l; T[4] = ay * by * (l + 2 * m) + m * (az * bz + ax * bx * m); T[5] = ay * bz * l + az * by * m;
+    T[6] = ax * bz * m + az * bx * l; T[7] = ay * bz * m + az * by * l; T[8] = m * (ax * bx + ay * by) + az * bz * (l + 2 * m);
+  }
+  static __device__ void vec(const PtView &, const double *, double *R) { R[0] = 0; R[1] = 0; R[2] = 0; }
+};
+template <> struct UserElasticity<1> : UserElasticity<0> {
+  static constexpr unsigned MAT_TEST_MASK = 0xEu;
+  static constexpr unsigned long long MAT_PAIR_MASK = (0xEull << 8) | (0xEull << 16) | (0xEull << 24);
+};
+"""
+
+
 @pytest.mark.parametrize("dim", [1, 2, 3])
 def test_user_form_compiles_without_a_gpu(dim):
     import petiga_amd as P
     g = P.IGX(dim, 1)
     g.set_form_source(ADVECTION_DIFFUSION, "AdvDiff<%d>" % dim, (1.0, 0.5, 0.25))
+
+
+@pytest.mark.parametrize("dim,p,dof,src,name,gram", [(2, 2, 1, ADVECTION_DIFFUSION, "AdvDiff<2>", False), (3, 3, 1, ADVECTION_DIFFUSION, "AdvDiff<3>", False),
+                                                    (3, 2, 3, USER_ELASTICITY, "UserElasticity<0>", False), (3, 3, 3, USER_ELASTICITY, "UserElasticity<1>", True)])
+def test_user_form_compiles_for_the_matrix_core_kernel_without_a_gpu(dim, p, dof, src, name, gram):
+    """IGXCheckFormSource: the feature_assemble instantiations the drivers would launch (matrix and vector-only)."""
+    import petiga_amd as P
+    g = P.IGX(dim, dof)
+    for i in range(dim):
+        g.axis_uniform(i, p, 4)
+    g.set_form_source(src, name, (1.0, 0.5, 0.25))
+    g.check_form_source(True, gram)
+    g.check_form_source(False, gram)
 
 
 def test_compile_errors_come_back_with_the_log():
@@ -57,9 +92,11 @@ def test_compile_errors_come_back_with_the_log():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 9, False), (2, 2, 7, False), (2, 3, 5, True), (3, 2, 4, False), (3, 3, 3, True)])
-def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo):
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 9, False), (2, 2, 7, False), (2, 3, 5, True), (3, 2, 4, False), (3, 3, 3, True), (3, 1, 5, True)])
+def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo, kernel):
     orc, eng = make_pair(dim, 1, p, N)
+    eng.set_kernel(kernel)
     if geo:
         X, W = warped_geometry(orc, dim, seed=dim + 20, rational=True, amp=0.1)
         orc.set_geometry(X, W)
@@ -75,6 +112,8 @@ def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo):
     eng.compute_system(A, b)
     eng.synchronize()
     assert "hiprtc" in eng.kernel_name()
+    # the matrix-core kernel when it covers the case (dim >= 2, nen <= 64), the point-form kernel otherwise / on request
+    assert ("mfma" in eng.kernel_name()) == (kernel == 0 and dim >= 2)
     tol = 1e-11 if geo else 1e-12
     compare_mats(A, A_o, tol)
     assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
@@ -87,8 +126,39 @@ def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo):
 
 
 @pytest.mark.gpu
-def test_nonlinear_source_form_through_function_and_jacobian_drivers():
+@pytest.mark.parametrize("gram", [0, 1])
+@pytest.mark.parametrize("p,N,geo", [(2, (4, 3, 5), False), (3, (3, 4, 3), False), (3, (3, 3, 4), True)])
+def test_vector_valued_source_form_on_the_matrix_cores(p, N, geo, gram):
+    """dof = 3: all row fields in one launch; with MAT_PAIR_MASK the Gram path of the feature kernel."""
+    orc, eng = make_pair(3, 3, p, list(N))
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=31, rational=True, amp=0.1)
+        orc.set_geometry(X, W)
+        eng.set_geometry(X, W)
+    for g in (orc, eng):
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(0, 1, 0, 1.0)
+        g.set_boundary_value(2, 1, 1, -0.5)
+    eng.set_form_source(USER_ELASTICITY, "UserElasticity<%d>" % gram, (2.5, 0.7))
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "hiprtc,mfma" in eng.kernel_name()
+    A_o, b_o = orc.compute_system("orc_form_elasticity", O.ElasticityCtx(2.5, 0.7))
+    tol = 1e-11 if geo else 1e-12
+    compare_mats(A, A_o, tol)
+    assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
+    eng.compute_vector(b)                  # the vector-only instantiation of the same source
+    eng.synchronize()
+    assert "vector only" in eng.kernel_name() and np.abs(b.get()).max() == 0.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_nonlinear_source_form_through_function_and_jacobian_drivers(kernel):
     orc, eng = make_pair(2, 1, 2, 6)
+    eng.set_kernel(kernel)
     for g in (orc, eng):
         for d in range(2):
             for s in range(2):
