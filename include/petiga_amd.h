@@ -122,8 +122,17 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  *       static __device__ void vec(const PtView &p,const double *Na,double *R);                  // R[i]: F entries of a
  *     };
  * Na / Nb: [0] N, [1+i] dN/dx_i, [1+dim+i*dim+j] d2N/dx_i dx_j; p.prm[] = params (the callback's ctx); the integrand is
- * un-weighted and mat() must be linear in Nb, as every IGAFormSystem/Jacobian is.  Compile errors come back as
- * PETSC_ERR_USER with the compiler log in IGXGetLastError().  The seven drivers then work as with a built-in form. */
+ * un-weighted and mat() must be linear in Na and in Nb, as every IGAFormSystem/Jacobian is.  Compile errors come back as
+ * PETSC_ERR_USER with the compiler log in IGXGetLastError().  The seven drivers then work as with a built-in form: on the
+ * matrix cores (feature_assemble<MyForm,...>, compiled on first use for the wave layout of the degree, about half a second)
+ * for dim >= 2 and (p+1)^dim <= 64, on the point-form kernel otherwise or with IGXSetKernel(1).  Optional declarations that
+ * speed the matrix-core kernel up, all bit masks over the feature index of Na / Nb:
+ *       static constexpr unsigned MAT_TEST_MASK = ...;         // features of Na that mat() reads (others never enter the GEMM)
+ *       static constexpr unsigned PHI_MASK = ...;              // features anything reads (others are not tabulated at all)
+ *       static constexpr unsigned long long MAT_PAIR_MASK = ...; // bit 8f+g: mat() has a point-INDEPENDENT coefficient on
+ *                                                              // Na[f]*Nb[g] and nothing else: Gram matrices on the matrix cores
+ *       static constexpr unsigned MAT_NEED = ...;              // subset of NEED that mat() reads (matrix-only drivers skip the rest)
+ *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept */
 int IGXSetFormSource(IGX iga,const char *source,const char *struct_name,const double params[],int nparams);
 
 /* On-disk formats (PETSc binary, big-endian): the discretisation + NURBS control net written by IGAWrite / igakit,
