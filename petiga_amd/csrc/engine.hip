@@ -467,6 +467,15 @@ extern "C" int IGXGetDeviceInfo(char *buf, int len) {
 // one launch per group of DOFI row fields: I0 = 0, DOFI, 2*DOFI, ...
 template <class Form, int DIM, int TA, int NW, int DOFI, int I0, bool HASM, bool PENCIL = false>
 static void launch_feature_passes(IGX g, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, const ColorRange &cr, const FCarve &cv, size_t nblocks, size_t lds_bytes, bool first, int &launches) {
+  if constexpr (HASM && !PENCIL && I0 == 0 && DOFI < Form::DOF) {
+    if (g->s.env.fuse_groups) {   // all groups of row fields in one launch: the element is tabulated once (feature_mfma.hpp, FUSE)
+      auto fused = feature_assemble<Form, DIM, TA, NW, 0, DOFI, true, false, true>;
+      if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fused), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+      hipLaunchKernelGGL(fused, dim3((unsigned)nblocks), dim3(64 * NW), lds_bytes, g->stream, S, prm, out, cr, cv);
+      launches++;
+      return;
+    }
+  }
   auto kern = feature_assemble<Form, DIM, TA, NW, I0, DOFI, HASM, PENCIL>;
   if (first) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(64 * NW), lds_bytes, g->stream, S, prm, out, cr, cv);
@@ -651,11 +660,13 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   if (g->dom.launches == 0) {   // dominant kernel of this assembly, for bench.py's roofline block
     if (g->timing && g->dom.ev1) (void)hipEventRecord(g->dom.ev1, g->stream);
     g->dom.name = std::string("feature_assemble<") + (pencil ? "pencil" : "element") + ">"; g->dom.launches = launches;
-    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * (HASM ? (DOF / DOFI) : 1);
-    g->dom.flop_per_element = HASM ? feature_mfma_flop<Form, TA>(cv.QC * cv.nchunk) * DOFI / DOF : 0.0;
+    const bool fused = HASM && !pencil && DOFI < DOF && s.env.fuse_groups;   // one launch forms all groups of row fields of its elements
+    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * ((HASM && !fused) ? (DOF / DOFI) : 1);
+    g->dom.flop_per_element = HASM ? feature_mfma_flop<Form, TA>(cv.QC * cv.nchunk) * (fused ? DOF : DOFI) / DOF : 0.0;
   }
   if (HASM) g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
-                   ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + (pencil ? ",pencil walk axis 0" : "") + ")";
+                   ",rowfields/launch=" + char('0' + DOFI) + ((!pencil && DOFI < DOF && s.env.fuse_groups) ? std::string("x") + char('0' + DOF / DOFI) + " fused" : std::string()) +
+                   ",chunks=" + std::to_string(cv.nchunk) + (pencil ? ",pencil walk axis 0" : "") + ")";
   else g->last_kernel = std::string("feature_assemble(vector only,waves=") + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
   return 0;

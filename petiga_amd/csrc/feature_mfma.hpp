@@ -188,11 +188,15 @@ constexpr int fm_min_waves() {
 // fixed up (IGAElementFixSystem on the combined values: the diagonal of a fixed row is the number of walked elements that
 // hold the node), written and cleared -- 7/16 of the entries per element reach memory, contributions of the elements of a
 // pencil never meet in memory, and only pencils sharing axis-1/2 nodes conflict: 16 colours instead of 64.
-template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM, bool PENCIL = false>
+// FUSE (element mode, DOFI < DOF): the groups of row fields are formed one after the other inside ONE launch -- the tabulation of
+// the element (phases 0-4) is done once instead of once per group (NS-VMS p=3: two groups of two row fields).
+template <class Form, int DIM, int TA, int NW, int I0, int DOFI, bool HASM, bool PENCIL = false, bool FUSE = false>
 __global__ void __launch_bounds__(64 * NW, (fm_min_waves<Form, TA, NW, DOFI, HASM, PENCIL>()))
 feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv) {
   static_assert(!PENCIL || (TA == 4 && HASM && DIM == 3), "pencil mode: 4x4 tiles, matrix drivers, dim 3");
   constexpr int DOF = Form::DOF;
+  static_assert(!FUSE || (HASM && !PENCIL && I0 == 0 && DOF % DOFI == 0), "fused groups: element mode, matrix drivers, all groups");
+  constexpr int NPASS = FUSE ? DOF / DOFI : 1;
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
   constexpr bool SECOND_S = shape_order_of<Form>::v >= 2;      // order of the shape-function features mat()/vec() read
   constexpr int D2 = DIM * DIM;
@@ -600,11 +604,23 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool dolift = anyfix && op == OP_SYSTEM;
   int npv = pow2_floor(nthr / NE); if (npv > 16) npv = 16;
 
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {     // (fully unrolled: I0p is a constant in every copy)
+  const int I0p = I0 + pass * DOFI;              // first row field of this group
+  const bool retab = (pass == 0) || (cv.nchunk > 1);   // a later group finds Phi and the field values of a single chunk still in LDS
+  if (pass > 0) {
+#pragma unroll
+    for (int k = 0; k < NACC; ++k)
+#pragma unroll
+      for (int t = 0; t < NTA; ++t) acc[k][t] = (fm_d4_t){0, 0, 0, 0};
+    if (retab) __syncthreads();          // the last chunk's readers of the group before are done with phi
+  }
   for (int ch = 0; ch < cv.nchunk; ++ch) {
     const int qc0 = ch * QC;
     if (ch) __syncthreads();             // the previous chunk's readers are done with phi / the field arrays
 
     // ---- phase 2: Phi of this chunk, [f][ql][a] with zero padding (a >= nen, q >= nqp)
+    if (retab)
     for (int idx = tid; idx < QC * NEP; idx += nthr) {
       const int ql = idx / NEP, a = idx - ql * NEP, q = qc0 + ql;
       double o[NFS];
@@ -616,11 +632,11 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #pragma unroll
       for (int f = 0; f < NFS; ++f) if (PHAS(f)) phi[(PS(f) * QC + ql) * NEP + a] = o[f];
     }
-    __syncthreads();
+    if (retab) __syncthreads();
 
     FM_STAMP();
     // ---- phase 3: field values at the chunk's points (src/petigaval.F90:182-232); np3 lanes per (point, field)
-    if (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
+    if (retab && (need & (NEED_U | NEED_UT | NEED_GU | NEED_HU))) {
       {
         int np3 = pow2_floor(nthr / (QC * DOF)); if (np3 > 16) np3 = 16;
         const int istep = nthr / np3;
@@ -650,7 +666,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       }
     }
     // ---- phase 4: Dirichlet lifting features of the chunk: lift[ql][j][:] = sum_b fixed(b,j) v_bj Phi[q][b][:]
-    if (dolift && hasV) {
+    if (retab && dolift && hasV) {
       for (int idx = tid; idx < QC * DOF * NFS; idx += nthr) {
         const int f = idx % NFS, j = (idx / NFS) % DOF, ql = idx / (NFS * DOF);
         double sm = 0;
@@ -714,8 +730,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           for (int i = 0; i < DOFI; ++i)
 #pragma unroll
             for (int j = 0; j < DOF; ++j) {
-              if (!((fm_block_mask<Form>(I0 + i, j) >> f) & 1u) && !(HASB && bpass)) continue;   // structurally zero for this block
-              const double B = live ? T[(I0 + i) * DOF + j] * jw : 0.0;
+              if (!((fm_block_mask<Form>(I0p + i, j) >> f) & 1u) && !(HASB && bpass)) continue;   // structurally zero for this block
+              const double B = live ? T[(I0p + i) * DOF + j] * jw : 0.0;
 #pragma unroll
               for (int t = 0; t < NTA; ++t)
                 acc[i * DOF + j][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[t], B, acc[i * DOF + j][t], 0, 0, 0);
@@ -740,7 +756,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       __syncthreads();
       if (tid < NS) for (int ql = 0; ql < QC; ++ql) Facc[0] += lift[ql * NS + tid];
     }
-    if constexpr (NS == 0) if (hasV && tid < NE * npv) {
+    if constexpr (NS == 0) if (hasV && pass == 0 && tid < NE * npv) {
       const int a = tid / npv, part = tid & (npv - 1);
       const int qn = (qc0 + QC <= NQ) ? QC : (NQ - qc0 > 0 ? NQ - qc0 : 0);
       for (int ql = part; ql < qn; ql += npv) {
@@ -792,7 +808,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
         const int v0 = pax[0 * 64 + a0 * 8 + b0], v1 = pax[1 * 64 + a1 * 8 + b1], v2 = pax[2 * 64 + a2 * 8 + b2];
         const int P0 = v0 & 0x3fffffff, P1 = v1 & 0x3fffffff, P2 = v2 & 0x3fffffff;
         const size_t pos = (size_t)rowbase[as] + ((size_t)P2 * cc[NE + as] + P1) * cc[as] + P0;
-        dst[r] = out.val + pos * (DOF * DOF) + I0 * DOF;
+        dst[r] = out.val + pos * (DOF * DOF) + I0p * DOF;
         // the first colour to reach a block stores it (no MatZeroEntries, no read)
         const bool first = ((v0 & v1 & v2) >> 30) & 1;
         if (ok[r] && !first && !(kDebug && (out.debug & 16))) load_run<DOFI * DOF>(dst[r], v[r]);
@@ -831,7 +847,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           for (int j = 0; j < DOF; ++j) {
             double x;
             if constexpr (GRAM) x = kij[r][i * DOF + j]; else x = acc[i * DOF + j][t][rb + r];
-            if (anyfix && (fixflag[a * DOF + I0 + i] || fixflag[b * DOF + j])) x = (a == b && I0 + i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
+            if (anyfix && (fixflag[a * DOF + I0p + i] || fixflag[b * DOF + j])) x = (a == b && I0p + i == j && !bpass) ? 1.0 : 0.0;   // the unit diagonal comes from the interior pass only
             v[r][i * DOF + j] += x;
           }
         if (!(kDebug && (out.debug & 32))) store_run<DOFI * DOF>(dst[r], v[r]);
@@ -839,6 +855,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       }   // row-group batches
     }
   }
+  }   // groups of row fields (FUSE)
   FM_STAMP();
   if constexpr (NS > 0) { if (tid < NS) out.vec[(out.elem_base + blockIdx.x) * NS + tid] = Facc[0]; }
   if (hasV && tid < NE * npv) {   // IGAElementFixSystem / FixFunction on F_e, IGAElementAssembleVec

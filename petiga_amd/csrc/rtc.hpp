@@ -150,8 +150,9 @@ static int rtc_feature_module(IGX g, RtcForm &F, int DIM, int DOF, int TA, int N
   std::vector<std::string> exprs;
   const std::string common = F.name + ", " + std::to_string(DIM) + ", " + std::to_string(TA) + ", " + std::to_string(NW) + ", ";
   std::string tail;
-  for (int I0 = 0; I0 < (HASM ? DOF : 1); I0 += DOFI) {
-    const std::string x = "igx::feature_assemble<" + common + std::to_string(I0) + ", " + std::to_string(DOFI) + ", " + (HASM ? "true" : "false") + ", false>";
+  const bool fuse = HASM && DOFI < DOF;   // all groups of row fields in one launch (feature_mfma.hpp, FUSE)
+  for (int I0 = 0; I0 < ((HASM && !fuse) ? DOF : 1); I0 += DOFI) {
+    const std::string x = "igx::feature_assemble<" + common + std::to_string(I0) + ", " + std::to_string(DOFI) + ", " + (HASM ? "true" : "false") + ", false, " + (fuse ? "true" : "false") + ">";
     exprs.push_back(x);
     tail += "template __global__ void " + x + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::FCarve);\n";
   }
@@ -268,11 +269,11 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   if (g->dom.launches == 0) {
     if (g->timing && g->dom.ev1) (void)hipEventRecord(g->dom.ev1, g->stream);
     g->dom.name = "feature_assemble<element, hiprtc>"; g->dom.launches = launches;
-    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * (HASM ? (DOF / DOFI) : 1);
-    g->dom.flop_per_element = HASM ? 2048.0 * K->meta[2] * TA * TA * (cv.QC * cv.nchunk / 4) * DOFI / DOF : 0.0;
+    g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+    g->dom.flop_per_element = HASM ? 2048.0 * K->meta[2] * TA * TA * (cv.QC * cv.nchunk / 4) : 0.0;
   }
   if (HASM) g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,mfma_f64_16x16x4,tiles=" + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
-                             ",rowfields/launch=" + char('0' + DOFI) + ",chunks=" + std::to_string(cv.nchunk) + ")";
+                             ",rowfields/launch=" + char('0' + DOFI) + (DOFI < DOF ? std::string("x") + char('0' + DOF / DOFI) + " fused" : std::string()) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   else g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,vector only,waves=" + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
   return 0;
