@@ -132,7 +132,8 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  *       static constexpr unsigned long long MAT_PAIR_MASK = ...; // bit 8f+g: mat() has a point-INDEPENDENT coefficient on
  *                                                              // Na[f]*Nb[g] and nothing else: Gram matrices on the matrix cores
  *       static constexpr unsigned MAT_NEED = ...;              // subset of NEED that mat() reads (matrix-only drivers skip the rest)
- *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept */
+ *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
+ *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only */
 int IGXSetFormSource(IGX iga,const char *source,const char *struct_name,const double params[],int nparams);
 
 /* On-disk formats (PETSc binary, big-endian): the discretisation + NURBS control net written by IGAWrite / igakit,

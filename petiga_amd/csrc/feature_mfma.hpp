@@ -39,6 +39,10 @@ template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> 
 template <class F, class = void> struct phi_mask_of { static constexpr unsigned v = 0xffffffffu; };
 template <class F> struct phi_mask_of<F, decltype((void)F::PHI_MASK)> { static constexpr unsigned v = F::PHI_MASK; };
 
+// VEC_ZERO: vec() returns zeros (Elasticity3D's F = 0): the vector phase runs only where Dirichlet values are lifted
+template <class F, class = void> struct vec_zero_of { static constexpr bool v = false; };
+template <class F> struct vec_zero_of<F, decltype((void)F::VEC_ZERO)> { static constexpr bool v = F::VEC_ZERO; };
+
 // Forms whose matrix integrand has point-independent coefficients in the physical-space features (Poisson, mass,
 // linear elasticity): K_e[(a,i),(b,j)] = sum_{f,g} C^{ij}_{fg} M_fg[a][b] with the feature Gram matrices
 // M_fg = sum_q JW Phi_f(a,q) Phi_g(b,q).  Only the M_fg go through the matrix cores (K dimension nqp instead of
@@ -756,7 +760,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       __syncthreads();
       if (tid < NS) for (int ql = 0; ql < QC; ++ql) Facc[0] += lift[ql * NS + tid];
     }
-    if constexpr (NS == 0) if (hasV && pass == 0 && tid < NE * npv) {
+    if constexpr (NS == 0) if (hasV && pass == 0 && (!vec_zero_of<Form>::v || dolift) && tid < NE * npv) {
       const int a = tid / npv, part = tid & (npv - 1);
       const int qn = (qc0 + QC <= NQ) ? QC : (NQ - qc0 > 0 ? NQ - qc0 : 0);
       for (int ql = part; ql < qn; ql += npv) {

@@ -98,6 +98,7 @@ struct FormElasticity {
   static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
   static constexpr unsigned MAT_TEST_MASK = 0xEu;   // gradients only
   static constexpr unsigned long long MAT_PAIR_MASK = (0xEull << 8) | (0xEull << 16) | (0xEull << 24);   // lambda, mu constant: all grad x grad pairs
+  static constexpr bool VEC_ZERO = true;            // F = 0 (demo/Elasticity3D.c:43-45)
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
     const double lambda = p.prm[0], mu = p.prm[1];
     const double Na_x = Na[1], Na_y = Na[2], Na_z = Na[3], Nb_x = Nb[1], Nb_y = Nb[2], Nb_z = Nb[3];
