@@ -33,6 +33,13 @@ def write_pmc(path, agg):
 shutil.copy(SRC + "/kt/kt_kernel_stats.csv", "%s/%s_bench256_kernel_stats.csv" % (DST, tag))
 shutil.copy(SRC + "/kt_elast/kt_kernel_stats.csv", "%s/%s_elasticity128_kernel_stats.csv" % (DST, tag))
 shutil.copy(SRC + "/configs.txt", "%s/%s_secondary_configs.txt" % (DST, tag))
+for src, dst in (("kt_ch", "cahnhilliard256"), ("kt_ns", "nsvms96")):
+    if os.path.exists(SRC + "/%s/kt_kernel_stats.csv" % src):
+        shutil.copy(SRC + "/%s/kt_kernel_stats.csv" % src, "%s/%s_%s_kernel_stats.csv" % (DST, tag, dst))
+if glob.glob(SRC + "/pmcc_SQ/*counter_collection.csv"):
+    write_pmc("%s/%s_ch128_nsvms32_pmc_summary.csv" % (DST, tag), pmc([SRC + "/pmcc_" + c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ")]))
+if os.path.exists(SRC + "/rtc.txt"):
+    shutil.copy(SRC + "/rtc.txt", "%s/%s_runtime_forms.txt" % (DST, tag))
 line = json.loads(open(SRC + "/bench_line.json").read().strip().splitlines()[-1])
 a = pmc([SRC + "/pmc_" + c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "LDS")])
 write_pmc("%s/%s_bench256_pmc_summary.csv" % (DST, tag), a)

@@ -22,5 +22,14 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmce_$c -o p -- python3 scripts/bench_configs.py c3 > $OUT/pmce_$c.log 2>&1
 done
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmce_SQ -o p -- python3 scripts/bench_configs.py c3 > $OUT/pmce_SQ.log 2>&1
-find $OUT -name "*.csv" | head -40
+# configs 4 and 5 (element mode of the feature kernel): kernel trace + MFMA / HBM counters on a smaller mesh of the same kind
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_ch -o kt -- python3 scripts/bench_configs.py full4 > $OUT/kt_ch.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_ns -o kt -- python3 scripts/bench_configs.py full5 > $OUT/kt_ns.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmcc_$c -o p -- python3 scripts/bench_configs.py c4 c5 > $OUT/pmcc_$c.log 2>&1
+done
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcc_SQ -o p -- python3 scripts/bench_configs.py c4 c5 > $OUT/pmcc_SQ.log 2>&1
+BENCH_COMPACT=1 python3 scripts/bench_configs.py c5g c6m c6p c7 >> $OUT/configs.txt 2>> $OUT/configs.err
+python3 scripts/bench_rtc.py > $OUT/rtc.txt 2> $OUT/rtc.err
+find $OUT -name "*.csv" | head -60
 tail -c 600 $OUT/bench_line.json
