@@ -125,20 +125,46 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   bool grew = false;
   for (size_t k = 0; k < out_plans.size(); ++k) if (c.sbuf[k].bytes < (size_t)doubles(out_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.sbuf[k].alloc((size_t)doubles(out_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
   for (size_t k = 0; k < in_plans.size(); ++k) if (c.rbuf[k].bytes < (size_t)doubles(in_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.rbuf[k].alloc((size_t)doubles(in_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
-  // the exchange stream picks up where the engine stream stands (the assembly's last launch)
+  // Ghost-row reduction over RCCL in two phases when axis 2 is split over ranks: the messages of the upper face of axis 2
+  // (offsets with o2 = 1) first, the others after them.  Every rank issues the two groups in this order; a rank whose assembly
+  // marked the moment the rows of that face were complete (slab_ev, engine.hip) starts the first group there, under its
+  // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
+  // receiver's own launches store into, so it waits for the end of the assembly either way.
+  const bool phased = reduce && c.kind == 1 && g->s.proc_sizes[2] > 1;
+  const bool early = phased && g->slab_valid && g->slab_A == A && g->slab_b == b;
+  g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
-  HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
   c.last_bytes = 0;
-  for (size_t k = 0; k < out_plans.size(); ++k) {
-    if (doubles(out_plans[k]) == 0) continue;
-    if (int rc = ghost_rows(g, A, b, (int)k, c.sbuf[k].as<double>(), reduce, 0, c.xs)) return rc;
-    c.last_bytes += doubles(out_plans[k]) * 8;
-  }
-  if (c.kind == 1) {
+  auto pack = [&](int phase) -> int {      // phase 0: everything; 1: o2 = 1; 2: o2 = 0
+    for (size_t k = 0; k < out_plans.size(); ++k) {
+      if (doubles(out_plans[k]) == 0 || (phase && (out_plans[k].off[2] == 1) != (phase == 1))) continue;
+      if (int rc = ghost_rows(g, A, b, (int)k, c.sbuf[k].as<double>(), reduce, 0, c.xs)) return rc;
+      c.last_bytes += doubles(out_plans[k]) * 8;
+    }
+    return 0;
+  };
+  auto group = [&](int phase) -> int {
     NCCLCK(rccl_api().GroupStart());
-    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k])) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
-    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k])) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
+    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && !(phase && (in_plans[k].off[2] == 1) != (phase == 1))) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
+    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && !(phase && (out_plans[k].off[2] == 1) != (phase == 1))) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
     NCCLCK(rccl_api().GroupEnd());
+    return 0;
+  };
+  if (phased) {
+    HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
+    if (int rc = pack(1)) return rc;
+    if (int rc = group(1)) return rc;
+    HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
+    if (int rc = pack(2)) return rc;
+    if (int rc = group(2)) return rc;
+  } else {
+    // the exchange stream picks up where the engine stream stands (the assembly's last launch)
+    HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
+    if (int rc = pack(0)) return rc;
+  }
+  if (phased) {
+  } else if (c.kind == 1) {
+    if (int rc = group(0)) return rc;
   } else {
     std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
     for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k])) { sp.push_back(out_plans[k].rank); sb.push_back(c.sbuf[k].as<double>()); sn.push_back(doubles(out_plans[k])); }

@@ -66,6 +66,9 @@ struct _p_IGX {
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
   std::shared_ptr<IgxComm> comm;   // transport of the ghost-row exchange (comm.hpp)
+  // recorded on the engine stream when the elements next to the upper face of axis 2 have been assembled (pencil kernel, several
+  // ranks): IGXReduceGhostRows starts the messages of that face behind it, under the launches of the other elements
+  hipEvent_t slab_ev = nullptr; bool slab_valid = false; IGXMat slab_A = nullptr; IGXVec slab_b = nullptr;
   std::shared_ptr<RtcForm> rtc; std::string rtc_source, rtc_name;   // run-time compiled user form (rtc.hpp)
 };
 
@@ -965,7 +968,13 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   bool done = false;
   g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
   if (g->kernel_choice != 1 && g->kernel_choice != 3) {
-    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix);
+    std::function<void()> slab_done;
+    g->slab_valid = false;
+    if (g->comm && s.env.overlap) slab_done = [&]() {
+      if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
+      if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid = true; g->slab_A = A; g->slab_b = b; }
+    };
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done);
     if (rc) return rc;
   }
   if (!done) {

@@ -11,6 +11,7 @@
 
 struct NbrPlan {
   int rank;              // peer
+  int off[3];            // neighbour offset o in {0,1}^3
   int start[3], count[3];  // local row-index box on this rank
   int64_t mat_doubles, vec_doubles;
 };
@@ -62,6 +63,7 @@ static std::vector<NbrPlan> neighbour_plans(const Space &s, bool send) {
     }
     if (!ok) continue;
     pl.rank = rank_of(s, pc);
+    for (int d = 0; d < 3; ++d) pl.off[d] = od[d];
     int64_t t[3];
     for (int d = 0; d < 3; ++d) { t[d] = 0; for (int k = 0; k < pl.count[d]; ++k) t[d] += s.lay[d].rcnt[pl.start[d] + k]; }
     pl.mat_doubles = t[0] * t[1] * t[2] * s.dof * s.dof;

@@ -244,6 +244,7 @@ struct PencilArgs {
   int ne_max;              // LDS capacity: elements (seg_len + 3 halo) ; layers = ne_max + 3
   int first_touch;         // 1: the matrix was NOT zeroed; the first colour that reaches an entry stores it (walk axis 0 only)
   int nelx, nely;          // local element counts on the two non-walked axes (for the first-touch rule)
+  int fty_lo, fty_hi, fty_blocked;   // first-touch rule on the Y axis when the launches of an assembly come in two passes (see launch_pencils)
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
   long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
 };
@@ -403,12 +404,16 @@ typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 // [e + max(a,b) - P, e + min(a,b)] (clipped to the rank's elements); colours are e mod (P+1) and launch in ascending
 // order, so the first launch to reach the entry is colour 0 if the range holds a multiple of P+1, else the colour of
 // its lowest element.  Along the walk axis a pencil combines everything in registers: one write per entry and pencil.
+// Two passes (the elements [blocked, nel) of the axis were assembled by earlier launches, this pass covers [rlo, rhi)): an entry
+// that the earlier pass reaches as well is never a first touch here, and the rule applies to the elements of this pass alone.
 template <int P>
-__device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel) {
+__device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel, int rlo = 0, int rhi = 0x7fffffff, int blocked = 0x7fffffff) {
   constexpr int NB = P + 1;
   int lo = e + (a > b ? a : b) - P, hi = e + (a < b ? a : b);
-  if (lo < 0) lo = 0;
   if (hi > nel - 1) hi = nel - 1;
+  if (hi >= blocked) return false;
+  if (lo < rlo) lo = rlo;
+  if (hi > rhi - 1) hi = rhi - 1;
   const int c0 = ((lo + NB - 1) / NB) * NB;       // smallest multiple of NB >= lo
   return (c0 <= hi) ? (e % NB == 0) : (e == lo);
 }
@@ -861,7 +866,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     if (W == 0 && pa.first_touch) {
       const bool fx1 = first_touch_axis<P>(elx, a < NB ? a : 0, b1 < NB ? b1 : 0, pa.nelx);
 #pragma unroll
-      for (int r = 0; r < NB; ++r) if (fx1 && first_touch_axis<P>(ely, r, b2 < NB ? b2 : 0, pa.nely)) L.stmask |= 1u << r;
+      for (int r = 0; r < NB; ++r) if (fx1 && first_touch_axis<P>(ely, r, b2 < NB ? b2 : 0, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) L.stmask |= 1u << r;
     }
   }
 
@@ -1004,13 +1009,16 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
 template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false>
-static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false) {
+// fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
+// (first_touch_axis); null: one pass over the whole axis
+static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false, const int *fty = nullptr) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
   const int nw = bx.hi[W] - bx.lo[W];
   for (int cy = 0; cy < s.lay[Y].ncolors; ++cy) for (int cx = 0; cx < s.lay[X].ncolors; ++cx) {
     PencilArgs pa; pa.forcing = forcing;
     pa.first_touch = (W == 0 && first_touch) ? 1 : 0; pa.nelx = s.elem_width[X]; pa.nely = s.elem_width[Y];
+    pa.fty_lo = fty ? fty[0] : 0; pa.fty_hi = fty ? fty[1] : 0x7fffffff; pa.fty_blocked = fty ? fty[2] : 0x7fffffff;
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
@@ -1077,8 +1085,11 @@ static bool axis_walkable(const Space &s, int d) {   // one new node layer per e
 }
 
 // zero_matrix: MatZeroEntries of the caller; called before the first launch unless the axis-0 walk stores first touches
+// slab_done (may be empty): called between the two passes of an assembly that forms the elements next to the upper face of axis
+// 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
-                         std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix) {
+                         std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix,
+                         const std::function<void()> &slab_done = std::function<void()>()) {
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
   if (s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
@@ -1126,28 +1137,41 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     }
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
+    auto run = [&](const Box &P, const int *fty) {
     if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
       const int v = (deg == 2 ? 0 : 4) + (sys ? 2 : 0) + (s.rational ? 1 : 0);
       switch (v) {
-      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
       }
     } else if (deg == 2) {
-      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch);
+      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {
-    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
-    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch); break;
+    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
     case 2: launch_pencils<false, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 3: launch_pencils<true, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 4: launch_pencils<false, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     default: launch_pencils<true, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     }
+    };
+    // Upper face of axis 2 first (multi-rank, axis-0 walk): the elements within p layers of that face in every colour, then a
+    // mark for the exchange (slab_done), then the rest.  The ghost rows of the face get nothing from the second pass.
+    const int n2 = s.elem_width[2];
+    const bool upper2 = s.proc_sizes[2] > 1 && (s.proc_ranks[2] < s.proc_sizes[2] - 1 || s.axis[2].periodic);
+    if (slab_done && walk_axis == 0 && upper2 && n2 >= 2 * (deg + 1) && P.lo[2] == 0 && P.hi[2] == n2) {
+      Box top = P, rest = P; top.lo[2] = n2 - deg; rest.hi[2] = n2 - deg;
+      const int ft_top[3] = {n2 - deg, n2, 0x7fffffff}, ft_rest[3] = {0, n2 - deg, n2 - deg};
+      run(top, ft_top);
+      slab_done();
+      run(rest, ft_rest);
+    } else run(P, nullptr);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
     dom.name = std::string("gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);

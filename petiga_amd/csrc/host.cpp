@@ -19,6 +19,7 @@ EnvSwitches read_env_switches() {
   e.nseg = num("IGX_NSEG", 0);
   e.no_first_touch = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
   e.fuse_groups = num("IGX_FUSE_GROUPS", 1);
+  e.overlap = num("IGX_OVERLAP", 1);
   e.clock_probe = getenv("IGX_CLOCK_PROBE") != nullptr;
   e.feature_lds_kb = num("IGX_FEATURE_LDS_KB", 0);
   e.combine = num("IGX_COMBINE", -1);

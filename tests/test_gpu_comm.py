@@ -30,7 +30,7 @@ def test_rccl_binding_loopback():
     g.comm_destroy()
 
 
-def _rank_main(rank, world, port, case, outdir):
+def _rank_main(rank, world, port, case, outdir, name=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
         if p not in sys.path:
@@ -74,6 +74,13 @@ def _rank_main(rank, world, port, case, outdir):
         g.compute_ijacobian(1e3, V, 0.0, U, A)
     else:
         g.compute_system(A, b)
+    if "pencil" in name:
+        # several ranks on axis 2 and a communicator: the elements next to the upper face of axis 2 are assembled first
+        # (all 16 colours), the rest after them: the ghost rows of that face are complete before the second pass starts
+        assert "gram_pencil" in g.kernel_name()
+        has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
+        # (p = 3 elements next to the face: 3 of the 4 colours of axis 2, times the 4 of axis 1, then all 16)
+        assert g.dominant_kernel()["launches"] == (28 if has_upper else 16)
     g.reduce_ghost_rows(A, b)          # enqueued; the copies below wait on the engine stream
     rows, cols, vals = A.to_coo_global()
     rp, _, _ = A.host()
@@ -87,6 +94,9 @@ def _rank_main(rank, world, port, case, outdir):
 CASES = {
     "poisson-p3-2ranks": (2, (3, 1, 3, (6, 5, 9), (0, 0, 0), "poisson", ())),
     "poisson-p2-4ranks-periodic": (4, (3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson", ())),
+    "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
+    "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
+    "poisson-p3-4ranks-pencil": (4, (3, 1, 3, (9, 16, 16), (0, 0, 0), "poisson", ())),
     "cahnhilliard-p2-2ranks": (2, (3, 1, 2, (6, 6, 8), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
 }
 
@@ -99,7 +109,7 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
     world, case = CASES[name]
     dim, dof, p, N, periodic, form, params = case
     port = 29600 + (os.getpid() + hash(name)) % 300
-    mp.spawn(_rank_main, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name), nprocs=world, join=True)
     orc, _ = make_pair(dim, dof, p, list(N), periodic=[bool(x) for x in periodic], engine=False)
     if form == "poisson":
         for d in range(dim):
