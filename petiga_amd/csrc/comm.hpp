@@ -130,7 +130,7 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   // marked the moment the rows of that face were complete (slab_ev, engine.hip) starts the first group there, under its
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
-  const bool phased = reduce && c.kind == 1 && g->s.proc_sizes[2] > 1;
+  const bool phased = reduce && c.kind == 1 && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
   const bool early = phased && g->slab_valid && g->slab_A == A && g->slab_b == b;
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
