@@ -62,6 +62,7 @@ struct _p_IGX {
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
   std::function<void()> zero_matrix;   // MatZeroEntries of the running IGXCompute*, called by the kernel path that needs it
+  std::function<void()> slab_done;     // set during an assembly with a communicator: marks "upper face of axis 2 assembled" on the engine stream
   DevBuf partials, dbgbuf, clkbuf;   // IGXComputeScalar: per-element partial sums + reduction stages
   DomInfo dom;
   int64_t nbrows = 0, nblocks = 0;
@@ -588,6 +589,16 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   if (SCAL) nc[0] = nc[1] = nc[2] = 1;
   if (g->timing && g->dom.ev0 && g->dom.launches == 0) (void)hipEventRecord(g->dom.ev0, g->stream);
   constexpr bool pencil = PEN;
+  // Several ranks on axis 2 and a communicator: the elements within p layers of the upper face of axis 2 first (every colour),
+  // a mark for the exchange (g->slab_done), then the rest -- as the pencil kernel does (gram_mfma.hpp, try_gram_mfma).
+  const int n2 = s.elem_width[2], p2 = s.axis[2].p;
+  bool split = g->slab_done && !SCAL && DIM == 3 && s.proc_sizes[2] > 1 && (s.proc_ranks[2] < s.proc_sizes[2] - 1 || s.axis[2].periodic) && n2 >= 2 * (p2 + 1) && axis_first_touch_ok(s, 2);
+  for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) split = false;
+  const int npass = split ? 2 : 1;
+  for (int pass = 0; pass < npass; ++pass) {
+  const int lo2 = (split && pass == 1) ? 0 : (split ? n2 - p2 : 0), hi2 = (split && pass == 1) ? n2 - p2 : n2;
+  if (split) { out_ft.ft2_lo = lo2; out_ft.ft2_hi = hi2; out_ft.ft2_blocked = pass == 1 ? n2 - p2 : 0x7fffffff; }
+  if (split && pass == 1) g->slab_done();
   if constexpr (PEN) {
     {
       for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) {
@@ -597,7 +608,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
         for (int d = 1; d < 3; ++d) {
           const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
           int firstel = -1, count = 0;
-          for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+          for (int e = (d == 2 ? lo2 : 0); e < (d == 2 ? hi2 : nel); ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
           if (count == 0) { empty = true; break; }
           cr.start[d] = firstel; cr.step[d] = L.p + 1; cr.count[d] = count;
         }
@@ -614,7 +625,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
     for (int d = 0; d < 3; ++d) {
       const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d], stride = L.p + 1;
       int firstel = -1, count = 0;
-      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+      for (int e = (d == 2 ? lo2 : 0); e < (d == 2 ? hi2 : nel); ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
       if (SCAL) { firstel = 0; count = nel; }
       if (count == 0) { empty = true; break; }
       cr.start[d] = firstel; cr.step[d] = SCAL ? 1 : stride; cr.count[d] = count;
@@ -630,6 +641,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       first = false;
     }
   }
+  }   // passes over axis 2
   // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447): the elements of this rank on a visited face,
   // one point layer at the face; their K_e / F_e add to what the interior pass left (stream order)
   if constexpr (!PEN) for (int bid = 0; bid < 2 * DIM; ++bid) {   // (the pencil plan is not chosen when a face is visited)
@@ -979,8 +991,13 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   }
   if (!done) {
     g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
+    g->slab_valid = false;
+    if (g->comm && s.env.overlap) g->slab_done = [&]() {
+      if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
+      if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid = true; g->slab_A = A; g->slab_b = b; }
+    };
     rc = (s.form == IGX_FORM_SOURCE) ? launch_generic_rtc(g, S, out) : dispatch_by_dim(g, S, out);
-    g->zero_matrix = nullptr;
+    g->zero_matrix = nullptr; g->slab_done = nullptr;
     if (rc) return rc;
   }
   if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }

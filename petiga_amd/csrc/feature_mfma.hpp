@@ -124,11 +124,14 @@ __device__ __forceinline__ void shape_features(const double *const t1d[3], const
 
 // First touch (as in the pencil kernel, gram_mfma.hpp): along one axis the entry (row slot a, column slot b) of element e
 // is shared by the elements [e + max(a,b) - p, e + min(a,b)]; colours are e mod (p+1), launched in ascending order.
-__device__ __forceinline__ bool fm_first_touch_axis(int e, int a, int b, int nel, int p) {
+// (two passes over the axis, as in gram_mfma.hpp: this pass covers the elements [rlo, rhi), [blocked, nel) were assembled before)
+__device__ __forceinline__ bool fm_first_touch_axis(int e, int a, int b, int nel, int p, int rlo = 0, int rhi = 0x7fffffff, int blocked = 0x7fffffff) {
   const int nb = p + 1;
   int lo = e + (a > b ? a : b) - p, hi = e + (a < b ? a : b);
-  if (lo < 0) lo = 0;
   if (hi > nel - 1) hi = nel - 1;
+  if (hi >= blocked) return false;
+  if (lo < rlo) lo = rlo;
+  if (hi > rhi - 1) hi = rhi - 1;
   const int c0 = ((lo + nb - 1) / nb) * nb;
   return (c0 <= hi) ? (e % nb == 0) : (e == lo);
 }
@@ -332,7 +335,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     if (tid < na[d] * na[d]) {   // column position, with the first-touch flag of the slot pair in bit 30
       const int ad = tid / na[d], bd = tid - ad * na[d];
       // (PENCIL: along the walk everything is combined on chip, so every entry is written once per pencil)
-      pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)] | ((out.first_touch && ((PENCIL && d == 0) || fm_first_touch_axis(el[d], ad, bd, S.ax[d].nel, S.ax[d].p))) ? (1 << 30) : 0);
+      const bool two = (d == 2) && out.ft2_hi > 0;
+      pv[d] = S.ax[d].P[(off[d] + ad) * Wd + (bd - ad + S.ax[d].p)] |
+              ((out.first_touch && ((PENCIL && d == 0) || fm_first_touch_axis(el[d], ad, bd, S.ax[d].nel, S.ax[d].p, two ? out.ft2_lo : 0, two ? out.ft2_hi : 0x7fffffff, two ? out.ft2_blocked : 0x7fffffff))) ? (1 << 30) : 0);
     }
   }
   const int gw0 = S.ax[0].gwidth, gw1 = S.ax[1].gwidth;

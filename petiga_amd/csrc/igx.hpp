@@ -169,6 +169,7 @@ struct OutDev {
   int debug;               // experiment switches (IGX_DEBUG_FEATURE): 1 no scatter, 2 atomic scatter, 4 no MFMA phase
   long long *clk;          // IGX_CLOCK_PROBE: [ticks, wall ticks, elements] of workgroup 0 of the last pencil launch, or null
   long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
+  int ft2_lo, ft2_hi, ft2_blocked;   // feature kernel, assembly in two passes over axis 2 (upper face first): first-touch rule of the pass; ft2_hi = 0: one pass
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
 };
 

@@ -32,6 +32,8 @@ def test_rccl_binding_loopback():
 
 def _rank_main(rank, world, port, case, outdir, name=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if "combine" in name:
+        os.environ["IGX_COMBINE"] = "1"
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -51,6 +53,10 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         for d in range(dim):
             for s in range(2):
                 g.set_boundary_value(d, s, 0, 1.0 + d)
+    elif form == "elasticity":
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(2, 1, 0, 1.0)
     g.set_form(form, params)
     assert exchange.init_comm(g) == "host"
     A, b = g.create_mat(), g.create_vec()
@@ -74,6 +80,13 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         g.compute_ijacobian(1e3, V, 0.0, U, A)
     else:
         g.compute_system(A, b)
+    if "split" in name:       # the feature kernel makes the same two passes: more launches than colours on a rank with an upper neighbour
+        has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
+        ncol = int(np.prod(g.coloring()))
+        if "combine" in name:     # 16 colours over axes 1, 2; the face pass adds 3 of the 4 colours of axis 2
+            assert "pencil walk" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16)
+        else:
+            assert "feature_assemble" in g.kernel_name() and (g.dominant_kernel()["launches"] > ncol) == has_upper
     if "pencil" in name:
         # several ranks on axis 2 and a communicator: the elements next to the upper face of axis 2 are assembled first
         # (all 16 colours), the rest after them: the ghost rows of that face are complete before the second pass starts
@@ -97,6 +110,10 @@ CASES = {
     "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
     "poisson-p3-4ranks-pencil": (4, (3, 1, 3, (9, 16, 16), (0, 0, 0), "poisson", ())),
+    "elasticity-p3-2ranks-split-combine": (2, (3, 3, 3, (8, 5, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),   # pencil mode of the feature kernel
+    "elasticity-p3-2ranks-split": (2, (3, 3, 3, (8, 5, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),
+    "elasticity-p2-2ranks-split": (2, (3, 3, 2, (5, 6, 13), (0, 0, 0), "elasticity", (1.5, 0.8))),
+    "cahnhilliard-p2-2ranks-split": (2, (3, 1, 2, (6, 6, 12), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
     "cahnhilliard-p2-2ranks": (2, (3, 1, 2, (6, 6, 8), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
 }
 
@@ -116,6 +133,11 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
             for s in range(2):
                 orc.set_boundary_value(d, s, 0, 1.0 + d)
         A_o, b_o = orc.compute_system("orc_form_poisson")
+    elif form == "elasticity":
+        for f in range(3):
+            orc.set_boundary_value(0, 0, f, 0.0)
+        orc.set_boundary_value(2, 1, 0, 1.0)
+        A_o, b_o = orc.compute_system("orc_form_elasticity", O.ElasticityCtx(*params))
     else:
         ctx = O.CahnHilliardCtx(*params)
         rng = np.random.default_rng(5)
