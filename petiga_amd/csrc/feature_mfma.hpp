@@ -436,6 +436,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   // axis, 6 pairs after two axes, 10 sums per component and point; x, dx/du, d2x/du2 follow by the quotient rule.  The
   // per-point loop over the 64 basis functions with its 39 accumulators cost 540k cycles per element of NS-VMS on a NURBS.
   const bool sumfact = geo || rat;
+  // second-order geometry only when something reads it: second derivatives of N (SECOND_S) or the Hessians of the fields this
+  // driver's callback needs (NS-VMS: the Residual does, the Tangent does not -- its tabulation stays first order)
+  const bool need2 = SECOND && (SECOND_S || (need & NEED_HU) != 0);
   constexpr int SF_NV = SECOND ? 3 : 2, SF_NM = SECOND ? 6 : 3, SF_NK = SECOND ? 10 : 4;
   double *SF = phi;                                   // [NC][SF_NK][NQ], in the (not yet used) Phi region
   if (sumfact) {
@@ -444,6 +447,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     double *T1 = phi + n3, *T2 = T1 + n1;
     for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v], v = derivative order on axis 0
       int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r % SF_NV, c = r / SF_NV;
+      if (v == 2 && !need2) continue;
       double sm = 0;
       for (int a0 = 0; a0 < na[0]; ++a0) {
         const int a = slot_of<PENCIL>(a0, a1, a2, na);
@@ -457,6 +461,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     for (int i = tid; i < n2; i += nthr) {            // T2[c][m][q0][q1][a2], m -> orders (v0, v1): (0,0) (1,0) (0,1) | (2,0) (1,1) (0,2)
       int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % SF_NM, c = r / SF_NM;
       const int v0 = (m == 1 || m == 4) ? 1 : (m == 3 ? 2 : 0), v1 = (m == 2 || m == 4) ? 1 : (m == 5 ? 2 : 0);
+      if (m >= 3 && !need2) continue;
       double sm = 0;
       for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * SF_NV + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1];
       T2[i] = sm;
@@ -468,6 +473,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       // (m, v2) of k: value (0,0); d0 (1,0) d1 (2,0) d2 (0,1); d00 (3,0) d01 (4,0) d02 (1,1) d11 (5,0) d12 (2,1) d22 (0,2)
       const int m = (k == 1 || k == 6) ? 1 : ((k == 2 || k == 8) ? 2 : (k == 4 ? 3 : (k == 5 ? 4 : (k == 7 ? 5 : 0))));
       const int v2 = (k == 3 || k == 6 || k == 8) ? 1 : (k == 9 ? 2 : 0);
+      if (k >= 4 && !need2) continue;
       double sm = 0;
       for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * SF_NM + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2];
       SF[i] = sm;
@@ -495,14 +501,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
           if (rat) {
             w0 = SF[(DIM * SF_NK + 0) * NQ + q];
             for (int i = 0; i < DIM; ++i) w1[i] = SF[(DIM * SF_NK + 1 + i) * NQ + q];
-            if (SECOND) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) w2[i * DIM + j] = SF[(DIM * SF_NK + k2(i, j)) * NQ + q];
+            if (SECOND && need2) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) w2[i * DIM + j] = SF[(DIM * SF_NK + k2(i, j)) * NQ + q];
           }
           if (geo) {   // quotient rule on the homogeneous sums A = sum w X N, W = sum w N
             const double iw = 1.0 / w0;
             for (int c = 0; c < DIM; ++c) {
               x0[c] = SF[(c * SF_NK + 0) * NQ + q] * iw;
               for (int al = 0; al < DIM; ++al) X1[c * DIM + al] = (SF[(c * SF_NK + 1 + al) * NQ + q] - x0[c] * w1[al]) * iw;
-              if (SECOND) for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be)
+              if (SECOND && need2) for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be)
                 X2[c * D2 + al * DIM + be] = (SF[(c * SF_NK + k2(al, be)) * NQ + q] - x0[c] * w2[al * DIM + be] - X1[c * DIM + al] * w1[be] - X1[c * DIM + be] * w1[al]) * iw;
             }
           }
@@ -513,14 +519,14 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       if (rat) {
         W0[q] = w0;
         for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
-        if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
+        if (SECOND && need2) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
       }
       if (geo) {
         detX = det3(X1, DIM);
         double e1[9];
         inv3(X1, DIM, detX, e1);
         for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
-        if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45: E2[c][i][j] = -X2[k][a][b] e1[a][i] e1[b][j] e1[c][k],
+        if (SECOND && need2) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45: E2[c][i][j] = -X2[k][a][b] e1[a][i] e1[b][j] e1[c][k],
           double e2[27];  // contracted one index at a time (3 x 81 products instead of 729)
           for (int i = 0; i < D2 * DIM; ++i) e2[i] = 0;
           for (int k = 0; k < DIM; ++k) {
