@@ -125,52 +125,53 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   bool grew = false;
   for (size_t k = 0; k < out_plans.size(); ++k) if (c.sbuf[k].bytes < (size_t)doubles(out_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.sbuf[k].alloc((size_t)doubles(out_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
   for (size_t k = 0; k < in_plans.size(); ++k) if (c.rbuf[k].bytes < (size_t)doubles(in_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.rbuf[k].alloc((size_t)doubles(in_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
-  // Ghost-row reduction over RCCL in two phases when axis 2 is split over ranks: the messages of the upper face of axis 2
+  // Ghost-row reduction in two phases when axis 2 is split over ranks: the messages of the upper face of axis 2
   // (offsets with o2 = 1) first, the others after them.  Every rank issues the two groups in this order; a rank whose assembly
   // marked the moment the rows of that face were complete (slab_ev, engine.hip) starts the first group there, under its
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
-  const bool phased = reduce && c.kind == 1 && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
+  const bool phased = reduce && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
   const bool early = phased && g->slab_valid && g->slab_A == A && g->slab_b == b;
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
   c.last_bytes = 0;
-  auto pack = [&](int phase) -> int {      // phase 0: everything; 1: o2 = 1; 2: o2 = 0
+  auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (p.off[2] == 1) == (phase == 1); };   // 0: everything; 1: o2 = 1; 2: o2 = 0
+  auto pack = [&](int phase) -> int {
     for (size_t k = 0; k < out_plans.size(); ++k) {
-      if (doubles(out_plans[k]) == 0 || (phase && (out_plans[k].off[2] == 1) != (phase == 1))) continue;
+      if (doubles(out_plans[k]) == 0 || !in_phase(out_plans[k], phase)) continue;
       if (int rc = ghost_rows(g, A, b, (int)k, c.sbuf[k].as<double>(), reduce, 0, c.xs)) return rc;
       c.last_bytes += doubles(out_plans[k]) * 8;
     }
     return 0;
   };
-  auto group = [&](int phase) -> int {
-    NCCLCK(rccl_api().GroupStart());
-    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && !(phase && (in_plans[k].off[2] == 1) != (phase == 1))) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
-    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && !(phase && (out_plans[k].off[2] == 1) != (phase == 1))) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
-    NCCLCK(rccl_api().GroupEnd());
+  auto move = [&](int phase) -> int {      // the messages of a phase: one RCCL group, or one call of the host transport
+    if (c.kind == 1) {
+      NCCLCK(rccl_api().GroupStart());
+      for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
+      for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
+      NCCLCK(rccl_api().GroupEnd());
+      return 0;
+    }
+    std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
+    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) { sp.push_back(out_plans[k].rank); sb.push_back(c.sbuf[k].as<double>()); sn.push_back(doubles(out_plans[k])); }
+    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) { rp.push_back(in_plans[k].rank); rb.push_back(c.rbuf[k].as<double>()); rn.push_back(doubles(in_plans[k])); }
+    HIPCK(hipStreamSynchronize(c.xs));      // a host transport reads the packed buffers (the engine stream keeps running)
+    if (sp.empty() && rp.empty()) return 0;
+    if (int rc = c.fn(c.fnctx, (int)sp.size(), sp.data(), sb.data(), sn.data(), (int)rp.size(), rp.data(), rb.data(), rn.data())) return fail(IGX_ERR_LIB, "transport callback failed with code " + std::to_string(rc));
     return 0;
   };
   if (phased) {
     HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
     if (int rc = pack(1)) return rc;
-    if (int rc = group(1)) return rc;
+    if (int rc = move(1)) return rc;
     HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
     if (int rc = pack(2)) return rc;
-    if (int rc = group(2)) return rc;
+    if (int rc = move(2)) return rc;
   } else {
     // the exchange stream picks up where the engine stream stands (the assembly's last launch)
     HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
     if (int rc = pack(0)) return rc;
-  }
-  if (phased) {
-  } else if (c.kind == 1) {
-    if (int rc = group(0)) return rc;
-  } else {
-    std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
-    for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k])) { sp.push_back(out_plans[k].rank); sb.push_back(c.sbuf[k].as<double>()); sn.push_back(doubles(out_plans[k])); }
-    for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k])) { rp.push_back(in_plans[k].rank); rb.push_back(c.rbuf[k].as<double>()); rn.push_back(doubles(in_plans[k])); }
-    HIPCK(hipStreamSynchronize(c.xs));      // a host transport reads the packed buffers
-    if (int rc = c.fn(c.fnctx, (int)sp.size(), sp.data(), sb.data(), sn.data(), (int)rp.size(), rp.data(), rb.data(), rn.data())) return fail(IGX_ERR_LIB, "transport callback failed with code " + std::to_string(rc));
+    if (int rc = move(0)) return rc;
   }
   for (size_t k = 0; k < in_plans.size(); ++k) {
     if (doubles(in_plans[k]) == 0) continue;
