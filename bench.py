@@ -274,6 +274,10 @@ def main():
     # ghost row cannot print a rate.
     cs = g.checksum(A, b)
     check = None
+    try:                       # ms by which the upper face of axis 2 was packed before the assembly's last launch finished
+        overlap_ms = g.comm_overlap_ms() if world > 1 else None
+    except Exception:
+        overlap_ms = None
     if world > 1:
         tcs = torch.tensor(cs, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tcs, op=dist.ReduceOp.SUM)
@@ -330,7 +334,7 @@ def main():
                                    % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
                                       ", rational NURBS geometry map" if geometry else ""),
                        "kernels": g.kernel_name(), "partition": g.sizes()["proc_sizes"],
-                       "transport": transport, "checksum": [float(x) for x in cs], "checksum_check": check},
+                       "transport": transport, "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
             # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (it skips the 6
             # mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
             # (2*nen^2*nqp*dim flop per element, SURVEY 8d / BASELINE.md 3) is kept next to it.

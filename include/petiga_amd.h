@@ -328,6 +328,12 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
  * dof = 4; on a GPU the flag is read from the compiled module).  Returns 0 or IGX_ERR_USER with the compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
+/* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly
+ * that formed the upper face of axis 2 first, the time in ms by which that face's messages were packed BEFORE the assembly's
+ * last launch finished (positive: they travelled under the remaining launches).  PETSC_ERR_ARG_WRONGSTATE when the last
+ * reduction did not start early (one rank on axis 2, IGX_OVERLAP=0, another kernel path). */
+int IGXCommGetOverlap(IGX iga,double *ms);
+
 /* Shader clock under load.  With IGX_CLOCK_PROBE=1 in the environment at IGXCreate, the first and the last workgroup of every
  * pencil-kernel launch add their s_memtime ticks and the ticks of the constant 100 MHz s_memrealtime counter over their walk to
  * two sums; this returns the ratio (MHz) and the elements those wavefronts walked since the previous call, and clears the sums.  The MFMA roofline in bench.py is quoted against the

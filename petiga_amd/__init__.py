@@ -92,7 +92,7 @@ def lib(build_if_needed=False):
         "IGXGetNeighborCount": [V, _ip, _ip], "IGXGetNeighborInfo": [V, C.c_int, C.c_int, _ip, C.POINTER(C.c_int64), C.POINTER(C.c_int64)],
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
-        "IGXChecksum": [V, V, V, _dp], "IGXCheckFormSource": [V, C.c_int, C.c_int], "IGXGetClockProbe": [V, _dp, C.POINTER(C.c_int64)], "IGXSetFormSource": [V, C.c_char_p, C.c_char_p, _dp, C.c_int],
+        "IGXChecksum": [V, V, V, _dp], "IGXCommGetOverlap": [V, _dp], "IGXCheckFormSource": [V, C.c_int, C.c_int], "IGXGetClockProbe": [V, _dp, C.POINTER(C.c_int64)], "IGXSetFormSource": [V, C.c_char_p, C.c_char_p, _dp, C.c_int],
         "IGXMatGetCOO": [V, C.c_int, C.c_int, V, V, C.c_int], "IGXVecGetIndices": [V, C.c_int, C.c_int, V, C.c_int],
         "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
@@ -430,6 +430,12 @@ class IGX:
     def check_form_source(self, with_matrix=True, gram=False):
         """Compile-only check of the run-time form against the matrix-core kernel of the current degrees (no GPU needed)."""
         _ck(lib().IGXCheckFormSource(self.h, 1 if with_matrix else 0, 1 if gram else 0))
+
+    def comm_overlap_ms(self):
+        """ms by which the upper face of axis 2 was packed before the end of the assembly in the last reduce_ghost_rows."""
+        ms = C.c_double(0)
+        _ck(lib().IGXCommGetOverlap(self.h, C.byref(ms)))
+        return ms.value
 
     def clock_probe(self):
         """(shader MHz, elements walked) over the probe workgroups of the pencil-kernel launches since the last call; needs IGX_CLOCK_PROBE=1 at creation."""

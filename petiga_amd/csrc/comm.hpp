@@ -63,12 +63,14 @@ struct IgxComm {
   IGXTransportFn fn = nullptr; void *fnctx = nullptr;
   hipStream_t xs = nullptr;           // exchange stream
   hipEvent_t ready = nullptr, done = nullptr;
+  hipEvent_t packed1 = nullptr; bool packed1_valid = false;   // exchange stream, after the first phase's messages were packed (IGXCommGetOverlap)
   std::vector<DevBuf> sbuf, rbuf;     // one per neighbour of the larger of the two lists
   int64_t last_bytes = 0;
   ~IgxComm() {
     if (nccl && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(nccl);
     if (ready) (void)hipEventDestroy(ready);
     if (done) (void)hipEventDestroy(done);
+    if (packed1) (void)hipEventDestroy(packed1);
     if (xs) (void)hipStreamDestroy(xs);
   }
 };
@@ -77,7 +79,8 @@ struct IgxComm {
 
 static int comm_common_init(IGX g, std::unique_ptr<IgxComm> &c) {
   HIPCK(hipStreamCreateWithFlags(&c->xs, hipStreamNonBlocking));
-  HIPCK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+  HIPCK(hipEventCreate(&c->ready));      // (with time stamps: IGXCommGetOverlap)
+  HIPCK(hipEventCreate(&c->packed1));
   HIPCK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
   g->comm = std::move(c);
   return 0;
@@ -131,10 +134,11 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
   const bool phased = reduce && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
-  const bool early = phased && g->slab_valid && g->slab_A == A && g->slab_b == b;
+  // (whatever the last assembly wrote is face-complete at its mark; a matrix / vector it did not write was complete before)
+  const bool early = phased && g->slab_valid;
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
-  c.last_bytes = 0;
+  c.last_bytes = 0; c.packed1_valid = false;
   auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (p.off[2] == 1) == (phase == 1); };   // 0: everything; 1: o2 = 1; 2: o2 = 0
   auto pack = [&](int phase) -> int {
     for (size_t k = 0; k < out_plans.size(); ++k) {
@@ -163,6 +167,7 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   if (phased) {
     HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
     if (int rc = pack(1)) return rc;
+    c.packed1_valid = early && hipEventRecord(c.packed1, c.xs) == hipSuccess;
     if (int rc = move(1)) return rc;
     HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
     if (int rc = pack(2)) return rc;
@@ -191,6 +196,19 @@ extern "C" int IGXReduceGhostRows(IGX g, IGXMat A, IGXVec b) {
 extern "C" int IGXRefreshGhosts(IGX g, IGXVec v) {
   if (!v || v->iga != g) return fail(IGX_ERR_ARG_WRONG, "vector missing or created by another IGX");
   return comm_exchange(g, nullptr, v, false);
+}
+// How far ahead of the end of the assembly the upper face of axis 2 was packed in the last IGXReduceGhostRows: time from "the
+// first phase's messages are packed" (exchange stream) to "the assembly's last launch has finished" (engine stream), in ms.
+extern "C" int IGXCommGetOverlap(IGX g, double *ms) {
+  NEEDIGA(g);
+  if (!ms) return fail(IGX_ERR_ARG_WRONG, "null result");
+  if (!g->comm || !g->comm->packed1_valid) return fail(IGX_ERR_ARG_WRONGSTATE, "the last ghost-row reduction did not start ahead of the end of its assembly");
+  IgxComm &c = *g->comm;
+  HIPCK(hipEventSynchronize(c.done));
+  float t = 0;
+  HIPCK(hipEventElapsedTime(&t, c.packed1, c.ready));
+  *ms = t;
+  return 0;
 }
 extern "C" int IGXCommGetLastBytes(IGX g, int64_t *bytes) { NEEDIGA(g); if (bytes) *bytes = g->comm ? g->comm->last_bytes : 0; return 0; }
 
