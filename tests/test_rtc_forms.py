@@ -180,3 +180,41 @@ def test_nonlinear_source_form_through_function_and_jacobian_drivers(kernel):
     F_o = orc.compute_ifunction("orc_form_bratu_ifunction", lam, 12.5, V, 0.0, U)
     assert np.abs(F.get() - F_o).max() <= 1e-12 * np.abs(F_o).max()
     compare_mats(J, orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 12.5, V, 0.0, U), 1e-12)
+
+
+USER_MASS4 = r"""
+// four fields coupled through a constant matrix C (params: its diagonal and off-diagonal value) times the mass matrix, plus a load:
+// K[(a,i),(b,j)] = C_ij Na Nb, F[(a,i)] = (i+1) Na.  No MAT_PAIR_MASK: the kernel takes it as a general (point-dependent) form.
+struct UserMass4 {
+  static constexpr int DOF = 4, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 0x1u;
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) T[i * 4 + j] = (i == j ? p.prm[0] : p.prm[1]) * Na[0] * Nb[0];
+  }
+  static __device__ void vec(const PtView &, const double *Na, double *R) { for (int i = 0; i < 4; ++i) R[i] = (i + 1) * Na[0]; }
+};
+"""
+
+
+@pytest.mark.gpu
+def test_four_field_source_form_runs_as_fused_groups_on_the_matrix_cores():
+    """dof = 4 at p = 3 (4x4 tiles): two groups of two row fields in one launch (feature_mfma.hpp, FUSE), here through hiprtc.
+    The oracle's mass form gives M (dof = 1); the expected matrix is the Kronecker product M x C."""
+    import scipy.sparse as sp
+    orc1, _ = make_pair(3, 1, 3, [3, 4, 3], engine=False)
+    M, m = orc1.compute_system("orc_form_mass")
+    _, eng = make_pair(3, 4, 3, [3, 4, 3])
+    d, o = 2.0, -0.25
+    eng.set_form_source(USER_MASS4, "UserMass4", (d, o))
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "hiprtc,mfma" in eng.kernel_name() and "fused" in eng.kernel_name()
+    Cm = np.full((4, 4), o) + (d - o) * np.eye(4)
+    K_ref = sp.kron(M.scipy(), Cm).tocsr()
+    rows, cols, vals = A.to_coo_global()
+    K = sp.coo_matrix((vals, (rows, cols)), shape=K_ref.shape).tocsr()
+    assert abs(K - K_ref).max() <= 1e-12 * abs(K_ref).max()
+    # F[(a,i)] = (i+1) * integral of N_a = (i+1) * (M 1)_a
+    rowsum = np.asarray(M.scipy().sum(axis=1)).ravel()
+    assert np.abs(b.get().reshape(-1, 4) - rowsum[:, None] * np.arange(1, 5)[None, :]).max() <= 1e-12 * rowsum.max()
