@@ -1077,6 +1077,85 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
   }
 }
 
+// ---- boundary loads on the identity geometry (IGAElementBuildFix: AddFlux with BoundaryArea's no-geometry branch,
+// src/petigaelem.c:1118-1132,1191-1212; IGAElementFixSystem adds them to F_e before the fixed rows are set, :1371-1376).
+// A boundary element lumps load * 4 * prod_{i != d} (J_i / nen_i) onto each of its basis functions on the face, so a face node
+// receives load * 4 * (sum over its elements on axis t of J_t / nen_t) * (the same on axis u): the two 1-D sums come from the
+// host, one thread per face node adds the product to its F row -- unless a Dirichlet value holds that dof (FixSystem discards
+// the flux of a fixed row).  Sequential launches per face: one writer per row and launch, fixed order.
+struct FluxArgs {
+  int d, t, u;                 // face axis and the two axes of the face
+  int rd;                      // row index of the face nodes on axis d
+  int nt, nu;                  // face nodes (rank-local rows) on axes t, u
+  const double *st, *su;       // [nt], [nu]: sum over the rank's elements holding the node of J / nen
+  double value;                // load * 4
+  int gfirst[3], glast[3];     // global node index of row 0 on every axis; last global node index (nnp - 1)
+  int fixlo[3], fixhi[3];      // a Dirichlet value holds field 0 on the lower / upper face of the axis
+};
+static __global__ void k_boundary_loads(FluxArgs F, int nr0, int nr1, double *vec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.nt * F.nu) return;
+  int r[3]; r[F.d] = F.rd; r[F.t] = i % F.nt; r[F.u] = i / F.nt;
+  for (int a = 0; a < 3; ++a) {        // a row on a Dirichlet face keeps the fixed value
+    const int gi = F.gfirst[a] + r[a];
+    if ((F.fixlo[a] && gi == 0) || (F.fixhi[a] && gi == F.glast[a])) return;
+  }
+  const double v = F.value * F.st[r[F.t]] * F.su[r[F.u]];
+  if (v != 0.0) vec[(size_t)r[0] + (size_t)nr0 * ((size_t)r[1] + (size_t)nr1 * (size_t)r[2])] += v;
+}
+
+// dof = 1, dim = 3, no geometry, no axis wrapped inside the rank on the loaded faces' axes (rows = ghosted nodes)
+static bool boundary_loads_supported(const Space &s) {
+  for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
+    if (!s.load[d][sd].count) continue;
+    for (int a = 0; a < 3; ++a) if (s.lay[a].alias) return false;
+  }
+  return true;
+}
+
+static int launch_boundary_loads(const Space &s, const OutDev &out, hipStream_t stream, std::string &err) {
+  for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
+    const BC &bl = s.load[d][sd];
+    if (!bl.count || s.axis[d].periodic) continue;
+    // the rank holds elements on this face?
+    if (sd == 0 ? s.elem_start[d] != 0 : s.elem_start[d] + s.elem_width[d] != s.elem_sizes[d]) continue;
+    double load = 0; bool any = false;
+    for (int k = 0; k < bl.count; ++k) if (bl.field[k] == 0) { load += bl.value[k]; any = true; }     // (dof = 1: field 0)
+    if (!any) continue;
+    const int t = (d + 1) % 3, u = (d + 2) % 3;
+    FluxArgs F; F.d = d; F.t = t; F.u = u; F.value = load * 4.0;
+    F.rd = sd == 0 ? 0 : s.axis[d].nnp - 1 - s.lay[d].gstart;
+    std::vector<double> sum[2];
+    const int ax2[2] = {t, u};
+    for (int k = 0; k < 2; ++k) {
+      const int a = ax2[k]; const AxisLayout &L = s.lay[a]; const Basis1D &b = s.basis[a];
+      sum[k].assign((size_t)L.nrow, 0.0);
+      for (int e = 0; e < s.elem_width[a]; ++e) {
+        const int ge = s.elem_start[a] + e, first = b.offset[ge] - L.gstart;   // ghost-local index of the element's first basis function
+        for (int j = 0; j < b.nen; ++j) { const int i = first + j; if (i >= 0 && i < L.nrow) sum[k][(size_t)i] += b.detJac[ge] / (double)b.nen; }
+      }
+    }
+    F.nt = s.lay[t].nrow; F.nu = s.lay[u].nrow;
+    for (int a = 0; a < 3; ++a) {
+      F.gfirst[a] = s.lay[a].gstart; F.glast[a] = s.axis[a].nnp - 1;
+      auto holds = [&](const BC &bv) { for (int k = 0; k < bv.count; ++k) if (bv.field[k] == 0) return 1; return 0; };
+      F.fixlo[a] = s.axis[a].periodic ? 0 : holds(s.value[a][0]); F.fixhi[a] = s.axis[a].periodic ? 0 : holds(s.value[a][1]);
+    }
+    // the two short tables live for this launch only: stream-ordered allocation, copy, kernel, free
+    double *dt = nullptr;
+    const size_t bytes = (sum[0].size() + sum[1].size()) * sizeof(double);
+    if (hipMallocAsync(reinterpret_cast<void **>(&dt), bytes, stream) != hipSuccess) { err = "device allocation of the boundary-load sums failed"; return IGX_ERR_MEM; }
+    (void)hipMemcpyAsync(dt, sum[0].data(), sum[0].size() * sizeof(double), hipMemcpyHostToDevice, stream);
+    (void)hipMemcpyAsync(dt + sum[0].size(), sum[1].data(), sum[1].size() * sizeof(double), hipMemcpyHostToDevice, stream);
+    (void)hipStreamSynchronize(stream);      // (pageable host memory: the vectors go out of scope below; a face with loads is rare and small)
+    F.st = dt; F.su = dt + sum[0].size();
+    const int n = F.nt * F.nu;
+    hipLaunchKernelGGL(k_boundary_loads, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, F, s.lay[0].nrow, s.lay[1].nrow, out.vec);
+    (void)hipFreeAsync(dt, stream);
+  }
+  return 0;
+}
+
 static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
   if (s.lay[d].alias || s.elem_width[d] < 8) return false;
   for (int e = 0; e + 1 < s.elem_width[d]; ++e)
@@ -1103,7 +1182,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");
   for (int d = 0; d < 3; ++d) {
     if (s.axis[d].p != deg || s.basis[d].nqp != deg + 1) return no("needs the same degree p and p+1 Gauss points on every axis");
-    for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count) return no("boundary loads");
+    for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count && out.op == OP_SYSTEM && (geo || !boundary_loads_supported(s))) return no("boundary loads on a mapped geometry / a wrapped axis");
   }
   GramArgs ga; ga.forcing = (s.form == IGX_FORM_POISSON) ? 1.0 : -6.0; ga.nwaves = 0;
   launches = 0;
@@ -1120,6 +1199,9 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
   if (!first_touch) zero_matrix();
   else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);   // the only entries no local element reaches
+  // boundary loads first: F is zeroed and only added to, so the order is free -- and the ghost rows of the upper face of axis 2
+  // must be complete when the first pass of a multi-rank assembly ends (slab_done below)
+  if (sys) { if (int rc = launch_boundary_loads(s, out, stream, err)) return rc; }
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);

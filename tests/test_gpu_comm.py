@@ -30,6 +30,15 @@ def test_rccl_binding_loopback():
     g.comm_destroy()
 
 
+def _poisson_loads(g):
+    """a Dirichlet face, loads on three others (IGASetBoundaryLoad): lumped by the per-face kernel next to the pencil kernel"""
+    g.set_boundary_value(0, 0, 0, 0.5)
+    g.set_boundary_load(0, 1, 0, 2.0)
+    g.set_boundary_load(1, 0, 0, -0.75)
+    g.set_boundary_load(2, 1, 0, 1.25)
+    g.set_boundary_load(2, 0, 0, 0.4)
+
+
 def _rank_main(rank, world, port, case, outdir, name=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if "combine" in name:
@@ -49,7 +58,9 @@ def _rank_main(rank, world, port, case, outdir, name=""):
     for i in range(dim):
         g.axis_uniform(i, p, N[i], periodic=bool(periodic[i]))
     g.setup()
-    if form == "poisson":
+    if form == "poisson" and "loads" in name:
+        _poisson_loads(g)
+    elif form == "poisson":
         for d in range(dim):
             for s in range(2):
                 g.set_boundary_value(d, s, 0, 1.0 + d)
@@ -92,8 +103,8 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         # (all 16 colours), the rest after them: the ghost rows of that face are complete before the second pass starts
         assert "gram_pencil" in g.kernel_name()
         has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
-        # (p = 3 elements next to the face: 3 of the 4 colours of axis 2, times the 4 of axis 1, then all 16)
-        assert g.dominant_kernel()["launches"] == (28 if has_upper else 16)
+        # (the p elements next to the face: p of the p+1 colours of axis 2, times the p+1 of axis 1, then all (p+1)^2)
+        assert g.dominant_kernel()["launches"] == (p + 1) ** 2 + (p * (p + 1) if has_upper else 0)
     g.reduce_ghost_rows(A, b)          # enqueued; the copies below wait on the engine stream
     if "pencil" in name or "split" in name:
         has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
@@ -115,6 +126,8 @@ def _rank_main(rank, world, port, case, outdir, name=""):
 CASES = {
     "poisson-p3-2ranks": (2, (3, 1, 3, (6, 5, 9), (0, 0, 0), "poisson", ())),
     "poisson-p2-4ranks-periodic": (4, (3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson", ())),
+    "poisson-p3-2ranks-pencil-loads": (2, (3, 1, 3, (8, 6, 16), (0, 0, 0), "poisson", ())),
+    "poisson-p2-4ranks-pencil-loads": (4, (3, 1, 2, (9, 12, 12), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
     "poisson-p3-4ranks-pencil": (4, (3, 1, 3, (9, 16, 16), (0, 0, 0), "poisson", ())),
@@ -136,7 +149,10 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
     port = 29600 + (os.getpid() + hash(name)) % 300
     mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name), nprocs=world, join=True)
     orc, _ = make_pair(dim, dof, p, list(N), periodic=[bool(x) for x in periodic], engine=False)
-    if form == "poisson":
+    if form == "poisson" and "loads" in name:
+        _poisson_loads(orc)
+        A_o, b_o = orc.compute_system("orc_form_poisson")
+    elif form == "poisson":
         for d in range(dim):
             for s in range(2):
                 orc.set_boundary_value(d, s, 0, 1.0 + d)

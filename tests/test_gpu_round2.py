@@ -197,3 +197,31 @@ def test_boundary_loads_function_driver(dim, geo):
     eng.synchronize()
     _vec_close(F.get(), F_o, 1e-11)
 
+
+
+@pytest.mark.parametrize("p,N,stretch", [(2, (9, 4, 5), False), (3, (8, 5, 4), False), (3, (9, 4, 6), True), (2, (10, 5, 4), True)])
+def test_boundary_loads_on_the_pencil_kernel(p, N, stretch, kernel_family):
+    """Identity geometry, dof 1, a walkable axis 0: the pencil kernel assembles K and F, a per-face kernel adds the lumped loads
+    (AddFlux / BoundaryArea, src/petigaelem.c:1118-1132,1191-1212) to the rows no Dirichlet value holds."""
+    knots = None
+    if stretch:      # non-uniform element sizes on the axes of the loaded faces (C^{p-1} interior knots)
+        knots = []
+        for n in N:
+            x = np.linspace(0.0, 1.0, n + 1) ** 1.5
+            knots.append(np.concatenate([[0.0] * p, x, [1.0] * p]))
+    orc, eng = make_pair(3, 1, p, list(N), knots=knots)
+    _loads((orc, eng), 3, 1)
+    for g in (orc, eng):
+        g.set_boundary_load(0, 0, 0, 0.6)          # a load on a face that also carries a Dirichlet value: discarded there
+    A_o, b_o = orc.compute_system("orc_form_poisson")
+    eng.set_form("poisson")
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    if kernel_family == "auto":
+        assert "gram_pencil" in eng.kernel_name()
+    compare_mats(A, A_o, 1e-12)
+    _vec_close(b.get(), b_o, 1e-12)
+    orc.clear_boundary()
+    _, b_free = orc.compute_system("orc_form_poisson")
+    assert np.abs(b_free - b_o).max() > 1e-3
