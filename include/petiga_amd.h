@@ -125,7 +125,8 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * un-weighted and mat() must be linear in Na and in Nb, as every IGAFormSystem/Jacobian is.  Compile errors come back as
  * PETSC_ERR_USER with the compiler log in IGXGetLastError().  The seven drivers then work as with a built-in form: on the
  * matrix cores (feature_assemble<MyForm,...>, compiled on first use for the wave layout of the degree, about half a second)
- * for dim >= 2 and (p+1)^dim <= 64, on the point-form kernel otherwise or with IGXSetKernel(1).  Optional declarations that
+ * for dim >= 2 and (p+1)^dim <= 64, on the point-form kernel otherwise or with IGXSetKernel(1).  IGX_RTC_CACHE_DIR in the
+ * environment keeps the compiled code objects on disk for later processes.  Optional declarations that
  * speed the matrix-core kernel up, all bit masks over the feature index of Na / Nb:
  *       static constexpr unsigned MAT_TEST_MASK = ...;         // features of Na that mat() reads (others never enter the GEMM)
  *       static constexpr unsigned PHI_MASK = ...;              // features anything reads (others are not tabulated at all)

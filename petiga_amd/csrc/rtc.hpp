@@ -10,6 +10,7 @@
 // hiprtc is bound with dlopen, as RCCL is.  The compile itself needs no GPU (tests/test_rtc_forms.py checks the compile and
 // its error log on the CPU; the launch is a GPU test against the oracle).
 #include <dlfcn.h>
+#include <unistd.h>
 #include <map>
 #include "rtc_sources.inc"
 
@@ -73,11 +74,54 @@ struct RtcForm {
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
+// Code-object cache on disk (IGX_RTC_CACHE_DIR): key = FNV-1a of the whole program text -- the library's own headers are part of
+// it, so another library build never finds a stale object -- and of the name expressions.  File: [count][len, lowered name]...[code].
+static unsigned long long rtc_fnv(const std::string &t, unsigned long long h = 1469598103934665603ull) {
+  for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; }
+  return h;
+}
+static std::string rtc_cache_path(const std::string &src, const std::vector<std::string> &exprs) {
+  const char *dir = getenv("IGX_RTC_CACHE_DIR");
+  if (!dir || !*dir) return std::string();
+  unsigned long long h = rtc_fnv(src);
+  for (const std::string &x : exprs) h = rtc_fnv(x, h ^ 0x9e3779b97f4a7c15ull);
+  char name[64]; snprintf(name, sizeof(name), "/igx_%016llx.bin", h);
+  return std::string(dir) + name;
+}
+static bool rtc_cache_load(const std::string &path, size_t nexpr, std::vector<char> &code, std::vector<std::string> &lowered) {
+  FILE *f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
+  if (!f) return false;
+  bool ok = false;
+  unsigned n = 0;
+  if (fread(&n, sizeof(n), 1, f) == 1 && n == nexpr) {
+    lowered.clear(); ok = true;
+    for (unsigned i = 0; i < n && ok; ++i) {
+      unsigned len = 0;
+      ok = fread(&len, sizeof(len), 1, f) == 1 && len < (1u << 16);
+      if (ok) { std::string t(len, '\0'); ok = len == 0 || fread(&t[0], 1, len, f) == len; lowered.push_back(t); }
+    }
+    unsigned long long cs = 0;
+    ok = ok && fread(&cs, sizeof(cs), 1, f) == 1 && cs > 0 && cs < (1ull << 31);
+    if (ok) { code.resize((size_t)cs); ok = fread(code.data(), 1, (size_t)cs, f) == cs; }
+  }
+  fclose(f);
+  return ok;
+}
+static void rtc_cache_store(const std::string &path, const std::vector<char> &code, const std::vector<std::string> &lowered) {
+  if (path.empty()) return;
+  const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const unsigned n = (unsigned)lowered.size(); bool ok = fwrite(&n, sizeof(n), 1, f) == 1;
+  for (const std::string &t : lowered) { const unsigned len = (unsigned)t.size(); ok = ok && fwrite(&len, sizeof(len), 1, f) == 1 && (len == 0 || fwrite(t.data(), 1, len, f) == len); }
+  const unsigned long long cs = code.size(); ok = ok && fwrite(&cs, sizeof(cs), 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());     // (rename: concurrent ranks write the same object)
+}
+
 // compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
 static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
                      std::vector<char> &code, std::vector<std::string> &lowered) {
-  std::string e; if (int rc = load_hiprtc(e)) return fail(rc, e);
-  HiprtcApi &a = hiprtc_api();
   std::string src;
   src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
@@ -87,6 +131,10 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   src += source;
   src += "\n";
   src += tail;
+  const std::string cache = rtc_cache_path(src, exprs);
+  if (rtc_cache_load(cache, exprs.size(), code, lowered)) return 0;
+  std::string e; if (int rc = load_hiprtc(e)) return fail(rc, e);
+  HiprtcApi &a = hiprtc_api();
   void *prog = nullptr;
   if (a.Create(&prog, src.c_str(), "igx_user_form.hip", 0, nullptr, nullptr) != 0) return fail(IGX_ERR_LIB, "hiprtcCreateProgram failed");
   for (const std::string &x : exprs) (void)a.AddName(prog, x.c_str());
@@ -105,6 +153,7 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   }
   size_t cs = 0; (void)a.CodeSize(prog, &cs); code.resize(cs); (void)a.Code(prog, code.data());
   (void)a.Destroy(&prog);
+  rtc_cache_store(cache, code, lowered);
   return 0;
 }
 

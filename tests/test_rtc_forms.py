@@ -218,3 +218,32 @@ def test_four_field_source_form_runs_as_fused_groups_on_the_matrix_cores():
     # F[(a,i)] = (i+1) * integral of N_a = (i+1) * (M 1)_a
     rowsum = np.asarray(M.scipy().sum(axis=1)).ravel()
     assert np.abs(b.get().reshape(-1, 4) - rowsum[:, None] * np.arange(1, 5)[None, :]).max() <= 1e-12 * rowsum.max()
+
+
+def test_code_object_cache_on_disk(tmp_path, monkeypatch):
+    """IGX_RTC_CACHE_DIR: the second compile of the same program is a file read (and needs no hiprtc); a changed source misses."""
+    import time
+    import petiga_amd as P
+    monkeypatch.setenv("IGX_RTC_CACHE_DIR", str(tmp_path))
+
+    def compile_once(src):
+        g = P.IGX(3, 1)
+        for i in range(3):
+            g.axis_uniform(i, 2, 4)
+        t = time.perf_counter()
+        g.set_form_source(src, "AdvDiff<3>", (1.0, 0.5, 0.25))
+        g.check_form_source(True)
+        return time.perf_counter() - t
+
+    t_cold = compile_once(ADVECTION_DIFFUSION)
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 2 and all(f.startswith("igx_") and f.endswith(".bin") for f in files)      # point-form kernel + matrix-core kernel
+    t_warm = compile_once(ADVECTION_DIFFUSION)
+    assert sorted(p.name for p in tmp_path.iterdir()) == files and t_warm < 0.5 * t_cold
+    compile_once(ADVECTION_DIFFUSION + "\n// another program\n")
+    assert len(list(tmp_path.iterdir())) == 4
+    # a damaged entry is ignored and rewritten
+    victim = tmp_path / files[0]
+    victim.write_bytes(victim.read_bytes()[:100])
+    compile_once(ADVECTION_DIFFUSION)
+    assert victim.stat().st_size > 1000
