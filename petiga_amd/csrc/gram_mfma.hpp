@@ -427,8 +427,17 @@ struct PencilBC {
   int wlo, whi;             // fixed node layers on axis 0 (ghost-local), or -1000
   double vwlo, vwhi, vxlo, vxhi, vylo, vyhi;
 };
-template <int P>
-__device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, int lay, double &val) {
+// IGASetFixTable (src/petigaform.c:273-298): the value of a fixed dof is read from a row-indexed table instead of the face's
+// constant.  FIXT variants of the kernel carry what it takes to find the row of node (ix, iy, layer) of the pencil.
+template <bool FIXT> struct PencilFix {};
+template <> struct PencilFix<true> {
+  const double *table;       // [rows]
+  const int *rmx, *rmy;      // rowmap of axes X, Y at the pencil's first basis function
+  long long sx, sy;          // row strides of axes X, Y
+  const int *rho; int lay0, nl;   // row index of the node layers the segment holds (LDS)
+};
+template <int P, bool FIXT = false>
+__device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, int lay, double &val, const PencilFix<FIXT> &fx = PencilFix<FIXT>()) {
   bool f = false;
   if (lay == b.wlo) { f = true; val = b.vwlo; }
   if (lay == b.whi) { f = true; val = b.vwhi; }
@@ -436,6 +445,13 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
   if (b.xhi && ix == P) { f = true; val = b.vxhi; }
   if (b.ylo && iy == 0) { f = true; val = b.vylo; }
   if (b.yhi && iy == P) { f = true; val = b.vyhi; }
+  if constexpr (FIXT) {
+    if (f) {
+      const int li = lay - fx.lay0;
+      // (a layer outside the segment's window holds no node of this rank: its entries are zero, any finite value does)
+      val = (li >= 0 && li < fx.nl && ix <= P && iy <= P) ? fx.table[(long long)fx.rho[li] + fx.sx * fx.rmx[ix] + fx.sy * fx.rmy[iy]] : 0.0;
+    }
+  }
   return f;
 }
 
@@ -447,10 +463,11 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
 // left 1..P steps ago (K_e is symmetric, only tiles ta <= tb are computed): each leaving row parks its tiles
 // (0,1..P) transposed in a per-wavefront LDS area, [P(P+1)/2 slots][4 r][HOLD_LD lanes], until the partner
 // row leaves (distance d uses d slots, keyed by the column layer mod d).
-template <bool SYSTEM, int P>
+template <bool SYSTEM, int P, bool FIXT = false>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
-                                              int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem) {
+                                              int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem,
+                                              const PencilFix<FIXT> &fxt = PencilFix<FIXT>()) {
   constexpr int NB = P + 1, BW = 2 * P + 1;
   const int li = lay - T.lay0;
   const bool exists = li >= 0 && li < nl && T.cnt[li] > 0;
@@ -490,11 +507,11 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       double corr[NB];
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
-        double rv = 0; const bool rf = pencil_fixed<P>(bc, a, r, lay, rv);
+        double rv = 0; const bool rf = pencil_fixed<P, FIXT>(bc, a, r, lay, rv, fxt);
         double c = 0;
 #pragma unroll
         for (int d = 0; d < BW; ++d) {
-          double cv = 0; const bool cf = pencil_fixed<P>(bc, b1, b2, lay + d - P, cv);
+          double cv = 0; const bool cf = pencil_fixed<P, FIXT>(bc, b1, b2, lay + d - P, cv, fxt);
           if (cf) c += v[r][d] * cv;
           if (rf || cf) v[r][d] = (d == P && b1 == a && b2 == r && rf) ? (double)nelem : 0.0;
         }
@@ -506,7 +523,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       double t = 0;
 #pragma unroll
       for (int r = 0; r < NB; ++r) { const double cr = __shfl(corr[r], fx * 16); if (r == fy) t = cr; }
-      double fv = 0; const bool ff = pencil_fixed<P>(bc, fx, fy, lay, fv);
+      double fv = 0; const bool ff = pencil_fixed<P, FIXT>(bc, fx, fy, lay, fv, fxt);
       Fnew = ff ? (double)nelem * fv : Facc - t;
     }
     if (full) {   // interior row: one BW-entry run per (lane, r)
@@ -764,10 +781,11 @@ __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, cons
   return s;
 }
 
-template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false>
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
+  static_assert(!FIXT || (SYSTEM && W == 0 && !GEO), "fix tables: System driver, axis-0 walk, identity geometry");
   constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
@@ -914,6 +932,8 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
     bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
   }
+  PencilFix<FIXT> fxt;
+  if constexpr (FIXT) { fxt.table = S.fixtable; fxt.rmx = AX.rowmap + offx; fxt.rmy = AY.rowmap + offy; fxt.sx = rs[X]; fxt.sy = rs[Y]; fxt.rho = T.rho; fxt.lay0 = T.lay0; fxt.nl = nl; }
   int held[4] = {0, 0, 0, 0};   // elements walked so far that hold the layer in window slot t
 
   // Ping-pong schedule.  Wavefronts w and w+4 of this 512-thread workgroup share a SIMD; group 0 (waves 0-3)
@@ -954,7 +974,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     }
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM, P>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0]);
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -974,7 +994,7 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
-        pencil0_leave<SYSTEM, P>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0]);
+        pencil0_leave<SYSTEM, P, FIXT>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
         held[NB - 1] = 0;
@@ -1008,7 +1028,7 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
-template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false>
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
 // fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
 // (first_touch_axis); null: one pass over the whole axis
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false, const int *fty = nullptr) {
@@ -1052,7 +1072,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
-    auto kern = gram_pencil<SYSTEM, W, P, GEO, RAT>;
+    auto kern = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
     if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
@@ -1177,7 +1197,6 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool geo = s.nsd != 0;
   if (geo && s.nsd != 3) return no("mapped geometry of another dimension");
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
-  if (S.fixtable) return no("fix table");
   const int deg = s.axis[0].p;
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");
   for (int d = 0; d < 3; ++d) {
@@ -1194,6 +1213,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool walk = walk_axis >= 0;
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   if (geo && walk_axis != 0) return no("a mapped geometry needs a walkable axis 0");
+  const bool fixt = S.fixtable != nullptr && sys;       // IGASetFixTable: Dirichlet values per node (the Matrix driver applies none)
+  if (fixt && (geo || walk_axis != 0)) return no("fix table on a mapped geometry / without a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
@@ -1232,6 +1253,9 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
       default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
       }
+    } else if (fixt) {
+      if (deg == 2) launch_pencils<true, 0, 2, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
+      else launch_pencils<true, 0, 3, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
     } else if (deg == 2) {
       if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {

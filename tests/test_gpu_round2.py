@@ -225,3 +225,32 @@ def test_boundary_loads_on_the_pencil_kernel(p, N, stretch, kernel_family):
     orc.clear_boundary()
     _, b_free = orc.compute_system("orc_form_poisson")
     assert np.abs(b_free - b_o).max() > 1e-3
+
+
+@pytest.mark.parametrize("p,N,faces", [(2, (9, 4, 5), "all"), (3, (8, 5, 4), "all"), (3, (9, 4, 5), "some"), (2, (10, 6, 4), "some")])
+def test_fix_table_on_the_pencil_kernel(p, N, faces, kernel_family):
+    """IGASetFixTable (src/petigaform.c:273-298; test/IGAFixTable.c): Dirichlet values per node from a vector.  The axis-0 walk of
+    the pencil kernel reads them from the table in its fix-up (lifting of F through the fixed columns, F of the fixed rows)."""
+    orc, eng = make_pair(3, 1, p, list(N))
+    rng = np.random.default_rng(41)
+    table = rng.standard_normal(orc.global_size())
+    for g in (orc, eng):
+        for d in range(3):
+            for s in range(2):
+                if faces == "all" or (d + s) % 2 == 0:
+                    g.set_boundary_value(d, s, 0, 7.0)          # the constant is ignored: the table holds the values
+    orc.set_fixtable(table)
+    eng.set_fixtable(eng.create_vec().set(table))
+    A_o, b_o = orc.compute_system("orc_form_poisson_f")
+    eng.set_form("poisson_f")
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    if kernel_family == "auto":
+        assert "gram_pencil" in eng.kernel_name()
+    compare_mats(A, A_o, 1e-12)
+    _vec_close(b.get(), b_o, 1e-12)
+    # the table is what fixes the values: with the constant instead, F differs
+    orc.set_fixtable(None)
+    _, b_const = orc.compute_system("orc_form_poisson_f")
+    assert np.abs(b_const - b_o).max() > 1e-3
