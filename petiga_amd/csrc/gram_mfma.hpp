@@ -785,7 +785,7 @@ template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FI
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
-  static_assert(!FIXT || (SYSTEM && W == 0 && !GEO), "fix tables: System driver, axis-0 walk, identity geometry");
+  static_assert(!FIXT || (SYSTEM && W == 0), "fix tables: System driver, axis-0 walk");
   constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
@@ -1214,7 +1214,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   if (geo && walk_axis != 0) return no("a mapped geometry needs a walkable axis 0");
   const bool fixt = S.fixtable != nullptr && sys;       // IGASetFixTable: Dirichlet values per node (the Matrix driver applies none)
-  if (fixt && (geo || walk_axis != 0)) return no("fix table on a mapped geometry / without a walkable axis 0");
+  if (fixt && walk_axis != 0) return no("fix table without a walkable axis 0");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
@@ -1241,7 +1241,14 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     auto run = [&](const Box &P, const int *fty) {
-    if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
+    if (geo && fixt) {
+      switch ((deg == 2 ? 0 : 2) + (s.rational ? 1 : 0)) {
+      case 0: launch_pencils<true, 0, 2, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 1: launch_pencils<true, 0, 2, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 2: launch_pencils<true, 0, 3, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      default: launch_pencils<true, 0, 3, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      }
+    } else if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
       const int v = (deg == 2 ? 0 : 4) + (sys ? 2 : 0) + (s.rational ? 1 : 0);
       switch (v) {
       case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
