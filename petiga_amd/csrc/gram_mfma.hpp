@@ -1124,6 +1124,76 @@ static __global__ void k_boundary_loads(FluxArgs F, int nr0, int nr1, double *ve
   if (v != 0.0) vec[(size_t)r[0] + (size_t)nr0 * ((size_t)r[1] + (size_t)nr1 * (size_t)r[2])] += v;
 }
 
+// ---- the same on a mapped geometry (BoundaryArea's geometry branch, src/petigaelem.c:1133-1165): the lumped value of a face
+// element is load * prod_{i != d} (J_i / nen_i) * dS with dS = sum_q w_t w_u |x_,t x x_,u| over its Gauss points on the face
+// (basis of axis d at the end knot: only the first / last layer of the element's control points counts; the routine's own
+// Rationalize for NURBS).  One thread per face element fills area[e_u][e_t]; one thread per face node then adds the areas of the
+// elements that hold it, in a fixed order (sums over <= (p+1)^2 elements).
+struct FaceAreaArgs {
+  int d, t, u, side;
+  int nt, nu;                    // face elements of the rank on axes t, u
+  double *area;                  // [nu][nt]
+};
+static __global__ void k_face_areas(SpaceDev S, FaceAreaArgs F) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.nt * F.nu) return;
+  int el[3]; el[F.t] = i % F.nt; el[F.u] = i / F.nt; el[F.d] = F.side ? S.ax[F.d].nel - 1 : 0;
+  const AxisDev &At = S.ax[F.t], &Au = S.ax[F.u], &Ad = S.ax[F.d];
+  const int n0 = At.nen, n1 = Au.nen, q0n = At.nqp, q1n = Au.nqp;
+  const double *t0 = At.tab + (size_t)el[F.t] * q0n * n0 * NDER, *t1 = Au.tab + (size_t)el[F.u] * q1n * n1 * NDER;
+  const double *w0 = At.w + (size_t)el[F.t] * q0n, *w1 = Au.w + (size_t)el[F.u] * q1n;
+  const bool rat = S.rational != 0;
+  int off[3]; for (int a = 0; a < 3; ++a) off[a] = S.ax[a].off[el[a]];
+  const int ld = off[F.d] + (F.side ? Ad.nen - 1 : 0);      // the face layer of the control points
+  auto node = [&](int a0, int a1) { int g[3]; g[F.d] = ld; g[F.t] = off[F.t] + a0; g[F.u] = off[F.u] + a1; return (size_t)g[0] + (size_t)S.ax[0].gwidth * ((size_t)g[1] + (size_t)S.ax[1].gwidth * (size_t)g[2]); };
+  double dS = 0;
+  for (int q1 = 0; q1 < q1n; ++q1) for (int q0 = 0; q0 < q0n; ++q0) {
+    double W0 = 1, S1[2] = {0, 0};
+    if (rat) {
+      W0 = 0;
+      for (int a1 = 0; a1 < n1; ++a1) for (int a0 = 0; a0 < n0; ++a0) {
+        const double *r0 = t0 + (q0 * n0 + a0) * NDER, *r1 = t1 + (q1 * n1 + a1) * NDER;
+        const double w = S.W[node(a0, a1)];
+        W0 += w * r0[0] * r1[0]; S1[0] += w * r0[1] * r1[0]; S1[1] += w * r0[0] * r1[1];
+      }
+    }
+    double G[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    for (int a1 = 0; a1 < n1; ++a1) for (int a0 = 0; a0 < n0; ++a0) {
+      const double *r0 = t0 + (q0 * n0 + a0) * NDER, *r1 = t1 + (q1 * n1 + a1) * NDER;
+      const size_t g = node(a0, a1);
+      double N0 = r0[0] * r1[0], N1[2] = {r0[1] * r1[0], r0[0] * r1[1]};
+      if (rat) { const double w = S.W[g]; N0 = w * N0 / W0; for (int r = 0; r < 2; ++r) N1[r] = (w * N1[r] - N0 * S1[r]) / W0; }
+      for (int r = 0; r < 2; ++r) for (int c = 0; c < 3; ++c) G[r][c] += N1[r] * S.X[g * 3 + c];
+    }
+    double M[2][2] = {{0, 0}, {0, 0}};
+    for (int r = 0; r < 2; ++r) for (int c2 = 0; c2 < 2; ++c2) for (int c = 0; c < 3; ++c) M[r][c2] += G[r][c] * G[c2][c];
+    dS += sqrt(fabs(M[0][0] * M[1][1] - M[0][1] * M[1][0])) * w0[q0] * w1[q1];
+  }
+  F.area[i] = dS * (At.J[el[F.t]] / (double)n0) * (Au.J[el[F.u]] / (double)n1);
+}
+static __global__ void k_boundary_loads_mapped(SpaceDev S, FluxArgs F, FaceAreaArgs A, int nr0, int nr1, double *vec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= F.nt * F.nu) return;
+  int r[3]; r[F.d] = F.rd; r[F.t] = i % F.nt; r[F.u] = i / F.nt;
+  for (int a = 0; a < 3; ++a) {
+    const int gi = F.gfirst[a] + r[a];
+    if ((F.fixlo[a] && gi == 0) || (F.fixhi[a] && gi == F.glast[a])) return;
+  }
+  const AxisDev &At = S.ax[F.t], &Au = S.ax[F.u];
+  double sum = 0;
+  for (int eu = 0; eu < A.nu; ++eu) {
+    const int ou = Au.off[eu];
+    if (r[F.u] < ou || r[F.u] >= ou + Au.nen) continue;
+    for (int et = 0; et < A.nt; ++et) {
+      const int ot = At.off[et];
+      if (r[F.t] < ot || r[F.t] >= ot + At.nen) continue;
+      sum += A.area[eu * A.nt + et];
+    }
+  }
+  const double v = F.value * sum;      // (F.value = the load itself here)
+  if (v != 0.0) vec[(size_t)r[0] + (size_t)nr0 * ((size_t)r[1] + (size_t)nr1 * (size_t)r[2])] += v;
+}
+
 // dof = 1, dim = 3, no geometry, no axis wrapped inside the rank on the loaded faces' axes (rows = ghosted nodes)
 static bool boundary_loads_supported(const Space &s) {
   for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
@@ -1133,7 +1203,7 @@ static bool boundary_loads_supported(const Space &s) {
   return true;
 }
 
-static int launch_boundary_loads(const Space &s, const OutDev &out, hipStream_t stream, std::string &err) {
+static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, std::string &err) {
   for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) {
     const BC &bl = s.load[d][sd];
     if (!bl.count || s.axis[d].periodic) continue;
@@ -1160,6 +1230,16 @@ static int launch_boundary_loads(const Space &s, const OutDev &out, hipStream_t 
       F.gfirst[a] = s.lay[a].gstart; F.glast[a] = s.axis[a].nnp - 1;
       auto holds = [&](const BC &bv) { for (int k = 0; k < bv.count; ++k) if (bv.field[k] == 0) return 1; return 0; };
       F.fixlo[a] = s.axis[a].periodic ? 0 : holds(s.value[a][0]); F.fixhi[a] = s.axis[a].periodic ? 0 : holds(s.value[a][1]);
+    }
+    if (s.nsd) {      // mapped geometry: face areas per element on the device, then the per-node sums
+      FaceAreaArgs A; A.d = d; A.t = t; A.u = u; A.side = sd; A.nt = s.elem_width[t]; A.nu = s.elem_width[u];
+      const int ne = A.nt * A.nu, nn = F.nt * F.nu;
+      if (hipMallocAsync(reinterpret_cast<void **>(&A.area), (size_t)ne * sizeof(double), stream) != hipSuccess) { err = "device allocation of the face areas failed"; return IGX_ERR_MEM; }
+      F.value = load; F.st = F.su = nullptr;
+      hipLaunchKernelGGL(k_face_areas, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, stream, S, A);
+      hipLaunchKernelGGL(k_boundary_loads_mapped, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, S, F, A, s.lay[0].nrow, s.lay[1].nrow, out.vec);
+      (void)hipFreeAsync(A.area, stream);
+      continue;
     }
     // the two short tables live for this launch only: stream-ordered allocation, copy, kernel, free
     double *dt = nullptr;
@@ -1201,7 +1281,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");
   for (int d = 0; d < 3; ++d) {
     if (s.axis[d].p != deg || s.basis[d].nqp != deg + 1) return no("needs the same degree p and p+1 Gauss points on every axis");
-    for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count && out.op == OP_SYSTEM && (geo || !boundary_loads_supported(s))) return no("boundary loads on a mapped geometry / a wrapped axis");
+    for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count && out.op == OP_SYSTEM && !boundary_loads_supported(s)) return no("boundary loads next to an axis wrapped inside the rank");
   }
   GramArgs ga; ga.forcing = (s.form == IGX_FORM_POISSON) ? 1.0 : -6.0; ga.nwaves = 0;
   launches = 0;
@@ -1222,7 +1302,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);   // the only entries no local element reaches
   // boundary loads first: F is zeroed and only added to, so the order is free -- and the ghost rows of the upper face of axis 2
   // must be complete when the first pass of a multi-rank assembly ends (slab_done below)
-  if (sys) { if (int rc = launch_boundary_loads(s, out, stream, err)) return rc; }
+  if (sys) { if (int rc = launch_boundary_loads(s, S, out, stream, err)) return rc; }
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
