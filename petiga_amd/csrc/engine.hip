@@ -520,7 +520,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
   constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
-  constexpr int NTA = (TA == 4) ? 16 / NW : 1;
+  constexpr int NTA = (TA == 8) ? 8 : ((TA == 4) ? 16 / NW : 1);
   constexpr int SCALN = nscalar_of<Form>::v;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
@@ -690,7 +690,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
 template <class Form, int DIM, int TA>
 static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &done) {
   constexpr int DOF = Form::DOF;
-  constexpr int NW = (TA == 4) ? 8 : 4;
+  constexpr int NW = (TA >= 4) ? 8 : 4;
   // 4x4 tiles: 8 waves, <= 144 accumulator VGPRs per wave (dof 4: two launches of two row fields).  Measured on
   // Elasticity3D p=3: one launch of all row fields with 8 waves 2.67 M elements/s (3.2 with Gram accumulators); three
   // launches of one row field with 4-wave workgroups, two per CU, 1.63 M elements/s (tabulation repeated per launch).
@@ -701,7 +701,8 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
     constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
     // a scalar form at nen = 64 has 4 tiles per wave with 4-wave workgroups: small enough for 4 workgroups per CU
     // (Poisson p=3 on a NURBS geometry: 11.9 vs 10.4 M elements/s with the 8-wave layout)
-    constexpr int DOFI = (TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF;
+    // 8x8 tiles (nen <= 128): a wave holds 8 tiles per accumulator set, so one row field per group (the groups are fused)
+    constexpr int DOFI = (TA == 8 && !GRAM) ? 1 : ((TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF);
     if constexpr (TA == 4 && DIM == 3) {
       // pencil mode: the same wave layouts as the element mode (scalar forms: 4 waves with 4 tiles each, 4 workgroups per CU)
       constexpr int NWP = (DOF == 1) ? 4 : 8;
@@ -731,7 +732,15 @@ static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &don
     constexpr bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
     if (s.dof != Form::DOF && (nscalar_of<Form>::v == 0 || fields)) return 0;
     int NE = 1; for (int d = 0; d < 3; ++d) NE *= s.basis[d].nen;
-    if (NE > 64) return 0;
+    if (NE > 128) return 0;
+    if (NE > 64) {   // 8x8 tiles (p = 4 in 3-D: nen = 125) while the accumulators fit: <= 2 sets of 8 tiles per wave
+      constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
+      constexpr int NACC8 = PR ? fm_popcount(PR) : Form::DOF;      // Gram pairs, or the dof blocks of one row field
+      if constexpr (DIM == 3 && NACC8 <= 2 && nscalar_of<Form>::v == 0 && !has_boundary_of<Form>::v) {
+        for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return 0;
+        return launch_feature_ta<Form, DIM, 8>(g, S, out, done);
+      } else return 0;
+    }
     if (NE <= 16) return launch_feature_ta<Form, DIM, 1>(g, S, out, done);
     if (NE <= 32) return launch_feature_ta<Form, DIM, 2>(g, S, out, done);
     return launch_feature_ta<Form, DIM, 4>(g, S, out, done);

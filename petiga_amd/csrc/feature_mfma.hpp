@@ -177,7 +177,7 @@ constexpr int fm_min_waves() {
   const int nacc = !HASM ? 0 : (pairs ? fm_popcount(PENCIL ? fm_pairs_upper(pairs) : pairs) : DOFI * Form::DOF);   // accumulator sets per wave
   if (NW != 4) return 1;      // 8 waves per workgroup: 256 VGPRs each (measured: a 128-VGPR cap gains nothing for scalar
                               // forms and costs the NS-VMS residual 20 % in spills)
-  const int tiles = nacc * ((TA == 4) ? 4 : 1);   // 16x16 accumulator tiles per wave, 8 VGPRs each
+  const int tiles = nacc * ((TA == 8) ? 8 : ((TA == 4) ? 4 : 1));   // 16x16 accumulator tiles per wave, 8 VGPRs each
   // pencil mode keeps the tiles live through every phase of an element: above 16 tiles (128 registers) a wave gets a SIMD
   // to itself, i.e. the unified 512-entry file with the accumulators in AGPRs
   if (PENCIL) return tiles > 16 ? 1 : (tiles <= 4 ? 3 : 2);   // (a scalar form's 4 tiles stay live next to ~110 registers of tabulation: 3 waves)
@@ -214,8 +214,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #define PS(f) fm_phi_slot(PM, (f))
 #define PHAS(f) (((PM >> (f)) & 1u) != 0)
   constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
-  static_assert(NW == 4 || (NW == 8 && TA == 4), "wave layout");
-  constexpr int NTA = (TA == 4) ? 16 / NW : 1;                 // tiles per wave and (i,j) block
+  static_assert(NW == 4 || (NW == 8 && (TA == 4 || TA == 8)), "wave layout");
+  static_assert(TA != 8 || (NW == 8 && !PENCIL), "8x8 tiles (nen <= 128: p = 4 in 3-D): wave w owns tile column w and all 8 tile rows");
+  constexpr int NTA = (TA == 8) ? 8 : ((TA == 4) ? 16 / NW : 1);   // tiles per wave and (i,j) block
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
@@ -284,8 +285,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
   // ---- accumulators (PENCIL: they live across the elements of the walk)
   const bool wave_active = (TA >= 2) || (wave_ == 0);
-  const int tb = (TA == 4) ? (wave_ & 3) : (TA == 2 ? (wave_ & 1) : 0);
-  const int ta0 = (TA == 4) ? NTA * (wave_ >> 2) : (TA == 2 ? (wave_ >> 1) : 0);   // first row tile of this wave
+  const int tb = (TA == 8) ? wave_ : ((TA == 4) ? (wave_ & 3) : (TA == 2 ? (wave_ & 1) : 0));
+  const int ta0 = (TA == 8) ? 0 : ((TA == 4) ? NTA * (wave_ >> 2) : (TA == 2 ? (wave_ >> 1) : 0));   // first row tile of this wave
   fm_d4_t acc[NACC][NTA];
 #pragma unroll
   for (int k = 0; k < NACC; ++k)

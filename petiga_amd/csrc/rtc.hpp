@@ -223,9 +223,9 @@ static int rtc_feature_module(IGX g, RtcForm &F, int DIM, int DOF, int TA, int N
 // wave layouts of launch_feature_ta (engine.hip): 8 waves at 4x4 tiles, except scalar matrix forms (4 waves with 4 tiles each);
 // dof 4 at 4x4 tiles takes two launches of two row fields
 static void rtc_feature_layout(int NE, int DOF, bool GRAM, bool HASM, int &TA, int &NW, int &DOFI) {
-  TA = NE <= 16 ? 1 : (NE <= 32 ? 2 : 4);
-  NW = (TA == 4) ? 8 : 4; DOFI = DOF;
-  if (HASM) { if (TA == 4 && DOF == 4 && !GRAM) DOFI = 2; if (TA == 4 && DOF == 1) NW = 4; }
+  TA = NE <= 16 ? 1 : (NE <= 32 ? 2 : (NE <= 64 ? 4 : 8));
+  NW = (TA >= 4) ? 8 : 4; DOFI = DOF;
+  if (HASM) { if (TA == 8 && !GRAM) DOFI = 1; if (TA == 4 && DOF == 4 && !GRAM) DOFI = 2; if (TA == 4 && DOF == 1) NW = 4; }
 }
 
 static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done) {
@@ -235,8 +235,9 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   if (DIM < 2 || DOF > 4) return 0;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
-  if (NE > 64) return 0;
+  if (NE > 128) return 0;
   const bool SECOND = F.meta[1] >= 2, SECOND_S = F.meta[4] >= 2, GRAM = F.meta[6] != 0;
+  if (NE > 64 && (DIM != 3 || GRAM || DOF > 2)) return 0;      // 8x8 tiles: p = 4 in 3-D, at most two accumulator sets per wave
   if (GRAM && DOF * DOF > 16) return 0;
   const bool HASM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
   int TA, NW, DOFI; rtc_feature_layout(NE, DOF, GRAM, HASM, TA, NW, DOFI);
@@ -435,7 +436,7 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   if (s.dim < 2) return 0;   // dim 1: the point-form kernel only
   int NE = 1;
   for (int d = 0; d < s.dim; ++d) { if (s.axis[d].p < 1) return fail(IGX_ERR_ARG_WRONGSTATE, "set the axes (degrees) first"); NE *= s.axis[d].p + 1; }
-  if (NE > 64) return 0;
+  if (NE > 128 || (NE > 64 && (s.dim != 3 || gram || s.dof > 2))) return 0;
   int TA, NW, DOFI; rtc_feature_layout(NE, s.dof, gram != 0, with_matrix != 0, TA, NW, DOFI);
   std::shared_ptr<RtcFeature> K;
   return rtc_feature_module(g, *g->rtc, s.dim, s.dof, TA, NW, DOFI, with_matrix != 0, false, K);
