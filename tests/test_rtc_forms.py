@@ -93,7 +93,7 @@ def test_compile_errors_come_back_with_the_log():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 9, False), (2, 2, 7, False), (2, 3, 5, True), (3, 2, 4, False), (3, 3, 3, True), (3, 1, 5, True)])
+@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 9, False), (2, 2, 7, False), (2, 3, 5, True), (3, 2, 4, False), (3, 3, 3, True), (3, 1, 5, True), (3, 4, 2, True)])
 def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo, kernel):
     orc, eng = make_pair(dim, 1, p, N)
     eng.set_kernel(kernel)
@@ -114,6 +114,8 @@ def test_advection_diffusion_source_form_matches_oracle(dim, p, N, geo, kernel):
     assert "hiprtc" in eng.kernel_name()
     # the matrix-core kernel when it covers the case (dim >= 2, nen <= 64), the point-form kernel otherwise / on request
     assert ("mfma" in eng.kernel_name()) == (kernel == 0 and dim >= 2)
+    if p == 4 and kernel == 0:
+        assert "tiles=8x8" in eng.kernel_name()
     tol = 1e-11 if geo else 1e-12
     compare_mats(A, A_o, tol)
     assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
