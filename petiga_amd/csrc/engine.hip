@@ -736,9 +736,14 @@ static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &don
     if (NE > 64) {   // 8x8 tiles (p = 4 in 3-D: nen = 125) while the accumulators fit: <= 2 sets of 8 tiles per wave
       constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
       constexpr int NACC8 = PR ? fm_popcount(PR) : Form::DOF;      // Gram pairs, or the dof blocks of one row field
-      if constexpr (DIM == 3 && NACC8 <= 2 && nscalar_of<Form>::v == 0 && !has_boundary_of<Form>::v) {
+      if constexpr (DIM == 3 && nscalar_of<Form>::v == 0 && !has_boundary_of<Form>::v) {
         for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return 0;
-        return launch_feature_ta<Form, DIM, 8>(g, S, out, done);
+        if constexpr (NACC8 <= 2) return launch_feature_ta<Form, DIM, 8>(g, S, out, done);
+        else {   // more accumulator sets than a wave holds at 8 tiles each: the vector-only drivers still take the kernel
+          const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+          if (hasM) return 0;
+          return launch_feature_plan<Form, DIM, 8, 8, Form::DOF, false>(g, S, out, done);
+        }
       } else return 0;
     }
     if (NE <= 16) return launch_feature_ta<Form, DIM, 1>(g, S, out, done);

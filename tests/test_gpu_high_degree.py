@@ -88,3 +88,28 @@ def test_cahn_hilliard_at_degree_four():
     ctx = O.CahnHilliardCtx(*params)
     compare_mats(A, orc.compute_ijacobian("orc_form_ch_tangent", ctx, 7.5, V, 0.0, U), 1e-11)
     assert rel_err(F.get(), orc.compute_ifunction("orc_form_ch_residual", ctx, 7.5, V, 0.0, U)) <= 1e-11
+
+
+def test_vector_only_drivers_at_degree_four_for_a_four_field_form():
+    """NS-VMS at p = 4: the Tangent has too many accumulator sets for 8x8 tiles (point-form kernel), the Residual needs none"""
+    orc, eng = make_pair(3, 4, 4, [5, 2, 2], periodic=[True, False, False])
+    for g in (orc, eng):
+        for side in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, side, f, 0.0)
+    nu, fx, dt = 1.472e-4, 3.37204e-3, 1e-2
+    ctx = O.NSVMSCtx(nu, fx, 0.0, 0.0, dt)
+    rng = np.random.default_rng(2)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n) * 0.1
+    eng.set_form("nsvms", (nu, fx, 0.0, 0.0, dt))
+    Uv, Vv, F, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec(), eng.create_mat()
+    eng.compute_ifunction(200.0, Vv, 0.0, Uv, F)
+    eng.synchronize()
+    assert "feature_assemble(vector only" in eng.kernel_name()
+    F_o = orc.compute_ifunction("orc_form_ns_residual", ctx, 200.0, V, 0.0, U)
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * np.abs(F_o).max()
+    eng.compute_ijacobian(200.0, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "generic_assemble" in eng.kernel_name()
+    compare_mats(J, orc.compute_ijacobian("orc_form_ns_tangent", ctx, 200.0, V, 0.0, U), 1e-11)
