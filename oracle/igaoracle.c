@@ -154,9 +154,9 @@ int orc_axis_set_knots(OrcIGA *iga,int i,int m,const double *U)
 /* ------------------------------------------------------------------ */
 void orc_bspline_ders(int i,double uu,int p,int n,const double *U,double *B)
 {
-  double ndu[6][6], a[2][6], left[6], right[6], ders[6][5];
+  double ndu[10][10], a[2][10], left[10], right[10], ders[10][5];   /* p <= 9 */
   int j,k,r;
-  /* p <= 5 is enough for every config; the reference allows any p */
+  /* p <= 9 (the reference allows any p; the engine takes p <= 7) */
   ndu[0][0] = 1;
   for (j=1; j<=p; j++) {
     double saved = 0;

@@ -520,7 +520,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
   constexpr int DOF = Form::DOF;
   constexpr bool SECOND = Form::ORDER >= 2, SECOND_S = shape_order_of<Form>::v >= 2;
   constexpr int D2 = DIM * DIM, NFS = SECOND_S ? 1 + DIM + D2 : 1 + DIM;
-  constexpr int NTA = (TA == 8) ? 8 : ((TA == 4) ? 16 / NW : 1);
+  constexpr int NTA = (TA >= 8) ? TA : ((TA == 4) ? 16 / NW : 1);
   constexpr int SCALN = nscalar_of<Form>::v;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
@@ -679,7 +679,7 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
     g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] * ((HASM && !fused) ? (DOF / DOFI) : 1);
     g->dom.flop_per_element = HASM ? feature_mfma_flop<Form, TA>(cv.QC * cv.nchunk) * (fused ? DOF : DOFI) / DOF : 0.0;
   }
-  if (HASM) g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
+  if (HASM) g->last_kernel = std::string("feature_assemble(mfma_f64_16x16x4,tiles=") + std::to_string(TA) + "x" + std::to_string(TA) + ",waves=" + char('0' + NW) +
                    ",rowfields/launch=" + char('0' + DOFI) + ((!pencil && DOFI < DOF && s.env.fuse_groups) ? std::string("x") + char('0' + DOF / DOFI) + " fused" : std::string()) +
                    ",chunks=" + std::to_string(cv.nchunk) + (pencil ? ",pencil walk axis 0" : "") + ")";
   else g->last_kernel = std::string("feature_assemble(vector only,waves=") + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
@@ -702,7 +702,7 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
     // a scalar form at nen = 64 has 4 tiles per wave with 4-wave workgroups: small enough for 4 workgroups per CU
     // (Poisson p=3 on a NURBS geometry: 11.9 vs 10.4 M elements/s with the 8-wave layout)
     // 8x8 tiles (nen <= 128): a wave holds 8 tiles per accumulator set, so one row field per group (the groups are fused)
-    constexpr int DOFI = (TA == 8 && !GRAM) ? 1 : ((TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF);
+    constexpr int DOFI = (TA >= 8 && !GRAM) ? 1 : ((TA == 4 && DOF == 4 && !GRAM) ? 2 : DOF);
     if constexpr (TA == 4 && DIM == 3) {
       // pencil mode: the same wave layouts as the element mode (scalar forms: 4 waves with 4 tiles each, 4 workgroups per CU)
       constexpr int NWP = (DOF == 1) ? 4 : 8;
@@ -732,7 +732,20 @@ static int launch_feature(IGX g, const SpaceDev &S, const OutDev &out, bool &don
     constexpr bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
     if (s.dof != Form::DOF && (nscalar_of<Form>::v == 0 || fields)) return 0;
     int NE = 1; for (int d = 0; d < 3; ++d) NE *= s.basis[d].nen;
-    if (NE > 128) return 0;
+    if (NE > 256) return 0;
+    if (NE > 128) {  // 16 tile rows x two panels of 8 tile columns (p = 5 in 3-D: nen = 216): one accumulator set of 16 tiles per wave
+      constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
+      constexpr int NACC16 = PR ? fm_popcount(PR) : Form::DOF;
+      if constexpr (DIM == 3 && nscalar_of<Form>::v == 0 && !has_boundary_of<Form>::v) {
+        for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return 0;
+        if constexpr (NACC16 == 1) return launch_feature_ta<Form, DIM, 16>(g, S, out, done);
+        else {
+          const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+          if (hasM) return 0;
+          return launch_feature_plan<Form, DIM, 16, 8, Form::DOF, false>(g, S, out, done);
+        }
+      } else return 0;
+    }
     if (NE > 64) {   // 8x8 tiles (p = 4 in 3-D: nen = 125) while the accumulators fit: <= 2 sets of 8 tiles per wave
       constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
       constexpr int NACC8 = PR ? fm_popcount(PR) : Form::DOF;      // Gram pairs, or the dof blocks of one row field

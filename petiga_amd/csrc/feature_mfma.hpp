@@ -177,7 +177,7 @@ constexpr int fm_min_waves() {
   const int nacc = !HASM ? 0 : (pairs ? fm_popcount(PENCIL ? fm_pairs_upper(pairs) : pairs) : DOFI * Form::DOF);   // accumulator sets per wave
   if (NW != 4) return 1;      // 8 waves per workgroup: 256 VGPRs each (measured: a 128-VGPR cap gains nothing for scalar
                               // forms and costs the NS-VMS residual 20 % in spills)
-  const int tiles = nacc * ((TA == 8) ? 8 : ((TA == 4) ? 4 : 1));   // 16x16 accumulator tiles per wave, 8 VGPRs each
+  const int tiles = nacc * ((TA >= 8) ? TA : ((TA == 4) ? 4 : 1));   // 16x16 accumulator tiles per wave, 8 VGPRs each
   // pencil mode keeps the tiles live through every phase of an element: above 16 tiles (128 registers) a wave gets a SIMD
   // to itself, i.e. the unified 512-entry file with the accumulators in AGPRs
   if (PENCIL) return tiles > 16 ? 1 : (tiles <= 4 ? 3 : 2);   // (a scalar form's 4 tiles stay live next to ~110 registers of tabulation: 3 waves)
@@ -203,7 +203,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   static_assert(!PENCIL || (TA == 4 && HASM && DIM == 3), "pencil mode: 4x4 tiles, matrix drivers, dim 3");
   constexpr int DOF = Form::DOF;
   static_assert(!FUSE || (HASM && !PENCIL && I0 == 0 && DOF % DOFI == 0), "fused groups: element mode, matrix drivers, all groups");
-  constexpr int NPASS = FUSE ? DOF / DOFI : 1;
+  constexpr int NGROUP = FUSE ? DOF / DOFI : 1;
+  constexpr int NPASS = NGROUP * ((TA == 16 && HASM) ? 2 : 1);     // (TA = 16: two column panels per group)
   constexpr bool SECOND = Form::ORDER >= 2;                    // tabulation order (fields may need Hessians)
   constexpr bool SECOND_S = shape_order_of<Form>::v >= 2;      // order of the shape-function features mat()/vec() read
   constexpr int D2 = DIM * DIM;
@@ -214,9 +215,12 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 #define PS(f) fm_phi_slot(PM, (f))
 #define PHAS(f) (((PM >> (f)) & 1u) != 0)
   constexpr unsigned FMASK = mat_test_mask_of<Form>::v;
-  static_assert(NW == 4 || (NW == 8 && (TA == 4 || TA == 8)), "wave layout");
-  static_assert(TA != 8 || (NW == 8 && !PENCIL), "8x8 tiles (nen <= 128: p = 4 in 3-D): wave w owns tile column w and all 8 tile rows");
-  constexpr int NTA = (TA == 8) ? 8 : ((TA == 4) ? 16 / NW : 1);   // tiles per wave and (i,j) block
+  static_assert(NW == 4 || (NW == 8 && (TA == 4 || TA == 8 || TA == 16)), "wave layout");
+  static_assert(TA < 8 || (NW == 8 && !PENCIL), "8x8 tiles (nen <= 128: p = 4 in 3-D): wave w owns tile column w and all 8 tile rows");
+  // TA = 16 (nen <= 256: p = 5 in 3-D): 16 tile rows, the 16 tile columns in two panels of 8 formed one after the other (the
+  // passes of the group loop below); one accumulator set only
+  constexpr int NPANEL = (TA == 16 && HASM) ? 2 : 1;
+  constexpr int NTA = (TA >= 8) ? TA : ((TA == 4) ? 16 / NW : 1);   // tiles per wave and (i,j) block
   constexpr int NEP = 16 * TA;                                 // padded nen
   constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU);
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
@@ -285,8 +289,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
   // ---- accumulators (PENCIL: they live across the elements of the walk)
   const bool wave_active = (TA >= 2) || (wave_ == 0);
-  const int tb = (TA == 8) ? wave_ : ((TA == 4) ? (wave_ & 3) : (TA == 2 ? (wave_ & 1) : 0));
-  const int ta0 = (TA == 8) ? 0 : ((TA == 4) ? NTA * (wave_ >> 2) : (TA == 2 ? (wave_ >> 1) : 0));   // first row tile of this wave
+  const int tb_ = (TA >= 8) ? wave_ : ((TA == 4) ? (wave_ & 3) : (TA == 2 ? (wave_ & 1) : 0));     // (TA = 16: within the panel)
+  const int ta0 = (TA >= 8) ? 0 : ((TA == 4) ? NTA * (wave_ >> 2) : (TA == 2 ? (wave_ >> 1) : 0));   // first row tile of this wave
   fm_d4_t acc[NACC][NTA];
 #pragma unroll
   for (int k = 0; k < NACC; ++k)
@@ -622,8 +626,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
 
 #pragma unroll
   for (int pass = 0; pass < NPASS; ++pass) {     // (fully unrolled: I0p is a constant in every copy)
-  const int I0p = I0 + pass * DOFI;              // first row field of this group
-  const bool retab = (pass == 0) || (cv.nchunk > 1);   // a later group finds Phi and the field values of a single chunk still in LDS
+  const int I0p = I0 + (pass / NPANEL) * DOFI;   // first row field of this group
+  const int tb = tb_ + (pass % NPANEL) * 8;      // tile column of this wave (TA = 16: in this pass's panel)
+  const bool retab = (pass == 0) || (cv.nchunk > 1);   // a later pass finds Phi and the field values of a single chunk still in LDS
   if (pass > 0) {
 #pragma unroll
     for (int k = 0; k < NACC; ++k)
@@ -925,7 +930,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       __syncthreads();                     // Phi (MFMA / vector phases of this element) or the previous pass's staging is free
       const int ncolb = 4 - lv;            // column layers of the row part = its tile slots
       if (wave_active && !(kDebug && (out.debug & 1))) {
-        const int lb = rslot(tb);
+        const int lb = rslot(tb_);
 #pragma unroll
         for (int t = 0; t < NTA; ++t) {
           const int la = rslot(ta0 + t);

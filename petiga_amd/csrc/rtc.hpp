@@ -223,7 +223,7 @@ static int rtc_feature_module(IGX g, RtcForm &F, int DIM, int DOF, int TA, int N
 // wave layouts of launch_feature_ta (engine.hip): 8 waves at 4x4 tiles, except scalar matrix forms (4 waves with 4 tiles each);
 // dof 4 at 4x4 tiles takes two launches of two row fields
 static void rtc_feature_layout(int NE, int DOF, bool GRAM, bool HASM, int &TA, int &NW, int &DOFI) {
-  TA = NE <= 16 ? 1 : (NE <= 32 ? 2 : (NE <= 64 ? 4 : 8));
+  TA = NE <= 16 ? 1 : (NE <= 32 ? 2 : (NE <= 64 ? 4 : (NE <= 128 ? 8 : 16)));
   NW = (TA >= 4) ? 8 : 4; DOFI = DOF;
   if (HASM) { if (TA == 8 && !GRAM) DOFI = 1; if (TA == 4 && DOF == 4 && !GRAM) DOFI = 2; if (TA == 4 && DOF == 1) NW = 4; }
 }
@@ -235,9 +235,10 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   if (DIM < 2 || DOF > 4) return 0;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
-  if (NE > 128) return 0;
+  if (NE > 256) return 0;
   const bool SECOND = F.meta[1] >= 2, SECOND_S = F.meta[4] >= 2, GRAM = F.meta[6] != 0;
   if (NE > 64 && (DIM != 3 || GRAM || DOF > 2)) return 0;      // 8x8 tiles: p = 4 in 3-D, at most two accumulator sets per wave
+  if (NE > 128 && DOF > 1) return 0;                           // 16 tile rows x two column panels: p = 5 in 3-D, one set
   if (GRAM && DOF * DOF > 16) return 0;
   const bool HASM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
   int TA, NW, DOFI; rtc_feature_layout(NE, DOF, GRAM, HASM, TA, NW, DOFI);
@@ -322,7 +323,7 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
     g->dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
     g->dom.flop_per_element = HASM ? 2048.0 * K->meta[2] * TA * TA * (cv.QC * cv.nchunk / 4) : 0.0;
   }
-  if (HASM) g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,mfma_f64_16x16x4,tiles=" + char('0' + TA) + "x" + char('0' + TA) + ",waves=" + char('0' + NW) +
+  if (HASM) g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,mfma_f64_16x16x4,tiles=" + std::to_string(TA) + "x" + std::to_string(TA) + ",waves=" + char('0' + NW) +
                              ",rowfields/launch=" + char('0' + DOFI) + (DOFI < DOF ? std::string("x") + char('0' + DOF / DOFI) + " fused" : std::string()) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   else g->last_kernel = std::string("feature_assemble<") + F.name + ">(hiprtc,vector only,waves=" + char('0' + NW) + ",chunks=" + std::to_string(cv.nchunk) + ")";
   done = true;
@@ -436,7 +437,7 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   if (s.dim < 2) return 0;   // dim 1: the point-form kernel only
   int NE = 1;
   for (int d = 0; d < s.dim; ++d) { if (s.axis[d].p < 1) return fail(IGX_ERR_ARG_WRONGSTATE, "set the axes (degrees) first"); NE *= s.axis[d].p + 1; }
-  if (NE > 128 || (NE > 64 && (s.dim != 3 || gram || s.dof > 2))) return 0;
+  if (NE > 256 || (NE > 64 && (s.dim != 3 || gram || s.dof > 2)) || (NE > 128 && s.dof > 1)) return 0;
   int TA, NW, DOFI; rtc_feature_layout(NE, s.dof, gram != 0, with_matrix != 0, TA, NW, DOFI);
   std::shared_ptr<RtcFeature> K;
   return rtc_feature_module(g, *g->rtc, s.dim, s.dof, TA, NW, DOFI, with_matrix != 0, false, K);

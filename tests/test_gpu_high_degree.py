@@ -16,7 +16,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("p,N,geo,form,dof", [((4, 4, 4), (3, 2, 3), "none", "poisson", 1), ((4, 4, 4), (2, 3, 2), "nurbs", "poisson", 1),
                                              ((4, 4, 3), (3, 3, 2), "poly", "poisson", 1), ((5, 4, 4), (2, 2, 3), "none", "poisson", 1),
                                              ((4, 4, 4), (2, 2, 3), "none", "mass", 2), ((4, 4, 4), (3, 2, 2), "nurbs", "mass", 3),
-                                             ((4, 4, 4), (2, 3, 2), "none", "mass", 1)])
+                                             ((4, 4, 4), (2, 3, 2), "none", "mass", 1),
+                                             ((5, 5, 5), (2, 2, 2), "none", "poisson", 1), ((5, 5, 4), (2, 2, 2), "nurbs", "poisson", 1),
+                                             ((5, 5, 5), (2, 1, 2), "none", "mass", 2), ((7, 4, 4), (1, 2, 2), "poly", "poisson", 1)])
 def test_system_at_degree_four(p, N, geo, form, dof, kernel):
     orc, eng = make_pair(3, dof, list(p), list(N))
     eng.set_kernel(kernel)
@@ -34,8 +36,9 @@ def test_system_at_degree_four(p, N, geo, form, dof, kernel):
     eng.compute_system(A, b)
     eng.synchronize()
     nen = int(np.prod([q + 1 for q in p]))
-    if kernel == 0:
+    if kernel == 0:      # 8x8 tiles up to nen = 128, 16 tile rows x two column panels up to 256 (one accumulator set: scalar forms, mass)
         assert ("tiles=8x8" in eng.kernel_name()) == (64 < nen <= 128), eng.kernel_name()
+        assert ("tiles=16x16" in eng.kernel_name()) == (128 < nen <= 256), eng.kernel_name()
     tol = 1e-12 if geo == "none" else 2e-11
     compare_mats(A, A_o, tol)
     assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
