@@ -128,6 +128,7 @@ CASES = {
     "poisson-p2-4ranks-periodic": (4, (3, 1, 2, (8, 8, 8), (1, 0, 1), "poisson", ())),
     "poisson-p3-2ranks-pencil-loads": (2, (3, 1, 3, (8, 6, 16), (0, 0, 0), "poisson", ())),
     "poisson-p2-4ranks-pencil-loads": (4, (3, 1, 2, (9, 12, 12), (0, 0, 0), "poisson", ())),
+    "poisson-p2-8ranks-pencil": (8, (3, 1, 2, (16, 12, 12), (0, 0, 0), "poisson", ())),      # [2,2,2]: faces, edges and the corner
     "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
     "poisson-p3-4ranks-pencil": (4, (3, 1, 3, (9, 16, 16), (0, 0, 0), "poisson", ())),
