@@ -558,7 +558,11 @@ static int launch_feature_plan(IGX g, const SpaceDev &S, const OutDev &out, bool
       cv.lift = take(SCALN > 0 ? QC * SCALN : (out.op == OP_SYSTEM ? QC * DOF * NFS : 0));
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
       // the sum-factorised geometry sums of phase 1 borrow the Phi region before Phi exists
-      const int sf_need = (s.nsd || s.rational) ? (DIM + 1) * ((SECOND ? 3 : 2) * nq[0] * na[1] * na[2] + (SECOND ? 6 : 3) * nq[0] * nq[1] * na[2] + (SECOND ? 10 : 4) * NQ) : 0;
+      // (and so do the sums behind the field Hessians of a form that reads them without second derivatives of N: DOF components)
+      constexpr bool HU_FLY = SECOND && !SECOND_S && (Form::NEED & NEED_HU) != 0;
+      cv.sfb = (NE > 64) ? 1 : DOF;      // large elements: one field at a time
+      const int sf_nc = std::max((s.nsd || s.rational) ? DIM + 1 : 0, (HU_FLY && (need & NEED_HU)) ? cv.sfb : 0);
+      const int sf_need = sf_nc * ((SECOND ? 3 : 2) * nq[0] * na[1] * na[2] + (SECOND ? 6 : 3) * nq[0] * nq[1] * na[2] + (SECOND ? 10 : 4) * NQ);
       // pencil mode parks the 7 leaving tiles of every (i,j) block of a launch in the Phi region before they are written out
       constexpr unsigned long long PR = mat_pair_mask_of<Form>::v;
       const int stage_need = PEN ? 7 * 16 * 17 * (PR ? fm_popcount(fm_pairs_upper(PR)) : DOFI * DOF) : 0;   // the leaving tiles (feature_mfma.hpp)

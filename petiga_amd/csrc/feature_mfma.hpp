@@ -76,6 +76,7 @@ struct FCarve {            // offsets in doubles into the dynamic LDS block
   int JW, xq, E1, E2, W0, W1, W2, G;
   int u, ut, gu, hu, hpart, lift, phi;
   int rowbase, rowid, cc, pax, adec, qdec, nrm, boff;
+  int sfb;                 // field Hessians by sum factorisation: components per batch (DOF; 1 when the sums of all would not fit)
   int total;
   int QC, nchunk, NEP;     // points per chunk (multiple of 4), chunks, padded nen (16 * tiles)
 };
@@ -446,8 +447,8 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool need2 = SECOND && (SECOND_S || (need & NEED_HU) != 0);
   constexpr int SF_NV = SECOND ? 3 : 2, SF_NM = SECOND ? 6 : 3, SF_NK = SECOND ? 10 : 4;
   double *SF = phi;                                   // [NC][SF_NK][NQ], in the (not yet used) Phi region
-  if (sumfact) {
-    constexpr int NC = DIM + 1;                       // components: X (times w) and w
+  // sum_a coef(a, c) * (tensor-product basis function a and its parametric derivatives) at every point, NC components
+  auto sum_factorise = [&](const int NC, auto coef) {
     const int n1 = NC * SF_NV * nq[0] * na[1] * na[2], n2 = NC * SF_NM * nq[0] * nq[1] * na[2], n3 = NC * SF_NK * NQ;
     double *T1 = phi + n3, *T2 = T1 + n1;
     for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v], v = derivative order on axis 0
@@ -456,9 +457,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       double sm = 0;
       for (int a0 = 0; a0 < na[0]; ++a0) {
         const int a = slot_of<PENCIL>(a0, a1, a2, na);
-        const double w = rat ? gW[a] : 1.0;
-        const double cv = (c < DIM) ? (geo ? gX[a * DIM + c] * w : 0.0) : w;
-        sm += cv * t1d[0][(q0 * na[0] + a0) * NDER + v];
+        sm += coef(a, c) * t1d[0][(q0 * na[0] + a0) * NDER + v];
       }
       T1[i] = sm;
     }
@@ -484,7 +483,9 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
       SF[i] = sm;
     }
     __syncthreads();
-  }
+  };
+  // components of the geometry sums: X (times w) and w
+  if (sumfact) sum_factorise(DIM + 1, [&](int a, int c) { const double w = rat ? gW[a] : 1.0; return (c < DIM) ? (geo ? gX[a * DIM + c] * w : 0.0) : w; });
   {
     const int np1 = 1;                 // one lane per point: the sums over the basis functions are done (sum factorisation above)
     const int qstep = nthr / np1;
@@ -580,41 +581,61 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   __syncthreads();
 
   if (HU_FLY && (need & NEED_HU)) {
-    // Hessians of the fields when the form itself never reads second derivatives of N: the second-derivative
-    // features are formed on the fly (never stored), nph lanes per point; done for all points before the
-    // accumulators become live
-    int nph = pow2_floor(nthr / NQP); if (nph > 16) nph = 16;
-    const int qstep = nthr / nph;
-    for (int qb = 0; qb < NQP; qb += qstep) {
-      const int q = qb + tid / nph, part = tid & (nph - 1);
-      const bool valid = q < NQ && useU;
-      double hp[DOF][D2];
+    // Hessians of the fields when the form itself never reads second derivatives of N (NS-VMS): no second-derivative feature
+    // is ever formed.  The homogeneous sums A_c = sum_a (w_a U_a,c) N_a with their first and second PARAMETRIC derivatives come
+    // from the same sum factorisation as the geometry (three short contractions through LDS); u, du, d2u follow by the
+    // quotient rule with W, dW, d2W of the point (Rationalize summed over a, src/petigarat.f90.in), and the physical Hessian is
+    // H_ij = d2u_ab E1_ai E1_bj + du_a E2_aij (ShapeFunctions summed over a, src/petigamapshf.f90.in:30-58): one lane per
+    // (point, field) instead of nen second-order shape functions per point -- 50k of the 145k cycles of an NS-VMS residual
+    // element on a NURBS.
+    auto k2 = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
+    const int sfb = (cv.sfb > 0 && cv.sfb < DOF) ? cv.sfb : DOF;      // components per batch
+    for (int c0 = 0; c0 < DOF; c0 += sfb) {
+    sum_factorise(sfb, [&](int a, int cl) { return useU ? (rat ? gW[a] : 1.0) * Ue[a * DOF + c0 + cl] : 0.0; });
+    for (int idx = tid; idx < NQP * sfb; idx += nthr) {
+      const int q = idx / sfb, cl = idx - q * sfb, c = c0 + cl;
+      double H[D2];
 #pragma unroll
-      for (int c = 0; c < DOF; ++c)
+      for (int i = 0; i < D2; ++i) H[i] = 0;
+      if (q < NQ) {
+        const double w0 = rat ? W0[q] : 1.0, iw = 1.0 / w0;
+        const double u = SF[(cl * SF_NK + 0) * NQ + q] * iw;
+        double u1[DIM], u2[D2];
 #pragma unroll
-        for (int i = 0; i < D2; ++i) hp[c][i] = 0;
-      if (valid) for (int a = part; a < NE; a += nph) {
-        double o[NF];
-        shape_features<DIM, true>(t1d, na, qdec, adec, q, a, rat, geo, gW, W0, W1, W2, E1, E2, o);
+        for (int al = 0; al < DIM; ++al) u1[al] = (SF[(cl * SF_NK + 1 + al) * NQ + q] - (rat ? u * W1[q * DIM + al] : 0.0)) * iw;
 #pragma unroll
-        for (int c = 0; c < DOF; ++c) {
-          const double Ua = Ue[a * DOF + c];
+        for (int al = 0; al < DIM; ++al)
 #pragma unroll
-          for (int i = 0; i < D2; ++i) hp[c][i] += o[1 + DIM + i] * Ua;
+          for (int be = 0; be < DIM; ++be) {
+            double t = SF[(cl * SF_NK + k2(al, be)) * NQ + q];
+            if (rat) t -= u * W2[q * D2 + al * DIM + be] + u1[al] * W1[q * DIM + be] + u1[be] * W1[q * DIM + al];
+            u2[al * DIM + be] = t * iw;
+          }
+        if (geo) {
+          const double *e1 = E1 + q * D2, *e2 = E2 + (size_t)q * DIM * D2;
+#pragma unroll
+          for (int i = 0; i < DIM; ++i)
+#pragma unroll
+            for (int j = 0; j < DIM; ++j) {
+              double sm = 0;
+#pragma unroll
+              for (int al = 0; al < DIM; ++al) {
+#pragma unroll
+                for (int be = 0; be < DIM; ++be) sm += u2[al * DIM + be] * e1[al * DIM + i] * e1[be * DIM + j];
+                sm += u1[al] * e2[al * D2 + i * DIM + j];
+              }
+              H[i * DIM + j] = sm;
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < D2; ++i) H[i] = u2[i];
         }
       }
 #pragma unroll
-      for (int c = 0; c < DOF; ++c)
-#pragma unroll
-        for (int i = 0; i < D2; ++i) hp[c][i] = group_sum(hp[c][i], nph);
-      if (part == 0 && q < NQP) {
-#pragma unroll
-        for (int c = 0; c < DOF; ++c)
-#pragma unroll
-          for (int i = 0; i < D2; ++i) fhu[(q * DOF + c) * D2 + i] = hp[c][i];
-      }
+      for (int i = 0; i < D2; ++i) fhu[(q * DOF + c) * D2 + i] = H[i];
     }
     __syncthreads();
+    }   // batches of components
   }
 
   FM_STAMP();

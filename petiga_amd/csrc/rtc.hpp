@@ -274,7 +274,10 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
       cv.hpart = 0;
       cv.lift = take(out.op == OP_SYSTEM ? QC * DOF * NFS : 0);
       cv.rowbase = take(HASM ? NE : 0); cv.rowid = take(NE); cv.cc = take(NE); cv.pax = take(96); cv.adec = take(NEP / 2); cv.qdec = take((NQP + 1) / 2); cv.nrm = take(NQP * DIM);
-      const int sf_need = (s.nsd || s.rational) ? (DIM + 1) * ((SECOND ? 3 : 2) * nq[0] * na[1] * na[2] + (SECOND ? 6 : 3) * nq[0] * nq[1] * na[2] + (SECOND ? 10 : 4) * NQ) : 0;
+      const bool hu_fly = SECOND && !SECOND_S && ((unsigned)F.meta[2] & NEED_HU) != 0;
+      cv.sfb = (NE > 64) ? 1 : DOF;
+      const int sf_nc = std::max((s.nsd || s.rational) ? DIM + 1 : 0, (hu_fly && (need & NEED_HU)) ? cv.sfb : 0);
+      const int sf_need = sf_nc * ((SECOND ? 3 : 2) * nq[0] * na[1] * na[2] + (SECOND ? 6 : 3) * nq[0] * nq[1] * na[2] + (SECOND ? 10 : 4) * NQ);
       cv.boff = 0;
       cv.phi = take(std::max(NPS * QC * NEP, sf_need));
       cv.total = pos; cv.QC = QC; cv.nchunk = nchunk; cv.NEP = NEP;
