@@ -69,6 +69,7 @@ def test_user_form_compiles_without_a_gpu(dim):
 
 
 @pytest.mark.parametrize("dim,p,dof,src,name,gram", [(2, 2, 1, ADVECTION_DIFFUSION, "AdvDiff<2>", False), (3, 3, 1, ADVECTION_DIFFUSION, "AdvDiff<3>", False),
+                                                    (3, 5, 1, ADVECTION_DIFFUSION, "AdvDiff<3>", False),      # 16 tile rows x two column panels
                                                     (3, 2, 3, USER_ELASTICITY, "UserElasticity<0>", False), (3, 3, 3, USER_ELASTICITY, "UserElasticity<1>", True)])
 def test_user_form_compiles_for_the_matrix_core_kernel_without_a_gpu(dim, p, dof, src, name, gram):
     """IGXCheckFormSource: the feature_assemble instantiations the drivers would launch (matrix and vector-only)."""
