@@ -116,3 +116,39 @@ def test_vector_only_drivers_at_degree_four_for_a_four_field_form():
     eng.synchronize()
     assert "generic_assemble" in eng.kernel_name()
     compare_mats(J, orc.compute_ijacobian("orc_form_ns_tangent", ctx, 200.0, V, 0.0, U), 1e-11)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_high_degree_discretisation(seed):
+    """seeded sweep: degrees 3..5 per axis (nen up to 256), 1..3 elements per axis, Poisson / mass (1-2 fields), identity /
+    polynomial / NURBS geometry, random Dirichlet values and loads"""
+    rng = np.random.default_rng(9000 + seed)
+    p = [int(rng.integers(3, 6)) for _ in range(3)]
+    if np.prod([q + 1 for q in p]) > 256:
+        p[int(rng.integers(0, 3))] = 3
+    N = [int(rng.integers(1, 4)) for _ in range(3)]
+    form = str(rng.choice(["poisson", "mass"]))
+    dof = 1 if form == "poisson" else int(rng.integers(1, 3))
+    geo = str(rng.choice(["none", "poly", "nurbs"]))
+    orc, eng = make_pair(3, dof, p, N)
+    if geo != "none":
+        X, W = warped_geometry(orc, 3, seed=seed, rational=(geo == "nurbs"), amp=0.06)
+        orc.set_geometry(X, W)
+        eng.set_geometry(X, W)
+    for d in range(3):
+        for s in range(2):
+            r, f, v = rng.random(), int(rng.integers(0, dof)), float(rng.normal())
+            for g in (orc, eng):
+                if r < 0.4:
+                    g.set_boundary_value(d, s, f, v)
+                elif r < 0.6:
+                    g.set_boundary_load(d, s, 0, v)
+    A_o, b_o = orc.compute_system("orc_form_" + form)
+    eng.set_form(form)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "feature_assemble" in eng.kernel_name()
+    tol = 1e-12 if geo == "none" else 5e-11
+    compare_mats(A, A_o, tol)
+    assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
