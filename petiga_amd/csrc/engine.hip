@@ -702,6 +702,10 @@ static int launch_feature_ta(IGX g, const SpaceDev &S, const OutDev &out, bool &
   else {
     const bool hasM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
     if (!hasM) return launch_feature_plan<Form, DIM, TA, NW, DOF, false>(g, S, out, done);
+    // field Hessians on the fly live in the vector-only kernels unless the matrix callback reads them too (feature_mfma.hpp,
+    // HU_HERE): IGAComputeSystem of such a form (NS-VMS: nobody calls it) is left to the point-form kernel
+    constexpr bool HU_SPLIT = Form::ORDER >= 2 && shape_order_of<Form>::v < 2 && (Form::NEED & NEED_HU) != 0 && (mat_need_of<Form>::v & NEED_HU) == 0;
+    if (HU_SPLIT && out.op == OP_SYSTEM) return 0;
     constexpr bool GRAM = mat_pair_mask_of<Form>::v != 0ull;   // all row fields from one set of Gram accumulators
     // a scalar form at nen = 64 has 4 tiles per wave with 4-wave workgroups: small enough for 4 workgroups per CU
     // (Poisson p=3 on a NURBS geometry: 11.9 vs 10.4 M elements/s with the 8-wave layout)

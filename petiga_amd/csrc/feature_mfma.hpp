@@ -580,7 +580,10 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   }
   __syncthreads();
 
-  if (HU_FLY && (need & NEED_HU)) {
+  // (a matrix-producing kernel of a form whose matrix callback never reads the field Hessians carries no code for them: the
+  // launcher sends the one driver that would need both, IGAComputeSystem, to the point-form kernel for such a form)
+  constexpr bool HU_HERE = HU_FLY && (!HASM || (mat_need_of<Form>::v & NEED_HU) != 0);
+  if constexpr (HU_HERE) if (need & NEED_HU) {
     // Hessians of the fields when the form itself never reads second derivatives of N (NS-VMS): no second-derivative feature
     // is ever formed.  The homogeneous sums A_c = sum_a (w_a U_a,c) N_a with their first and second PARAMETRIC derivatives come
     // from the same sum factorisation as the geometry (three short contractions through LDS); u, du, d2u follow by the

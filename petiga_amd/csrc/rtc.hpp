@@ -241,6 +241,7 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   if (NE > 128 && DOF > 1) return 0;                           // 16 tile rows x two column panels: p = 5 in 3-D, one set
   if (GRAM && DOF * DOF > 16) return 0;
   const bool HASM = (out.op == OP_SYSTEM || out.op == OP_MATRIX || out.op == OP_JACOBIAN || out.op == OP_IJACOBIAN);
+  if (HASM && out.op == OP_SYSTEM && SECOND && !SECOND_S && ((unsigned)F.meta[2] & NEED_HU) && !((unsigned)F.meta[5] & NEED_HU)) return 0;   // (HU_HERE, feature_mfma.hpp)
   int TA, NW, DOFI; rtc_feature_layout(NE, DOF, GRAM, HASM, TA, NW, DOFI);
   std::shared_ptr<RtcFeature> K;
   if (int rc = rtc_feature_module(g, F, DIM, DOF, TA, NW, DOFI, HASM, true, K)) return rc;
