@@ -447,45 +447,49 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   const bool need2 = SECOND && (SECOND_S || (need & NEED_HU) != 0);
   constexpr int SF_NV = SECOND ? 3 : 2, SF_NM = SECOND ? 6 : 3, SF_NK = SECOND ? 10 : 4;
   double *SF = phi;                                   // [NC][SF_NK][NQ], in the (not yet used) Phi region
-  // sum_a coef(a, c) * (tensor-product basis function a and its parametric derivatives) at every point, NC components
-  auto sum_factorise = [&](const int NC, auto coef) {
-    const int n1 = NC * SF_NV * nq[0] * na[1] * na[2], n2 = NC * SF_NM * nq[0] * nq[1] * na[2], n3 = NC * SF_NK * NQ;
-    double *T1 = phi + n3, *T2 = T1 + n1;
-    for (int i = tid; i < n1; i += nthr) {            // T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v], v = derivative order on axis 0
-      int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r % SF_NV, c = r / SF_NV;
-      if (v == 2 && !need2) continue;
-      double sm = 0;
-      for (int a0 = 0; a0 < na[0]; ++a0) {
-        const int a = slot_of<PENCIL>(a0, a1, a2, na);
-        sm += coef(a, c) * t1d[0][(q0 * na[0] + a0) * NDER + v];
-      }
-      T1[i] = sm;
-    }
-    __syncthreads();
-    for (int i = tid; i < n2; i += nthr) {            // T2[c][m][q0][q1][a2], m -> orders (v0, v1): (0,0) (1,0) (0,1) | (2,0) (1,1) (0,2)
-      int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % SF_NM, c = r / SF_NM;
-      const int v0 = (m == 1 || m == 4) ? 1 : (m == 3 ? 2 : 0), v1 = (m == 2 || m == 4) ? 1 : (m == 5 ? 2 : 0);
-      if (m >= 3 && !need2) continue;
-      double sm = 0;
-      for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * SF_NV + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1];
-      T2[i] = sm;
-    }
-    __syncthreads();
-    for (int i = tid; i < n3; i += nthr) {            // SF[c][k][q], k: 0 value, 1..3 d/du_i, 4..9 d2/du_i du_j for (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
-      const int q = i % NQ, k = (i / NQ) % SF_NK, c = i / (SF_NK * NQ);
-      const int qp = qdec[q]; const int q0 = qp & 255, q1 = (qp >> 8) & 255, q2 = qp >> 16;
-      // (m, v2) of k: value (0,0); d0 (1,0) d1 (2,0) d2 (0,1); d00 (3,0) d01 (4,0) d02 (1,1) d11 (5,0) d12 (2,1) d22 (0,2)
-      const int m = (k == 1 || k == 6) ? 1 : ((k == 2 || k == 8) ? 2 : (k == 4 ? 3 : (k == 5 ? 4 : (k == 7 ? 5 : 0))));
-      const int v2 = (k == 3 || k == 6 || k == 8) ? 1 : (k == 9 ? 2 : 0);
-      if (k >= 4 && !need2) continue;
-      double sm = 0;
-      for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * SF_NM + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2];
-      SF[i] = sm;
-    }
-    __syncthreads();
-  };
+  // sum_a COEF(a, c) * (tensor-product basis function a and its parametric derivatives) at every point, NC components:
+  //   T1[c][v][q0][a1][a2] = sum_a0 C[a][c] n0[q0][a0][v], v = derivative order on axis 0
+  //   T2[c][m][q0][q1][a2], m -> orders (v0, v1): (0,0) (1,0) (0,1) | (2,0) (1,1) (0,2)
+  //   SF[c][k][q], k: 0 value, 1..3 d/du_i, 4..9 d2/du_i du_j for (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+  // (a macro, not a lambda: the matrix kernels hold one copy of these loops, laid out as before the field sums existed)
+#define FM_SUM_FACTORISE(NCEXPR, COEF) do { const int NC = (NCEXPR); \
+    const int n1 = NC * SF_NV * nq[0] * na[1] * na[2], n2 = NC * SF_NM * nq[0] * nq[1] * na[2], n3 = NC * SF_NK * NQ; \
+    double *T1 = phi + n3, *T2 = T1 + n1; \
+    for (int i = tid; i < n1; i += nthr) { \
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int a1 = r % na[1]; r /= na[1]; const int q0 = r % nq[0]; r /= nq[0]; const int v = r % SF_NV, c = r / SF_NV; \
+      if (v == 2 && !need2) continue; \
+      double sm = 0; \
+      for (int a0 = 0; a0 < na[0]; ++a0) { \
+        const int a = slot_of<PENCIL>(a0, a1, a2, na); \
+        sm += (COEF) * t1d[0][(q0 * na[0] + a0) * NDER + v]; \
+      } \
+      T1[i] = sm; \
+    } \
+    __syncthreads(); \
+    for (int i = tid; i < n2; i += nthr) { \
+      int r = i; const int a2 = r % na[2]; r /= na[2]; const int q1 = r % nq[1]; r /= nq[1]; const int q0 = r % nq[0]; r /= nq[0]; const int m = r % SF_NM, c = r / SF_NM; \
+      const int v0 = (m == 1 || m == 4) ? 1 : (m == 3 ? 2 : 0), v1 = (m == 2 || m == 4) ? 1 : (m == 5 ? 2 : 0); \
+      if (m >= 3 && !need2) continue; \
+      double sm = 0; \
+      for (int a1 = 0; a1 < na[1]; ++a1) sm += T1[(((c * SF_NV + v0) * nq[0] + q0) * na[1] + a1) * na[2] + a2] * t1d[1][(q1 * na[1] + a1) * NDER + v1]; \
+      T2[i] = sm; \
+    } \
+    __syncthreads(); \
+    for (int i = tid; i < n3; i += nthr) { \
+      const int q = i % NQ, k = (i / NQ) % SF_NK, c = i / (SF_NK * NQ); \
+      const int qp = qdec[q]; const int q0 = qp & 255, q1 = (qp >> 8) & 255, q2 = qp >> 16; \
+ \
+      const int m = (k == 1 || k == 6) ? 1 : ((k == 2 || k == 8) ? 2 : (k == 4 ? 3 : (k == 5 ? 4 : (k == 7 ? 5 : 0)))); \
+      const int v2 = (k == 3 || k == 6 || k == 8) ? 1 : (k == 9 ? 2 : 0); \
+      if (k >= 4 && !need2) continue; \
+      double sm = 0; \
+      for (int a2 = 0; a2 < na[2]; ++a2) sm += T2[(((c * SF_NM + m) * nq[0] + q0) * nq[1] + q1) * na[2] + a2] * t1d[2][(q2 * na[2] + a2) * NDER + v2]; \
+      SF[i] = sm; \
+    } \
+    __syncthreads(); \
+  } while (0)
   // components of the geometry sums: X (times w) and w
-  if (sumfact) sum_factorise(DIM + 1, [&](int a, int c) { const double w = rat ? gW[a] : 1.0; return (c < DIM) ? (geo ? gX[a * DIM + c] * w : 0.0) : w; });
+  if (sumfact) FM_SUM_FACTORISE(DIM + 1, ((c < DIM) ? (geo ? gX[a * DIM + c] * (rat ? gW[a] : 1.0) : 0.0) : (rat ? gW[a] : 1.0)));
   {
     const int np1 = 1;                 // one lane per point: the sums over the basis functions are done (sum factorisation above)
     const int qstep = nthr / np1;
@@ -594,7 +598,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
     auto k2 = [](int i, int j) { const int lo = i < j ? i : j, hi = i < j ? j : i; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
     const int sfb = (cv.sfb > 0 && cv.sfb < DOF) ? cv.sfb : DOF;      // components per batch
     for (int c0 = 0; c0 < DOF; c0 += sfb) {
-    sum_factorise(sfb, [&](int a, int cl) { return useU ? (rat ? gW[a] : 1.0) * Ue[a * DOF + c0 + cl] : 0.0; });
+    FM_SUM_FACTORISE(sfb, (useU ? (rat ? gW[a] : 1.0) * Ue[a * DOF + c0 + c] : 0.0));
     for (int idx = tid; idx < NQP * sfb; idx += nthr) {
       const int q = idx / sfb, cl = idx - q * sfb, c = c0 + cl;
       double H[D2];
@@ -1055,6 +1059,7 @@ feature_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, FCarve cv
   }   // walk
   if (stamp) out.dbg[31] = nst;
 #undef FM_STAMP
+#undef FM_SUM_FACTORISE
 #undef PS
 #undef PHAS
 }
