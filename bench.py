@@ -23,10 +23,12 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 FLOP_PER_ELEM = {3: 1572864, 2: 118098}        # 2*nen^2*nqp*dim (SURVEY 8d / BASELINE.md 3)
 BYTES_PER_ELEM = {3: 2785, 2: 1019}            # compulsory CSR bytes per element
+# the other BASELINE configs ("Same figures, other configs"): algorithmic flop and compulsory bytes per element
+ALG = {"elasticity": (4718592, 25400), "cahnhilliard": (790000, 1009), "nsvms": (8388608, 44000)}
 NOMINAL_MHZ = 2400.0
 FP64_PEAK_TFLOPS = 78.6                        # MI355X fp64 vector = matrix peak (256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-KERNEL_TAG = "r02"                             # profiles/traffic.json must describe this round's kernel to be quoted
+KERNEL_TAG = "r03"                             # profiles/traffic.json must describe this round's kernel to be quoted
 
 
 def physical_cores():
@@ -61,7 +63,11 @@ def physical_cores():
     return max(1, n)
 
 
-def cpu_baseline(degree, seconds_target=15.0):
+# single-core rates of the oracle (elements/s), only to size the bounded sample
+CPU_RATE_GUESS = {"poisson": 900.0, "elasticity": 160.0, "cahnhilliard": 2500.0, "nsvms": 60.0}
+
+
+def cpu_baseline(form, degree, seconds_target=15.0):
     """Times the CPU oracle (port of the reference loop) on this box's host cores on a bounded sample of the same
     workload.  One worker per PHYSICAL core; every worker assembles its own box of m^3 elements into its own local
     matrix -- what a rank of `mpiexec -n cores` does with its ghosted box (the reference's MatSetValuesLocal works on the
@@ -69,42 +75,93 @@ def cpu_baseline(degree, seconds_target=15.0):
     rate and cores x single-core (the no-loss bound); the speed-up quoted next to it uses the larger of the two."""
     import multiprocessing as mp
     cores = physical_cores()
-    rate1 = 900.0 if degree == 3 else 9000.0          # rough single-core rate, only to size the sample
+    rate1 = (900.0 if degree == 3 else 9000.0) if form == "poisson" else CPU_RATE_GUESS[form]
     m = int(round((rate1 * seconds_target) ** (1.0 / 3.0)))
     m = max(8, min(m, 40))
     # one core alone first (also warms the page cache / builds nothing: the .so is prebuilt)
-    e1, t1 = _cpu_worker((degree, m))
+    e1, t1 = _cpu_worker((form, degree, m))
     t0 = time.time()
     if cores > 1:
         with mp.get_context("spawn").Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(degree, m)] * cores)
+            res = pool.map(_cpu_worker, [(form, degree, m)] * cores)
     else:
         res = [(e1, t1)]
     wall = max(r[1] for r in res)
     elems = sum(r[0] for r in res)
     single = e1 / t1
+    what = {"poisson": "3-D p=%d Poisson System (Dirichlet on 6 faces)" % degree,
+            "elasticity": "3-D p=3 Elasticity System (orc_form_elasticity; clamped face, u_x = 1 on the opposite one)",
+            "cahnhilliard": "3-D p=2 C1 CahnHilliard IFunction + IJacobian (orc_form_ch_residual / orc_form_ch_tangent)",
+            "nsvms": "3-D p=3 NavierStokesVMS IFunction + IJacobian on the bench's rational NURBS map (orc_form_ns_residual / orc_form_ns_tangent; axes 0, 2 periodic, no-slip on axis 1)"}[form]
     return dict(value=elems / wall, unit="elements/s", cores=cores, kind="port", single_core_value=single,
                 cores_x_single_core=cores * single,
                 logical_cpus=os.cpu_count(),
-                sample="3-D p=%d Poisson System (Dirichlet on 6 faces), %d^3 elements per core into a core-local matrix, %d physical cores at once "
-                       "(oracle/igaoracle.c, the reference's loop: order-%d tabulation, scalar callback, search-insert); slowest core %.1f s, "
-                       "one core alone %.1f s, pool wall %.1f s" % (degree, m, cores, degree, wall, t1, time.time() - t0))
+                sample="%s, %d^3 elements per core into a core-local matrix, %d physical cores at once "
+                       "(oracle/igaoracle.c + igaforms.c, the reference's loop: full-order tabulation, scalar callback, search-insert); slowest core %.1f s, "
+                       "one core alone %.1f s, pool wall %.1f s" % (what, m, cores, wall, t1, time.time() - t0))
+
+
+def _bench_geometry(p, size, periodic):
+    """The smooth rational map of `--geometry` (config 5's premise): the same control net for the engine and the oracle."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import greville
+    gv = []
+    for i in range(3):
+        U = (np.arange(-p, size + p + 1) / size) if periodic[i] else np.concatenate([[0.0] * (p + 1), np.arange(1, size) / size, [1.0] * (p + 1)])
+        gv.append(greville(U, p))
+    mesh = np.meshgrid(*gv[::-1], indexing="ij")[::-1]
+    X = np.stack([m.copy() for m in mesh], axis=-1)
+    X[..., 0] += 0.05 * np.sin(2 * np.pi * mesh[1])
+    X[..., 1] += 0.05 * np.sin(2 * np.pi * mesh[2])
+    W = 1.0 + 0.1 * np.cos(2 * np.pi * mesh[0])
+    return X.reshape(-1, 3), W.reshape(-1)
 
 
 def _cpu_worker(args):
-    degree, m = args
+    form, degree, m = args
+    import numpy as np
     import oracle_api as O
-    g = O.OracleIGA(3, 1)
+    w = WORKLOADS[form]
+    p = degree if form == "poisson" else w["p"]
+    g = O.OracleIGA(3, w["dof"])
     for i in range(3):
-        g.axis_uniform(i, degree, m)
+        g.axis_uniform(i, p, m, periodic=bool(w["periodic"][i]))
     g.setup()
-    for d in range(3):
-        for s in range(2):
-            g.set_boundary_value(d, s, 0, 1.0)
+    ctx = None
+    if form == "poisson":
+        for d in range(3):
+            for s in range(2):
+                g.set_boundary_value(d, s, 0, 1.0)
+    elif form == "elasticity":
+        for f in range(3):
+            g.set_boundary_value(0, 0, f, 0.0)
+        g.set_boundary_value(0, 1, 0, 1.0)
+        ctx = O.ElasticityCtx(1.0, 1.0)
+    elif form == "cahnhilliard":
+        ctx = O.CahnHilliardCtx(1.5, 200.0, 0.63, 1.0, 1.0 / (3.0 * m * m), 1.0)
+    elif form == "nsvms":
+        for s_ in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, s_, f, 0.0)
+        ctx = O.NSVMSCtx(1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2)
+        X, W = _bench_geometry(p, m, w["periodic"])
+        g.set_geometry(X, W)
     A = g.create_mat()
-    t = time.time()
-    g.compute_system("orc_form_poisson", A=A)
-    dt = time.time() - t
+    if w["op"] == "system":
+        t = time.time()
+        g.compute_system("orc_form_" + form, ctx, A=A)
+        dt = time.time() - t
+    else:
+        n = g.global_size()
+        rng = np.random.default_rng(0)
+        U = (0.63 if form == "cahnhilliard" else 0.1) + 0.05 * (2 * rng.random(n) - 1)
+        V = 0.01 * (2 * rng.random(n) - 1)
+        res, tan = ("orc_form_ch_residual", "orc_form_ch_tangent") if form == "cahnhilliard" else ("orc_form_ns_residual", "orc_form_ns_tangent")
+        t = time.time()
+        g.compute_ifunction(res, ctx, 1.0e3, V, 0.0, U)
+        g.compute_ijacobian(tan, ctx, 1.0e3, V, 0.0, U, A=A)
+        dt = time.time() - t
     return m ** 3, dt
 
 
@@ -164,19 +221,8 @@ def build_problem(P, name, size, degree, world, rank, kernel, geometry):
                 g.set_boundary_value(1, s_, f, 0.0)
         params = (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2)
     if geometry:                    # a smooth rational map (config 5's premise), the same net on every rank
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from common import greville
-        gv = []
-        for i in range(3):
-            per = bool(w["periodic"][i])
-            U = (np.arange(-p, size + p + 1) / size) if per else np.concatenate([[0.0] * (p + 1), np.arange(1, size) / size, [1.0] * (p + 1)])
-            gv.append(greville(U, p))
-        mesh = np.meshgrid(*gv[::-1], indexing="ij")[::-1]
-        X = np.stack([m.copy() for m in mesh], axis=-1)
-        X[..., 0] += 0.05 * np.sin(2 * np.pi * mesh[1])
-        X[..., 1] += 0.05 * np.sin(2 * np.pi * mesh[2])
-        W = 1.0 + 0.1 * np.cos(2 * np.pi * mesh[0])
-        g.set_geometry(X.reshape(-1, 3), W.reshape(-1))
+        X, W = _bench_geometry(p, size, [bool(x) for x in w["periodic"]])
+        g.set_geometry(X, W)
     g.set_form(w["form"], params)
     g.set_kernel(kernel)
     A, b = g.create_mat(), g.create_vec()
@@ -274,57 +320,127 @@ def main():
     # ghost row cannot print a rate.
     cs = g.checksum(A, b)
     check = None
+    kernel_name, proc_sizes, local_elements = g.kernel_name(), g.sizes()["proc_sizes"], int(g.element_count())
     try:                       # ms by which the upper face of axis 2 was packed before the assembly's last launch finished
         overlap_ms = g.comm_overlap_ms() if world > 1 else None
     except Exception:
         overlap_ms = None
+
+    def assemble(gg, AA, bb, UU, VV):
+        if tangent:
+            if world > 1 and gg.comm_size() > 1:
+                gg.refresh_ghosts(UU)
+                gg.refresh_ghosts(VV)
+            gg.compute_ifunction(shift, VV, 0.0, UU, bb)
+            gg.compute_ijacobian(shift, VV, 0.0, UU, AA)
+        else:
+            gg.compute_system(AA, bb)
+        if gg.comm_size() > 1:
+            gg.reduce_ghost_rows(AA, bb)
+
+    def rel_diff(cs_n, ref, nrows):
+        # the signed sums may cancel: they are measured against sum|A| and sqrt(n sum b^2) (their natural bounds)
+        scale = [max(float(ref[1]), 1e-300), max(float(ref[1]), 1e-300), max((nrows * float(ref[3])) ** 0.5, 1e-300), max(float(ref[3]), 1e-300)]
+        return [abs(float(x) - float(y)) / sc for x, y, sc in zip(cs_n, ref, scale)]
+
     if world > 1:
-        tcs = torch.tensor(cs, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        dev = "cuda" if backend == "nccl" else "cpu"
+        tcs = torch.tensor(cs, dtype=torch.float64, device=dev)
         dist.all_reduce(tcs, op=dist.ReduceOp.SUM)
         cs = tcs.cpu().numpy()
-        if rank == 0 and not args.no_check:
-            g1, A1, b1, U1, V1, _ = build_problem(P, args.form, size, args.degree, 1, 0, args.kernel, geometry)
-            if tangent:
-                g1.compute_ifunction(shift, V1, 0.0, U1, b1)
-                g1.compute_ijacobian(shift, V1, 0.0, U1, A1)
-            else:
-                g1.compute_system(A1, b1)
-            g1.synchronize()
-            ref = g1.checksum(A1, b1)
-            # the signed sums may cancel: they are measured against sum|A| and sqrt(n sum b^2) (their natural bounds)
-            nrows = float(b1.n)
-            scale = [max(float(ref[1]), 1e-300), max(float(ref[1]), 1e-300), max((nrows * float(ref[3])) ** 0.5, 1e-300), max(float(ref[3]), 1e-300)]
-            rel = [abs(float(x) - float(y)) / sc for x, y, sc in zip(cs, ref, scale)]
-            check = dict(reference="single-rank assembly of the same mesh on rank 0's GPU", rel_diff=rel)
-            del A1, b1, g1
-            assert max(rel) < 1e-9, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs), list(ref))
+        if not args.no_check:
+            # Reference: the same mesh assembled by ONE rank on rank 0's GPU.  Its matrix must fit next to rank 0's share: the
+            # headline (70 GB) does on a 288 GB GPU, NavierStokesVMS at 192^3 (313 GB of values) does not.  Then the whole flow --
+            # partition, ghost refresh, assembly, ghost-row reduction -- is verified on the largest mesh of the same kind that
+            # fits, with the same ranks and the same transport, and the line says so: nothing is skipped silently and nothing
+            # dies in IGXCreateMat.
+            bs = wl["dof"]
+            def single_rank_bytes(n):
+                per = [(n if wl["periodic"][i] else n + p) for i in range(3)]
+                rows = per[0] * per[1] * per[2]
+                blocks = rows * (2 * p + 1) ** 3
+                return blocks * (bs * bs * 8 + 4) + rows * (8 + 4 * bs * 8)
+            free = torch.tensor([torch.cuda.mem_get_info()[0] if rank == 0 else 0], dtype=torch.float64, device=dev)
+            dist.broadcast(free, src=0)
+            budget = 0.85 * float(free.item())
+            csize = size
+            while csize > 16 and single_rank_bytes(csize) > budget:
+                csize = max(16, (csize * 3 // 4) // world * world) if csize * 3 // 4 >= world else 16
+            if csize == size:
+                cs_n = cs
+            else:           # every rank assembles its share of the reduced mesh through the same exchange
+                A = b = None            # (their memory goes back before the reduced meshes are created)
+                gk, Ak, bk, Uk, Vk, _ = build_problem(P, args.form, csize, args.degree, world, rank, args.kernel, geometry)
+                exchange.init_comm(gk, transport="rccl" if transport == "rccl" else "host")
+                assemble(gk, Ak, bk, Uk, Vk)
+                gk.synchronize()
+                tk = torch.tensor(gk.checksum(Ak, bk), dtype=torch.float64, device=dev)
+                dist.all_reduce(tk, op=dist.ReduceOp.SUM)
+                cs_n = tk.cpu().numpy()
+                Ak = bk = gk = None
+            if rank == 0:
+                g1, A1, b1, U1, V1, _ = build_problem(P, args.form, csize, args.degree, 1, 0, args.kernel, geometry)
+                assemble(g1, A1, b1, U1, V1)
+                g1.synchronize()
+                ref = g1.checksum(A1, b1)
+                rel = rel_diff(cs_n, ref, float(b1.n))
+                check = dict(reference="single-rank assembly of the %s mesh on rank 0's GPU" % ("same" if csize == size else "%d^3 (the largest that fits next to rank 0's share; the %d^3 matrix needs %.0f GB on one GPU)" % (csize, size, single_rank_bytes(size) / 1e9)),
+                             size=csize, rel_diff=rel)
+                A1 = b1 = g1 = None
+                assert max(rel) < 1e-9, "N-rank checksums differ from the single-rank assembly: %s vs %s" % (list(cs_n), list(ref))
 
-    if rank == 0:
-        # shader clock the chip sustained while the pencil kernel ran (s_memtime ticks per 100 MHz s_memrealtime tick of the first
-        # and last workgroup of every timed launch, IGXGetClockProbe): `peak` stays the nominal 2.4 GHz figure, this says how much of the gap is clock
+    # ---- roofline of the dominant kernel, on every rank (north_star: "achieved-vs-roofline HBM and MFMA fractions reported at
+    # 1/2/4/8 GPUs"); rank 0's block is the line's `roofline`, the others travel in `roofline_per_rank`
+    # shader clock the chip sustained while the pencil kernel ran (s_memtime ticks per 100 MHz s_memrealtime tick of the first
+    # and last workgroup of every timed launch, IGXGetClockProbe): `peak` stays the nominal 2.4 GHz figure, this says how much of the gap is clock
+    try:
+        clock_mhz = g.clock_probe()[0]
+    except Exception:
+        clock_mhz = None
+    if args.form == "poisson":
+        flop, cbytes = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3), BYTES_PER_ELEM.get(args.degree)
+    else:
+        flop, cbytes = ALG[args.form]
+    avg_launch_s = (dom_ms / 1e3) / max(dom_launches, 1)
+    elems_per_launch = dom_elems / max(dom_launches, 1)
+    achieved = flop * elems_per_launch / avg_launch_s / 1e12 if (avg_launch_s > 0 and flop) else None
+    executed = dom_flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
+    # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes of this same command
+    # (scripts/profile_round.sh), committed as profiles/traffic.json: they are NOT measured inside this run, so the
+    # line names the file; null when the file does not describe this configuration (form, size, degree, ranks, round).
+    traffic, traffic_source = None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
         try:
-            clock_mhz = g.clock_probe()[0]
+            tj = json.load(open(tf))
+            for ent in tj.get("configs", [tj]):
+                if ent.get("form", "poisson") == args.form and ent.get("size") == size and ent.get("degree", p) == p and ent.get("n_gpus") == world and ent.get("kernel_tag") == KERNEL_TAG:
+                    # PMC passes run one step: bytes per launch of the dominant kernel of THIS step shape
+                    traffic = ent.get("bytes_per_launch")
+                    traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % ent.get("round", tj.get("round"))
         except Exception:
-            clock_mhz = None
-        nen, nqp = (p + 1) ** 3, (p + 1) ** 3
-        flop = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3) if args.form == "poisson" else None
-        avg_launch_s = (dom_ms / 1e3) / max(dom_launches, 1)
-        elems_per_launch = dom_elems / max(dom_launches, 1)
-        achieved = flop * elems_per_launch / avg_launch_s / 1e12 if (avg_launch_s > 0 and flop) else None
-        executed = dom_flop * elems_per_launch / avg_launch_s / 1e12 if avg_launch_s > 0 else 0.0
-        # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes of this same command
-        # (scripts/profile_round.sh), committed as profiles/traffic.json: they are NOT measured inside this run, so the
-        # line names the file and the commit that last touched it; null when the file does not describe this configuration.
-        traffic, traffic_source = None, None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                tj = json.load(open(tf))
-                if args.form == "poisson" and tj.get("size") == size and tj.get("degree") == args.degree and tj.get("n_gpus") == world and tj.get("kernel_tag") == KERNEL_TAG:
-                    traffic = tj.get("bytes_per_launch")
-                    traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % tj.get("round")
-            except Exception:
-                traffic = None
+            traffic = None
+    # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (the headline kernel skips the
+    # 6 mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
+    # (SURVEY 8d / BASELINE.md 3 flop per element) is kept next to it.  For the two-assembly steps (IFunction + IJacobian) the
+    # dominant kernel is the IJacobian's.
+    roof = {"bound": "mfma", "achieved": executed, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": executed / FP64_PEAK_TFLOPS,
+            "achieved_algorithmic": achieved, "frac_algorithmic": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
+            "shader_clock_mhz": clock_mhz, "nominal_clock_mhz": NOMINAL_MHZ,
+            "frac_at_measured_clock": (executed / (FP64_PEAK_TFLOPS * clock_mhz / NOMINAL_MHZ)) if clock_mhz else None,
+            "kernel": dom_name, "launches_per_step": dom_launches // max(args.steps, 1),
+            "avg_launch_ms": avg_launch_s * 1e3, "elements_per_launch": elems_per_launch,
+            "flop_per_element": flop, "executed_flop_per_element": dom_flop,
+            "algorithmic_bytes_per_element": cbytes,
+            "algorithmic_hbm_gbs": (cbytes * elems_per_launch / avg_launch_s / 1e9) if avg_launch_s > 0 else None}
+    roofs = None
+    if world > 1:
+        roofs = [None] * world
+        dist.all_gather_object(roofs, dict(rank=rank, local_elements=local_elements, **{k: roof[k] for k in ("achieved", "frac", "achieved_algorithmic", "frac_algorithmic", "hbm_frac", "algorithmic_hbm_gbs", "shader_clock_mhz", "avg_launch_ms", "elements_per_launch", "launches_per_step", "kernel")}))
+    if rank == 0:
         line = {
             "metric": wl["metric"],
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,26 +449,15 @@ def main():
             "config": {"workload": "%s: p=%d C%d, %d^3 elements, dof=%d, Gauss %d^3%s%s"
                                    % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
                                       ", rational NURBS geometry map" if geometry else ""),
-                       "kernels": g.kernel_name(), "partition": g.sizes()["proc_sizes"],
+                       "kernels": kernel_name, "partition": proc_sizes,
                        "transport": transport, "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
-            # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (it skips the 6
-            # mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
-            # (2*nen^2*nqp*dim flop per element, SURVEY 8d / BASELINE.md 3) is kept next to it.
-            "roofline": {"bound": "mfma", "achieved": executed, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": executed / FP64_PEAK_TFLOPS,
-                         "achieved_algorithmic": achieved, "frac_algorithmic": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
-                         "traffic": traffic, "traffic_source": traffic_source,
-                         "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
-                         "shader_clock_mhz": clock_mhz, "nominal_clock_mhz": NOMINAL_MHZ,
-                         "frac_at_measured_clock": (executed / (FP64_PEAK_TFLOPS * clock_mhz / NOMINAL_MHZ)) if clock_mhz else None,
-                         "kernel": dom_name, "launches_per_step": dom_launches // max(args.steps, 1),
-                         "avg_launch_ms": avg_launch_s * 1e3, "elements_per_launch": elems_per_launch,
-                         "flop_per_element": flop, "executed_flop_per_element": dom_flop,
-                         "algorithmic_bytes_per_element": BYTES_PER_ELEM.get(args.degree) if args.form == "poisson" else None},
+            "roofline": roof,
             "device": P.device_info(),
         }
-        if world == 1 and not args.no_cpu_baseline and args.form == "poisson":
-            cb = cpu_baseline(args.degree)
+        if roofs:
+            line["roofline_per_rank"] = roofs
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(args.form, args.degree)
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = value / max(cb["value"], cb["cores_x_single_core"])
         print(json.dumps(line))

@@ -274,7 +274,11 @@ class IGX:
     def set_dof(self, dof): _ck(lib().IGXSetDof(self.h, dof)); self.dof = dof
     def set_order(self, o): _ck(lib().IGXSetOrder(self.h, o))
     def set_quadrature(self, i, q): _ck(lib().IGXSetQuadrature(self.h, i, q))
-    def set_comm(self, size, rank): _ck(lib().IGXSetComm(self.h, size, rank))
+    def set_comm(self, size, rank):
+        _ck(lib().IGXSetComm(self.h, size, rank))
+        self._comm = (size, rank)
+
+    def comm_size(self): return getattr(self, "_comm", (1, 0))[0]
     def set_processors(self, i, n): _ck(lib().IGXSetProcessors(self.h, i, n))
 
     def axis_uniform(self, i, p, N, C_=-1, Ui=0.0, Uf=1.0, periodic=False):

@@ -67,6 +67,7 @@ struct IgxComm {
   std::vector<DevBuf> sbuf, rbuf;     // one per neighbour of the larger of the two lists
   int64_t last_bytes = 0;
   ~IgxComm() {
+    if (xs) (void)hipStreamSynchronize(xs);      // nothing of this communicator is in flight when it goes
     if (nccl && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(nccl);
     if (ready) (void)hipEventDestroy(ready);
     if (done) (void)hipEventDestroy(done);
@@ -134,8 +135,10 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
   const bool phased = reduce && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
-  // (whatever the last assembly wrote is face-complete at its mark; a matrix / vector it did not write was complete before)
-  const bool early = phased && g->slab_valid;
+  // The mark belongs to the matrix / vector the marked assembly wrote: only those are face-complete there.  Anything else --
+  // another object, or one that an entry point has written to since (IGXVecCopyFromHost, IGXVecCopyFromGhosted, IGXReadVec and
+  // every exchange clear the mark) -- is packed where the engine stream stands now.
+  const bool early = phased && g->slab_valid && (!A || A == g->slab_A) && (!b || b == g->slab_b);
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
   c.last_bytes = 0; c.packed1_valid = false;
@@ -151,9 +154,12 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   auto move = [&](int phase) -> int {      // the messages of a phase: one RCCL group, or one call of the host transport
     if (c.kind == 1) {
       NCCLCK(rccl_api().GroupStart());
-      for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) NCCLCK(rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs));
-      for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) NCCLCK(rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs));
-      NCCLCK(rccl_api().GroupEnd());
+      int rc_ = 0;      // (an error inside the group still closes it: RCCL must not be left with an open group)
+      for (size_t k = 0; k < in_plans.size() && !rc_; ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) rc_ = rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs);
+      for (size_t k = 0; k < out_plans.size() && !rc_; ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) rc_ = rccl_api().Send(c.sbuf[k].p, (size_t)doubles(out_plans[k]), kNcclDouble, out_plans[k].rank, c.nccl, c.xs);
+      const int re_ = rccl_api().GroupEnd();
+      NCCLCK(rc_);
+      NCCLCK(re_);
       return 0;
     }
     std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
@@ -164,20 +170,29 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
     if (int rc = c.fn(c.fnctx, (int)sp.size(), sp.data(), sb.data(), sn.data(), (int)rp.size(), rp.data(), rb.data(), rn.data())) return fail(IGX_ERR_LIB, "transport callback failed with code " + std::to_string(rc));
     return 0;
   };
+  // What the exchange stream waits for.  Only a PACK reads what the engine stream writes; a receive lands in a buffer of the
+  // exchange itself.  So a phase in which this rank sends nothing is issued at once -- its receives are posted while the rank
+  // still assembles, and the sender's early face message moves under the receiver's remaining launches (in a non-periodic
+  // [1,1,2] / [2,2,2] grid the receiver of the axis-2 face is exactly the rank without an upper neighbour there).  A phase with
+  // sends waits for what it packs: the face mark (phase 1 of a marked assembly) or the assembly's last launch.  Sends and
+  // receives of a phase stay in ONE group: split into two groups on one stream, two ranks that both receive first would wait
+  // for each other's sends for ever.  The unpack adds into rows the rank's own launches store into: it always waits for c.ready.
+  auto sends_in = [&](int phase) { for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) return true; return false; };
   if (phased) {
-    HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
+    if (sends_in(1)) HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
     if (int rc = pack(1)) return rc;
-    c.packed1_valid = early && hipEventRecord(c.packed1, c.xs) == hipSuccess;
+    c.packed1_valid = early && sends_in(1) && hipEventRecord(c.packed1, c.xs) == hipSuccess;
     if (int rc = move(1)) return rc;
-    HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
+    if (sends_in(2)) HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
     if (int rc = pack(2)) return rc;
     if (int rc = move(2)) return rc;
   } else {
     // the exchange stream picks up where the engine stream stands (the assembly's last launch)
-    HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
+    if (sends_in(0)) HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
     if (int rc = pack(0)) return rc;
     if (int rc = move(0)) return rc;
   }
+  HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));        // the unpack (and a refresh's assignment) behind everything the engine stream has enqueued
   for (size_t k = 0; k < in_plans.size(); ++k) {
     if (doubles(in_plans[k]) == 0) continue;
     if (int rc = ghost_rows(g, A, b, (int)k, c.rbuf[k].as<double>(), !reduce, reduce ? 1 : 2, c.xs)) return rc;

@@ -129,6 +129,7 @@ extern "C" int IGXVecGetIndices(IGXVec v, int numbering, int owned_only, int64_t
 static int ghosted_copy(IGXVec v, double *array, int on_device, int to_ghosted) {
   if (!v || !array) return fail(IGX_ERR_ARG_WRONG, "null argument");
   IGX g = v->iga; const Space &s = g->s;
+  if (!to_ghosted) g->slab_valid = false;      // the vector is written after the assembly's face mark (comm.hpp)
   const int64_t n = (int64_t)s.lay[0].gwidth * s.lay[1].gwidth * s.lay[2].gwidth * s.dof;
   DevBuf tmp; double *p = array;
   if (!on_device) { if (tmp.alloc((size_t)n * 8)) return fail(IGX_ERR_MEM, "device allocation failed"); p = tmp.as<double>(); if (!to_ghosted) HIPCK(hipMemcpy(p, array, (size_t)n * 8, hipMemcpyHostToDevice)); }

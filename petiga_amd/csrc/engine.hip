@@ -15,6 +15,9 @@
 #include "first_touch.hpp"
 #ifndef IGX_TU_DISPATCH
 #include "gram_mfma.hpp"
+#elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)
+#include "block_pencil.hpp"
+#define IGX_HAVE_BLOCK_PENCIL 1
 #endif
 
 using namespace igx;
@@ -88,7 +91,9 @@ extern "C" const char *IGXGetLastError(void) { return g_err.c_str(); }
 extern "C" int IGXCreate(IGX *iga) { if (!iga) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *iga = new _p_IGX(); return 0; }
 extern "C" int IGXDestroy(IGX *iga) {
   if (!iga || !*iga) return 0;
+  (*iga)->comm.reset();       // (synchronises its exchange stream first)
   for (auto &e : (*iga)->ev) if (e) (void)hipEventDestroy(e);
+  if ((*iga)->slab_ev) (void)hipEventDestroy((*iga)->slab_ev);
   delete *iga; *iga = nullptr; return 0;
 }
 #define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
@@ -403,7 +408,7 @@ extern "C" int IGXVecDestroy(IGXVec *v) { if (v && *v) { delete *v; *v = nullptr
 extern "C" int IGXVecGetSize(IGXVec v, int64_t *n) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); *n = v->n; return 0; }
 extern "C" int IGXVecGetDeviceArray(IGXVec v, double **a) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); *a = v->a.as<double>(); return 0; }
 extern "C" int IGXVecCopyToHost(IGXVec v, double *h) { if (!v || !h) return fail(IGX_ERR_ARG_WRONG, "null argument"); HIPCK(hipStreamSynchronize(v->iga->stream)); HIPCK(hipMemcpy(h, v->a.p, v->a.bytes, hipMemcpyDeviceToHost)); return 0; }
-extern "C" int IGXVecCopyFromHost(IGXVec v, const double *h) { if (!v || !h) return fail(IGX_ERR_ARG_WRONG, "null argument"); HIPCK(hipStreamSynchronize(v->iga->stream)); HIPCK(hipMemcpy(v->a.p, h, v->a.bytes, hipMemcpyHostToDevice)); return 0; }
+extern "C" int IGXVecCopyFromHost(IGXVec v, const double *h) { if (!v || !h) return fail(IGX_ERR_ARG_WRONG, "null argument"); v->iga->slab_valid = false; /* a write after the assembly's face mark (comm.hpp) */ HIPCK(hipStreamSynchronize(v->iga->stream)); HIPCK(hipMemcpy(v->a.p, h, v->a.bytes, hipMemcpyHostToDevice)); return 0; }
 
 extern "C" int IGXSetFixTable(IGX g, IGXVec U) {   // src/petigaform.c:273-298
   NEEDIGA(g);
@@ -426,7 +431,7 @@ extern "C" int IGXSynchronize(IGX g) {
   }
   return 0;
 }
-extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1, 2 or 3"); g->kernel_choice = which; return 0; }
+extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 4) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1, 2, 3 or 4"); g->kernel_choice = which; return 0; }
 extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s", g->last_kernel.c_str()); return 0; }
 extern "C" int IGXSetTiming(IGX g, int flag) {
   NEEDIGA(g); g->timing = flag != 0;
@@ -781,6 +786,16 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   constexpr bool SECOND = Form::ORDER >= 2;
   constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   constexpr int NS = nscalar_of<Form>::v;
+#ifdef IGX_HAVE_BLOCK_PENCIL
+  if constexpr (DIM == 3) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer (block_pencil.hpp)
+    bool done = false;
+    ParamsDev prm; memset(&prm, 0, sizeof(prm));
+    for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+    if (int rc = try_block_pencil<Form>(s, S, prm, out, g->stream, g->last_kernel, g->last_launches, g_err, done, g->dom, g->zero_matrix, g->slab_done)) return rc;
+    if (done) return 0;
+  }
+#endif
+  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the block pencil kernel does not cover this case (3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0)");
   if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;

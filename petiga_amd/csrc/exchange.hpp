@@ -148,12 +148,12 @@ extern "C" int IGXGetNeighborInfo(IGX g, int send, int k, int *rank, int64_t *ma
   return 0;
 }
 extern "C" int IGXPackGhostRows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf) { return ghost_rows(g, A, b, k, devbuf, true, 0); }
-extern "C" int IGXUnpackGhostRows(IGX g, IGXMat A, IGXVec b, int k, const double *devbuf) { return ghost_rows(g, A, b, k, const_cast<double *>(devbuf), false, 1); }
+extern "C" int IGXUnpackGhostRows(IGX g, IGXMat A, IGXVec b, int k, const double *devbuf) { if (g) g->slab_valid = false; return ghost_rows(g, A, b, k, const_cast<double *>(devbuf), false, 1); }
 // the reverse direction, before a nonlinear assembly: the owner's values travel to the ranks that hold the node as a ghost
 // (IGAGetLocalVecArray = DMGlobalToLocal, src/petigavec.c:256-269).  Pack: entry k of the RECEIVE list (a lower neighbour,
 // whose ghosts are my first owned nodes); unpack: entry k of the SEND list (an upper neighbour, owner of my ghost part).
 extern "C" int IGXPackOwnerValues(IGX g, IGXVec v, int k, double *devbuf) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); return ghost_rows(g, nullptr, v, k, devbuf, false, 0); }
-extern "C" int IGXUnpackGhostValues(IGX g, IGXVec v, int k, const double *devbuf) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); return ghost_rows(g, nullptr, v, k, const_cast<double *>(devbuf), true, 2); }
+extern "C" int IGXUnpackGhostValues(IGX g, IGXVec v, int k, const double *devbuf) { if (!v) return fail(IGX_ERR_ARG_WRONG, "null vector"); if (g) g->slab_valid = false; return ghost_rows(g, nullptr, v, k, const_cast<double *>(devbuf), true, 2); }
 // 1 if this rank owns the row node with local row indices (r0,r1,r2) -- after the exchange only owned rows are final
 extern "C" int IGXRowOwned(IGX g, int r0, int r1, int r2) {
   if (!g || !g->s.setup) return 0;

@@ -20,10 +20,10 @@
 #include <string>
 #include <vector>
 #include "igx.hpp"
+#include "pencil_common.hpp"
 
 namespace igx {
 
-typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int HOLD_LD = 66;   // padded row stride (doubles) of the pencil kernel's per-wavefront hold area [6 slots][4 r][HOLD_LD]
 
 // the launches of the dominant kernel of one assembly, for the roofline line of bench.py
@@ -398,25 +398,7 @@ __device__ __forceinline__ void pencil_shift(d4_t (&acc)[4][4], double &Facc, in
   Facc = (fslot >= NB - 1) ? 0.0 : up;
 }
 
-typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
 
-// First touch.  An entry (row slot a, column slot b of element e on one axis) receives contributions from the elements
-// [e + max(a,b) - P, e + min(a,b)] (clipped to the rank's elements); colours are e mod (P+1) and launch in ascending
-// order, so the first launch to reach the entry is colour 0 if the range holds a multiple of P+1, else the colour of
-// its lowest element.  Along the walk axis a pencil combines everything in registers: one write per entry and pencil.
-// Two passes (the elements [blocked, nel) of the axis were assembled by earlier launches, this pass covers [rlo, rhi)): an entry
-// that the earlier pass reaches as well is never a first touch here, and the rule applies to the elements of this pass alone.
-template <int P>
-__device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel, int rlo = 0, int rhi = 0x7fffffff, int blocked = 0x7fffffff) {
-  constexpr int NB = P + 1;
-  int lo = e + (a > b ? a : b) - P, hi = e + (a < b ? a : b);
-  if (hi > nel - 1) hi = nel - 1;
-  if (hi >= blocked) return false;
-  if (lo < rlo) lo = rlo;
-  if (hi > rhi - 1) hi = rhi - 1;
-  const int c0 = ((lo + NB - 1) / NB) * NB;       // smallest multiple of NB >= lo
-  return (c0 <= hi) ? (e % NB == 0) : (e == lo);
-}
 
 // Dirichlet data seen by one pencil of the axis-0 walk (all wave-uniform).  A node is fixed by position only:
 // first / last basis function of the first / last element of a non-periodic axis with boundary values
@@ -1003,14 +985,6 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 }
 
 // ------------------------------------------------------------------ dispatch
-struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
-
-// colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element
-static bool color_range(const AxisLayout &L, int c, int lo, int hi, int &start, int &step, int &count) {
-  start = -1; count = 0; step = L.p + 1;
-  for (int e = lo; e < hi; ++e) if (L.color[e] == c) { if (start < 0) start = e; count++; }
-  return count > 0;
-}
 
 template <bool SYSTEM>
 static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, const GramArgs &g0, int &launches) {
@@ -1103,15 +1077,6 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
 // receives load * 4 * (sum over its elements on axis t of J_t / nen_t) * (the same on axis u): the two 1-D sums come from the
 // host, one thread per face node adds the product to its F row -- unless a Dirichlet value holds that dof (FixSystem discards
 // the flux of a fixed row).  Sequential launches per face: one writer per row and launch, fixed order.
-struct FluxArgs {
-  int d, t, u;                 // face axis and the two axes of the face
-  int rd;                      // row index of the face nodes on axis d
-  int nt, nu;                  // face nodes (rank-local rows) on axes t, u
-  const double *st, *su;       // [nt], [nu]: sum over the rank's elements holding the node of J / nen
-  double value;                // load * 4
-  int gfirst[3], glast[3];     // global node index of row 0 on every axis; last global node index (nnp - 1)
-  int fixlo[3], fixhi[3];      // a Dirichlet value holds field 0 on the lower / upper face of the axis
-};
 static __global__ void k_boundary_loads(FluxArgs F, int nr0, int nr1, double *vec) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= F.nt * F.nu) return;
@@ -1256,12 +1221,6 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
   return 0;
 }
 
-static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
-  if (s.lay[d].alias || s.elem_width[d] < 8) return false;
-  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
-    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
-  return true;
-}
 
 // zero_matrix: MatZeroEntries of the caller; called before the first launch unless the axis-0 walk stores first touches
 // slab_done (may be empty): called between the two passes of an assembly that forms the elements next to the upper face of axis

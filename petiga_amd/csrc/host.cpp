@@ -14,13 +14,14 @@ namespace igx {
 EnvSwitches read_env_switches() {
   EnvSwitches e;
   auto num = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
-  e.kernel = num("IGX_KERNEL", 0); if (e.kernel < 0 || e.kernel > 3) e.kernel = 0;
+  e.kernel = num("IGX_KERNEL", 0); if (e.kernel < 0 || e.kernel > 4) e.kernel = 0;
   e.walk_axis = num("IGX_WALK_AXIS", 0);
   e.nseg = num("IGX_NSEG", 0);
-  e.no_first_touch = getenv("IGX_NO_FIRST_TOUCH") != nullptr;
+  e.no_first_touch = num("IGX_NO_FIRST_TOUCH", 0) != 0;
+  e.block_pencil = num("IGX_BLOCK_PENCIL", 1);
   e.fuse_groups = num("IGX_FUSE_GROUPS", 1);
   e.overlap = num("IGX_OVERLAP", 1);
-  e.clock_probe = getenv("IGX_CLOCK_PROBE") != nullptr;
+  e.clock_probe = num("IGX_CLOCK_PROBE", 0) != 0;
   e.feature_lds_kb = num("IGX_FEATURE_LDS_KB", 0);
   e.combine = num("IGX_COMBINE", -1);
   if (kDebug) { e.debug_feature = num("IGX_DEBUG_FEATURE", 0); e.debug_noflush = num("IGX_DEBUG_NOFLUSH", 0); e.debug_timing = getenv("IGX_DEBUG_TIMING") != nullptr; }

@@ -27,7 +27,7 @@ constexpr bool kDebug = false;
 #ifndef IGX_RTC
 // Environment switches, read once when an IGX is created (IGXCreate / IGXCreateFromTables)
 struct EnvSwitches {
-  int kernel = 0;            // IGX_KERNEL=0..3 presets IGXSetKernel (the parity suite runs every case under two kernel families)
+  int kernel = 0;            // IGX_KERNEL=0..4 presets IGXSetKernel (the parity suite runs every case under two kernel families)
   int walk_axis = 0;         // IGX_WALK_AXIS: preferred walk axis of the pencil kernel
   int nseg = 0;              // IGX_NSEG: segments per pencil (0 = model)
   int clock_probe = 0;       // IGX_CLOCK_PROBE: the pencil kernel records shader-clock ticks against the 100 MHz wall clock (IGXGetClockProbe)
@@ -35,6 +35,7 @@ struct EnvSwitches {
   int fuse_groups = 1;       // IGX_FUSE_GROUPS=0: one launch per group of row fields again (NS-VMS p=3; experiment switch)
   int no_first_touch = 0;    // IGX_NO_FIRST_TOUCH: MatZeroEntries + read-modify-write everywhere
   int feature_lds_kb = 0;    // IGX_FEATURE_LDS_KB: LDS target of the feature kernel
+  int block_pencil = 1;      // IGX_BLOCK_PENCIL=0: constant-coefficient multi-field forms stay on the feature kernel (block_pencil.hpp)
   int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)
   int debug_feature = 0, debug_noflush = 0, debug_timing = 0;   // only honoured by -DIGX_DEBUG builds
 };

@@ -1,0 +1,60 @@
+// pencil_common.hpp -- what the pencil kernels share (gram_mfma.hpp: scalar gradient-Gram forms, sliding window;
+// block_pencil.hpp: constant-coefficient multi-field forms, band rows by node layer): vector types, the first-touch rule,
+// colour ranges of a box of elements, the walkability test of an axis.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "first_touch.hpp"
+#include "igx.hpp"
+
+namespace igx {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+typedef double d2u_t __attribute__((ext_vector_type(2), aligned(8)));
+
+// First touch.  An entry (row slot a, column slot b of element e on one axis) receives contributions from the elements
+// [e + max(a,b) - P, e + min(a,b)] (clipped to the rank's elements); colours are e mod (P+1) and launch in ascending
+// order, so the first launch to reach the entry is colour 0 if the range holds a multiple of P+1, else the colour of
+// its lowest element.  Along the walk axis a pencil combines everything in registers: one write per entry and pencil.
+// Two passes (the elements [blocked, nel) of the axis were assembled by earlier launches, this pass covers [rlo, rhi)): an entry
+// that the earlier pass reaches as well is never a first touch here, and the rule applies to the elements of this pass alone.
+template <int P>
+__device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel, int rlo = 0, int rhi = 0x7fffffff, int blocked = 0x7fffffff) {
+  constexpr int NB = P + 1;
+  int lo = e + (a > b ? a : b) - P, hi = e + (a < b ? a : b);
+  if (hi > nel - 1) hi = nel - 1;
+  if (hi >= blocked) return false;
+  if (lo < rlo) lo = rlo;
+  if (hi > rhi - 1) hi = rhi - 1;
+  const int c0 = ((lo + NB - 1) / NB) * NB;       // smallest multiple of NB >= lo
+  return (c0 <= hi) ? (e % NB == 0) : (e == lo);
+}
+
+struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
+
+// colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element
+static bool color_range(const AxisLayout &L, int c, int lo, int hi, int &start, int &step, int &count) {
+  start = -1; count = 0; step = L.p + 1;
+  for (int e = lo; e < hi; ++e) if (L.color[e] == c) { if (start < 0) start = e; count++; }
+  return count > 0;
+}
+
+// boundary loads on the identity geometry: see k_boundary_loads (gram_mfma.hpp)
+struct FluxArgs {
+  int d, t, u;                 // face axis and the two axes of the face
+  int rd;                      // row index of the face nodes on axis d
+  int nt, nu;                  // face nodes (rank-local rows) on axes t, u
+  const double *st, *su;       // [nt], [nu]: sum over the rank's elements holding the node of J / nen
+  double value;                // load * 4
+  int gfirst[3], glast[3];     // global node index of row 0 on every axis; last global node index (nnp - 1)
+  int fixlo[3], fixhi[3];      // a Dirichlet value holds field 0 on the lower / upper face of the axis
+};
+
+static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
+  if (s.lay[d].alias || s.elem_width[d] < 8) return false;
+  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
+    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
+  return true;
+}
+
+}  // namespace igx

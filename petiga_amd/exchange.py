@@ -54,25 +54,33 @@ def init_comm(iga, transport=None):
     gloo stages through the host, so ranks may share one GPU)."""
     transport = transport or ("rccl" if dist.get_backend() == "nccl" else "host")
     if transport == "rccl":
-        # every rank must end up on the same transport: the outcome of the binding is agreed on before anything is sent
-        err = None
+        # Every rank must end up on the same transport, and ncclCommInitRank is a blocking collective: a rank that cannot bind
+        # librccl.so must be known BEFORE anybody enters it (the others would wait in it for ever).  So: (1) every rank binds the
+        # library only (IGXCommGetUniqueId into a scratch id: dlopen + one local call) and the outcomes are gathered;
+        # (2) only when all of them succeeded does rank 0's id travel and the communicator get created; (3) the outcome of
+        # that is gathered once more.
+        err, uid = None, None
         try:
-            ids = [iga.comm_unique_id() if dist.get_rank() == 0 else None]
-        except Exception as e:          # librccl.so could not be bound on rank 0
-            ids, err = [None], e
-        dist.broadcast_object_list(ids, src=0)
-        ok = ids[0] is not None
+            uid = iga.comm_unique_id()
+        except Exception as e:          # librccl.so could not be bound on this rank
+            err = e
+        flags = [None] * dist.get_world_size()
+        dist.all_gather_object(flags, uid is not None)
+        ok = all(flags)
         if ok:
+            ids = [uid if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
             try:
                 iga.comm_init_rccl(ids[0])
             except Exception as e:
                 ok, err = False, e
-        flags = [None] * dist.get_world_size()
-        dist.all_gather_object(flags, bool(ok))
+            flags = [None] * dist.get_world_size()
+            dist.all_gather_object(flags, bool(ok))
         if not all(flags):
             import sys
             if dist.get_rank() == 0:
-                print("petiga_amd.exchange: the library's RCCL binding failed (%s); falling back to torch.distributed point-to-point" % (err,), file=sys.stderr)
+                print("petiga_amd.exchange: the library's RCCL binding failed on rank(s) %s (%s); falling back to torch.distributed point-to-point"
+                      % ([i for i, f in enumerate(flags) if not f], err), file=sys.stderr)
             if ok:
                 iga.comm_destroy()
             transport = "host"

@@ -59,6 +59,18 @@ def rel_err(a, b):
     return d / max(np.abs(b).max(), 1e-300) if b.size else d
 
 
+def free_row_scale(rows, cols, vals):
+    """max|K| over the rows that are NOT Dirichlet rows (a fixed row holds only its diagonal, the element multiplicity -- up to
+    16 and more -- while stiffness entries are O(h^(dim-2)): scaling by the global maximum would loosen a stated tolerance on
+    the real entries by 10^2-10^3).  rows / cols / vals: coordinate list of the reference matrix."""
+    n = int(rows.max()) + 1 if rows.size else 0
+    offdiag = np.zeros(n, dtype=bool)
+    nzoff = (rows != cols) & (vals != 0.0)
+    offdiag[rows[nzoff]] = True
+    free = offdiag[rows]
+    return np.abs(vals[free]).max() if free.any() else np.abs(vals).max()
+
+
 def compare_mats(eng_mat, orc_mat, tol):
     """Engine matrix (device block CSR) vs oracle CSR: identical pattern (explicit zeros included, as
     IGACreateMat preallocates it), values within tol of max|K| over the rows without a Dirichlet condition."""
@@ -75,12 +87,7 @@ def compare_mats(eng_mat, orc_mat, tol):
     # Scale: max|K| over the rows that are NOT Dirichlet rows.  A fixed row holds only its diagonal (the element
     # multiplicity, up to 2^dim * ... = 16 and more), while stiffness entries are O(h^(dim-2)): scaling by the global maximum
     # would loosen the stated tolerance on the real entries by 10^2-10^3.
-    ro, co = ko // n, ko % n
-    offdiag = np.zeros(n, dtype=bool)
-    nzoff = (ro != co) & (vo != 0.0)
-    offdiag[ro[nzoff]] = True
-    free = offdiag[ro]
-    scale = np.abs(vo[free]).max() if free.any() else np.abs(vo).max()
+    scale = free_row_scale(ko // n, ko % n, vo)
     err = np.abs(vals - vo).max()
     assert err <= tol * scale, "matrix values differ: %g (scale %g)" % (err, scale)
     return err / scale

@@ -43,6 +43,8 @@ def _rank_main(rank, world, port, case, outdir, name=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if "combine" in name:
         os.environ["IGX_COMBINE"] = "1"
+    if "split" in name and "block" not in name:
+        os.environ["IGX_BLOCK_PENCIL"] = "0"      # these cases pin the feature kernel's two modes (the automatic choice takes the block pencil at p = 3)
     for p in (os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle"), HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -68,6 +70,9 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         for f in range(3):
             g.set_boundary_value(0, 0, f, 0.0)
         g.set_boundary_value(2, 1, 0, 1.0)
+        if "loads" in name:
+            g.set_boundary_load(1, 1, 2, 0.5)
+            g.set_boundary_load(2, 0, 1, -0.25)
     g.set_form(form, params)
     assert exchange.init_comm(g) == "host"
     A, b = g.create_mat(), g.create_vec()
@@ -94,7 +99,9 @@ def _rank_main(rank, world, port, case, outdir, name=""):
     if "split" in name:       # the feature kernel makes the same two passes: more launches than colours on a rank with an upper neighbour
         has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
         ncol = int(np.prod(g.coloring()))
-        if "combine" in name:     # 16 colours over axes 1, 2; the face pass adds 3 of the 4 colours of axis 2
+        if "block" in name:       # block_pencil.hpp: the same 16 + 12 launches
+            assert "block_pencil" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16), (g.kernel_name(), g.dominant_kernel())
+        elif "combine" in name:     # 16 colours over axes 1, 2; the face pass adds 3 of the 4 colours of axis 2
             assert "pencil walk" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16)
         else:
             assert "feature_assemble" in g.kernel_name() and (g.dominant_kernel()["launches"] > ncol) == has_upper
@@ -134,6 +141,9 @@ CASES = {
     "poisson-p3-4ranks-pencil": (4, (3, 1, 3, (9, 16, 16), (0, 0, 0), "poisson", ())),
     "elasticity-p3-2ranks-split-combine": (2, (3, 3, 3, (8, 5, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),   # pencil mode of the feature kernel
     "elasticity-p3-2ranks-split": (2, (3, 3, 3, (8, 5, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),
+    "elasticity-p3-2ranks-split-block-loads": (2, (3, 3, 3, (8, 5, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),   # block pencil, upper face of axis 2 first
+    "elasticity-p3-4ranks-split-block": (4, (3, 3, 3, (9, 16, 16), (0, 0, 0), "elasticity", (1.5, 0.8))),
+    "elasticity-p3-2ranks-split-block-periodic": (2, (3, 3, 3, (8, 8, 16), (0, 0, 1), "elasticity", (1.5, 0.8))),
     "elasticity-p2-2ranks-split": (2, (3, 3, 2, (5, 6, 13), (0, 0, 0), "elasticity", (1.5, 0.8))),
     "cahnhilliard-p2-2ranks-split": (2, (3, 1, 2, (6, 6, 12), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
     "cahnhilliard-p2-2ranks": (2, (3, 1, 2, (6, 6, 8), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
@@ -162,6 +172,9 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
         for f in range(3):
             orc.set_boundary_value(0, 0, f, 0.0)
         orc.set_boundary_value(2, 1, 0, 1.0)
+        if "loads" in name:
+            orc.set_boundary_load(1, 1, 2, 0.5)
+            orc.set_boundary_load(2, 0, 1, -0.25)
         A_o, b_o = orc.compute_system("orc_form_elasticity", O.ElasticityCtx(*params))
     else:
         ctx = O.CahnHilliardCtx(*params)
@@ -189,7 +202,8 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
     ko = orow * n + A_o.colidx.astype(np.int64)
     oo = np.argsort(ko, kind="stable")
     assert np.array_equal(key[o], ko[oo])
-    scale = np.abs(A_o.val).max()
+    from common import free_row_scale
+    scale = free_row_scale(orow[oo], A_o.colidx.astype(np.int64)[oo], A_o.val[oo])     # rows without a Dirichlet condition (tests/common.py)
     assert np.abs(vals[o] - A_o.val[oo]).max() <= 1e-11 * scale
     vrow, vval = np.concatenate(vrow), np.concatenate(vval)
     assert np.array_equal(np.sort(vrow), np.arange(n))

@@ -100,7 +100,7 @@ def test_elasticity_full_size_properties():
     n = N + p
     assert A.nbrows == n ** 3 and A.bs == 3 and A.nblocks == (n * 7 - 12) ** 3
     g.compute_system(A, b); g.synchronize()
-    assert "feature_assemble(mfma" in g.kernel_name()
+    assert "block_pencil(mfma" in g.kernel_name()
     rp, ci, val = A.device_ptrs()
     rpt = torch.as_tensor(_DevArray(rp, A.nbrows + 1, "<i8"), device="cuda")
     v = torch.as_tensor(_DevArray(val, A.nblocks * 9, "<f8"), device="cuda").view(-1, 9)

@@ -52,7 +52,7 @@ def test_two_pass_assembly_equals_single_pass(seed, monkeypatch):
         results.append((A.host(True).copy(), b.get().copy(), g.dominant_kernel()["launches"], g.kernel_name()))
     (v1, b1, l1, k1), (v0, b0, l0, k0) = results
     assert k1 == k0
-    if ("gram_pencil" in k1 and "walk=0" in k1) or "feature_assemble" in k1:     # (the other walks of the pencil kernel keep one pass)
+    if ("gram_pencil" in k1 and "walk=0" in k1) or "feature_assemble" in k1 or "block_pencil" in k1:     # (the other walks of the pencil kernel keep one pass)
         assert l1 > l0, (c, k1, l1, l0)                 # the face pass adds launches
     scale = np.abs(v0).max()
     assert np.abs(v1 - v0).max() <= 1e-13 * scale, c
