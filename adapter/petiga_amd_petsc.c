@@ -14,7 +14,9 @@
  * PETSc >= 3.17 (MatSetPreallocationCOO / VecSetPreallocationCOO), a device matrix type (-iga_mat_type aijhipsparse or
  * aijkokkos) and, above 2^31 stored scalars per rank, --with-64-bit-indices.
  *
- * Data flow per assembly (nothing is copied through the host when the Mat / Vec are device types):
+ * Data flow per assembly (nothing is copied through the host when the Mat / Vec are device types: state arrays are taken with
+ * VecGetArrayReadAndMemType and handed over as device pointers, the coordinate lists are built on the device by the library --
+ * IGXMatGetCOODevice, in PetscInt's width -- and the values are the engine's own device array):
  *   U,V (global Vec) --IGAGetLocalVecArray--> ghosted local array --IGXVecCopyFromGhosted--> IGXVec        (state)
  *   IGXCompute*  ->  IGXMat values / IGXVec on the device
  *   MatSetValuesCOO(A, engine value array, INSERT_VALUES)  with the coordinate list set once (IGXMatGetCOO, PETSc numbering):
@@ -23,8 +25,16 @@
  *   first, coordinate list with owned_only = 1.)
  *
  * The point callback: host function pointers cannot run on the GPU.  The user program registers the device form next to
- * its host callback,  IGASetFormAMD(iga, IGX_FORM_ELASTICITY, (PetscReal[]){lambda,mu}, 2);  when none is registered (or the
- * engine answers PETSC_ERR_SUP) the driver falls through to PetIGA's own CPU loop, so every program keeps working.
+ * its host callback,  IGASetFormAMD(iga, IGX_FORM_ELASTICITY, (PetscReal[]){lambda,mu}, 2);  or, for a callback that is not one
+ * of the built-in forms, its HIP source:  IGASetFormSourceAMD(iga, source, "MyForm", params, n)  (IGXSetFormSource: compiled at
+ * run time against the library's own headers, include/petiga_amd.h).  When none is registered, or the engine answers
+ * PETSC_ERR_SUP (IGX_ERR_SUP: a case no device kernel covers), the driver falls through to PetIGA's own CPU loop
+ * (IGACompute*_CPU, the original bodies), so every program keeps working; any other engine error is raised.
+ *
+ * Memory of the coordinate lists: MatSetPreallocationCOO wants all n = nnz index pairs at once (2 x sizeof(PetscInt) x n: 93 GB
+ * for the metric configuration's 5.84e9 non-zeros with 64-bit indices, which that configuration needs on one rank).  They live
+ * on the device inside the IGXMat until the preallocation is done and are freed right after (IGXMatFreeCOO); PETSc's own
+ * permutation arrays are PETSc's business.  A host Mat type gets host copies, in chunks of at most 2^28 entries.
  */
 #if defined(PETIGA_HAVE_AMD)
 #include <petiga.h>
@@ -36,25 +46,32 @@ typedef struct {
   IGXVec    b,U,V;
   PetscBool coo_mat,coo_vec;   /* coordinate lists handed to the Mat / Vec */
   IGXFormKind kind; PetscReal params[8]; PetscInt nparams;
+  char     *source,*struct_name;   /* run-time form (IGASetFormSourceAMD) or NULL */
+  int      *span32[3],*offset32[3];  /* narrowed copies of ax->span / bd->offset when PetscInt is 64 bits wide */
 } IGAAmdCtx;
 
 static PetscErrorCode IGAAmdCtxDestroy(void *p)
 {
   IGAAmdCtx *c = (IGAAmdCtx*)p;
   PetscFunctionBegin;
-  if (c) { IGXVecDestroy(&c->V); IGXVecDestroy(&c->U); IGXVecDestroy(&c->b); IGXMatDestroy(&c->A); IGXDestroy(&c->igx); PetscCall(PetscFree(c)); }
+  if (c) {
+    PetscInt i;
+    IGXVecDestroy(&c->V); IGXVecDestroy(&c->U); IGXVecDestroy(&c->b); IGXMatDestroy(&c->A); IGXDestroy(&c->igx);
+    for (i=0; i<3; i++) { PetscCall(PetscFree(c->span32[i])); PetscCall(PetscFree(c->offset32[i])); }
+    PetscCall(PetscFree(c->source)); PetscCall(PetscFree(c->struct_name));
+    PetscCall(PetscFree(c));
+  }
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
 #define IGXCHK(comm,call) do { int rc_ = (call); if (PetscUnlikely(rc_)) SETERRQ(comm,(PetscErrorCode)rc_,"%s",IGXGetLastError()); } while (0)
+/* a driver's IGXCompute* call: PETSC_ERR_SUP from the engine means "no device kernel covers this case" -> PetIGA's own loop */
+#define IGXTRY(comm,call,fallback) do { int rc_ = (call); if (rc_ == IGX_ERR_SUP) PetscFunctionReturn(fallback); if (PetscUnlikely(rc_)) SETERRQ(comm,(PetscErrorCode)rc_,"%s",IGXGetLastError()); } while (0)
 
-/* user-facing: which device form stands for the host callback of this IGA */
-PetscErrorCode IGASetFormAMD(IGA iga,IGXFormKind kind,const PetscReal params[],PetscInt nparams)
+static PetscErrorCode IGAAmdCtxGet(IGA iga,IGAAmdCtx **out)
 {
-  IGAAmdCtx *c; PetscContainer box; PetscInt i;
+  IGAAmdCtx *c; PetscContainer box;
   PetscFunctionBegin;
-  PetscValidHeaderSpecific(iga,IGA_CLASSID,1);
-  PetscCheck(nparams >= 0 && nparams <= 8,PetscObjectComm((PetscObject)iga),PETSC_ERR_ARG_OUTOFRANGE,"at most 8 form parameters");
   PetscCall(PetscObjectQuery((PetscObject)iga,"IGAAmdCtx",(PetscObject*)&box));
   if (!box) {
     PetscCall(PetscNew(&c));
@@ -64,6 +81,37 @@ PetscErrorCode IGASetFormAMD(IGA iga,IGXFormKind kind,const PetscReal params[],P
     PetscCall(PetscObjectCompose((PetscObject)iga,"IGAAmdCtx",(PetscObject)box));
     PetscCall(PetscContainerDestroy(&box));
   } else PetscCall(PetscContainerGetPointer(box,(void**)&c));
+  *out = c;
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* user-facing: the HIP source of a device form (struct `struct_name` with the contract of include/petiga_amd.h, IGXSetFormSource)
+   stands for the host callback of this IGA: the open end of the plugin API reaches PetIGA programs */
+PetscErrorCode IGASetFormSourceAMD(IGA iga,const char source[],const char struct_name[],const PetscReal params[],PetscInt nparams)
+{
+  IGAAmdCtx *c; PetscInt i;
+  PetscFunctionBegin;
+  PetscValidHeaderSpecific(iga,IGA_CLASSID,1);
+  PetscAssertPointer(source,2); PetscAssertPointer(struct_name,3);
+  PetscCheck(nparams >= 0 && nparams <= 8,PetscObjectComm((PetscObject)iga),PETSC_ERR_ARG_OUTOFRANGE,"at most 8 form parameters");
+  PetscCall(IGAAmdCtxGet(iga,&c));
+  PetscCall(PetscFree(c->source)); PetscCall(PetscFree(c->struct_name));
+  PetscCall(PetscStrallocpy(source,&c->source));
+  PetscCall(PetscStrallocpy(struct_name,&c->struct_name));
+  c->kind = IGX_FORM_SOURCE; c->nparams = nparams;
+  for (i=0; i<nparams; i++) c->params[i] = params[i];
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
+
+/* user-facing: which built-in device form stands for the host callback of this IGA */
+PetscErrorCode IGASetFormAMD(IGA iga,IGXFormKind kind,const PetscReal params[],PetscInt nparams)
+{
+  IGAAmdCtx *c; PetscInt i;
+  PetscFunctionBegin;
+  PetscValidHeaderSpecific(iga,IGA_CLASSID,1);
+  PetscCheck(nparams >= 0 && nparams <= 8,PetscObjectComm((PetscObject)iga),PETSC_ERR_ARG_OUTOFRANGE,"at most 8 form parameters");
+  PetscCall(IGAAmdCtxGet(iga,&c));
+  PetscCall(PetscFree(c->source)); PetscCall(PetscFree(c->struct_name));
   c->kind = kind; c->nparams = nparams;
   for (i=0; i<nparams; i++) c->params[i] = params[i];
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -85,8 +133,19 @@ static PetscErrorCode IGAGetAmd(IGA iga,IGAAmdCtx **out)
     for (i=0; i<iga->dim; i++) {
       IGAAxis ax = iga->axis[i]; IGABasis bd = iga->basis[i];
       t.axis[i].p = (int)ax->p; t.axis[i].m = (int)ax->m; t.axis[i].periodic = (int)ax->periodic;
-      t.axis[i].nel = (int)ax->nel; t.axis[i].nnp = (int)ax->nnp; t.axis[i].U = ax->U; t.axis[i].span = (const int*)ax->span; /* 32-bit PetscInt; widen otherwise */
-      t.axis[i].nqp = (int)bd->nqp; t.axis[i].nen = (int)bd->nen; t.axis[i].offset = (const int*)bd->offset;
+      t.axis[i].nel = (int)ax->nel; t.axis[i].nnp = (int)ax->nnp; t.axis[i].U = ax->U;
+      t.axis[i].nqp = (int)bd->nqp; t.axis[i].nen = (int)bd->nen;
+      /* IGXTables carries C ints.  With --with-64-bit-indices (which the metric configuration needs on one rank) the span and
+         offset tables are narrowed into copies the context owns: their values are node indices of ONE axis, far below 2^31 */
+      if (sizeof(PetscInt) == sizeof(int)) { t.axis[i].span = (const int*)ax->span; t.axis[i].offset = (const int*)bd->offset; }
+      else {
+        PetscInt e;
+        PetscCall(PetscFree(c->span32[i])); PetscCall(PetscFree(c->offset32[i]));
+        PetscCall(PetscMalloc1(ax->nel,&c->span32[i])); PetscCall(PetscMalloc1(bd->nel,&c->offset32[i]));
+        for (e=0; e<ax->nel; e++) c->span32[i][e] = (int)ax->span[e];
+        for (e=0; e<bd->nel; e++) c->offset32[i][e] = (int)bd->offset[e];
+        t.axis[i].span = c->span32[i]; t.axis[i].offset = c->offset32[i];
+      }
       t.axis[i].detJac = bd->detJac; t.axis[i].weight = bd->weight; t.axis[i].point = bd->point;
       t.axis[i].value = bd->value;                    /* [nel][nqp][nen][5], src/petigabasis.c:192-196 */
     }
@@ -118,20 +177,28 @@ static PetscErrorCode IGAGetAmd(IGA iga,IGAAmdCtx **out)
       IGXCHK(comm,IGXVecCopyFromGhosted(c->U,iga->fixtableU,0));
       IGXCHK(comm,IGXSetFixTable(c->igx,c->U));
     } else IGXCHK(comm,IGXSetFixTable(c->igx,NULL));
-    IGXCHK(comm,IGXSetForm(c->igx,c->kind,c->params,(int)c->nparams));
+    if (c->source) IGXCHK(comm,IGXSetFormSource(c->igx,c->source,c->struct_name,c->params,(int)c->nparams));   /* compiled once per source text */
+    else           IGXCHK(comm,IGXSetForm(c->igx,c->kind,c->params,(int)c->nparams));
   }
   *out = c;
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
 /* state vector -> engine: the ghosted local form IS the engine's row numbering (IGAGetLocalVecArray, src/petigavec.c:256-269) */
-static PetscErrorCode IGAAmdSetState(IGA iga,Vec vecU,IGXVec U)
+static PetscErrorCode IGAAmdSetState(IGA iga,IGAAmdCtx *c,Vec vecU,IGXVec U)
 {
-  Vec localU; const PetscScalar *arrayU;
+  Vec localU; const PetscScalar *arrayU; PetscMemType mtype;
   PetscFunctionBegin;
-  PetscCall(IGAGetLocalVecArray(iga,vecU,&localU,&arrayU));
-  IGXCHK(PetscObjectComm((PetscObject)iga),IGXVecCopyFromGhosted(U,(const double*)arrayU,0));
-  PetscCall(IGARestoreLocalVecArray(iga,vecU,&localU,&arrayU));
+  /* IGAGetLocalVecArray = IGAGetLocalVec + DMGlobalToLocal + VecGetArrayRead (src/petigavec.c:256-269); the array is taken with
+     its memory type instead, so that a device Vec's values never visit the host */
+  PetscCall(IGAGetLocalVec(iga,&localU));
+  PetscCall(IGAGlobalToLocal(iga,vecU,localU));
+  PetscCall(VecGetArrayReadAndMemType(localU,&arrayU,&mtype));
+  IGXCHK(PetscObjectComm((PetscObject)iga),IGXVecCopyFromGhosted(U,(const double*)arrayU,PetscMemTypeDevice(mtype) ? 1 : 0));
+  /* a device copy is a kernel on the engine's stream: done before PETSc gets its array back (include/petiga_amd.h) */
+  if (PetscMemTypeDevice(mtype)) IGXCHK(PetscObjectComm((PetscObject)iga),IGXSynchronize(c->igx));
+  PetscCall(VecRestoreArrayReadAndMemType(localU,&arrayU));
+  PetscCall(IGARestoreLocalVec(iga,&localU));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
@@ -143,14 +210,33 @@ static PetscErrorCode IGAAmdHandBackMat(IGA iga,IGAAmdCtx *c,Mat mat)
   IGXCHK(comm,IGXMatGetInfo(c->A,&nb,&nblk,&bs));
   PetscCall(PetscObjectQuery((PetscObject)mat,"IGAAmdCOO",(PetscObject*)&tag));
   if (!tag) {
-    PetscCount n = (PetscCount)nblk*bs*bs; int64_t *ci,*cj; PetscInt *pi,*pj; PetscCount e;
-    PetscCall(PetscMalloc2(n,&ci,n,&cj));
-    IGXCHK(comm,IGXMatGetCOO(c->A,1 /* PETSc numbering = iga->ao */,0 /* PETSc moves the not-owned rows */,ci,cj,0));
-    if (sizeof(PetscInt) == sizeof(int64_t)) { pi = (PetscInt*)ci; pj = (PetscInt*)cj; }
-    else { PetscCall(PetscMalloc2(n,&pi,n,&pj)); for (e=0; e<n; e++) { pi[e] = (PetscInt)ci[e]; pj[e] = (PetscInt)cj[e]; } }
-    PetscCall(MatSetPreallocationCOO(mat,n,pi,pj));
-    if ((void*)pi != (void*)ci) PetscCall(PetscFree2(pi,pj));
-    PetscCall(PetscFree2(ci,cj));
+    PetscCount n = (PetscCount)nblk*bs*bs; void *di,*dj; PetscBool device_mat; MatType mtype;
+    PetscCall(MatGetType(mat,&mtype));
+    PetscCall(PetscStrendswith(mtype,"hipsparse",&device_mat));
+    if (!device_mat) PetscCall(PetscStrendswith(mtype,"kokkos",&device_mat));
+    if (device_mat) {
+      /* the lists stay on the device, in PetscInt's width (a 32-bit PetscInt whose range the problem exceeds is refused by the
+         library with PETSC_ERR_ARG_OUTOFRANGE); MatSetPreallocationCOO of the device types takes device pointers (PETSc >= 3.18) */
+      IGXCHK(comm,IGXMatGetCOODevice(c->A,1 /* PETSc numbering = iga->ao */,0 /* PETSc moves the not-owned rows */,(int)sizeof(PetscInt),&di,&dj));
+      PetscCall(MatSetPreallocationCOO(mat,n,(PetscInt*)di,(PetscInt*)dj));
+      IGXCHK(comm,IGXMatFreeCOO(c->A));
+    } else {
+      /* host Mat type: host lists, fetched from the library in chunks through one bounded staging pair */
+      PetscInt *pi,*pj; int64_t *ci,*cj; PetscCount e,e0; const PetscCount chunk = (PetscCount)1 << 28;
+      PetscCall(PetscMalloc2(n,&pi,n,&pj));
+      IGXCHK(comm,IGXMatGetCOODevice(c->A,1,0,8,&di,&dj));
+      PetscCall(PetscMalloc2(PetscMin(n,chunk),&ci,PetscMin(n,chunk),&cj));
+      for (e0=0; e0<n; e0+=chunk) {
+        const PetscCount m = PetscMin(chunk,n-e0);
+        IGXCHK(comm,IGXDeviceToHost(ci,(const int64_t*)di+e0,(size_t)m*8));
+        IGXCHK(comm,IGXDeviceToHost(cj,(const int64_t*)dj+e0,(size_t)m*8));
+        for (e=0; e<m; e++) { pi[e0+e] = (PetscInt)ci[e]; pj[e0+e] = (PetscInt)cj[e]; }
+      }
+      PetscCall(PetscFree2(ci,cj));
+      IGXCHK(comm,IGXMatFreeCOO(c->A));
+      PetscCall(MatSetPreallocationCOO(mat,n,pi,pj));
+      PetscCall(PetscFree2(pi,pj));
+    }
     PetscCall(PetscContainerCreate(comm,&tag));
     PetscCall(PetscObjectCompose((PetscObject)mat,"IGAAmdCOO",(PetscObject)tag));
     PetscCall(PetscContainerDestroy(&tag));
@@ -186,8 +272,8 @@ static PetscErrorCode IGAAmdHandBackVec(IGA iga,IGAAmdCtx *c,Vec vec)
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 
-/* ---- the seven drivers.  Each returns PETSC_ERR_SUP untouched from the engine when the case is not covered (the caller,
- *      the original body kept as IGACompute*_CPU, then runs PetIGA's own loop). ---- */
+/* ---- the seven drivers.  IGXTRY: PETSC_ERR_SUP from the engine (no device kernel covers the case: a forced kernel, a boundary-
+ *      form pass of a run-time form, ...) hands the call to the original body, kept as IGACompute*_CPU; other errors are raised. ---- */
 #define IGAAMD_BEGIN(iga) \
   IGAAmdCtx *c; MPI_Comm comm = PetscObjectComm((PetscObject)(iga)); \
   PetscFunctionBegin; \
@@ -199,7 +285,7 @@ PetscErrorCode IGAComputeSystem(IGA iga,Mat matA,Vec vecB)
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeSystem_CPU(iga,matA,vecB));
   IGACheckFormOp(iga,1,System);
-  IGXCHK(comm,IGXComputeSystem(c->igx,c->A,c->b));
+  IGXTRY(comm,IGXComputeSystem(c->igx,c->A,c->b),IGAComputeSystem_CPU(iga,matA,vecB));
   PetscCall(IGAAmdHandBackMat(iga,c,matA));
   PetscCall(IGAAmdHandBackVec(iga,c,vecB));
   PetscFunctionReturn(PETSC_SUCCESS);
@@ -208,7 +294,7 @@ PetscErrorCode IGAComputeMatrix(IGA iga,Mat matA)
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeMatrix_CPU(iga,matA));
-  IGXCHK(comm,IGXComputeMatrix(c->igx,c->A));
+  IGXTRY(comm,IGXComputeMatrix(c->igx,c->A),IGAComputeMatrix_CPU(iga,matA));
   PetscCall(IGAAmdHandBackMat(iga,c,matA));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -216,7 +302,7 @@ PetscErrorCode IGAComputeVector(IGA iga,Vec vecB)
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeVector_CPU(iga,vecB));
-  IGXCHK(comm,IGXComputeVector(c->igx,c->b));
+  IGXTRY(comm,IGXComputeVector(c->igx,c->b),IGAComputeVector_CPU(iga,vecB));
   PetscCall(IGAAmdHandBackVec(iga,c,vecB));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -224,8 +310,8 @@ PetscErrorCode IGAComputeFunction(IGA iga,Vec vecU,Vec vecF)
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeFunction_CPU(iga,vecU,vecF));
-  PetscCall(IGAAmdSetState(iga,vecU,c->U));
-  IGXCHK(comm,IGXComputeFunction(c->igx,c->U,c->b));
+  PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
+  IGXTRY(comm,IGXComputeFunction(c->igx,c->U,c->b),IGAComputeFunction_CPU(iga,vecU,vecF));
   PetscCall(IGAAmdHandBackVec(iga,c,vecF));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -233,8 +319,8 @@ PetscErrorCode IGAComputeJacobian(IGA iga,Vec vecU,Mat matJ)
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeJacobian_CPU(iga,vecU,matJ));
-  PetscCall(IGAAmdSetState(iga,vecU,c->U));
-  IGXCHK(comm,IGXComputeJacobian(c->igx,c->U,c->A));
+  PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
+  IGXTRY(comm,IGXComputeJacobian(c->igx,c->U,c->A),IGAComputeJacobian_CPU(iga,vecU,matJ));
   PetscCall(IGAAmdHandBackMat(iga,c,matJ));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -242,9 +328,9 @@ PetscErrorCode IGAComputeIFunction(IGA iga,PetscReal a,Vec vecV,PetscReal t,Vec 
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeIFunction_CPU(iga,a,vecV,t,vecU,vecF));
-  PetscCall(IGAAmdSetState(iga,vecV,c->V));
-  PetscCall(IGAAmdSetState(iga,vecU,c->U));
-  IGXCHK(comm,IGXComputeIFunction(c->igx,(double)a,c->V,(double)t,c->U,c->b));
+  PetscCall(IGAAmdSetState(iga,c,vecV,c->V));
+  PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
+  IGXTRY(comm,IGXComputeIFunction(c->igx,(double)a,c->V,(double)t,c->U,c->b),IGAComputeIFunction_CPU(iga,a,vecV,t,vecU,vecF));
   PetscCall(IGAAmdHandBackVec(iga,c,vecF));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
@@ -252,9 +338,9 @@ PetscErrorCode IGAComputeIJacobian(IGA iga,PetscReal a,Vec vecV,PetscReal t,Vec 
 {
   IGAAMD_BEGIN(iga);
   if (!c) PetscFunctionReturn(IGAComputeIJacobian_CPU(iga,a,vecV,t,vecU,matJ));
-  PetscCall(IGAAmdSetState(iga,vecV,c->V));
-  PetscCall(IGAAmdSetState(iga,vecU,c->U));
-  IGXCHK(comm,IGXComputeIJacobian(c->igx,(double)a,c->V,(double)t,c->U,c->A));
+  PetscCall(IGAAmdSetState(iga,c,vecV,c->V));
+  PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
+  IGXTRY(comm,IGXComputeIJacobian(c->igx,(double)a,c->V,(double)t,c->U,c->A),IGAComputeIJacobian_CPU(iga,a,vecV,t,vecU,matJ));
   PetscCall(IGAAmdHandBackMat(iga,c,matJ));
   PetscFunctionReturn(PETSC_SUCCESS);
 }

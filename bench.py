@@ -247,7 +247,9 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
     args = ap.parse_args()
     wl = WORKLOADS[args.form]
-    size = args.size or wl["size"]
+    # (NavierStokesVMS at 192^3 is an 8-GPU configuration -- 313 GB of matrix values; on fewer than 4 GPUs the default mesh is
+    #  one GPU's share of it, 96^3, and the workload string says so)
+    size = args.size or (wl["size"] if (args.form != "nsvms" or args.gpus >= 4) else 96)
     geometry = args.geometry or args.form == "nsvms"
 
     import torch
@@ -448,7 +450,8 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: p=%d C%d, %d^3 elements, dof=%d, Gauss %d^3%s%s"
                                    % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
-                                      ", rational NURBS geometry map" if geometry else ""),
+                                      ", rational NURBS geometry map" if geometry else "") +
+                                   (" (one GPU's share of the 192^3 configuration)" if (args.form == "nsvms" and size == 96 and not args.size) else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
                        "transport": transport, "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
             "roofline": roof,

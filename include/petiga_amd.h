@@ -132,7 +132,15 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  *       static constexpr unsigned PHI_MASK = ...;              // features anything reads (others are not tabulated at all)
  *       static constexpr unsigned long long MAT_PAIR_MASK = ...; // bit 8f+g: mat() has a point-INDEPENDENT coefficient on
  *                                                              // Na[f]*Nb[g] and nothing else: Gram matrices on the matrix cores
+ *       static constexpr unsigned pair_block_mask(int f,int g); // with MAT_PAIR_MASK: bit i*DOF+j set when the pair (f,g) reaches
+ *                                                              // block entry (i,j) (x*0 does not fold under IEEE rules)
  *       static constexpr unsigned MAT_NEED = ...;              // subset of NEED that mat() reads (matrix-only drivers skip the rest)
+ *       static constexpr bool MAT_SYMMETRIC = true;            // mat(p,Na,Nb) == mat(p,Nb,Na) at every point (the form's promise)
+ *       static constexpr unsigned VEC_TEST_MASK = ...;         // features of Na that vec() reads
+ * A scalar (DOF 1) first-order form with MAT_TEST_MASK = the gradients, MAT_SYMMETRIC and VEC_TEST_MASK = 1 (N) whose NEED is at
+ * most NEED_X -- demo/Poisson3D.c's System, with any x-dependent or anisotropic diffusion tensor and load -- takes the pencil
+ * walk of the headline kernel in 3-D at p = 2, 3 (form_pencil<MyForm>: combined band rows, first-touch stores, the Dirichlet
+ * fix-up inside the walk, identity or mapped / NURBS geometry) instead of the element mode: IGXSetKernel(2) insists on it.
  *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
  *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only */
 int IGXSetFormSource(IGX iga,const char *source,const char *struct_name,const double params[],int nparams);
@@ -238,7 +246,9 @@ int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default s
 int IGXSynchronize(IGX iga);
 /* 0 = automatic; 1 = generic point-form kernel (no MFMA); 2 = MFMA gradient-Gram pencil kernel (Poisson, uniform
  * degree 2/3, no geometry); 3 = feature-GEMM element kernel (any form/geometry, dim >= 2, nen <= 64;
- * K_e on MFMA, vector-only operations share its tabulation) */
+ * K_e on MFMA, vector-only operations share its tabulation); 4 = block pencil kernel (band rows by node layer:
+ * constant-coefficient forms with 2 or 3 fields and F = 0, dim 3, p = 3, identity geometry, System / Matrix drivers;
+ * the automatic choice takes it where it applies).  A forced kernel that does not cover the case answers PETSC_ERR_SUP. */
 int IGXSetKernel(IGX iga,int which);
 int IGXGetKernelName(IGX iga,char *buf,int len);
 /* name of the kernel the last IGXCompute* used   */
@@ -310,8 +320,15 @@ int IGXCommLoopbackTest(IGX iga,int64_t n,double *maxdiff);
  * Arrays have nblocks*bs*bs (matrix) / vector-size entries, on the device (on_device != 0) or on the host.
  * IGXVecCopyFromGhosted / ToGhosted: the rank's ghosted local array [gw2][gw1][gw0][dof] (IGAGetLocalVecArray,
  * src/petigavec.c:256-269) to / from an IGXVec: identical unless a periodic axis is wrapped inside the rank.
- * ------------------------------------------------------------------------------------------ */
+ * IGXMatGetCOODevice: the same lists kept on the device by the matrix (freed by IGXMatFreeCOO / IGXMatDestroy), in the caller's
+ * index width (index_bytes 8, or 4 for a PETSc with 32-bit PetscInt; PETSC_ERR_ARG_OUTOFRANGE when an index does not fit):
+ * what a device Mat type's MatSetPreallocationCOO takes without 2 x 8 bytes per stored scalar of host staging on this side.
+ * on_device copies (IGXVecCopyFromGhosted / ToGhosted, IGXMatGetCOO, IGXVecGetIndices) are ordered on the IGX's own stream:
+ * a caller on another stream calls IGXSynchronize first (or shares the stream, IGXSetStream). */
 int IGXMatGetCOO(IGXMat A,int numbering,int owned_only,int64_t *coo_i,int64_t *coo_j,int on_device);
+int IGXMatGetCOODevice(IGXMat A,int numbering,int owned_only,int index_bytes,void **coo_i,void **coo_j);
+int IGXMatFreeCOO(IGXMat A);
+int IGXDeviceToHost(void *host,const void *dev,size_t bytes);   /* hipMemcpy for a caller without the HIP headers (the adapter) */
 int IGXVecGetIndices(IGXVec v,int numbering,int owned_only,int64_t *idx,int on_device);
 int IGXVecGetGhostedSize(IGXVec v,int64_t *n);
 int IGXVecCopyFromGhosted(IGXVec v,const double *array,int on_device);
@@ -326,7 +343,9 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
 /* Compile-only check of a run-time form (no GPU needed): IGXSetFormSource compiles the point-form kernel; this compiles the
  * matrix-core kernel the drivers would launch for the degrees set so far (dim >= 2, (p+1)^dim <= 64), for the matrix drivers
  * (with_matrix != 0) or the vector-only ones.  gram != 0 when the struct declares MAT_PAIR_MASK (it decides the wave layout at
- * dof = 4; on a GPU the flag is read from the compiled module).  Returns 0 or IGX_ERR_USER with the compiler's log. */
+ * dof = 4; on a GPU the flag is read from the compiled module).  gram == 2: the pencil walk's instantiations instead (form_pencil,
+ * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  Returns 0 or IGX_ERR_USER with the
+ * compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
 /* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly

@@ -93,7 +93,8 @@ def lib(build_if_needed=False):
         "IGXPackGhostRows": [V, V, V, C.c_int, V], "IGXUnpackGhostRows": [V, V, V, C.c_int, V], "IGXRowOwned": [V, C.c_int, C.c_int, C.c_int],
         "IGXPackOwnerValues": [V, V, C.c_int, V], "IGXUnpackGhostValues": [V, V, C.c_int, V],
         "IGXChecksum": [V, V, V, _dp], "IGXCommGetOverlap": [V, _dp], "IGXCheckFormSource": [V, C.c_int, C.c_int], "IGXGetClockProbe": [V, _dp, C.POINTER(C.c_int64)], "IGXSetFormSource": [V, C.c_char_p, C.c_char_p, _dp, C.c_int],
-        "IGXMatGetCOO": [V, C.c_int, C.c_int, V, V, C.c_int], "IGXVecGetIndices": [V, C.c_int, C.c_int, V, C.c_int],
+        "IGXMatGetCOO": [V, C.c_int, C.c_int, V, V, C.c_int], "IGXMatGetCOODevice": [V, C.c_int, C.c_int, C.c_int, C.POINTER(V), C.POINTER(V)], "IGXMatFreeCOO": [V],
+        "IGXVecGetIndices": [V, C.c_int, C.c_int, V, C.c_int],
         "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
         "IGXCommDestroy": [V], "IGXReduceGhostRows": [V, V, V], "IGXRefreshGhosts": [V, V], "IGXCommGetLastBytes": [V, C.POINTER(C.c_int64)],
@@ -203,6 +204,14 @@ class Mat:
         ci, cj = np.empty(n, dtype=np.int64), np.empty(n, dtype=np.int64)
         _ck(lib().IGXMatGetCOO(self.h, numbering, int(owned_only), ci.ctypes.data, cj.ctypes.data, 0))
         return ci, cj
+
+    def coo_device(self, numbering=0, owned_only=False, index_bytes=8):
+        """Device pointers of the coordinate lists the matrix keeps for the hand-back (IGXMatGetCOODevice); free_coo() drops them."""
+        pi, pj = C.c_void_p(), C.c_void_p()
+        _ck(lib().IGXMatGetCOODevice(self.h, numbering, int(owned_only), index_bytes, C.byref(pi), C.byref(pj)))
+        return pi.value, pj.value
+
+    def free_coo(self): _ck(lib().IGXMatFreeCOO(self.h))
 
     def layout(self):
         nrow, ncol = (C.c_int * 3)(), (C.c_int * 3)()

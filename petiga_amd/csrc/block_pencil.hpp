@@ -39,7 +39,8 @@ struct BlockPencilArgs {
   int first_touch;                   // 1: the matrix was not zeroed; the first colour to reach a block stores it
   int nelx, nely;                    // local element counts on axes 1, 2 (first-touch rule)
   int fty_lo, fty_hi, fty_blocked;   // first-touch rule on axis 2 when the assembly comes in two passes over it (gram_mfma.hpp)
-  int debug;                         // -DIGX_DEBUG builds: 1 no read-add-write, 2 no MFMA
+  int debug;                         // -DIGX_DEBUG builds: 1 no read-add-write, 2 no MFMA, 16 no priority for the flush, 32 priority for the MFMA phase
+  int dbg_block;                     // -DIGX_DEBUG builds: the workgroup whose wave 0 stamps its phases (IGX_DEBUG_FEATURE & 8)
 };
 
 typedef double bp_d2_t __attribute__((ext_vector_type(2)));   // 16-byte aligned pair (LDS side of the read-add-write)
@@ -47,7 +48,7 @@ constexpr unsigned bp_row_features(unsigned long long pairs) { unsigned m = 0; f
 constexpr unsigned bp_col_features(unsigned long long pairs) { unsigned m = 0; for (int f = 0; f < 8; ++f) for (int g = 0; g < 8; ++g) if ((pairs >> (f * 8 + g)) & 1ull) m |= 1u << g; return m; }
 
 // offsets (in doubles) into the dynamic LDS block
-struct BpCarve { int stage, zt, pre, cnt, rho, P, pen, vy, fcorr, bc, total; };
+struct BpCarve { int stage, zt, pre, cnt, rho, P, pen, vy, fcorr, bc, arrive, total; };
 __host__ __device__ static inline BpCarve bp_carve(int seg_len, int dof) {
   BpCarve c; int pos = 0;
   auto take = [&](int n) { const int o = pos; pos += (n + 1) & ~1; return o; };
@@ -58,6 +59,7 @@ __host__ __device__ static inline BpCarve bp_carve(int seg_len, int dof) {
   c.vy = take(32);
   c.fcorr = take(2 * 4 * 16 * dof);
   c.bc = take(6 + 6 * 4);
+  c.arrive = take(2);            // per group: waves that have deposited so far (monotonic)
   c.total = pos;
   return c;
 }
@@ -91,8 +93,11 @@ __device__ __forceinline__ bool bp_fixed(const BpBC &b, int ix, int iy, int lay,
 // one tile product: acc[pair] += A_f(element e, row slot ta)^T B_g(element e, column slot tb) over the element's 64 points;
 // k-step (qw, qy), k slot = qx (lane >> 4).  zt: the element's walk-axis rows [q][a][2] (value, derivative), scaled by sqrt(w J).
 // uv[qy][c]: u0 vy0, u1 vy0, u0 vy1 of this lane (axes 1, 2; scaled likewise): sqrt(JW) sits on both operands.
+// accumulator sets of a band tile: the Gram pairs, and room for the dof^2 entries of the blocks they are turned into in place
+template <class Form> constexpr int bp_nacc() { return fm_popcount(mat_pair_mask_of<Form>::v) > Form::DOF * Form::DOF ? fm_popcount(mat_pair_mask_of<Form>::v) : Form::DOF * Form::DOF; }
+
 template <class Form>
-__device__ __forceinline__ void bp_product(d4_t (&acc)[fm_popcount(mat_pair_mask_of<Form>::v)], const double *zt, int ta, int tb, const double (&uv)[4][3]) {
+__device__ __forceinline__ void bp_product(d4_t (&acc)[bp_nacc<Form>()], const double *zt, int ta, int tb, const double (&uv)[4][3]) {
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
   constexpr unsigned FR = bp_row_features(PAIRS), FC = bp_col_features(PAIRS);
 #pragma unroll
@@ -122,13 +127,49 @@ __device__ __forceinline__ void bp_product(d4_t (&acc)[fm_popcount(mat_pair_mask
   }
 }
 
+// Gram sums -> blocks, in place: K^{ij} = sum_{fg} C^{ij}_{fg} M_fg with C = mat(e_f, e_g) (the form's constants).  Done by the
+// wave that holds the accumulators, at the end of its own MFMA phase: fp64 VALU work of the OTHER wave of the SIMD waits for a
+// gap in this wave's MFMA stream, about one MFMA (64 cycles) per instruction -- in the flush phase these 21 multiply-adds per
+// block took 11k cycles per layer and kept the MFMA group waiting at the deposit barrier.
+template <class Form>
+__device__ __forceinline__ void bp_transform(d4_t (&acc)[bp_nacc<Form>()], const PtView &p0) {
+  constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+  constexpr int NP = fm_popcount(PAIRS), BS = Form::DOF * Form::DOF;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double M[NP], K[BS];
+#pragma unroll
+    for (int n = 0; n < NP; ++n) M[n] = acc[n][r];
+#pragma unroll
+    for (int n = 0; n < BS; ++n) K[n] = 0.0;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+        double ef[4], eg[4], T[BS];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) { ef[n] = (n == f) ? 1.0 : 0.0; eg[n] = (n == g) ? 1.0 : 0.0; }
+        Form::mat(p0, ef, eg, T);
+#pragma unroll
+        for (int n = 0; n < BS; ++n) if ((fm_pair_block_mask<Form>(f, g) >> n) & 1u) K[n] += T[n] * M[fm_pair_index(PAIRS, f, g)];
+      }
+#pragma unroll
+    for (int n = 0; n < BS; ++n) {
+      // (pinned here: left to itself the compiler sinks these multiply-adds past the barrier into the deposit, their only user)
+      asm volatile("" : "+v"(K[n]));
+      acc[n][r] = K[n];
+    }
+  }
+}
+
 template <class Form, int P, bool SYSTEM>
 __global__ void __launch_bounds__(512, 2)
 block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
   static_assert(P == 3, "4 x 4 x 4 basis functions: the band tiles of a layer split evenly over four wavefronts");
   constexpr int NB = P + 1, BW = 2 * P + 1, DOF = Form::DOF, BS = DOF * DOF;
   constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
-  constexpr int NP = fm_popcount(PAIRS);
+  constexpr int NACC = bp_nacc<Form>();
   static_assert(PAIRS != 0ull && (PAIRS >> 32) == 0ull && ((PAIRS >> 4) & 0x0f0f0f0full) == 0ull, "Gram pairs over N and grad N");
   static_assert(DOF <= 3, "the LDS stage holds one band row: 16 x 16 x 7 blocks of dof^2 values");
   extern __shared__ __attribute__((aligned(16))) double bp_sm[];
@@ -155,6 +196,8 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
   BpPencil *pen = reinterpret_cast<BpPencil *>(bp_sm + cv.pen);
   unsigned *bcm = reinterpret_cast<unsigned *>(bp_sm + cv.bc);      // [6] field masks (0: face not touched), then 6 x 4 values
   double *bcv = bp_sm + cv.bc + 6;
+  int *arrive = reinterpret_cast<int *>(bp_sm + cv.arrive) + grp * 2;
+  if (tid < 4) reinterpret_cast<int *>(bp_sm + cv.arrive)[tid] = 0;
 
   // ---- stage the tables of the segment and of the pencil
   {
@@ -241,41 +284,47 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
   PtView p0; p0.x = nullptr; p0.u = nullptr; p0.ut = nullptr; p0.gu = nullptr; p0.hu = nullptr; p0.G = nullptr; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t; p0.normal = nullptr; p0.atboundary = 0; p0.boundary_id = -1;
 
   const int nit = (nlay + 1) >> 1;
-  if (grp == 1) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+  // -DIGX_DEBUG, IGX_DEBUG_FEATURE & 8: cycles per phase of wave 0 of one workgroup, summed over its iterations
+  const bool stamp = kDebug && out.dbg && (int)blockIdx.x == pa.dbg_block && tid == 0;
+  long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define BP_STAMP(k) do { if (stamp) { const long long t_ = (long long)__builtin_readcyclecounter(); ph[k] += t_ - tlast; tlast = t_; } } while (0)
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  if (stamp) tlast = (long long)__builtin_readcyclecounter();
   for (int it = 0; it < nit; ++it) {
     const int k = 2 * it + grp;
     const bool act = k < nlay;
     const int li = li_lo + (act ? k : 0);       // layer of this group in this iteration
     const int lay = lay_first + li;
-    d4_t accA[NP], accB[NP];
+    d4_t accA[NACC], accB[NACC];
 #pragma unroll
-    for (int n = 0; n < NP; ++n) { accA[n] = (d4_t){0, 0, 0, 0}; accB[n] = (d4_t){0, 0, 0, 0}; }
+    for (int n = 0; n < NACC; ++n) { accA[n] = (d4_t){0, 0, 0, 0}; accB[n] = (d4_t){0, 0, 0, 0}; }
 
     // ---- MFMA phase: the tile products of this wave's band tiles; elements [max(l, l+d) - P, min(l, l+d)] of the pencil
+    if (kDebug && (pa.debug & 32)) __builtin_amdgcn_s_setprio(2);
     {
       int eloA = max(li, li + dA) - P, ehiA = min(li, li + dA);
       if (eloA < 0) eloA = 0;
       if (ehiA > pa.nel0 - 1) ehiA = pa.nel0 - 1;
       if (!act || (kDebug && (pa.debug & 2))) ehiA = eloA - 1;
-      bool first = true;
-      for (int e = eloA; e <= ehiA; ++e) {
-        bp_product<Form>(accA, zts + (e - e0) * 32, li - e, li + dA - e, uv);
-        if (first) { __builtin_amdgcn_s_barrier(); first = false; }     // the other group has deposited its band row by now
-      }
-      if (first) __builtin_amdgcn_s_barrier();
+      for (int e = eloA; e <= ehiA; ++e) bp_product<Form>(accA, zts + (e - e0) * 32, li - e, li + dA - e, uv);
+      BP_STAMP(0); BP_STAMP(1);
+      bp_transform<Form>(accA, p0);
       if (hasB) {
         int eloB = max(li, li + dB) - P, ehiB = min(li, li + dB);
         if (eloB < 0) eloB = 0;
         if (ehiB > pa.nel0 - 1) ehiB = pa.nel0 - 1;
         if (!act || (kDebug && (pa.debug & 2))) ehiB = eloB - 1;
         for (int e = eloB; e <= ehiB; ++e) bp_product<Form>(accB, zts + (e - e0) * 32, li - e, li + dB - e, uv);
+        bp_transform<Form>(accB, p0);
       }
     }
+    BP_STAMP(2);
     __builtin_amdgcn_s_barrier();
+    BP_STAMP(3);
 
     // ---- deposit: blocks K^{ij} = sum_{fg} C^{ij}_{fg} M_fg of this lane's (row slot, column slot) pairs, IGAElementFixSystem on
     // the combined values, into the stage in matrix order
-    __builtin_amdgcn_s_setprio(3);
+    if (!(kDebug && (pa.debug & 16))) __builtin_amdgcn_s_setprio(3);
     const int kk = act ? k : 0;
     const int c0 = __builtin_amdgcn_readfirstlane(Lcnt[kk]);
     const int held = min(li, pa.nel0 - 1) - max(li - P, 0) + 1;      // elements of this pencil that hold the layer
@@ -287,27 +336,14 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < DOF; ++i) corr[r][i] = 0.0;
-      auto deposit = [&](const d4_t (&acc)[NP], int d) {
+      auto deposit = [&](const d4_t (&acc)[NACC], int d) {
         const int p0d = __builtin_amdgcn_readfirstlane(LP[kk * 8 + d + P]);
         if (p0d < 0 || !act) return;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {       // a2 = r
           double K[BS];
 #pragma unroll
-          for (int n = 0; n < BS; ++n) K[n] = 0.0;
-#pragma unroll
-          for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
-              double ef[4], eg[4], T[BS];
-#pragma unroll
-              for (int n = 0; n < 4; ++n) { ef[n] = (n == f) ? 1.0 : 0.0; eg[n] = (n == g) ? 1.0 : 0.0; }
-              Form::mat(p0, ef, eg, T);
-              const double m = acc[fm_pair_index(PAIRS, f, g)][r];
-#pragma unroll
-              for (int n = 0; n < BS; ++n) K[n] += T[n] * m;
-            }
+          for (int n = 0; n < BS; ++n) K[n] = acc[n][r];
           if (bcrow) {
             bool fa[DOF], fb[DOF]; double vb[DOF];
 #pragma unroll
@@ -325,8 +361,10 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
           for (int n = 0; n < BS; ++n) sp[n] = K[n];
         }
       };
+      BP_STAMP(8);       // (set-up of the phase: layer data, Dirichlet flags)
       deposit(accA, dA);
       if (hasB) deposit(accB, dB);
+      BP_STAMP(9);       // (the deposits)
       if (bcrow) {       // F_i -= sum over fixed columns of K_ik v_k: sum over the 16 column slots of this wave's tiles, then over the waves
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -339,13 +377,21 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
       }
     }
 
+    // This wave's part of the band row is in the stage: tell the other three waves of the group.  Not a barrier: s_barrier is
+    // workgroup wide, and the other group's MFMA waves would stand at it while this group's loads below push through the memory
+    // pipeline (measured: 7k-11k cycles of every 45k-cycle layer).  A counter in LDS per group, polled after the loads are out.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    BP_STAMP(4);
     // ---- read-add-write of the band row: wave `role` takes the rows a2 = role; run (a1, b2) = 4 c0 blocks, contiguous in the
-    // stage and in the matrix.  The old values are requested before the barrier: they travel while the other waves deposit.
+    // stage and in the matrix.  With 121 KB of reads per layer the memory pipeline pushes back on the issue itself (measured: 11k
+    // cycles to get the 32 loads of a lane out): they are requested before the wave waits for the other deposits.
     const int runlen = 4 * c0 * BS;                 // doubles per run (even)
     double *gp[16]; d2u_t oldv[16][2]; bool ldm[16];
     const long long ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(Lpre[kk] >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(Lpre[kk] & 0xffffffffll));
     const bool dowrite = act && !(kDebug && (pa.debug & 1));
     const long long mypos = run_base + run_cc * ps0 + (long long)run_pp * c0;
+    BP_STAMP(10);        // (the Dirichlet sums)
 #pragma unroll
     for (int ru = 0; ru < 16; ++ru) {
       const int a1 = ru >> 2, b2 = ru & 3, a2 = role;
@@ -361,11 +407,12 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
         if (ldm[ru] && o < runlen) oldv[ru][h] = *reinterpret_cast<const d2u_t *>(gp[ru] + o);
       }
     }
-    // every wave of this group has deposited (the other group: after its first tile product).  Not __syncthreads(): only the
-    // LDS writes have to land, the global loads above stay in flight across the barrier.
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    {   // every wave of this group has deposited
+      const int target = 4 * (it + 1);
+      while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+      asm volatile("" ::: "memory");
+    }
+    BP_STAMP(5);
     if (dowrite) {
       const int blk = c0 * BS;        // doubles per b1 group
 #pragma unroll
@@ -404,9 +451,17 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
       }
     }
     __builtin_amdgcn_s_setprio(0);
+    BP_STAMP(6);
     __builtin_amdgcn_s_barrier();
+    BP_STAMP(7);
   }
-  if (grp == 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+  if (stamp) {     // cumulative, in the layout engine.hip prints ("[feature stamps]": differences of consecutive entries)
+    long long c = 0; out.dbg[0] = 0;
+    for (int k = 0; k < 12; ++k) { c += ph[k] / (nit > 0 ? nit : 1); out.dbg[k + 1] = c; }
+    out.dbg[31] = 13;
+  }
+#undef BP_STAMP
 }
 
 // ---- boundary loads of a multi-field form on the identity geometry: gram_mfma.hpp's k_boundary_loads per field
@@ -523,7 +578,7 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
       while (pencils * nseg < 4LL * ncu && NL / (nseg + 1) >= 8) nseg++;
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
-      pa.debug = s.env.debug_feature;
+      pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
       const size_t lds = (size_t)bp_carve(pa.seg_len, DOF).total * sizeof(double);
       auto kern = sys ? block_pencil<Form, P, true> : block_pencil<Form, P, false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

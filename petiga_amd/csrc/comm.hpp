@@ -135,10 +135,11 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
   const bool phased = reduce && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
-  // The mark belongs to the matrix / vector the marked assembly wrote: only those are face-complete there.  Anything else --
-  // another object, or one that an entry point has written to since (IGXVecCopyFromHost, IGXVecCopyFromGhosted, IGXReadVec and
-  // every exchange clear the mark) -- is packed where the engine stream stands now.
-  const bool early = phased && g->slab_valid && (!A || A == g->slab_A) && (!b || b == g->slab_b);
+  // What the marked assembly wrote is face-complete at its mark, and a matrix / vector an EARLIER call wrote was complete before
+  // it (one engine stream).  The mark is only good while it is the last write: every entry point that writes to an IGXMat /
+  // IGXVec afterwards clears it (IGXCompute*, IGXVecCopyFromHost, IGXVecCopyFromGhosted, IGXReadVec, IGXUnpackGhost*, every
+  // exchange), and the reduction then packs where the engine stream stands.
+  const bool early = phased && g->slab_valid;
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
   c.last_bytes = 0; c.packed1_valid = false;

@@ -113,6 +113,43 @@ extern "C" int IGXMatGetCOO(IGXMat A, int numbering, int owned_only, int64_t *co
   return 0;
 }
 
+// The same lists, kept on the device by the matrix itself (for MatSetPreallocationCOO of a device Mat type: no host staging of
+// 2 x 8 bytes per stored scalar -- 93 GB for the metric configuration -- on this side), in the caller's index width: 8 bytes, or
+// 4 when PETSc is built with 32-bit PetscInt (refused when an index does not fit).  Freed by IGXMatFreeCOO / IGXMatDestroy.
+__global__ void k_narrow_i64(const int64_t *src, int32_t *dst, int64_t n) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = (int32_t)src[t];
+}
+extern "C" int IGXMatGetCOODevice(IGXMat A, int numbering, int owned_only, int index_bytes, void **coo_i, void **coo_j) {
+  if (!A || !coo_i || !coo_j) return fail(IGX_ERR_ARG_WRONG, "null argument");
+  if (index_bytes != 4 && index_bytes != 8) return fail(IGX_ERR_ARG_OUTOFRANGE, "index width must be 4 or 8 bytes");
+  IGX g = A->iga; const Space &s = g->s;
+  const int64_t nglobal = (int64_t)s.node_sizes[0] * s.node_sizes[1] * s.node_sizes[2] * s.dof;
+  if (index_bytes == 4 && nglobal > 0x7fffffffll) return fail(IGX_ERR_ARG_OUTOFRANGE, "row indices do not fit 32 bits: PETSc needs --with-64-bit-indices for this problem");
+  const size_t n = (size_t)A->nblocks * s.dof * s.dof;
+  DevBuf wi, wj;
+  if (wi.alloc(n * 8) || wj.alloc(n * 8)) return fail(IGX_ERR_MEM, "device allocation of the coordinate lists failed");
+  if (int rc = IGXMatGetCOO(A, numbering, owned_only, wi.as<int64_t>(), wj.as<int64_t>(), 1)) return rc;
+  if (index_bytes == 8) { std::swap(A->coo_i.p, wi.p); std::swap(A->coo_i.bytes, wi.bytes); std::swap(A->coo_j.p, wj.p); std::swap(A->coo_j.bytes, wj.bytes); }
+  else {
+    if (A->coo_i.alloc(n * 4) || A->coo_j.alloc(n * 4)) return fail(IGX_ERR_MEM, "device allocation of the coordinate lists failed");
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_narrow_i64, dim3(nb), dim3(256), 0, g->stream, wi.as<int64_t>(), A->coo_i.as<int32_t>(), (int64_t)n);
+    hipLaunchKernelGGL(k_narrow_i64, dim3(nb), dim3(256), 0, g->stream, wj.as<int64_t>(), A->coo_j.as<int32_t>(), (int64_t)n);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(g->stream));
+  }
+  *coo_i = A->coo_i.p; *coo_j = A->coo_j.p;
+  return 0;
+}
+// a caller without the HIP runtime headers (the PETSc adapter is plain C) fetches pieces of a device array through this
+extern "C" int IGXDeviceToHost(void *host, const void *dev, size_t bytes) {
+  if (!host || !dev) return fail(IGX_ERR_ARG_WRONG, "null argument");
+  HIPCK(hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+extern "C" int IGXMatFreeCOO(IGXMat A) { if (!A) return fail(IGX_ERR_ARG_WRONG, "null matrix"); A->coo_i.alloc(0); A->coo_j.alloc(0); return 0; }
+
 extern "C" int IGXVecGetIndices(IGXVec v, int numbering, int owned_only, int64_t *idx, int on_device) {
   if (!v || !idx) return fail(IGX_ERR_ARG_WRONG, "null argument");
   IGX g = v->iga; NumTables T; NumDev N;
@@ -126,6 +163,9 @@ extern "C" int IGXVecGetIndices(IGXVec v, int numbering, int owned_only, int64_t
   return 0;
 }
 
+// on_device != 0: the copy is a kernel on the IGX's stream and returns without waiting for it -- a caller on another stream (a
+// device Vec's array belongs to PETSc's stream) calls IGXSynchronize before it touches the array again, or shares the stream
+// (IGXSetStream).  Host arrays are staged and the call returns when the data is in place.
 static int ghosted_copy(IGXVec v, double *array, int on_device, int to_ghosted) {
   if (!v || !array) return fail(IGX_ERR_ARG_WRONG, "null argument");
   IGX g = v->iga; const Space &s = g->s;

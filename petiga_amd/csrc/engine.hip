@@ -79,6 +79,7 @@ struct _p_IGX {
 struct _p_IGXMat {
   IGX iga; int bs; int64_t nbrows, nblocks;
   DevBuf browptr, bcolidx, val;
+  DevBuf coo_i, coo_j;     // coordinate lists kept on the device for the hand-back (IGXMatGetCOODevice), or empty
 };
 struct _p_IGXVec { IGX iga; int64_t n; DevBuf a; };
 
@@ -1029,7 +1030,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   int rc;
   bool done = false;
   g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
-  if (g->kernel_choice != 1 && g->kernel_choice != 3) {
+  if (g->kernel_choice != 1 && g->kernel_choice != 3 && s.form != IGX_FORM_SOURCE) {   // (a run-time form reaches the pencil walk through rtc.hpp)
     std::function<void()> slab_done;
     g->slab_valid = false;
     if (g->comm && s.env.overlap) slab_done = [&]() {

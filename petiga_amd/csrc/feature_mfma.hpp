@@ -39,6 +39,14 @@ template <class F> struct mat_test_mask_of<F, decltype((void)F::MAT_TEST_MASK)> 
 template <class F, class = void> struct phi_mask_of { static constexpr unsigned v = 0xffffffffu; };
 template <class F> struct phi_mask_of<F, decltype((void)F::PHI_MASK)> { static constexpr unsigned v = F::PHI_MASK; };
 
+// MAT_SYMMETRIC: mat(p, Na, Nb) == mat(p, Nb, Na) for every point (the form's own promise, like the masks); VEC_TEST_MASK: features
+// of Na that vec() reads.  A scalar first-order form with MAT_TEST_MASK = gradients, MAT_SYMMETRIC and VEC_TEST_MASK = N runs
+// on the pencil walk of gram_mfma.hpp (form_pencil): 480 MFMAs per element and combined band rows instead of the element mode.
+template <class F, class = void> struct mat_symmetric_of { static constexpr bool v = false; };
+template <class F> struct mat_symmetric_of<F, decltype((void)F::MAT_SYMMETRIC)> { static constexpr bool v = F::MAT_SYMMETRIC; };
+template <class F, class = void> struct vec_test_mask_of { static constexpr unsigned v = 0xffffffffu; };
+template <class F> struct vec_test_mask_of<F, decltype((void)F::VEC_TEST_MASK)> { static constexpr unsigned v = F::VEC_TEST_MASK; };
+
 // VEC_ZERO: vec() returns zeros (Elasticity3D's F = 0): the vector phase runs only where Dirichlet values are lifted
 template <class F, class = void> struct vec_zero_of { static constexpr bool v = false; };
 template <class F> struct vec_zero_of<F, decltype((void)F::VEC_ZERO)> { static constexpr bool v = F::VEC_ZERO; };
@@ -59,6 +67,11 @@ constexpr unsigned long long fm_pairs_upper(unsigned long long mask) {
   for (int f = 0; f < 8; ++f) for (int g = 0; g < 8; ++g) if ((mask >> (f * 8 + g)) & 1ull) u |= 1ull << ((f < g ? f : g) * 8 + (f < g ? g : f));
   return u;
 }
+
+// optional refinement of MAT_PAIR_MASK: Form::pair_block_mask(f, g) = bit i*DOF+j set when C^{ij}_{fg} is not identically zero
+template <class F, class = void> struct has_pair_block_mask { static constexpr bool v = false; };
+template <class F> struct has_pair_block_mask<F, decltype((void)F::pair_block_mask(0, 0))> { static constexpr bool v = true; };
+template <class F> constexpr unsigned fm_pair_block_mask(int f, int g) { if constexpr (has_pair_block_mask<F>::v) return F::pair_block_mask(f, g); else return 0xffffffffu; }
 
 // optional per-block refinement of MAT_TEST_MASK: Form::block_mask(i,j) = test features block (i,j) of mat() reads
 template <class F, class = void> struct has_block_mask { static constexpr bool v = false; };

@@ -44,6 +44,7 @@ template <int DIM, int DOF_> struct FormMass {
   static constexpr int DOF = DOF_, ORDER = 1; static constexpr unsigned NEED = 0;
   static constexpr unsigned MAT_TEST_MASK = 1u;   // values only
   static constexpr unsigned long long MAT_PAIR_MASK = 1ull;   // N x N
+  static constexpr unsigned pair_block_mask(int, int) { unsigned m = 0; for (int i = 0; i < DOF_; ++i) m |= 1u << (i * DOF_ + i); return m; }   // block diagonal
   static __device__ __forceinline__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
 #pragma unroll
     for (int i = 0; i < DOF * DOF; ++i) T[i] = 0;
@@ -99,6 +100,9 @@ struct FormElasticity {
   static constexpr unsigned MAT_TEST_MASK = 0xEu;   // gradients only
   static constexpr unsigned long long MAT_PAIR_MASK = (0xEull << 8) | (0xEull << 16) | (0xEull << 24);   // lambda, mu constant: all grad x grad pairs
   static constexpr bool VEC_ZERO = true;            // F = 0 (demo/Elasticity3D.c:43-45)
+  // entries i*3+j of the block that the Gram pair (d_f N_a, d_g N_b) reaches: the diagonal for f = g, else (f,g) and (g,f)
+  // (x * 0 does not fold under IEEE rules: without this the coefficient transform runs 81 multiply-adds per block instead of 21)
+  static constexpr unsigned pair_block_mask(int f, int g) { return f == g ? 0x111u : ((1u << ((f - 1) * 3 + (g - 1))) | (1u << ((g - 1) * 3 + (f - 1)))); }
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
     const double lambda = p.prm[0], mu = p.prm[1];
     const double Na_x = Na[1], Na_y = Na[2], Na_z = Na[3], Nb_x = Nb[1], Nb_y = Nb[2], Nb_z = Nb[3];

@@ -11,7 +11,9 @@
 //   operand(q2,q3,alpha,t) = n0[q1][a1][alpha==0] * n1[q2][a2][alpha==1] * n2[q3][t][alpha==2]
 // so a k-step costs ~11 v_mul_f64 for 16 MFMAs.  Result layout (measured, scripts/mfma_probe.hip):
 // lane l, reg r of tile (ta,tb) holds K_e[a=(l>>4, r, ta)][b=(l&3, (l>>2)&3, tb)].
+// IGX_RTC: the device half of this header is also compiled at run time for a user form (rtc.hpp: form_pencil below).
 #pragma once
+#ifndef IGX_RTC
 #include <functional>
 #include "first_touch.hpp"
 #include <hip/hip_runtime.h>
@@ -19,8 +21,10 @@
 #include <cstdlib>
 #include <string>
 #include <vector>
+#endif
 #include "igx.hpp"
 #include "pencil_common.hpp"
+#include "forms.hpp"
 
 namespace igx {
 
@@ -695,6 +699,123 @@ __device__ __forceinline__ void pencil_geo_eval(double *geo, int lane, const dou
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
+// ---- run-time scalar forms on this kernel (include/petiga.h:153-197: the point callback is an arbitrary user function; here a
+// struct compiled at run time, rtc.hpp).  A dof-1, first-order form whose matrix integrand reads the gradients only and is
+// symmetric, k_q[a][b] = sum_ij d_i N_a C_ij(q) d_j N_b with C = mat(p, e_i, e_j) -- Poisson (demo/Poisson3D.c:3-23) is C = I; an
+// anisotropic or x-dependent diffusion is the same shape -- has the metric JW F^-1 C F^-T in the place of JW F^-1 F^-T above, and
+// its load term vec(p, e_N) in the place of the constant forcing: the rest of the walk (operands, symmetric tiles, band-row flush,
+// first touch, Dirichlet fix-up) does not know the difference.  IDENT: no geometry, x = the parametric point, F = I.
+template <class Form> struct is_builtin_gram { static constexpr bool v = false; };
+template <> struct is_builtin_gram<void> { static constexpr bool v = true; };
+
+template <int P, class Form, bool IDENT>
+__device__ __forceinline__ void pencil_form_eval(double *geo, int lane, const double *uxr, const double *vyr, const double *ztg,
+                                                 double wj, bool rational, int *errflag, const double *prm, double shift, double tt, const double (&xpar)[3]) {
+  constexpr int NB = P + 1;
+  const int qx = lane & 3, qy = (lane >> 2) & 3, qw = lane >> 4;
+  const bool valid = qx < NB && qy < NB && qw < NB;
+  double H[4][4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) H[c][k] = 0.0;
+  if constexpr (!IDENT) {      // the sums over the control points, as in pencil_geo_eval
+    double *T1 = geo + 256, *T2 = geo + 384;
+    const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+    double zv[4] = {0, 0, 0, 0}, zd[4] = {0, 0, 0, 0};
+    if (i2 < NB) {
+#pragma unroll
+      for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[(i2 * 4 + aw) * 2 + 0]; zd[aw] = ztg[(i2 * 4 + aw) * 2 + 1]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      {
+        double tv = 0, td = 0;
+#pragma unroll
+        for (int ax = 0; ax < 4; ++ax) { const double C = geo[((i2 * 4 + i1) * 4 + ax) * 4 + c]; tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1]; }
+        T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td;
+      }
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      {
+        double m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+        for (int ay = 0; ay < 4; ++ay) {
+          const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0];
+          const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1];
+          m0 += a * yv; m1 += d * yv; m2 += a * yd;
+        }
+        T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
+      }
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      {
+        double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+        for (int aw = 0; aw < 4; ++aw) {
+          const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
+          h0 += t0 * zv[aw]; h1 += t0 * zd[aw]; h2 += t1 * zv[aw]; h3 += t2 * zv[aw];
+        }
+        H[c][0] = h0; H[c][1] = h1; H[c][2] = h2; H[c][3] = h3;
+      }
+      __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  double M[GEO_M] = {0, 0, 0, 0, 0, 0, 0}, R[4] = {0, 0, 0, 0};
+  if (valid) {
+    double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, x[3] = {xpar[0], xpar[1], xpar[2]}, det = 1.0, iw = 1.0;
+    if constexpr (!IDENT) {
+      iw = 1.0 / H[3][0];
+      double F[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        x[c] = H[c][0] * iw;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) F[c][b] = (H[c][1 + b] - x[c] * H[3][1 + b]) * iw;
+      }
+      det = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) + F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+      if (!(det > 0.0)) atomicExch(errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      const double id = 1.0 / det;
+      E[0][0] = (F[1][1] * F[2][2] - F[1][2] * F[2][1]) * id; E[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id; E[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id;
+      E[1][0] = (F[1][2] * F[2][0] - F[1][0] * F[2][2]) * id; E[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id; E[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
+      E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
+      R[0] = iw; R[1] = H[3][1] * iw; R[2] = H[3][2] * iw; R[3] = H[3][3] * iw;
+    }
+    // the user's integrand at this point: C_ij = mat(p, e_i, e_j), load = vec(p, e_N)
+    PtView p; p.x = x; p.u = nullptr; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
+    p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+    double C[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = i; j < 3; ++j) {
+        double ei[4] = {0, 0, 0, 0}, ej[4] = {0, 0, 0, 0}, T[1];
+        ei[1 + i] = 1.0; ej[1 + j] = 1.0;
+        Form::mat(p, ei, ej, T);
+        C[i][j] = T[0]; C[j][i] = T[0];     // (declared symmetric: MAT_SYMMETRIC)
+      }
+    double e0[4] = {1, 0, 0, 0}, Fv[1];
+    Form::vec(p, e0, Fv);
+    const double JW = det * wj;
+    int k = 0;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      double EC[3];      // (E C)[b][j]
+#pragma unroll
+      for (int j = 0; j < 3; ++j) EC[j] = E[b][0] * C[0][j] + E[b][1] * C[1][j] + E[b][2] * C[2][j];
+#pragma unroll
+      for (int g = b; g < 3; ++g) M[k++] = JW * (EC[0] * E[g][0] + EC[1] * E[g][1] + EC[2] * E[g][2]);
+    }
+    M[6] = Fv[0] * JW * (rational ? iw : 1.0);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int k = 0; k < GEO_M; ++k) geo[lane * GEO_M + k] = M[k];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) geo[64 * GEO_M + lane * 4 + k] = R[k];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
 // the MFMAs of one element on a mapped geometry: k-step (qw, qy, beta), k slot = qx (lane>>4); 10 tiles (K_e is symmetric)
 // (the walk-axis point loop stays rolled and the rational branch is a template parameter: fully unrolled with both branches
 // the kernel was 60 KB of code and its MFMA phase took 55k cycles against 31k of MFMA issue: instruction-cache bound)
@@ -763,10 +884,11 @@ __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, cons
   return s;
 }
 
-template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
-__global__ void __launch_bounds__(512, 2)
-gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT>
+__device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
+  static_assert(is_builtin_gram<Form>::v || (GEO && !FIXT), "a run-time form takes the metric path");
+  static_assert(!IDENT || (GEO && !RAT && !is_builtin_gram<Form>::v), "IDENT: a run-time form without a geometry");
   static_assert(!FIXT || (SYSTEM && W == 0), "fix tables: System driver, axis-0 walk");
   constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
@@ -896,9 +1018,18 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
       // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
       // there stalls the in-order MFMA issue for its whole latency)
       if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
-      pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
+      if constexpr (!IDENT) pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
+      else { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }     // (the walk-axis rows above)
       const int gqw = lane >> 4;
-      pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
+      if constexpr (is_builtin_gram<Form>::v) pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
+      else {
+        double xpar[3] = {0, 0, 0};
+        if constexpr (IDENT) {
+          const int gqx = lane & 3, gqy = (lane >> 2) & 3;
+          if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[(wh + ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
+        }
+        pencil_form_eval<P, Form, IDENT>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), rational, out.errflag, prm, out.shift, out.t, xpar);
+      }
     }
   };
   geometry(0);
@@ -984,6 +1115,20 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
     }
 }
 
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
+__global__ void __launch_bounds__(512, 2)
+gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
+  gram_pencil_body<SYSTEM, W, P, GEO, RAT, FIXT, void, false>(S, out, pa, nullptr);
+}
+
+// the same walk for a run-time scalar form (rtc.hpp compiles this instantiation with hiprtc; IDENT: no geometry)
+template <bool SYSTEM, int P, bool IDENT, bool RAT, class Form>
+__global__ void __launch_bounds__(512, 2)
+form_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  gram_pencil_body<SYSTEM, 0, P, true, RAT, false, Form, IDENT>(S, out, pa, prm.v);
+}
+
+#ifndef IGX_RTC
 // ------------------------------------------------------------------ dispatch
 
 template <bool SYSTEM>
@@ -1000,12 +1145,16 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
   }
 }
 
+// a run-time form's instantiation of the walk (rtc.hpp): the module function for this driver / degree / geometry, its parameters
+struct PencilModule { hipFunction_t fn; ParamsDev prm; std::string name; };
+
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
 template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
 // fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
 // (first_touch_axis); null: one pass over the whole axis
-static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false, const int *fty = nullptr) {
+static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false, const int *fty = nullptr,
+                           const PencilModule *mod = nullptr) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
   const int nw = bx.hi[W] - bx.lo[W];
@@ -1046,9 +1195,18 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
+    if (mod) {      // form_pencil<SYSTEM, P, IDENT, RAT, UserForm> of a run-time form: a module function (rtc.hpp)
+      struct { SpaceDev S; OutDev out; PencilArgs pa; ParamsDev prm; } args;
+      memset(&args, 0, sizeof(args));
+      args.S = S; args.out = out; args.pa = pa; args.prm = mod->prm;
+      size_t asz = sizeof(args);
+      void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+      (void)hipModuleLaunchKernel(mod->fn, (unsigned)(pa.blocks_per_seg * pa.nseg), 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg);
+    } else {
     auto kern = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
+    }
     if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
       dbg_done = 1;
       (void)hipStreamSynchronize(stream);
@@ -1227,10 +1385,10 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
 // 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
                          std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix,
-                         const std::function<void()> &slab_done = std::function<void()>()) {
+                         const std::function<void()> &slab_done = std::function<void()>(), const PencilModule *mod = nullptr) {
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
-  if (s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
+  if (!mod && s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
   if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return no("only System / Matrix drivers");
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
   const bool geo = s.nsd != 0;
@@ -1251,9 +1409,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
-  if (geo && walk_axis != 0) return no("a mapped geometry needs a walkable axis 0");
+  if ((geo || mod) && walk_axis != 0) return no("a mapped geometry / a run-time form needs a walkable axis 0");
   const bool fixt = S.fixtable != nullptr && sys;       // IGASetFixTable: Dirichlet values per node (the Matrix driver applies none)
   if (fixt && walk_axis != 0) return no("fix table without a walkable axis 0");
+  if (fixt && mod) return no("fix table with a run-time form");
   Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
   if (!walk && deg != 3) return no("p=2 needs a walkable axis 0");
   const bool first_touch = walk_axis == 0 && !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
@@ -1287,17 +1446,17 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       case 2: launch_pencils<true, 0, 3, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
       default: launch_pencils<true, 0, 3, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
       }
-    } else if (geo) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation
+    } else if (geo || mod) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation (a run-time form: its own coefficients)
       const int v = (deg == 2 ? 0 : 4) + (sys ? 2 : 0) + (s.rational ? 1 : 0);
       switch (v) {
-      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
       }
     } else if (fixt) {
       if (deg == 2) launch_pencils<true, 0, 2, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
@@ -1325,7 +1484,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       run(rest, ft_rest);
     } else run(P, nullptr);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
-    dom.name = std::string("gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
+    dom.name = std::string(mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
     dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 27 * 6);
@@ -1337,11 +1496,13 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = std::string("gram_pencil(mfma_f64_16x16x4,p=") + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = (mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;
   return 0;
 }
+
+#endif   // !IGX_RTC
 
 }  // namespace igx

@@ -1,9 +1,12 @@
 // pencil_common.hpp -- what the pencil kernels share (gram_mfma.hpp: scalar gradient-Gram forms, sliding window;
 // block_pencil.hpp: constant-coefficient multi-field forms, band rows by node layer): vector types, the first-touch rule,
 // colour ranges of a box of elements, the walkability test of an axis.
+// IGX_RTC: the device half is also compiled at run time (rtc.hpp); hiprtc has neither the standard library nor files to include.
 #pragma once
+#ifndef IGX_RTC
 #include <hip/hip_runtime.h>
 #include "first_touch.hpp"
+#endif
 #include "igx.hpp"
 
 namespace igx {
@@ -30,6 +33,7 @@ __device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel, i
   return (c0 <= hi) ? (e % NB == 0) : (e == lo);
 }
 
+#ifndef IGX_RTC
 struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
 
 // colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element
@@ -38,6 +42,8 @@ static bool color_range(const AxisLayout &L, int c, int lo, int hi, int &start, 
   for (int e = lo; e < hi; ++e) if (L.color[e] == c) { if (start < 0) start = e; count++; }
   return count > 0;
 }
+
+#endif   // !IGX_RTC
 
 // boundary loads on the identity geometry: see k_boundary_loads (gram_mfma.hpp)
 struct FluxArgs {
@@ -50,11 +56,14 @@ struct FluxArgs {
   int fixlo[3], fixhi[3];      // a Dirichlet value holds field 0 on the lower / upper face of the axis
 };
 
+#ifndef IGX_RTC
 static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
   if (s.lay[d].alias || s.elem_width[d] < 8) return false;
   for (int e = 0; e + 1 < s.elem_width[d]; ++e)
     if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
   return true;
 }
+
+#endif   // !IGX_RTC
 
 }  // namespace igx

@@ -68,9 +68,12 @@ struct RtcForm {
   std::string name, source, lowered;
   int dim = 0;
   std::vector<char> code;
-  int meta[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch (read from the module)
+  // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch, MAT_TEST_MASK, MAT_SYMMETRIC,
+  // VEC_TEST_MASK, 0 (read from the module)
+  int meta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
+  std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -121,12 +124,13 @@ static void rtc_cache_store(const std::string &path, const std::vector<char> &co
 
 // compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
 static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
-                     std::vector<char> &code, std::vector<std::string> &lowered) {
+                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false) {
   std::string src;
   src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
   src += kRtcSrc_igx; src += "\n"; src += kRtcSrc_forms; src += "\n"; src += kRtcSrc_generic; src += "\n";
   if (with_feature) { src += kRtcSrc_feature; src += "\n"; }
+  if (with_pencil) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_gram; src += "\n"; }
   src += "using namespace igx;\n#line 1 \"user_form.hip\"\n";
   src += source;
   src += "\n";
@@ -159,8 +163,9 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
 
 static int rtc_compile(IGX g, const std::string &source, const std::string &name, int dim, std::shared_ptr<RtcForm> &out) {
   const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
-  std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[8] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
-                     ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v};\n";
+  std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[12] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
+                     ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v, (int)igx::mat_test_mask_of<" +
+                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, 0};\n";
   tail += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
   std::shared_ptr<RtcForm> f(new RtcForm());
   std::vector<std::string> low;
@@ -334,6 +339,52 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   return 0;
 }
 
+// ---- the pencil walk of gram_mfma.hpp for a run-time form (form_pencil): dof 1, first order, matrix integrand on the gradients only
+// and symmetric (MAT_TEST_MASK = gradients, MAT_SYMMETRIC), load term on N only (VEC_TEST_MASK = 1), point data = x at most;
+// dim 3, uniform degree 2 or 3 with p+1 Gauss points, System / Matrix drivers, axis 0 walkable, with or without a geometry.
+// Everything around the kernel -- colours, segments, first touch, the Dirichlet fix-up inside the walk, boundary loads, the
+// upper-face-first pass of a multi-rank assembly -- is try_gram_mfma itself.
+static bool rtc_pencil_eligible(const Space &s, const RtcForm &F, const OutDev &out) {
+  if (s.dim != 3 || F.meta[0] != 1 || F.meta[1] >= 2 || F.meta[4] >= 2 || F.meta[3] > 0 || F.meta[7]) return false;
+  if (((unsigned)F.meta[2] & ~NEED_X) != 0u) return false;
+  if (((unsigned)F.meta[8] & 0xfu) != 0xeu || !F.meta[9] || ((unsigned)F.meta[10] & 0xfu) != 0x1u) return false;
+  if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return false;
+  if (s.nsd != 0 && s.nsd != 3) return false;
+  const int deg = s.axis[0].p;
+  if (deg != 2 && deg != 3) return false;
+  for (int d = 0; d < 3; ++d) if (s.axis[d].p != deg || s.basis[d].nqp != deg + 1) return false;
+  return true;
+}
+
+static int launch_pencil_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false, int sys_only = -1) {
+  done = false;
+  const Space &s = g->s;
+  if (!compile_only && !rtc_pencil_eligible(s, F, out)) return 0;
+  const int deg = s.axis[0].p;
+  const bool sys = compile_only ? sys_only != 0 : out.op == OP_SYSTEM, ident = s.nsd == 0, rat = s.rational != 0;
+  const int key = (sys ? 1 : 0) | (deg << 1) | ((ident ? 1 : 0) << 4) | ((rat ? 1 : 0) << 5);
+  std::shared_ptr<RtcFeature> K;
+  auto it = F.pencil.find(key);
+  if (it != F.pencil.end() && (it->second->module || compile_only)) K = it->second;
+  else {
+    K.reset(new RtcFeature());
+    const std::string x = std::string("igx::form_pencil<") + (sys ? "true" : "false") + ", " + std::to_string(deg) + ", " + (ident ? "true" : "false") + ", " + (rat ? "true" : "false") + ", " + F.name + ">";
+    const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::OutDev, igx::PencilArgs, igx::ParamsDev);\n";
+    if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, true)) return rc;
+    if (!compile_only) {
+      HIPCK(hipModuleLoadData(&K->module, K->code.data()));
+      hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
+    }
+    F.pencil[key] = K;
+  }
+  if (compile_only) { done = true; return 0; }
+  PencilModule mod; memset(&mod.prm, 0, sizeof(mod.prm));
+  mod.fn = K->func[0]; mod.name = F.name;
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
+  std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
+  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
+}
+
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
@@ -348,6 +399,12 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "run-time forms are matrix / vector forms (no scalar functionals)");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes are not available for run-time forms");
+  if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // scalar symmetric gradient forms: the pencil walk (combine before write)
+    bool done = false;
+    if (int rc = launch_pencil_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+    if (g->kernel_choice == 2) return fail(IGX_ERR_SUP, "the pencil kernel does not cover this run-time form / configuration (dof 1, gradients only, MAT_SYMMETRIC, VEC_TEST_MASK = 1, dim 3, p = 2 or 3)");
+  }
   if (g->kernel_choice != 1) {   // the dense contraction on the matrix cores when the case is covered (as launch_generic does)
     bool done = false;
     if (int rc = launch_feature_rtc(g, F, S, out, done)) return rc;
@@ -438,6 +495,13 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   NEEDIGA(g);
   if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
   const Space &s = g->s;
+  if (gram == 2) {           // the pencil walk's instantiation (form_pencil) for the current degree / geometry: compile only
+    if (s.dim != 3 || (s.axis[0].p != 2 && s.axis[0].p != 3)) return fail(IGX_ERR_SUP, "the pencil walk needs dim 3 and degree 2 or 3");
+    bool done = false; OutDev o; memset(&o, 0, sizeof(o));
+    SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
+    if (int rc = launch_pencil_rtc(g, *g->rtc, Sd, o, done, true, 1)) return rc;      // System driver
+    return launch_pencil_rtc(g, *g->rtc, Sd, o, done, true, 0);                        // Matrix driver
+  }
   if (s.dim < 2) return 0;   // dim 1: the point-form kernel only
   int NE = 1;
   for (int d = 0; d < s.dim; ++d) { if (s.axis[d].p < 1) return fail(IGX_ERR_ARG_WRONGSTATE, "set the axes (degrees) first"); NE *= s.axis[d].p + 1; }

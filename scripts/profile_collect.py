@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """Turn the output of scripts/profile_round.sh (gpurun_out/prof) into the committed evidence under profiles/.
-usage: python scripts/profile_collect.py <round-tag, e.g. r01>"""
+usage: python scripts/profile_collect.py <round-tag, e.g. r03>
+
+Per workload: <tag>_<form>_line.json (the bench line; its roofline.traffic filled in from the PMC passes of the same gpurun
+call), <tag>_<form>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_<form>_pmc_summary.csv (mean per dispatch of every
+counter); profiles/traffic.json is what bench.py replays as `roofline.traffic` in later runs."""
 import collections
 import csv
 import glob
@@ -9,8 +13,10 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC, DST = "gpurun_out/prof", "profiles"
+SIZES = {"poisson": 256, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96}
+KEY = {"poisson": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "feature_assemble", "nsvms": "feature_assemble"}
 
 
 def pmc(dirs):
@@ -30,38 +36,46 @@ def write_pmc(path, agg):
                 f.write('"%s",%s,%d,%.6g\n' % (k, c, len(vals), sum(vals) / len(vals)))
 
 
-shutil.copy(SRC + "/kt/kt_kernel_stats.csv", "%s/%s_bench256_kernel_stats.csv" % (DST, tag))
-shutil.copy(SRC + "/kt_elast/kt_kernel_stats.csv", "%s/%s_elasticity128_kernel_stats.csv" % (DST, tag))
-shutil.copy(SRC + "/configs.txt", "%s/%s_secondary_configs.txt" % (DST, tag))
-for src, dst in (("kt_ch", "cahnhilliard256"), ("kt_ns", "nsvms96")):
-    if os.path.exists(SRC + "/%s/kt_kernel_stats.csv" % src):
-        shutil.copy(SRC + "/%s/kt_kernel_stats.csv" % src, "%s/%s_%s_kernel_stats.csv" % (DST, tag, dst))
-if glob.glob(SRC + "/pmcc_SQ/*counter_collection.csv"):
-    write_pmc("%s/%s_ch128_nsvms32_pmc_summary.csv" % (DST, tag), pmc([SRC + "/pmcc_" + c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ")]))
-if os.path.exists(SRC + "/rtc.txt"):
-    shutil.copy(SRC + "/rtc.txt", "%s/%s_runtime_forms.txt" % (DST, tag))
-line = json.loads(open(SRC + "/bench_line.json").read().strip().splitlines()[-1])
-a = pmc([SRC + "/pmc_" + c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "LDS")])
-write_pmc("%s/%s_bench256_pmc_summary.csv" % (DST, tag), a)
-write_pmc("%s/%s_elasticity64_pmc_summary.csv" % (DST, tag), pmc([SRC + "/pmce_" + c for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ")]))
-dom = [k for k in a if "gram_pencil" in k]
-if dom:
-    k = dom[0]
-    mean = lambda c: sum(a[k][c]) / len(a[k][c])
-    F, W = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+configs = []
+for form in ("poisson", "elasticity", "cahnhilliard", "nsvms"):
+    lf = "%s/line_%s.json" % (SRC, form)
+    if not os.path.exists(lf) or not open(lf).read().strip():
+        continue
+    line = json.loads(open(lf).read().strip().splitlines()[-1])
+    if os.path.exists("%s/kt_%s/kt_kernel_stats.csv" % (SRC, form)):
+        shutil.copy("%s/kt_%s/kt_kernel_stats.csv" % (SRC, form), "%s/%s_%s_kernel_stats.csv" % (DST, tag, form))
+    a = pmc(["%s/pmc_%s_%s" % (SRC, form, c) for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "LDS")])
+    if a:
+        write_pmc("%s/%s_%s_pmc_summary.csv" % (DST, tag, form), a)
     r = line["roofline"]
-    traffic = dict(round=int(tag[1:]), kernel_tag=tag, size=256, degree=3, n_gpus=1, kernel=k.replace("void igx::", ""), launches_per_step=r["launches_per_step"],
-                   FETCH_SIZE_KB_per_launch=F, WRITE_SIZE_KB_per_launch=W, raw_bytes_per_launch=(F + W) * 1024, bytes_per_launch=(2 * F + W) * 1024,
+    # the dominant kernel of the bench line: the IJacobian's for the two-assembly steps (the residual kernel is the vector-only
+    # instantiation: HASM = false, "Lb0" in the 7th template argument -- pick the one with the most MFMA work)
+    dom = [k for k in a if KEY[form] in k and "SQ_VALU_MFMA_BUSY_CYCLES" in a[k] and "FETCH_SIZE" in a[k]]
+    dom.sort(key=lambda k: -sum(a[k]["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(a[k]["SQ_VALU_MFMA_BUSY_CYCLES"]))
+    if dom:
+        k = dom[0]
+        mean = lambda c: sum(a[k][c]) / len(a[k][c])
+        F, W = mean("FETCH_SIZE"), mean("WRITE_SIZE")
+        ent = dict(form=form, round=int(tag[1:]), kernel_tag=tag, size=SIZES[form], n_gpus=1, kernel=k.replace("void igx::", ""),
+                   launches_per_step=r["launches_per_step"], FETCH_SIZE_KB_per_launch=F, WRITE_SIZE_KB_per_launch=W,
+                   raw_bytes_per_launch=(F + W) * 1024, bytes_per_launch=(2 * F + W) * 1024,
+                   bytes_per_element=(2 * F + W) * 1024 / max(r["elements_per_launch"], 1),
                    mfma_busy_pmc=mean("SQ_VALU_MFMA_BUSY_CYCLES") / mean("GRBM_GUI_ACTIVE") / 128.0,
-                   note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_bench256_pmc_summary.csv); "
-                        "hbm_bytes=(FETCH_SIZE+WRITE_SIZE)*1024 with FETCH_SIZE doubled (gfx950 reports half of a wide coalesced read, "
-                        "MI355X_MICROARCH.md HBM section); algorithmic read-modify-write bytes of the launch: 1 048 576 elements x 1792 entries "
-                        "x 8 B x 2 = 30.1e9; compulsory (write-once) bytes 2785 B/element = 2.9e9; mfma_busy_pmc = SQ_VALU_MFMA_BUSY_CYCLES / "
-                        "(GRBM_GUI_ACTIVE * 128)" % tag)
-    json.dump(traffic, open(DST + "/traffic.json", "w"), indent=1)
-    line["roofline"]["traffic"] = traffic["bytes_per_launch"]
-    line["roofline"]["traffic_source"] = "rocprofv3 --pmc passes of the same command in the same gpurun call (profiles/%s_bench256_pmc_summary.csv)" % tag
-    if r.get("avg_launch_ms"):
-        line["roofline"]["hbm_frac"] = traffic["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
-json.dump(line, open("%s/%s_bench256_line.json" % (DST, tag), "w"), indent=1)
-print(open(DST + "/traffic.json").read())
+                   note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_%s_pmc_summary.csv); bytes = (2 x FETCH_SIZE + "
+                        "WRITE_SIZE) x 1024: gfx950 reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section); mfma_busy_pmc = "
+                        "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)" % (tag, form))
+        if form == "poisson":
+            ent["degree"] = 3
+        configs.append(ent)
+        line["roofline"]["traffic"] = ent["bytes_per_launch"]
+        line["roofline"]["traffic_source"] = "rocprofv3 --pmc passes of the same command in the same gpurun call (profiles/%s_%s_pmc_summary.csv)" % (tag, form)
+        line["roofline"]["mfma_busy_pmc"] = ent["mfma_busy_pmc"]
+        if r.get("avg_launch_ms"):
+            line["roofline"]["hbm_frac"] = ent["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
+    json.dump(line, open("%s/%s_%s_line.json" % (DST, tag, form), "w"), indent=1)
+for src, dst in (("configs.txt", "secondary_configs.txt"), ("rtc.txt", "runtime_forms.txt")):
+    if os.path.exists(SRC + "/" + src):
+        shutil.copy(SRC + "/" + src, "%s/%s_%s" % (DST, tag, dst))
+if configs:
+    json.dump(dict(round=int(tag[1:]), kernel_tag=tag, configs=configs), open(DST + "/traffic.json", "w"), indent=1)
+    print(open(DST + "/traffic.json").read())

@@ -118,3 +118,141 @@ def test_elasticity_full_size_properties():
     v.fill_(float("nan"))
     g.compute_system(A, b); g.synchronize()
     assert (float(v.sum()), float(v.abs().sum())) == chk        # same bits -> same sums
+
+
+def _colsums(ci, val, ncols, bs=1, chunk=200_000_000):
+    """Column sums of a (block) CSR on the device: scalar column = block column * bs + j."""
+    import torch
+    out = torch.zeros(ncols * bs, dtype=torch.float64, device=val.device)
+    v = val.view(-1, bs, bs) if bs > 1 else None
+    for b0 in range(0, ci.numel(), chunk // (bs * bs)):
+        b1 = min(b0 + chunk // (bs * bs), ci.numel())
+        c = ci[b0:b1].to(torch.int64)
+        if bs == 1:
+            out.index_add_(0, c, val[b0:b1])
+        else:
+            blk = v[b0:b1].sum(dim=1)                       # sum over the block's rows: [blocks][bs columns]
+            out.view(ncols, bs).index_add_(0, c, blk)
+    return out
+
+
+def test_cahn_hilliard_full_size_properties():
+    """Config 4 (CahnHilliard3D p=2 C1, 256^3 elements, natural boundaries: 17.2 M rows, 2.1e9 non-zeros) on the device, the
+    invariants tests/test_oracle_invariants.py checks on the oracle: every term of the residual but N_a c_t carries grad N_a or
+    lap N_a, which sum to zero over a (partition of unity), so  sum_a R_a = int c_t = V . int N  and the column sums of the
+    tangent are shift * int N_b (demo/CahnHilliard3D.c:55-179); NaN-poisoned matrix reproduced bit for bit."""
+    import torch
+    import petiga_amd as P
+    N, p = 256, 2
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, p, N)
+    g.setup()
+    g.set_form("cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / (3.0 * N * N), 1.0))
+    A, b = g.create_mat(), g.create_vec()
+    n = N + p
+    assert A.nbrows == n ** 3 and A.nblocks == (n * 5 - 6) ** 3           # BASELINE.md 2: 17 173 512 rows, 2 116 874 304 non-zeros
+    rng = np.random.default_rng(3)
+    Uh, Vh = 0.63 + 0.05 * (2 * rng.random(n ** 3) - 1), rng.standard_normal(n ** 3)
+    U, V = g.create_vec().set(Uh), g.create_vec().set(Vh)
+    shift = 250.0
+    g.compute_ifunction(shift, V, 0.0, U, b)
+    g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
+    assert "feature_assemble" in g.kernel_name()
+    w = _int1d(p, N)
+    bN = (w[None, None, :] * w[None, :, None] * w[:, None, None]).reshape(-1)
+    F = b.get()
+    assert abs(F.sum() - Vh @ bN) <= 1e-11 * np.abs(F).sum()
+    rp, ci, val = _views(A)
+    scale = float(val.abs().max())
+    cs = _colsums(ci, val, n ** 3).cpu().numpy()
+    assert np.abs(cs - shift * bN).max() <= 1e-10 * scale
+    chk = float(val.sum()), float(val.abs().sum())
+    val.fill_(float("nan"))
+    g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
+    assert (float(val.sum()), float(val.abs().sum())) == chk            # first-touch stores reach every entry; same bits -> same sums
+
+
+def test_navier_stokes_vms_one_gpu_share_properties():
+    """Config 5's share of one GPU (NavierStokesVMS p=3, 96^3 elements of the 192^3 mesh, 4 fields, the bench's rational NURBS
+    map, axes 0 and 2 periodic, no-slip walls on axis 1: 3.65 M block rows, 40 GB of values) on the device
+    (demo/NavierStokesVMS.c:78-244):
+      * a uniform flow (zero pressure: axis 1 has faces, a constant pressure would leave p * int N_a n dS on them) without
+        forcing and without walls is a steady solution: R = 0 on the mapped geometry;
+      * with the walls, for any state the pressure rows sum to int div u = 0 (every other term of Rp carries grad N_a; u = 0 on
+        the walls, the other axes are periodic), whatever the geometry;
+      * IJacobian: a no-slip dof's row and column hold nothing but the diagonal = the number of elements that hold the node (16);
+      * NaN-poisoned matrix reproduced bit for bit."""
+    import os
+    import sys
+    import torch
+    import petiga_amd as P
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import _bench_geometry
+    N, p = 96, 3
+    per = (True, False, True)
+
+    def build(walls):
+        g = P.IGX(3, 4)
+        for i in range(3):
+            g.axis_uniform(i, p, N, periodic=per[i])
+        g.setup()
+        X, W = _bench_geometry(p, N, per)
+        g.set_geometry(X, W)
+        if walls:
+            for s in range(2):
+                for f in range(3):
+                    g.set_boundary_value(1, s, f, 0.0)
+        return g
+    nn = N * (N + p) * N
+    dt = 1e-2
+    # --- uniform flow, no forcing, no walls
+    g = build(False)
+    g.set_form("nsvms", (1.472e-4, 0.0, 0.0, 0.0, dt))
+    b = g.create_vec()
+    U = g.create_vec().set(np.tile([0.3, -0.2, 0.5, 0.0], nn))
+    V = g.create_vec().set(np.zeros(4 * nn))
+    g.compute_ifunction(2.0 / dt, V, 0.0, U, b); g.synchronize()
+    assert "feature_assemble" in g.kernel_name()
+    assert np.abs(b.get()).max() <= 1e-12
+    del g, b, U, V
+    # --- walls, random state
+    g = build(True)
+    g.set_form("nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, dt))
+    rng = np.random.default_rng(11)
+    U, V = g.create_vec().set(rng.standard_normal(4 * nn) * 0.3), g.create_vec().set(rng.standard_normal(4 * nn) * 0.1)
+    b, A = g.create_vec(), g.create_mat()
+    assert A.nbrows == nn and A.bs == 4 and A.nblocks == nn // (N + p) * ((N + p) * 7 - 12) * 49
+    g.compute_ifunction(2.0 / dt, V, 0.0, U, b)
+    F = b.get()
+    assert abs(F[3::4].sum()) <= 1e-10 * np.abs(F[3::4]).sum()
+    g.compute_ijacobian(2.0 / dt, V, 0.0, U, A); g.synchronize()
+    rp, ci, val = A.device_ptrs()
+    rpt = torch.as_tensor(_DevArray(rp, A.nbrows + 1, "<i8"), device="cuda")
+    cit = torch.as_tensor(_DevArray(ci, A.nblocks, "<i4"), device="cuda")
+    v = torch.as_tensor(_DevArray(val, A.nblocks * 16, "<f8"), device="cuda").view(-1, 4, 4)
+    # wall nodes: axis-1 index 0 and N+p-1; row index = i0 + N*(i1 + (N+p)*i2)
+    i0, i2 = torch.arange(N, device="cuda"), torch.arange(N, device="cuda")
+    for i1 in (0, N + p - 1):
+        rows = (i0[None, :] + N * (i1 + (N + p) * i2[:, None])).reshape(-1)
+        for r in rows[:: 97].tolist():                       # a sample of wall rows
+            lo, hi = int(rpt[r]), int(rpt[r + 1])
+            blk, cols = v[lo:hi], cit[lo:hi]
+            diag = blk[cols == r][0]
+            off = blk.clone(); off[cols == r] = 0
+            assert float(off[:, :3, :].abs().max()) == 0.0                     # fixed rows (u, v, w) hold nothing off the diagonal block
+            assert torch.equal(diag[:3, :3], 16.0 * torch.eye(3, dtype=torch.float64, device="cuda")) and float(diag[:3, 3].abs().max()) == 0.0
+    # fixed columns: a sample of interior rows next to the wall has zeros in the wall nodes' velocity columns
+    wall = torch.zeros(nn, dtype=torch.bool, device="cuda")
+    idx = torch.arange(nn, device="cuda")
+    i1_of = (idx // N) % (N + p)
+    wall[(i1_of == 0) | (i1_of == N + p - 1)] = True
+    r = int(5 + N * (1 + (N + p) * 7))
+    lo, hi = int(rpt[r]), int(rpt[r + 1])
+    wc = wall[cit[lo:hi].to(torch.int64)]
+    assert bool(wc.any()) and float(v[lo:hi][wc][:, :, :3].abs().max()) == 0.0
+    vf = v.view(-1)
+    chk = float(vf.sum()), float(vf.abs().sum())
+    vf.fill_(float("nan"))
+    g.compute_ijacobian(2.0 / dt, V, 0.0, U, A); g.synchronize()
+    assert (float(vf.sum()), float(vf.abs().sum())) == chk
