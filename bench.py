@@ -165,6 +165,18 @@ def _cpu_worker(args):
     return m ** 3, dt
 
 
+# demo/Poisson3D.c:3-23 (System) as a run-time form (IGXSetFormSource): what a PetIGA user's callback looks like to the library
+# when it is not one of the built-in structs.  bench.py --source assembles the metric configuration through it.
+USER_POISSON_SOURCE = r"""
+struct UserPoisson {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 0xEu, VEC_TEST_MASK = 0x1u;
+  static constexpr bool MAT_SYMMETRIC = true;
+  static __device__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[1] * Nb[1] + Na[2] * Nb[2] + Na[3] * Nb[3]; }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * p.prm[0]; }
+};
+"""
+
 WORKLOADS = {
     # name: (dim, dof, p, C, default size at N GPUs, periodic, form, op, description)
     "poisson": dict(dof=1, p=3, size=256, periodic=(0, 0, 0), form="poisson", op="system",
@@ -194,7 +206,7 @@ def _state(vec_like_mat, sizes, dof, amp, base):
     return out.reshape(-1)
 
 
-def build_problem(P, name, size, degree, world, rank, kernel, geometry):
+def build_problem(P, name, size, degree, world, rank, kernel, geometry, source=False):
     import numpy as np
     w = WORKLOADS[name]
     dof, p = w["dof"], (degree if name == "poisson" else w["p"])
@@ -223,7 +235,10 @@ def build_problem(P, name, size, degree, world, rank, kernel, geometry):
     if geometry:                    # a smooth rational map (config 5's premise), the same net on every rank
         X, W = _bench_geometry(p, size, [bool(x) for x in w["periodic"]])
         g.set_geometry(X, W)
-    g.set_form(w["form"], params)
+    if source:
+        g.set_form_source(USER_POISSON_SOURCE, "UserPoisson", (1.0,))
+    else:
+        g.set_form(w["form"], params)
     g.set_kernel(kernel)
     A, b = g.create_mat(), g.create_vec()
     U = V = None
@@ -243,6 +258,7 @@ def main():
     ap.add_argument("--degree", type=int, default=3, help="poisson only")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 MFMA pencil, 3 feature")
     ap.add_argument("--geometry", action="store_true", help="mapped rational geometry (default for nsvms)")
+    ap.add_argument("--source", action="store_true", help="poisson only: the form is given as run-time source (IGXSetFormSource), not as the built-in struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
     args = ap.parse_args()
@@ -268,7 +284,8 @@ def main():
 
     import petiga_amd as P
     from petiga_amd import exchange
-    g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry)
+    assert not args.source or args.form == "poisson", "--source is the metric configuration's form given as source"
+    g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry, args.source)
     transport = exchange.init_comm(g) if world > 1 else None      # the library's own exchange: RCCL (or the gloo test transport)
     tangent = wl["op"] == "tangent"
     shift = 1.0e3
@@ -372,7 +389,7 @@ def main():
                 cs_n = cs
             else:           # every rank assembles its share of the reduced mesh through the same exchange
                 A = b = None            # (their memory goes back before the reduced meshes are created)
-                gk, Ak, bk, Uk, Vk, _ = build_problem(P, args.form, csize, args.degree, world, rank, args.kernel, geometry)
+                gk, Ak, bk, Uk, Vk, _ = build_problem(P, args.form, csize, args.degree, world, rank, args.kernel, geometry, args.source)
                 exchange.init_comm(gk, transport="rccl" if transport == "rccl" else "host")
                 assemble(gk, Ak, bk, Uk, Vk)
                 gk.synchronize()
@@ -381,7 +398,7 @@ def main():
                 cs_n = tk.cpu().numpy()
                 Ak = bk = gk = None
             if rank == 0:
-                g1, A1, b1, U1, V1, _ = build_problem(P, args.form, csize, args.degree, 1, 0, args.kernel, geometry)
+                g1, A1, b1, U1, V1, _ = build_problem(P, args.form, csize, args.degree, 1, 0, args.kernel, geometry, args.source)
                 assemble(g1, A1, b1, U1, V1)
                 g1.synchronize()
                 ref = g1.checksum(A1, b1)
@@ -451,7 +468,8 @@ def main():
             "config": {"workload": "%s: p=%d C%d, %d^3 elements, dof=%d, Gauss %d^3%s%s"
                                    % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
                                       ", rational NURBS geometry map" if geometry else "") +
-                                   (" (one GPU's share of the 192^3 configuration)" if (args.form == "nsvms" and size == 96 and not args.size) else ""),
+                                   (" (one GPU's share of the 192^3 configuration)" if (args.form == "nsvms" and size == 96 and not args.size) else "") +
+                                   (" -- the form given as run-time source (IGXSetFormSource)" if args.source else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
                        "transport": transport, "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
             "roofline": roof,

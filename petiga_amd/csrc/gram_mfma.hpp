@@ -1177,6 +1177,8 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
         const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
         const size_t lds_n = pencil_lds_bytes(len + 3, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
+        // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
+        if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
         const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
         const long long cost = ((bps * ns + slots - 1) / slots) * (len + (ns > 1 ? P : 0));
         if (best < 0 || cost < best) { best = cost; best_n = n; }

@@ -250,3 +250,112 @@ def test_code_object_cache_on_disk(tmp_path, monkeypatch):
     victim.write_bytes(victim.read_bytes()[:100])
     compile_once(ADVECTION_DIFFUSION)
     assert victim.stat().st_size > 1000
+
+
+# ---- run-time scalar forms on the pencil walk (form_pencil, gram_mfma.hpp): the enum gate is off the headline path
+USER_POISSON = r"""
+// demo/Poisson3D.c:3-23 (System) as a user struct; params = {forcing}.  The three optional declarations tell the library what the
+// callback's shape is: gradients only, symmetric, load on N only.
+struct UserPoisson {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 0xEu, VEC_TEST_MASK = 0x1u;
+  static constexpr bool MAT_SYMMETRIC = true;
+  static __device__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[1] * Nb[1] + Na[2] * Nb[2] + Na[3] * Nb[3]; }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * p.prm[0]; }
+};
+// an anisotropic diffusion tensor and a load that both depend on the point: D(x) = diag(1 + x0, 2, 1 + x1 x2) + off-diagonal 0.3 x0
+// on (0,1); f(x) = prm[0] (1 + x0 - x2): not a built-in form, same shape
+struct UserDiffusion {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X;
+  static constexpr unsigned MAT_TEST_MASK = 0xEu, VEC_TEST_MASK = 0x1u;
+  static constexpr bool MAT_SYMMETRIC = true;
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const double d00 = 1.0 + p.x[0], d11 = 2.0, d22 = 1.0 + p.x[1] * p.x[2], d01 = 0.3 * p.x[0];
+    T[0] = d00 * Na[1] * Nb[1] + d11 * Na[2] * Nb[2] + d22 * Na[3] * Nb[3] + d01 * (Na[1] * Nb[2] + Na[2] * Nb[1]);
+  }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * p.prm[0] * (1.0 + p.x[0] - p.x[2]); }
+};
+"""
+
+
+@pytest.mark.parametrize("p,geo", [(3, False), (2, False), (3, True)])
+def test_pencil_walk_compiles_for_a_user_form_without_a_gpu(p, geo):
+    """IGXCheckFormSource(gram = 2): form_pencil<System / Matrix, p, no geometry / rational geometry, UserForm>."""
+    import petiga_amd as P
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, p, 8)
+    if geo:
+        orc, _ = make_pair(3, 1, p, 8, engine=False)
+        g.setup()
+        g.set_geometry(*warped_geometry(orc, 3, seed=1, rational=True, amp=0.1))
+    g.set_form_source(USER_POISSON, "UserPoisson", (1.0,))
+    g.check_form_source(True, 2)
+    g.set_form_source(USER_POISSON, "UserDiffusion", (0.7,))
+    g.check_form_source(True, 2)
+
+
+def _dirichlet(objs, kind):
+    for g in objs:
+        if kind == "all":
+            for d in range(3):
+                for s in range(2):
+                    g.set_boundary_value(d, s, 0, 0.5 + 0.25 * d + 0.125 * s)
+        elif kind == "partial":
+            g.set_boundary_value(0, 0, 0, 2.0)
+            g.set_boundary_value(2, 1, 0, -1.0)
+            g.set_boundary_load(1, 1, 0, 0.75)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,N,bc,geo", [(3, (9, 5, 6), "all", None), (3, (8, 4, 5), "partial", "nurbs"), (2, (8, 6, 5), "all", None), (2, (9, 4, 4), "partial", "poly"),
+                                        (3, (12, 4, 4), "none", "nurbs")])
+def test_user_poisson_on_the_pencil_walk_matches_oracle(p, N, bc, geo):
+    """demo/Poisson3D.c's System given as source runs on form_pencil (not on the element mode) and reproduces the oracle."""
+    orc, eng = make_pair(3, 1, p, list(N))
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=sum(N), rational=(geo == "nurbs"), amp=0.1)
+        orc.set_geometry(X, W)
+        eng.set_geometry(X, W)
+    _dirichlet((orc, eng), bc)
+    A_o, b_o = orc.compute_system("orc_form_poisson")
+    eng.set_form_source(USER_POISSON, "UserPoisson", (1.0,))
+    eng.set_kernel(2)                       # insist on the pencil walk: an uncovered case would be an error
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "form_pencil<UserPoisson>" in eng.kernel_name(), eng.kernel_name()
+    tol = 1e-11 if geo else 1e-12
+    compare_mats(A, A_o, tol)
+    assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1e-300)
+    orc.clear_boundary()
+    A_o2, _ = orc.compute_system("orc_form_poisson")
+    eng.compute_matrix(A)
+    eng.synchronize()
+    assert "form_pencil" in eng.kernel_name()
+    compare_mats(A, A_o2, tol)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,geo", [(3, False), (3, True), (2, True)])
+def test_variable_coefficient_user_form_pencil_walk_equals_element_mode(p, geo):
+    """A form no built-in covers (x-dependent anisotropic diffusion, x-dependent load): the pencil walk against the element mode of the
+    feature kernel and the point-form kernel on the same source -- three device paths, one matrix."""
+    orc, eng = make_pair(3, 1, p, [10, 5, 4])
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=9, rational=True, amp=0.1)
+        eng.set_geometry(X, W)
+    _dirichlet((eng,), "all")
+    eng.set_form_source(USER_POISSON, "UserDiffusion", (0.7,))
+    outs = {}
+    for kernel in (2, 3, 1):
+        eng.set_kernel(kernel)
+        A, b = eng.create_mat(), eng.create_vec()
+        eng.compute_system(A, b)
+        eng.synchronize()
+        outs[kernel] = (A.host(True), b.get(), eng.kernel_name())
+    assert "form_pencil" in outs[2][2] and "feature_assemble" in outs[3][2] and "generic_assemble" in outs[1][2]
+    scale = np.abs(outs[1][0]).max()
+    for k in (2, 3):
+        assert np.abs(outs[k][0] - outs[1][0]).max() <= 1e-11 * scale
+        assert np.abs(outs[k][1] - outs[1][1]).max() <= 1e-11 * np.abs(outs[1][1]).max()
