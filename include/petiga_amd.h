@@ -125,7 +125,8 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * un-weighted and mat() must be linear in Na and in Nb, as every IGAFormSystem/Jacobian is.  Compile errors come back as
  * PETSC_ERR_USER with the compiler log in IGXGetLastError().  The seven drivers then work as with a built-in form: on the
  * matrix cores (feature_assemble<MyForm,...>, compiled on first use for the wave layout of the degree, about half a second)
- * for dim >= 2 and (p+1)^dim <= 64, on the point-form kernel otherwise or with IGXSetKernel(1).  IGX_RTC_CACHE_DIR in the
+ * for dim >= 2 and (p+1)^dim <= 64 (in 3-D also p = 4, 5 for forms with at most two / one accumulator set), on the point-form
+ * kernel otherwise or with IGXSetKernel(1).  IGX_RTC_CACHE_DIR in the
  * environment keeps the compiled code objects on disk for later processes.  Optional declarations that
  * speed the matrix-core kernel up, all bit masks over the feature index of Na / Nb:
  *       static constexpr unsigned MAT_TEST_MASK = ...;         // features of Na that mat() reads (others never enter the GEMM)
@@ -341,7 +342,7 @@ int IGXVecCopyToGhosted(IGXVec v,double *array,int on_device);
 int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
 
 /* Compile-only check of a run-time form (no GPU needed): IGXSetFormSource compiles the point-form kernel; this compiles the
- * matrix-core kernel the drivers would launch for the degrees set so far (dim >= 2, (p+1)^dim <= 64), for the matrix drivers
+ * matrix-core kernel the drivers would launch for the degrees set so far (dim >= 2, (p+1)^dim <= 64; 3-D: <= 256), for the matrix drivers
  * (with_matrix != 0) or the vector-only ones.  gram != 0 when the struct declares MAT_PAIR_MASK (it decides the wave layout at
  * dof = 4; on a GPU the flag is read from the compiled module).  gram == 2: the pencil walk's instantiations instead (form_pencil,
  * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  Returns 0 or IGX_ERR_USER with the

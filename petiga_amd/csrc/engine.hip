@@ -801,7 +801,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;
     if (done) return 0;
-    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
+    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64; in 3-D nen <= 128 / 256 for forms with at most two / one accumulator set)");
   }
   if (g->zero_matrix) g->zero_matrix();
   const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;

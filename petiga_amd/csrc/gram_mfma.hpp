@@ -1065,6 +1065,14 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
     const double *ztg = geo + GEO_Z;   // GEO: the element's raw walk-axis rows [q][a][2] (staged with its metric)
+    if (SYSTEM && GEO) {   // F of this element (its point values are in the metric area).  Here, ahead of this wave's own MFMAs and
+      // while the partner wavefront is in its memory-bound flush: fp64 VALU work issued next to the PARTNER's MFMA stream waits
+      // about one MFMA (64 cycles) per instruction -- in the flush phase these 64 multiply-adds per lane kept the System driver's
+      // flush (46k cycles) longer than the MFMA phase (41k).
+      const int fs = lane >> 4;
+      const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
+      Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
+    }
     if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
@@ -1080,11 +1088,6 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
-    if (SYSTEM && GEO) {   // F of this element (its point values are still in the metric area), outside the MFMA phase
-      const int fs = lane >> 4;
-      const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
-      Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
-    }
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
     if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);

@@ -86,7 +86,9 @@ static unsigned long long rtc_fnv(const std::string &t, unsigned long long h = 1
 static std::string rtc_cache_path(const std::string &src, const std::vector<std::string> &exprs) {
   const char *dir = getenv("IGX_RTC_CACHE_DIR");
   if (!dir || !*dir) return std::string();
-  unsigned long long h = rtc_fnv(src);
+  // the compiler is part of the key as well: target, options and the HIP runtime this library was built against (a code object of
+  // another ROCm release is never picked up)
+  unsigned long long h = rtc_fnv(src, rtc_fnv(std::string("gfx950 -O3 -std=c++17 -munsafe-fp-atomics hip ") + std::to_string(HIP_VERSION)));
   for (const std::string &x : exprs) h = rtc_fnv(x, h ^ 0x9e3779b97f4a7c15ull);
   char name[64]; snprintf(name, sizeof(name), "/igx_%016llx.bin", h);
   return std::string(dir) + name;
@@ -155,7 +157,10 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
     if (a.Lowered(prog, x.c_str(), &low) != 0 || !low) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetLoweredName failed"); }
     lowered.push_back(low);
   }
-  size_t cs = 0; (void)a.CodeSize(prog, &cs); code.resize(cs); (void)a.Code(prog, code.data());
+  size_t cs = 0;
+  if (a.CodeSize(prog, &cs) != 0 || cs == 0) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetCodeSize failed"); }
+  code.resize(cs);
+  if (a.Code(prog, code.data()) != 0) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetCode failed"); }
   (void)a.Destroy(&prog);
   rtc_cache_store(cache, code, lowered);
   return 0;
@@ -409,7 +414,7 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
     bool done = false;
     if (int rc = launch_feature_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
-    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64)");
+    if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64; nen <= 128 with dof <= 2 and nen <= 256 with dof 1 in 3-D, no MAT_PAIR_MASK there)");
   }
   const int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   if (g->zero_matrix) g->zero_matrix();
