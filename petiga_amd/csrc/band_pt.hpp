@@ -1,0 +1,606 @@
+// band_pt.hpp -- band rows by node layer for multi-field forms with POINT-DEPENDENT coefficients: the Tangent of
+// demo/NavierStokesVMS.c:166-244 (BASELINE config 5: p = 3, 4 fields, rational NURBS geometry, axes 0 and 2 periodic).
+//
+// block_pencil.hpp turns the element loop inside out for constant-coefficient forms (Gram pairs, identity geometry).  The same
+// walk for a form whose matrix integrand depends on the point -- through the state, the metric, the geometry -- needs two more
+// things, and nothing else changes (layer-major, output stationary, LDS stage in matrix order, wave-coalesced read-add-write):
+//
+//   1. the operands are the PHYSICAL features of the basis functions at the Gauss point, built per k-step in registers from the
+//      three 1-D rows (tensor product), the point's rational data and its inverse Jacobian (src/petigarat.f90.in,
+//      petigamapshf.f90.in:30-58), and the B operand of a block (i,j) is the form's own mat_c() applied to the unit test feature
+//      (as in feature_mfma.hpp: K_e^{ij} = A^T B^{ij}; block_mask(i,j) keeps structurally zero products off the matrix cores);
+//   2. what depends on the point alone -- JW, F^-1, 1/W and dW/W, the state u, the form's point coefficients (tau_M, tau_C of
+//      the VMS model: Form::point_coef) -- is tabulated ONCE per element by a small kernel ahead of the launch (band_points: one
+//      wavefront per element, lane = Gauss point, sums over the control points factorised across the lanes as in
+//      gram_mfma.hpp) and travels through a ring of five element records in LDS.  (fp64 VALU work next to another wave's MFMA
+//      stream costs about one MFMA per instruction: a tabulation inside this kernel's flush phase would cost more than the
+//      contraction it feeds.)
+//
+// dof = 4: a block is 128 bytes; the row fields come in two groups ({0,1}, {2,3}: 8 of the 16 entries of a block, 128 accumulator
+// registers for a wave's two band tiles) and the two wave groups of the workgroup take one group each of the SAME layer, half a
+// period apart; a flush adds 64-byte half blocks.  The stage holds half of the rows of the band row at a time (57 KB).
+// Periodic axes wrapped inside the rank (config 5 on one GPU) are taken on the walk axis (layers and elements modulo nel) and on
+// axis 2 (its column positions come from the per-axis table); axis 1 must have consecutive positions.
+#pragma once
+#include "block_pencil.hpp"
+
+namespace igx {
+
+template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
+template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
+
+// element record (doubles): 64 points x NPD, then the element's walk-axis rows [q][a][2], then its 64 NURBS weights
+template <class Form> constexpr int bpt_npd() { return 1 + 9 + 4 + Form::DOF + Form::NCOEF; }     // JW | E1[b][c] | 1/W, dW_b/W | u | coefficients
+template <class Form> constexpr int bpt_rec() { return 64 * bpt_npd<Form>() + 32 + 64; }
+
+struct BandArgs {
+  int ex_start, ex_step, ex_count, ey_start, ey_step, ey_count;
+  int nel0, alias0;                  // elements on axis 0; axis 0 periodic and wrapped inside the rank
+  int seg_len, nseg;                 // node layers per segment
+  int first_touch, nelx, nely, fty_lo, fty_hi, fty_blocked;
+  double *pts;                       // element records of this launch: [pencil][element on axis 0][bpt_rec]
+  int debug, dbg_block;
+};
+
+// ---- the point tabulation: one wavefront per element
+template <class Form>
+__global__ void __launch_bounds__(256)
+band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
+  constexpr int P = 3, NB = 4, DOF = Form::DOF, NC = 4 + DOF, NPD = bpt_npd<Form>(), REC = bpt_rec<Form>();
+  __shared__ double sm_all[4][64 * NC + 128 + 192 + 96];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long elem = (long long)blockIdx.x * 4 + wave;
+  const int npen = pa.ex_count * pa.ey_count;
+  if (elem >= (long long)npen * pa.nel0) return;
+  double *coef = sm_all[wave], *T1 = coef + 64 * NC, *T2 = T1 + 128, *uxr = T2 + 192, *vyr = uxr + 32, *ztg = vyr + 32;
+  const int pencil = (int)(elem / pa.nel0), e0 = (int)(elem - (long long)pencil * pa.nel0);
+  const int tx = pencil % pa.ex_count, ty = pencil / pa.ex_count;
+  const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
+  const AxisDev &AW = S.ax[0], &AX = S.ax[1], &AY = S.ax[2];
+  const int off0 = AW.off[e0], offx = AX.off[elx], offy = AY.off[ely];
+  const bool geo = S.nsd > 0, rat = S.rational != 0;
+  {   // control points (homogeneous) and state of the lane's basis function (aw, ay, ax) = (lane >> 4, (lane >> 2) & 3, lane & 3)
+    const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+    const size_t g = (size_t)(off0 + aw) + (size_t)AW.gwidth * ((size_t)(offx + ax) + (size_t)AX.gwidth * (size_t)(offy + ay));
+    const double w = rat ? S.W[g] : 1.0;
+    double c[NC];
+    c[0] = geo ? S.X[g * 3 + 0] * w : 0.0; c[1] = geo ? S.X[g * 3 + 1] * w : 0.0; c[2] = geo ? S.X[g * 3 + 2] * w : 0.0; c[3] = w;
+    const size_t row = (size_t)AW.rowmap[off0 + aw] + (size_t)AW.nrow * ((size_t)AX.rowmap[offx + ax] + (size_t)AX.nrow * (size_t)AY.rowmap[offy + ay]);
+    // IGAElementFixValues (src/petigaelem.c:1327-1358): the state at a Dirichlet dof is the boundary value
+    const int el3[3] = {e0, elx, ely}, aa[3] = {aw, ax, ay};
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) {
+      double u = out.U ? out.U[row * DOF + f] : 0.0;
+      for (int d = 0; d < 3; ++d) {
+        const AxisDev &A = S.ax[d];
+        if (A.periodic) continue;
+        for (int sd = 0; sd < 2; ++sd) {
+          if (el3[d] + A.estart != (sd ? A.esizes - 1 : 0) || aa[d] != (sd ? P : 0)) continue;
+          const BCDev &bv = S.bcv[d][sd];
+          for (int k = 0; k < bv.count; ++k) if (bv.field[k] == f) u = S.fixtable ? S.fixtable[row * DOF + f] : bv.value[k];
+        }
+      }
+      c[4 + f] = u * w;
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) coef[lane * NC + k] = c[k];
+    if (lane < 32) {
+      const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1;
+      uxr[lane] = AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k];              // [q][a][2]
+      ztg[lane] = AW.tab[((size_t)e0 * NB * NB + q * NB + a) * NDER + k];               // [q][a][2]
+    } else {
+      const int l2 = lane - 32, a = l2 >> 3, q = (l2 >> 1) & 3, k = l2 & 1;
+      vyr[l2] = AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k];                // [a][q][2]
+    }
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // H[c][k] = sum_a C_a[c] D_k N_a(q), k = (value, d/du0, d/du1, d/du2): sum factorisation across the lanes (gram_mfma.hpp)
+  double H[NC][4];
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  double zv[4], zd[4];
+#pragma unroll
+  for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[(i2 * 4 + aw) * 2 + 0]; zd[aw] = ztg[(i2 * 4 + aw) * 2 + 1]; }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    {
+      double tv = 0, td = 0;
+#pragma unroll
+      for (int ax = 0; ax < 4; ++ax) { const double C = coef[((i2 * 4 + i1) * 4 + ax) * NC + c]; tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1]; }
+      T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {
+      double m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+      for (int ay = 0; ay < 4; ++ay) {
+        const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0];
+        const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1];
+        m0 += a * yv; m1 += d * yv; m2 += a * yd;
+      }
+      T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {
+      double h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+#pragma unroll
+      for (int aw = 0; aw < 4; ++aw) {
+        const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
+        h0 += t0 * zv[aw]; h1 += t0 * zd[aw]; h2 += t1 * zv[aw]; h3 += t2 * zv[aw];
+      }
+      H[c][0] = h0; H[c][1] = h1; H[c][2] = h2; H[c][3] = h3;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  // lane = Gauss point (qx, qy, qw) = (i0, i1, i2); record index = lane
+  double rec[NPD];
+  {
+    const double iw = 1.0 / H[3][0];
+    double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, det = 1.0;
+    if (geo) {
+      double F[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const double x = H[c][0] * iw;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) F[c][b] = (H[c][1 + b] - x * H[3][1 + b]) * iw;
+      }
+      det = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) + F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+      if (!(det > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      const double id = 1.0 / det;
+      E[0][0] = (F[1][1] * F[2][2] - F[1][2] * F[2][1]) * id; E[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id; E[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id;
+      E[1][0] = (F[1][2] * F[2][0] - F[1][0] * F[2][2]) * id; E[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id; E[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
+      E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
+    }
+    const double Jw = AW.J[e0], Jx = AX.J[elx], Jy = AY.J[ely];
+    rec[0] = det * (AW.w[e0 * NB + i2] * Jw) * (AX.w[elx * NB + i0] * Jx) * (AY.w[ely * NB + i1] * Jy);
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rec[1 + b * 3 + c] = E[b][c];
+    rec[10] = iw; rec[11] = H[3][1] * iw; rec[12] = H[3][2] * iw; rec[13] = H[3][3] * iw;
+    double u[DOF];
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) { u[f] = H[4 + f][0] * iw; rec[14 + f] = u[f]; }
+    // IGAPointFormInvGradGeomMap (src/petigapoint.c:269-294): G[a][i] = du_a/dx_i / (half length of the element on axis a)
+    double G[9];
+    const double L3[3] = {Jw, Jx, Jy};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) G[a * 3 + i] = E[a][i] / L3[a];
+    PtView p; p.x = nullptr; p.u = u; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = G; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+    p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+    Form::point_coef(p, rec + 14 + DOF);
+  }
+  double *dst = pa.pts + (size_t)elem * REC;
+#pragma unroll
+  for (int k = 0; k < NPD; ++k) dst[lane * NPD + k] = rec[k];
+  if (lane < 32) dst[64 * NPD + lane] = ztg[lane];
+  dst[64 * NPD + 32 + lane] = coef[lane * NC + 3];      // weight of control point (aw, ay, ax) = lane
+}
+
+// offsets (doubles) into the dynamic LDS block of band_pt
+struct BptCarve { int stage, ring, pre, cnt, rho, P, pen, uv, bc, arrive, total; };
+template <class Form>
+__host__ __device__ static inline BptCarve bpt_carve(int seg_len) {
+  BptCarve c; int pos = 0;
+  auto take = [&](int n) { const int o = pos; pos += (n + 1) & ~1; return o; };
+  c.stage = take(8 * 4 * 4 * 7 * (Form::DOF * Form::DOF / 2));      // half of the rows of a band row, half blocks
+  c.ring = take(5 * bpt_rec<Form>());
+  c.pre = take(seg_len); c.cnt = take((seg_len + 1) / 2); c.rho = take((seg_len + 1) / 2); c.P = take(seg_len * 4);
+  c.pen = take(64); c.uv = take(64); c.bc = take(6 + 6 * 4); c.arrive = take(2);
+  c.total = pos;
+  return c;
+}
+
+// ring slot of the element with the (unwrapped) index eu = layer - slot: five slots, a window holds four
+__device__ __forceinline__ int bpt_slot(int eu) { const int m = eu % 5; return m < 0 ? m + 5 : m; }
+
+// one tile product of a row-field group: acc[(i - I0) DOF + j] += A_f(e, ta)^T B^{ij}_f(e, tb) over the element's 64 points
+template <class Form, bool GEO, bool RAT, int I0, int DOFI>
+__device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
+  constexpr int DOF = Form::DOF, NPD = bpt_npd<Form>();
+  const double *zt = rec + 64 * NPD, *wts = zt + 32;
+  const int qx = lane >> 4;
+  const double wa = RAT ? wts[ta * 16 + (lane & 15)] : 1.0, wb = RAT ? wts[tb * 16 + (lane & 15)] : 1.0;
+#pragma unroll 1
+  for (int qw = 0; qw < 4; ++qw) {
+    const double zA0 = zt[(qw * 4 + ta) * 2 + 0], zA1 = zt[(qw * 4 + ta) * 2 + 1];
+    const double zB0 = zt[(qw * 4 + tb) * 2 + 0], zB1 = zt[(qw * 4 + tb) * 2 + 1];
+#pragma unroll
+    for (int qy = 0; qy < 4; ++qy) {
+      const double *pd = rec + ((qw * 4 + qy) * 4 + qx) * NPD;
+      const double jw = pd[0];
+      // parametric value and gradient of the row (A) and column (B) basis function at the point: n, d/du0, d/du1, d/du2
+      double fa[4] = {zA0 * uxy[qy][0], zA1 * uxy[qy][0], zA0 * uxy[qy][1], zA0 * uxy[qy][2]};
+      double fb[4] = {zB0 * uxy[qy][0], zB1 * uxy[qy][0], zB0 * uxy[qy][1], zB0 * uxy[qy][2]};
+      if (RAT) {      // Rationalize (src/petigarat.f90.in:3-57): R = w N / W, dR = (w / W) (dN - N dW / W)
+        const double ri = pd[10], o0 = pd[11], o1 = pd[12], o2 = pd[13];
+        const double sa = wa * ri, sb = wb * ri;
+        fa[1] = sa * (fa[1] - fa[0] * o0); fa[2] = sa * (fa[2] - fa[0] * o1); fa[3] = sa * (fa[3] - fa[0] * o2); fa[0] *= sa;
+        fb[1] = sb * (fb[1] - fb[0] * o0); fb[2] = sb * (fb[2] - fb[0] * o1); fb[3] = sb * (fb[3] - fb[0] * o2); fb[0] *= sb;
+      }
+      double na[4] = {fa[0], fa[1], fa[2], fa[3]}, nb[4] = {fb[0], fb[1], fb[2], fb[3]};
+      if (GEO) {      // ShapeFunctions (src/petigamapshf.f90.in:30-58): dN/dx_i = sum_b du_b/dx_i dN/du_b
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          na[1 + i] = pd[1 + 0 * 3 + i] * fa[1] + pd[1 + 1 * 3 + i] * fa[2] + pd[1 + 2 * 3 + i] * fa[3];
+          nb[1 + i] = pd[1 + 0 * 3 + i] * fb[1] + pd[1 + 1 * 3 + i] * fb[2] + pd[1 + 2 * 3 + i] * fb[3];
+        }
+      }
+      PtView p; p.x = nullptr; p.u = pd + 14; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = 0.0;
+      p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+      const double *cf = pd + 14 + DOF;
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        double ef[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) ef[g] = (g == f) ? 1.0 : 0.0;
+        double T[DOF * DOF];
+        Form::mat_c(cf, p, ef, nb, T);
+#pragma unroll
+        for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+          for (int j = 0; j < DOF; ++j) {
+            if (!((fm_block_mask<Form>(I0 + i, j) >> f) & 1u)) continue;
+            acc[i * DOF + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[f], T[(I0 + i) * DOF + j] * jw, acc[i * DOF + j], 0, 0, 0);
+          }
+      }
+    }
+  }
+}
+
+// the MFMA phase of one wave for one layer and one group of row fields, then the deposit; shared by the two instantiations
+template <class Form, bool GEO, bool RAT, int I0, int DOFI>
+__device__ __forceinline__ void bpt_mfma_phase(d4_t (&accA)[DOFI * Form::DOF], d4_t (&accB)[DOFI * Form::DOF], const double *ring, int li, int nel0, bool alias0,
+                                               bool act, int dA, int dB, bool hasB, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
+  constexpr int P = 3;
+  if (!act) return;
+#pragma unroll 1
+  for (int ta = 0; ta <= P; ++ta) {
+    const int tb = ta + dA;
+    if (tb < 0 || tb > P) continue;
+    const int eu = li - ta;        // (unwrapped: the ring slot follows it, the element itself is eu modulo nel on a wrapped axis)
+    if (!alias0 && (eu < 0 || eu >= nel0)) continue;
+    bpt_product<Form, GEO, RAT, I0, DOFI>(accA, ring + bpt_slot(eu) * bpt_rec<Form>(), ta, tb, uxy, lane, prm, shift);
+  }
+  if (hasB) {
+#pragma unroll 1
+    for (int ta = 0; ta <= P; ++ta) {
+      const int tb = ta + dB;
+      if (tb < 0 || tb > P) continue;
+      const int eu = li - ta;
+      if (!alias0 && (eu < 0 || eu >= nel0)) continue;
+      bpt_product<Form, GEO, RAT, I0, DOFI>(accB, ring + bpt_slot(eu) * bpt_rec<Form>(), ta, tb, uxy, lane, prm, shift);
+    }
+  }
+}
+
+template <class Form, bool GEO, bool RAT>
+__global__ void __launch_bounds__(512, 2)
+band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
+  constexpr int P = 3, NB = 4, BW = 7, DOF = Form::DOF, BS = DOF * DOF, DOFI = DOF / 2, HB = DOFI * DOF, REC = bpt_rec<Form>();
+  static_assert(DOF == 4 && has_point_coef<Form>::v, "two groups of two row fields; the form separates its point coefficients (NCOEF, point_coef, mat_c)");
+  extern __shared__ __attribute__((aligned(16))) double bpt_sm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, role = wave & 3;
+  const int npen = pa.ex_count * pa.ey_count;
+  const int seg = blockIdx.x / npen, pencil = blockIdx.x - seg * npen;
+  const int tx = pencil % pa.ex_count, ty = pencil / pa.ex_count;
+  const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
+  const AxisDev &AW = S.ax[0], &AX = S.ax[1], &AY = S.ax[2];
+  const bool alias0 = pa.alias0 != 0;
+  const int NL = alias0 ? pa.nel0 : pa.nel0 + P;       // node layers (rows) of the pencil
+  const int li_lo = seg * pa.seg_len, li_hi = min(li_lo + pa.seg_len, NL);
+  const int nlay = li_hi - li_lo;
+  const int lay_first = AW.off[0];
+  const int offx = AX.off[elx], offy = AY.off[ely];
+  const BptCarve cv = bpt_carve<Form>(pa.seg_len);
+  double *stage = bpt_sm + cv.stage, *ring = bpt_sm + cv.ring, *uvs = bpt_sm + cv.uv;
+  long long *Lpre = reinterpret_cast<long long *>(bpt_sm + cv.pre);
+  int *Lcnt = reinterpret_cast<int *>(bpt_sm + cv.cnt), *Lrho = reinterpret_cast<int *>(bpt_sm + cv.rho), *LP = reinterpret_cast<int *>(bpt_sm + cv.P);
+  BpPencil *pen = reinterpret_cast<BpPencil *>(bpt_sm + cv.pen);
+  unsigned *bcm = reinterpret_cast<unsigned *>(bpt_sm + cv.bc);
+  double *bcv = bpt_sm + cv.bc + 6;
+  int *arrive = reinterpret_cast<int *>(bpt_sm + cv.arrive) + grp * 2;
+  if (tid < 4) reinterpret_cast<int *>(bpt_sm + cv.arrive)[tid] = 0;
+  const double *recs = pa.pts + (size_t)pencil * pa.nel0 * REC;      // this pencil's element records
+
+  auto load_element = [&](int eu, int nt) {     // record of element eu (modulo nel on a wrapped axis) -> its ring slot, by threads 0 .. nt
+    int e = eu;
+    if (alias0) { e %= pa.nel0; if (e < 0) e += pa.nel0; } else if (e < 0 || e >= pa.nel0) return;
+    const double *src = recs + (size_t)e * REC; double *dst = ring + bpt_slot(eu) * REC;
+    for (int i = tid; i < REC / 2; i += nt) *reinterpret_cast<bp_d2_t *>(dst + 2 * i) = *reinterpret_cast<const bp_d2_t *>(src + 2 * i);
+  };
+  {   // tables of the segment and of the pencil; the window of the first layer
+    for (int i = tid; i < nlay; i += 512) {
+      const int lay = lay_first + li_lo + i, rho = AW.rowmap[lay];
+      Lrho[i] = rho; Lcnt[i] = AW.rcnt[rho]; Lpre[i] = AW.prefix[rho];
+      for (int d = 0; d < BW; ++d) LP[i * 8 + d] = AW.P[lay * BW + d];
+    }
+    if (tid < 4) {
+      const int a = tid;
+      const int ixg = offx + a, rhox = AX.rowmap[ixg], iyg = offy + a, rhoy = AY.rowmap[iyg];
+      pen->ps1[a] = AX.prefix[rhox]; pen->c1[a] = AX.rcnt[rhox]; pen->P1_0[a] = AX.P[ixg * BW + (0 - a + P)]; pen->rmx[a] = rhox;
+      pen->ps2[a] = AY.prefix[rhoy]; pen->c2[a] = AY.rcnt[rhoy]; pen->rmy[a] = rhoy;
+      for (int b = 0; b < 4; ++b) pen->P2[a * 4 + b] = AY.P[iyg * BW + (b - a + P)];
+    }
+    if (tid == 64) {
+      unsigned fx = 0, fy = 0;
+      if (pa.first_touch)
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+          if (first_touch_axis<P>(elx, a, b, pa.nelx)) fx |= 1u << (a * 4 + b);
+          if (first_touch_axis<P>(ely, a, b, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) fy |= 1u << (a * 4 + b);
+        }
+      pen->ftx = fx; pen->fty = fy;
+    }
+    if (tid >= 128 && tid < 192) {   // per (qx, ix): u0, u1 of axis 1; per (iy, qy): v0, v1 of axis 2 (raw rows)
+      const int l2 = tid - 128;
+      if (l2 < 32) { const int q = l2 >> 3, a = (l2 >> 1) & 3, k = l2 & 1; uvs[l2] = AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k]; }            // [q][a][2]
+      else { const int l3 = l2 - 32, a = l3 >> 3, q = (l3 >> 1) & 3, k = l3 & 1; uvs[l2] = AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k]; }       // [a][q][2]
+    }
+    if (tid >= 192 && tid < 198) {   // Dirichlet faces this pencil can touch (IGAElementFixJacobian; not the Matrix driver)
+      const int k = tid - 192, d = k >> 1, sd = k & 1;
+      const AxisDev &A = S.ax[d];
+      const int el = d == 0 ? 0 : (d == 1 ? elx : ely);
+      bool on = out.op != OP_MATRIX && !A.periodic && S.bcv[d][sd].count > 0;
+      if (on) on = (d == 0) ? (sd == 0 ? A.estart == 0 : A.estart + A.nel == A.esizes) : (sd == 0 ? el + A.estart == 0 : el + A.estart == A.esizes - 1);
+      unsigned m = 0;
+      for (int c = 0; c < 4; ++c) bcv[k * 4 + c] = 0.0;
+      if (on) for (int c = 0; c < S.bcv[d][sd].count; ++c) { const int fld = S.bcv[d][sd].field[c]; if (fld < DOF) m |= 1u << fld; }
+      bcm[k] = m;
+    }
+    // elements li_lo - P .. li_lo of the first layer's window (periodic: modulo nel)
+    for (int t = 0; t <= P; ++t) load_element(li_lo - t, 512);
+  }
+  __syncthreads();
+
+  BpBC bc; bc.any = false; bc.v = bcv;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { bc.m[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)bcm[k]); bc.on[k] = bc.m[k] != 0u; bc.any = bc.any || bc.on[k]; }
+  bc.wlo = bc.on[0] ? lay_first : -1000;
+  bc.whi = bc.on[1] ? lay_first + NL - 1 : -1000;
+
+  double uxy[4][3];     // per qy: u0 v0, u1 v0, u0 v1 of this lane's (qx, ix, iy)
+  {
+    const int qx = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
+    const double u0 = uvs[(qx * 4 + ix) * 2 + 0], u1 = uvs[(qx * 4 + ix) * 2 + 1];
+#pragma unroll
+    for (int qy = 0; qy < 4; ++qy) {
+      const double v0 = uvs[32 + (iy * 4 + qy) * 2 + 0], v1 = uvs[32 + (iy * 4 + qy) * 2 + 1];
+      uxy[qy][0] = u0 * v0; uxy[qy][1] = u1 * v0; uxy[qy][2] = u0 * v1;
+    }
+  }
+  const int dA = (role == 0) ? 0 : (role == 1 ? 1 : (role == 2 ? -1 : 2));
+  const int dB = (role == 1) ? -3 : (role == 2 ? 3 : -2);
+  const bool hasB = role != 0;
+  const long long T0 = S.ax[0].tot, T10 = S.ax[1].tot * S.ax[0].tot;
+  // read-add-write runs: sub-round s covers the rows a2 in {2s, 2s+1}; wave `role` takes a2 = 2s + (role >> 1), a1 in {2 (role & 1), +1}:
+  // 8 runs (a1, b2); lane ru < 8 holds what does not depend on the layer, for both sub-rounds
+  long long run_base[2], run_cc[2]; int run_pp[2];
+#pragma unroll
+  for (int sb = 0; sb < 2; ++sb) {
+    const int ru = lane & 7, a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3, a2 = 2 * sb + (role >> 1);
+    const long long c1 = pen->c1[a1], c2 = pen->c2[a2];
+    run_base[sb] = pen->ps2[a2] * T10 + c2 * (pen->ps1[a1] * T0);
+    run_cc[sb] = c2 * c1;
+    run_pp[sb] = (int)(pen->P2[a2 * 4 + b2] * c1 + pen->P1_0[a1]);
+  }
+  const unsigned ftx = (unsigned)__builtin_amdgcn_readfirstlane((int)pen->ftx), fty = (unsigned)__builtin_amdgcn_readfirstlane((int)pen->fty);
+  const int I0 = grp * DOFI;          // this group's row fields
+
+  // both groups take the same layer, group 1 half a period behind group 0
+  if (grp == 1) __builtin_amdgcn_s_barrier();
+  for (int it = 0; it < nlay; ++it) {
+    const int li = li_lo + it, lay = lay_first + li;
+    d4_t accA[HB], accB[HB];
+#pragma unroll
+    for (int n = 0; n < HB; ++n) { accA[n] = (d4_t){0, 0, 0, 0}; accB[n] = (d4_t){0, 0, 0, 0}; }
+    if (grp == 0) bpt_mfma_phase<Form, GEO, RAT, 0, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
+    else bpt_mfma_phase<Form, GEO, RAT, DOFI, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
+    __builtin_amdgcn_s_barrier();
+
+    // ---- flush phase.  Group 0 first brings the element that enters the window with the next layer into the ring: its slot was
+    // last read two phases ago (element li - 4, by group 1's MFMA phase of layer li - 1).
+    __builtin_amdgcn_s_setprio(3);
+    if (grp == 0 && it + 1 < nlay) load_element(li + 1, 256);
+    const int c0 = __builtin_amdgcn_readfirstlane(Lcnt[it]);
+    const int held = alias0 ? P + 1 : (min(li, pa.nel0 - 1) - max(li - P, 0) + 1);
+    const bool bcrow = bc.any && (bc.on[2] || bc.on[3] || bc.on[4] || bc.on[5] || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
+    const long long ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(Lpre[it] >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(Lpre[it] & 0xffffffffll));
+    const int runlen = 4 * c0 * HB;            // doubles of a run in the stage (dense); in the matrix the half blocks sit BS apart
+    const bool dowrite = !(kDebug && (pa.debug & 1));
+#pragma unroll
+    for (int sb = 0; sb < 2; ++sb) {
+      {   // deposit the rows a2 = r in {2 sb, 2 sb + 1}: IGAElementFixJacobian on the combined blocks (src/petigaelem.c:1463-1490)
+        const int a1 = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+        auto deposit = [&](const d4_t (&acc)[HB], int d) {
+          const int p0d = __builtin_amdgcn_readfirstlane(LP[it * 8 + d + P]);
+          if (p0d < 0) return;
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * sb + rr;
+            double K[HB];
+#pragma unroll
+            for (int n = 0; n < HB; ++n) K[n] = acc[n][r];
+            if (bcrow) {
+#pragma unroll
+              for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+                for (int j = 0; j < DOF; ++j) {
+                  double va = 0, vb = 0;
+                  const bool fa = bp_fixed<P>(bc, a1, r, lay, I0 + i, va), fb = bp_fixed<P>(bc, b1, b2, lay + d, j, vb);
+                  if (fa || fb) K[i * DOF + j] = (d == 0 && a1 == b1 && r == b2 && I0 + i == j) ? (double)held : 0.0;
+                }
+            }
+            double *sp = stage + ((size_t)(((a1 + 4 * rr) * 4 + b2) * 4 + b1) * c0 + p0d) * HB;
+#pragma unroll
+            for (int n = 0; n < HB; n += 2) { bp_d2_t t; t[0] = K[n]; t[1] = K[n + 1]; *reinterpret_cast<bp_d2_t *>(sp + n) = t; }
+          }
+        };
+        deposit(accA, dA);
+        if (hasB) deposit(accB, dB);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // the old values of this wave's 8 runs: a half block = HB / 2 pieces of 16 bytes, the blocks of a run BS doubles apart
+      const long long mypos = run_base[sb] + run_cc[sb] * ps0 + (long long)run_pp[sb] * c0;
+      const int npiece = 4 * c0 * (HB / 2);      // pieces of a run
+      double *gp[8]; d2u_t oldv[8][2];
+      const int a2 = 2 * sb + (role >> 1);
+#pragma unroll
+      for (int ru = 0; ru < 8; ++ru) {
+        const int a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3;
+        const long long pos = ((long long)__builtin_amdgcn_readlane((int)(mypos >> 32), ru) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)(mypos & 0xffffffffll), ru);
+        gp[ru] = out.val + pos * BS + I0 * DOF;
+        const bool ally = (fty >> (a2 * 4 + b2)) & 1u, allx = ((ftx >> (a1 * 4)) & 0xfu) == 0xfu;
+        const bool ld = dowrite && !(ally && allx);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pc = lane + 64 * h;
+          oldv[ru][h] = (d2u_t){0.0, 0.0};
+          if (ld && pc < npiece) oldv[ru][h] = *reinterpret_cast<const d2u_t *>(gp[ru] + (pc / (HB / 2)) * BS + (pc % (HB / 2)) * 2);
+        }
+      }
+      {   // every wave of this group has deposited this sub-round
+        const int target = 4 * (2 * it + sb + 1);
+        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+      }
+      if (dowrite) {
+        const int blk = c0 * (HB / 2);          // pieces per b1 group
+#pragma unroll
+        for (int ru = 0; ru < 8; ++ru) {
+          const int a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3, rr = role >> 1;
+          const double *sp = stage + (size_t)((a1 + 4 * rr) * 4 + b2) * runlen;
+          const bool fy1 = (fty >> (a2 * 4 + b2)) & 1u;
+          const unsigned fxm = fy1 ? ((ftx >> (a1 * 4)) & 0xfu) : 0u;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int pc = lane + 64 * h;
+            if (pc < npiece) {
+              const bp_d2_t nv = *reinterpret_cast<const bp_d2_t *>(sp + 2 * pc);
+              d2u_t ov = oldv[ru][h];
+              if (fxm) { const int g0 = (pc >= blk) + (pc >= 2 * blk) + (pc >= 3 * blk); if ((fxm >> g0) & 1u) { ov[0] = 0.0; ov[1] = 0.0; } }
+              d2u_t w; w[0] = ov[0] + nv[0]; w[1] = ov[1] + nv[1];
+              *reinterpret_cast<d2u_t *>(gp[ru] + (pc / (HB / 2)) * BS + (pc % (HB / 2)) * 2) = w;
+            }
+          }
+        }
+      }
+      if (sb == 0) {   // the stage is written again: every wave of the group is done reading it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int target = 4 * (it + 1);
+        while (__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+      }
+    }
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_barrier();
+  }
+  if (grp == 0) __builtin_amdgcn_s_barrier();
+}
+
+// ---- host side
+template <class Form> constexpr bool bpt_form_ok() {
+  if constexpr (!has_point_coef<Form>::v) return false;
+  else return Form::DOF == 4 && shape_order_of<Form>::v < 2 && !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0 && mat_pair_mask_of<Form>::v == 0ull &&
+              (mat_need_of<Form>::v & ~(NEED_U | NEED_G)) == 0u;
+}
+
+// 3-D, p = 3 with 4 Gauss points per axis, matrix-only drivers (Matrix / Jacobian / IJacobian); axis 0: one new node layer per
+// element (a periodic axis wrapped inside the rank is taken: layers and elements modulo nel, at least 2p+1 of them); axis 1 not
+// wrapped inside the rank; axis 2 either way; any geometry (none / polynomial / NURBS) of dimension 3
+template <class Form>
+static bool band_pt_covers(const Space &s, const SpaceDev &S, const OutDev &out) {
+  if constexpr (!bpt_form_ok<Form>()) return false;
+  else {
+    if (s.env.block_pencil == 0) return false;
+    if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) return false;
+    if (s.dim != 3 || s.dof != Form::DOF || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
+    for (int d = 0; d < 3; ++d) {
+      if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4) return false;
+      for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
+      if (s.lay[d].alias && s.axis[d].nnp < 7) return false;
+    }
+    if (s.lay[1].alias) return false;
+    if (s.elem_width[0] < 8) return false;
+    for (int e = 0; e + 1 < s.elem_width[0]; ++e) if (s.basis[0].offset[s.elem_start[0] + e + 1] != s.basis[0].offset[s.elem_start[0] + e] + 1) return false;
+    return true;
+  }
+}
+
+template <class Form>
+static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, hipStream_t stream, std::string &kname, int &launches,
+                       std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix, const std::function<void()> &slab_done) {
+  done = false;
+  if constexpr (!bpt_form_ok<Form>()) return 0;
+  else {
+  if (!band_pt_covers<Form>(s, S, out)) return 0;
+  constexpr int P = 3;
+  const bool alias0 = s.lay[0].alias != 0;
+  const bool first_touch = !s.env.no_first_touch && out.val && !alias0 && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
+  if (!first_touch) { if (zero_matrix) zero_matrix(); }
+  else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);
+  launches = 0;
+  static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  const int NL = alias0 ? s.elem_width[0] : s.elem_width[0] + P;
+  const bool geo = s.nsd != 0, rat = s.rational != 0;
+  int rc = 0;
+  auto run = [&](const Box &bx, const int *fty) {
+    for (int d = 1; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
+    for (int cy = 0; cy < s.lay[2].ncolors && !rc; ++cy) for (int cx = 0; cx < s.lay[1].ncolors && !rc; ++cx) {
+      BandArgs pa; memset(&pa, 0, sizeof(pa));
+      pa.first_touch = first_touch ? 1 : 0; pa.nelx = s.elem_width[1]; pa.nely = s.elem_width[2];
+      pa.fty_lo = fty ? fty[0] : 0; pa.fty_hi = fty ? fty[1] : 0x7fffffff; pa.fty_blocked = fty ? fty[2] : 0x7fffffff;
+      if (!color_range(s.lay[1], cx, bx.lo[1], bx.hi[1], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
+      if (!color_range(s.lay[2], cy, bx.lo[2], bx.hi[2], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
+      // (irregular colours of a wrapped axis hold single elements: color_range gives start / count with the regular step)
+      pa.nel0 = s.elem_width[0]; pa.alias0 = alias0 ? 1 : 0;
+      const long long pencils = (long long)pa.ex_count * pa.ey_count;
+      const int max_len = 64;
+      int nseg = (NL + max_len - 1) / max_len;
+      while (pencils * nseg < 2LL * ncu && NL / (nseg + 1) >= 8) nseg++;
+      if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
+      pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
+      pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
+      const size_t need = (size_t)pencils * pa.nel0 * bpt_rec<Form>() * sizeof(double);
+      if (hipMallocAsync(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
+      const long long nelem = pencils * pa.nel0;
+      hipLaunchKernelGGL(band_points<Form>, dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, pa);
+      const size_t lds = (size_t)bpt_carve<Form>(pa.seg_len).total * sizeof(double);
+      auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(512), lds, stream, S, prm, out, pa);
+      (void)hipFreeAsync(pa.pts, stream);
+      launches++;
+    }
+  };
+  Box all; for (int d = 0; d < 3; ++d) { all.lo[d] = 0; all.hi[d] = s.elem_width[d]; }
+  if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
+  const int n2 = s.elem_width[2];
+  const bool upper2 = s.proc_sizes[2] > 1 && (s.proc_ranks[2] < s.proc_sizes[2] - 1 || s.axis[2].periodic);
+  if (slab_done && upper2 && n2 >= 2 * (P + 1)) {
+    Box top = all, rest = all; top.lo[2] = n2 - P; rest.hi[2] = n2 - P;
+    const int ft_top[3] = {n2 - P, n2, 0x7fffffff}, ft_rest[3] = {0, n2 - P, n2 - P};
+    run(top, ft_top);
+    if (!rc) slab_done();
+    if (!rc) run(rest, ft_rest);
+  } else run(all, nullptr);
+  if (rc) return rc;
+  if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
+  if (hipGetLastError() != hipSuccess) { err = "band_pt kernel launch failed"; return IGX_ERR_LIB; }
+  int nm = 0;
+  for (int i = 0; i < Form::DOF; ++i) for (int j = 0; j < Form::DOF; ++j) for (int f = 0; f < 4; ++f) if ((fm_block_mask<Form>(i, j) >> f) & 1u) nm++;
+  dom.name = "band_pt<p=3>"; dom.launches = launches;
+  dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+  dom.flop_per_element = 2048.0 * nm * 16 * 16;
+  kname = std::string("band_pt(mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
+  done = true;
+  return 0;
+  }
+}
+
+}  // namespace igx

@@ -18,6 +18,9 @@
 #elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)
 #include "block_pencil.hpp"
 #define IGX_HAVE_BLOCK_PENCIL 1
+#elif IGX_TU_DIM == 3 && IGX_TU_GROUP == 2
+#include "band_pt.hpp"
+#define IGX_HAVE_BAND_PT 1
 #endif
 
 using namespace igx;
@@ -796,7 +799,16 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
   }
 #endif
-  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the block pencil kernel does not cover this case (3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0)");
+#ifdef IGX_HAVE_BAND_PT
+  if constexpr (DIM == 3) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer, point-dependent coefficients (band_pt.hpp)
+    bool done = false;
+    ParamsDev prm; memset(&prm, 0, sizeof(prm));
+    for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+    if (int rc = try_band_pt<Form>(s, S, prm, out, g->stream, g->last_kernel, g->last_launches, g_err, done, g->dom, g->zero_matrix, g->slab_done)) return rc;
+    if (done) return 0;
+  }
+#endif
+  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0; band_pt: 3-D, p = 3, matrix-only driver of a 4-field form with separated point coefficients)");
   if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;

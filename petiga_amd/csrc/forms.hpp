@@ -248,9 +248,17 @@ struct FormNSVMS {
     Ruz += -(Na_x * uz_s * (ux + ux_s) + Na_y * uz_s * (uy + uy_s) + Na_z * uz_s * (uz + uz_s));
     R[0] = Rux; R[1] = Ruy; R[2] = Ruz; R[3] = Rp;
   }
+  // Point coefficients apart from the basis functions (band_pt.hpp evaluates them once per Gauss point, ahead of the contraction):
+  // mat(p, Na, Nb) == mat_c(point_coef(p), p, Na, Nb)
+  static constexpr int NCOEF = 2;
+  static __device__ __forceinline__ void point_coef(const PtView &p, double *c) { tau(p, c[0], c[1]); }
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na_, const double *Nb_, double *T) {
+    double c[2]; point_coef(p, c);
+    mat_c(c, p, Na_, Nb_, T);
+  }
+  static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
-    double tauM, tauC; tau(p, tauM, tauC);
+    const double tauM = c[0], tauC = c[1];
     const double ux = p.u[0], uy = p.u[1], uz = p.u[2];
     const double Na = Na_[0], Na_x = Na_[1], Na_y = Na_[2], Na_z = Na_[3];
     const double Nb = Nb_[0], Nb_x = Nb_[1], Nb_y = Nb_[2], Nb_z = Nb_[3];
