@@ -26,6 +26,8 @@
 
 namespace igx {
 
+template <class F, class = void> struct has_mat_unit { static constexpr bool v = false; };
+template <class F> struct has_mat_unit<F, decltype((void)F::HAS_MAT_UNIT)> { static constexpr bool v = F::HAS_MAT_UNIT; };
 template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
 template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
 
@@ -196,6 +198,27 @@ __host__ __device__ static inline BptCarve bpt_carve(int seg_len) {
 // ring slot of the element with the (unwrapped) index eu = layer - slot: five slots, a window holds four
 __device__ __forceinline__ int bpt_slot(int eu) { const int m = eu % 5; return m < 0 ? m + 5 : m; }
 
+// the MFMAs of one test feature F at one k-step: B^{ij}_F = mat(e_F, Nb JW)[i][j] for the blocks whose mask names F
+template <class Form, int I0, int DOFI, int F>
+__device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const double *cf, const PtView &p, const double (&na)[4], const double (&nb)[4]) {
+  constexpr int DOF = Form::DOF;
+  double T[DOF * DOF];
+  if constexpr (has_mat_unit<Form>::v) Form::template mat_unit<F>(cf, p, nb, T);
+  else {
+    double ef[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ef[g] = (g == F) ? 1.0 : 0.0;
+    Form::mat_c(cf, p, ef, nb, T);
+  }
+#pragma unroll
+  for (int i = 0; i < DOFI; ++i)
+#pragma unroll
+    for (int j = 0; j < DOF; ++j) {
+      if (!((fm_block_mask<Form>(I0 + i, j) >> F) & 1u)) continue;
+      acc[i * DOF + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[F], T[(I0 + i) * DOF + j], acc[i * DOF + j], 0, 0, 0);
+    }
+}
+
 // one tile product of a row-field group: acc[(i - I0) DOF + j] += A_f(e, ta)^T B^{ij}_f(e, tb) over the element's 64 points
 template <class Form, bool GEO, bool RAT, int I0, int DOFI>
 __device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
@@ -231,21 +254,13 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const
       PtView p; p.x = nullptr; p.u = pd + 14; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = 0.0;
       p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
       const double *cf = pd + 14 + DOF;
+      // mat() is linear in the trial features: the weight goes onto them once instead of onto every block entry
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        double ef[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) ef[g] = (g == f) ? 1.0 : 0.0;
-        double T[DOF * DOF];
-        Form::mat_c(cf, p, ef, nb, T);
-#pragma unroll
-        for (int i = 0; i < DOFI; ++i)
-#pragma unroll
-          for (int j = 0; j < DOF; ++j) {
-            if (!((fm_block_mask<Form>(I0 + i, j) >> f) & 1u)) continue;
-            acc[i * DOF + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[f], T[(I0 + i) * DOF + j] * jw, acc[i * DOF + j], 0, 0, 0);
-          }
-      }
+      for (int g = 0; g < 4; ++g) nb[g] *= jw;
+      bpt_feature<Form, I0, DOFI, 0>(acc, cf, p, na, nb);
+      bpt_feature<Form, I0, DOFI, 1>(acc, cf, p, na, nb);
+      bpt_feature<Form, I0, DOFI, 2>(acc, cf, p, na, nb);
+      bpt_feature<Form, I0, DOFI, 3>(acc, cf, p, na, nb);
     }
   }
 }
@@ -560,9 +575,20 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       // (irregular colours of a wrapped axis hold single elements: color_range gives start / count with the regular step)
       pa.nel0 = s.elem_width[0]; pa.alias0 = alias0 ? 1 : 0;
       const long long pencils = (long long)pa.ex_count * pa.ey_count;
+      // One workgroup per CU (LDS): a launch takes ceil(workgroups / CUs) rounds of one segment each.  Segments cost a window of
+      // element records and one idle half period: the count with the fewest rounds x (layers + 1), at least 8 layers each
+      // (96^3 on 256 CUs: 576 pencils in one piece are 3 rounds of 96 layers, in four pieces 9 rounds of 24)
       const int max_len = 64;
       int nseg = (NL + max_len - 1) / max_len;
-      while (pencils * nseg < 2LL * ncu && NL / (nseg + 1) >= 8) nseg++;
+      {
+        long long best = -1; int best_n = nseg;
+        for (int n = nseg; n <= std::max(nseg, NL / 8); ++n) {
+          const int len = (NL + n - 1) / n, ns = (NL + len - 1) / len;
+          const long long cost = ((pencils * ns + ncu - 1) / ncu) * (len + 1);
+          if (best < 0 || cost < best) { best = cost; best_n = n; }
+        }
+        nseg = best_n;
+      }
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;

@@ -575,7 +575,15 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
       // over, at least 8 layers each, at most what the LDS holds next to the stage (zt: 256 bytes per element)
       const int max_len = 64;
       int nseg = (NL + max_len - 1) / max_len;
-      while (pencils * nseg < 4LL * ncu && NL / (nseg + 1) >= 8) nseg++;
+      {   // one workgroup per CU: the count with the fewest rounds x (layers + 1)
+        long long best = -1; int best_n = nseg;
+        for (int n = nseg; n <= std::max(nseg, NL / 8); ++n) {
+          const int len = (NL + n - 1) / n, ns = (NL + len - 1) / len;
+          const long long cost = ((pencils * ns + ncu - 1) / ncu) * (len + 1);
+          if (best < 0 || cost < best) { best = cost; best_n = n; }
+        }
+        nseg = best_n;
+      }
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;

@@ -251,10 +251,42 @@ struct FormNSVMS {
   // Point coefficients apart from the basis functions (band_pt.hpp evaluates them once per Gauss point, ahead of the contraction):
   // mat(p, Na, Nb) == mat_c(point_coef(p), p, Na, Nb)
   static constexpr int NCOEF = 2;
+  static constexpr bool HAS_MAT_UNIT = true;
   static __device__ __forceinline__ void point_coef(const PtView &p, double *c) { tau(p, c[0], c[1]); }
   static __device__ __forceinline__ void mat(const PtView &p, const double *Na_, const double *Nb_, double *T) {
     double c[2]; point_coef(p, c);
     mat_c(c, p, Na_, Nb_, T);
+  }
+  // mat_c(c, p, e_F, Nb) for the unit test feature F (0: N, 1 + g: dN/dx_g), written out: only the entries block_mask(i,j) names
+  // for F are set.  x * 0 does not fold under IEEE rules, so the generic call spends about four times these multiply-adds per
+  // point on products with the zeros of e_F (band_pt.hpp: the fp64 VALU work shares the pipe with the MFMAs it feeds).
+  template <int F>
+  static __device__ __forceinline__ void mat_unit(const double *c, const PtView &p, const double *Nb_, double *T) {
+    const double nu = p.prm[0], shift = p.shift, tauM = c[0], tauC = c[1];
+    const double Nb = Nb_[0];
+    const double S = shift * Nb + (p.u[0] * Nb_[1] + p.u[1] * Nb_[2] + p.u[2] * Nb_[3]);     // shift Nb + u . grad Nb
+    if constexpr (F == 0) {
+      T[0] = S; T[5] = S; T[10] = S;
+      T[12] = Nb_[1]; T[13] = Nb_[2]; T[14] = Nb_[3];
+    } else {
+      constexpr int g = F - 1;
+      const double a = tauM * p.u[g];
+      const double Tii = nu * Nb_[1 + g] + a * S;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (i != j && i != g && j != g) continue;
+          double t = (i == j) ? Tii : 0.0;
+          if (j == g) t += nu * Nb_[1 + i];
+          if (i == g) t += tauC * Nb_[1 + j];
+          T[i * 4 + j] = t;
+        }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T[i * 4 + 3] = (i == g) ? a * Nb_[1 + i] - Nb : a * Nb_[1 + i];
+      T[12 + g] = tauM * S;
+      T[15] = tauM * Nb_[1 + g];
+    }
   }
   static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
