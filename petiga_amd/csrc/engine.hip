@@ -13,6 +13,10 @@
 #include "generic_kernel.hpp"
 #include "feature_mfma.hpp"
 #include "first_touch.hpp"
+#if defined(IGX_TU_DISPATCH) && IGX_TU_DIM == 3
+#include "vec_sumfact.hpp"
+#define IGX_HAVE_VEC_SUMFACT 1
+#endif
 #ifndef IGX_TU_DISPATCH
 #include "gram_mfma.hpp"
 #elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)
@@ -790,6 +794,15 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   constexpr bool SECOND = Form::ORDER >= 2;
   constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   constexpr int NS = nscalar_of<Form>::v;
+#ifdef IGX_HAVE_VEC_SUMFACT
+  if constexpr (DIM == 3) if (g->kernel_choice == 0) {   // vector-only drivers: sum factorisation both ways (vec_sumfact.hpp)
+    bool done = false;
+    ParamsDev prm; memset(&prm, 0, sizeof(prm));
+    for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+    if (int rc = try_vec_sumfact<Form>(s, S, prm, out, g->stream, g->last_kernel, g->last_launches, done)) return fail(rc, "vec_sumfact kernel launch failed");
+    if (done) return 0;
+  }
+#endif
 #ifdef IGX_HAVE_BLOCK_PENCIL
   if constexpr (DIM == 3) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer (block_pencil.hpp)
     bool done = false;

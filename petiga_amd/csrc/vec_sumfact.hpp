@@ -1,0 +1,407 @@
+// vec_sumfact.hpp -- the vector-only drivers (IGAComputeVector / Function / IFunction, src/petigaksp.c:33, src/petigasnes.c:23,
+// src/petigats.c:23) by sum factorisation in both directions.
+//
+// The reference's point callback fills F[a] for every basis function a of the element at every quadrature point
+// (IGAPointAddVec, src/petigapoint.c:427-450): nen * nqp evaluations per element, and the feature kernel's vector-only mode keeps
+// that shape (Phi for all (a,q) pairs, vec() per pair).  But every IGAFormVector / Function / IFunction is LINEAR in the test
+// function, F_a^i = sum_q JW sum_f Phi_f(a,q) r^i_f(q) with r_f = vec(p, e_f), and on a tensor-product basis both halves factor over
+// the axes:
+//   forward   u, grad u, hess u (and x, dx/du, d2x/du2 of a mapped geometry) at the points from the nodal values: three short
+//             contractions, one axis at a time (src/petigaval.F90:182-232 summed the long way);
+//   point     the geometry chain K3-K6 (Rationalize, GeometryMap, InverseMap, src/petigarat/mapgeo/mapinv.f90.in), the form's
+//             vec() on the unit test features -- nqp evaluations instead of nen * nqp;
+//   backward  F_a = w_a sum_q sum_k C_k(q) D_k N_a(q) over the 10 parametric derivatives D_k up to order 2: the transpose of the
+//             forward contractions.
+// One wavefront per element (4 x 4 x 4 lanes = nodes = points; smaller degrees leave lanes idle), no matrix cores (there is no
+// dense contraction left: the work per element drops from ~nen * nqp * features to ~(nen + nqp) * (p+1) * components), coloured
+// scatter (conflict-free, fixed order: bitwise repeatable).  dim 3, nen <= 4 and nqp <= 4 per axis; first-order test features on
+// any geometry, second-order test features (Cahn-Hilliard's Laplacian) on the identity geometry; no boundary loads, no boundary
+// passes -- everything else stays on the feature kernel.
+#pragma once
+#include "feature_mfma.hpp"
+
+namespace igx {
+
+// derivative k of the 10 (value, d0, d1, d2, d00, d01, d02, d11, d12, d22): orders on the axes, and the two-axis stage m it comes from
+__device__ __forceinline__ constexpr int vs_v0(int k) { return (k == 1 || k == 5 || k == 6) ? 1 : (k == 4 ? 2 : 0); }
+__device__ __forceinline__ constexpr int vs_v1(int k) { return (k == 2 || k == 5 || k == 8) ? 1 : (k == 7 ? 2 : 0); }
+__device__ __forceinline__ constexpr int vs_v2(int k) { return (k == 3 || k == 6 || k == 8) ? 1 : (k == 9 ? 2 : 0); }
+// m -> (v0, v1): 0 (0,0) 1 (1,0) 2 (0,1) 3 (2,0) 4 (1,1) 5 (0,2)
+__device__ __forceinline__ constexpr int vs_m(int v0, int v1) { return v0 == 0 ? (v1 == 0 ? 0 : (v1 == 1 ? 2 : 5)) : (v0 == 1 ? (v1 == 0 ? 1 : 4) : 3); }
+__device__ __forceinline__ constexpr int vs_mv0(int m) { return (m == 1 || m == 4) ? 1 : (m == 3 ? 2 : 0); }
+__device__ __forceinline__ constexpr int vs_mv1(int m) { return (m == 2 || m == 4) ? 1 : (m == 5 ? 2 : 0); }
+
+#define VS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } while (0)
+
+// forward: D[k] = sum_a coef_a D_k N_a(q) at this lane's point; ORD = highest derivative order wanted.  buf: 10 x 64 doubles of this
+// wave; tab[d]: [q][a][3] (value, first, second derivative), zero padded to 4 x 4.
+template <int ORD>
+__device__ __forceinline__ void vs_forward(double coef, double *buf, const double *tab0, const double *tab1, const double *tab2, int lane, double (&D)[10]) {
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  double *in = buf, *T1 = buf + 64, *T2 = buf + 4 * 64;
+  VS_SYNC();
+  in[lane] = coef;
+  VS_SYNC();
+  {   // axis 0: lane (q0, a1, a2)
+    double t[3] = {0, 0, 0};
+#pragma unroll
+    for (int a0 = 0; a0 < 4; ++a0) {
+      const double c = in[a0 + 4 * i1 + 16 * i2];
+#pragma unroll
+      for (int v = 0; v <= ORD; ++v) t[v] += c * tab0[(i0 * 4 + a0) * 3 + v];
+    }
+#pragma unroll
+    for (int v = 0; v <= ORD; ++v) T1[v * 64 + lane] = t[v];
+  }
+  VS_SYNC();
+  {   // axis 1: lane (q0, q1, a2)
+    double t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int a1 = 0; a1 < 4; ++a1) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
+        t[m] += T1[vs_mv0(m) * 64 + i0 + 4 * a1 + 16 * i2] * tab1[(i1 * 4 + a1) * 3 + vs_mv1(m)];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) if (vs_mv0(m) + vs_mv1(m) <= ORD) T2[m * 64 + lane] = t[m];
+  }
+  VS_SYNC();
+#pragma unroll
+  for (int k = 0; k < 10; ++k) D[k] = 0.0;
+#pragma unroll
+  for (int a2 = 0; a2 < 4; ++a2) {
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+      if (vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
+      D[k] += T2[vs_m(vs_v0(k), vs_v1(k)) * 64 + i0 + 4 * i1 + 16 * a2] * tab2[(i2 * 4 + a2) * 3 + vs_v2(k)];
+    }
+  }
+}
+
+// backward: F_a = sum_q sum_k C_k(q) D_k N_a(q) at this lane's node; buf: 19 x 64 doubles of this wave
+template <int ORD>
+__device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf, const double *tab0, const double *tab1, const double *tab2, int lane) {
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  double *Cb = buf, *S2 = buf + 10 * 64, *S1 = buf + 16 * 64;
+  VS_SYNC();
+#pragma unroll
+  for (int k = 0; k < 10; ++k) if (vs_v0(k) + vs_v1(k) + vs_v2(k) <= ORD) Cb[k * 64 + lane] = C[k];
+  VS_SYNC();
+  {   // axis 2: lane (q0, q1, a2)
+    double t[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q2 = 0; q2 < 4; ++q2) {
+#pragma unroll
+      for (int k = 0; k < 10; ++k) {
+        if (vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
+        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[k * 64 + i0 + 4 * i1 + 16 * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < 6; ++m) if (vs_mv0(m) + vs_mv1(m) <= ORD) S2[m * 64 + lane] = t[m];
+  }
+  VS_SYNC();
+  {   // axis 1: lane (q0, a1, a2)
+    double t[3] = {0, 0, 0};
+#pragma unroll
+    for (int q1 = 0; q1 < 4; ++q1) {
+#pragma unroll
+      for (int m = 0; m < 6; ++m) {
+        if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
+        t[vs_mv0(m)] += S2[m * 64 + i0 + 4 * q1 + 16 * i2] * tab1[(q1 * 4 + i1) * 3 + vs_mv1(m)];
+      }
+    }
+#pragma unroll
+    for (int v = 0; v <= ORD; ++v) S1[v * 64 + lane] = t[v];
+  }
+  VS_SYNC();
+  double f = 0;
+#pragma unroll
+  for (int q0 = 0; q0 < 4; ++q0) {
+#pragma unroll
+    for (int v = 0; v <= ORD; ++v) f += S1[v * 64 + q0 + 4 * i1 + 16 * i2] * tab0[(q0 * 4 + i0) * 3 + v];
+  }
+  return f;
+}
+
+template <class Form>
+__global__ void __launch_bounds__(256)
+vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nelem) {
+  constexpr int DOF = Form::DOF;
+  constexpr bool SECOND_T = shape_order_of<Form>::v >= 2;                // second-order test features (identity geometry only)
+  constexpr bool NEEDHU = (Form::NEED & NEED_HU) != 0, NEEDGU = (Form::NEED & (NEED_GU | NEED_HU)) != 0;
+  constexpr int UORD = NEEDHU ? 2 : (NEEDGU ? 1 : 0);                    // derivative order of the state
+  constexpr int NFS = SECOND_T ? 13 : 4;
+  __shared__ double sm_all[4][19 * 64 + 3 * 48];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long w = (long long)blockIdx.x * 4 + wave;
+  if (w >= nelem) return;
+  double *buf = sm_all[wave], *tab0 = buf + 19 * 64, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
+  int el[3];
+  {
+    long long b = w;
+    const int t0 = (int)(b % cr.count[0]); b /= cr.count[0];
+    const int t1 = (int)(b % cr.count[1]); b /= cr.count[1];
+    el[0] = cr.start[0] + t0 * cr.step[0]; el[1] = cr.start[1] + t1 * cr.step[1]; el[2] = cr.start[2] + (int)b * cr.step[2];
+  }
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  const int il[3] = {i0, i1, i2};
+  const int op = out.op;
+  const bool geo = S.nsd > 0, rat = S.rational != 0;
+  const bool useU = out.U != nullptr, useV = out.V != nullptr;
+  int nb[3], nq[3], off[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) { nb[d] = S.ax[d].nen; nq[d] = S.ax[d].nqp; off[d] = S.ax[d].off[el[d]]; }
+  // 1-D rows of the element, [q][a][3], zero padded to 4 x 4
+  for (int i = lane; i < 3 * 48; i += 64) {
+    const int d = i / 48, j = i - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
+    tab0[i] = (q < nq[d] && a < nb[d]) ? S.ax[d].tab[((size_t)el[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v] : 0.0;
+  }
+  // this lane's node: control point, state, Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
+  const bool isnode = i0 < nb[0] && i1 < nb[1] && i2 < nb[2];
+  const bool ispoint = i0 < nq[0] && i1 < nq[1] && i2 < nq[2];
+  size_t row = 0; double Xw[3] = {0, 0, 0}, wgt = 0.0, Uv[DOF], Vv[DOF], ufix[DOF]; bool fixed[DOF];
+#pragma unroll
+  for (int f = 0; f < DOF; ++f) { Uv[f] = 0; Vv[f] = 0; ufix[f] = 0; fixed[f] = false; }
+  if (isnode) {
+    const size_t g = (size_t)(off[0] + i0) + (size_t)S.ax[0].gwidth * ((size_t)(off[1] + i1) + (size_t)S.ax[1].gwidth * (size_t)(off[2] + i2));
+    row = (size_t)S.ax[0].rowmap[off[0] + i0] + (size_t)S.ax[0].nrow * ((size_t)S.ax[1].rowmap[off[1] + i1] + (size_t)S.ax[1].nrow * (size_t)S.ax[2].rowmap[off[2] + i2]);
+    wgt = rat ? S.W[g] : 1.0;
+    if (geo) for (int c = 0; c < 3; ++c) Xw[c] = S.X[g * 3 + c] * wgt;
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) { if (useU) Uv[f] = out.U[row * DOF + f]; if (useV) Vv[f] = out.V[row * DOF + f]; }
+    if (op != OP_VECTOR) {
+      for (int d = 0; d < 3; ++d) {
+        const AxisDev &A = S.ax[d];
+        if (A.periodic) continue;
+        for (int sd = 0; sd < 2; ++sd) {
+          if (el[d] + A.estart != (sd ? A.esizes - 1 : 0) || il[d] != (sd ? nb[d] - 1 : 0)) continue;
+          const BCDev &bv = S.bcv[d][sd];
+          for (int k = 0; k < bv.count; ++k) {
+            const int f = bv.field[k];
+#pragma unroll
+            for (int ff = 0; ff < DOF; ++ff) if (ff == f) { fixed[ff] = true; ufix[ff] = S.fixtable ? S.fixtable[row * DOF + ff] : bv.value[k]; }
+          }
+        }
+      }
+    }
+  }
+  VS_SYNC();
+  // ---- forward: geometry (homogeneous coordinates), state
+  double x[3], E1[9], E2[27], iw = 1.0, o1[3] = {0, 0, 0}, o2[9], detX = 1.0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { E1[i] = (i % 4 == 0) ? 1.0 : 0.0; o2[i] = 0.0; }
+#pragma unroll
+  for (int i = 0; i < 27; ++i) E2[i] = 0.0;
+  x[0] = ispoint ? S.ax[0].pt[el[0] * nq[0] + i0] : 0.0; x[1] = ispoint ? S.ax[1].pt[el[1] * nq[1] + i1] : 0.0; x[2] = ispoint ? S.ax[2].pt[el[2] * nq[2] + i2] : 0.0;
+  // index of the second derivative (a, b) among the 10
+  auto k2 = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
+  if (geo || rat) {
+    double Dw[10], Dx[3][10];
+    if (UORD == 2) vs_forward<2>(wgt, buf, tab0, tab1, tab2, lane, Dw); else vs_forward<1>(wgt, buf, tab0, tab1, tab2, lane, Dw);
+    const double W0 = ispoint ? Dw[0] : 1.0;
+    iw = 1.0 / W0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) o1[a] = Dw[1 + a] * iw;
+    if (UORD == 2)
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o2[a * 3 + b] = Dw[k2(a, b)] * iw;
+    if (geo) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { if (UORD == 2) vs_forward<2>(Xw[c], buf, tab0, tab1, tab2, lane, Dx[c]); else vs_forward<1>(Xw[c], buf, tab0, tab1, tab2, lane, Dx[c]); }
+      double X1[9], X2[27];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {      // quotient rule on A = sum w X N, W = sum w N (src/petigarat.f90.in + petigamapgeo.f90.in)
+        x[c] = Dx[c][0] * iw;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) X1[c * 3 + a] = (Dx[c][1 + a] - x[c] * Dw[1 + a]) * iw;
+        if (UORD == 2)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) X2[c * 9 + a * 3 + b] = (Dx[c][k2(a, b)] - x[c] * Dw[k2(a, b)] - X1[c * 3 + a] * Dw[1 + b] - X1[c * 3 + b] * Dw[1 + a]) * iw;
+      }
+      if (!ispoint) { for (int i = 0; i < 9; ++i) X1[i] = (i % 4 == 0) ? 1.0 : 0.0; }
+      detX = det3(X1, 3);
+      inv3(X1, 3, detX, E1);
+      if (ispoint && !(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      if (UORD == 2) {   // InverseMap order 2 (src/petigamapinv.f90.in:32-45): E2[c][i][j] = -X2[k][a][b] E1[a][i] E1[b][j] E1[c][k]
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          double U9[9], T9[9];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { double sm = 0; for (int b = 0; b < 3; ++b) sm += X2[k * 9 + a * 3 + b] * E1[b * 3 + j]; U9[a * 3 + j] = sm; }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { double sm = 0; for (int a = 0; a < 3; ++a) sm += U9[a * 3 + j] * E1[a * 3 + i]; T9[i * 3 + j] = sm; }
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) E2[c * 9 + i] -= T9[i] * E1[c * 3 + k];
+        }
+      }
+    }
+  }
+  double u[DOF], ut[DOF], gu[DOF * 3], hu[DOF * 9];
+#pragma unroll
+  for (int f = 0; f < DOF; ++f) {
+    u[f] = 0; ut[f] = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gu[f * 3 + i] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) hu[f * 9 + i] = 0;
+    if ((Form::NEED & (NEED_U | NEED_GU | NEED_HU)) && useU) {
+      double D[10];
+      vs_forward<UORD>((fixed[f] ? ufix[f] : Uv[f]) * wgt, buf, tab0, tab1, tab2, lane, D);
+      u[f] = D[0] * iw;
+      if (UORD >= 1) {
+        double u1[3], u2[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) u1[a] = D[1 + a] * iw - u[f] * o1[a];      // u = A / W, du = (dA - u dW) / W (o1 = dW / W; 0 without weights)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) gu[f * 3 + i] = u1[0] * E1[0 * 3 + i] + u1[1] * E1[1 * 3 + i] + u1[2] * E1[2 * 3 + i];
+        if (UORD == 2) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+              double t = D[k2(a, b)] * iw;
+              if (rat) t -= u[f] * o2[a * 3 + b] + u1[a] * o1[b] + u1[b] * o1[a];
+              u2[a * 3 + b] = t;
+            }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {     // ShapeFunctions summed over a (src/petigamapshf.f90.in:30-58)
+              double sm = 0;
+#pragma unroll
+              for (int a = 0; a < 3; ++a) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) sm += u2[a * 3 + b] * E1[a * 3 + i] * E1[b * 3 + j];
+                sm += u1[a] * E2[a * 9 + i * 3 + j];
+              }
+              hu[f * 9 + i * 3 + j] = sm;
+            }
+        }
+      }
+    }
+    if ((Form::NEED & NEED_UT) && useV) {
+      double D[10];
+      vs_forward<0>((fixed[f] ? 0.0 : Vv[f]) * wgt, buf, tab0, tab1, tab2, lane, D);
+      ut[f] = D[0] * iw;
+    }
+  }
+  // ---- point: JW and the form's vec() on the unit test features
+  double JW = 0.0, G[9];
+  if (ispoint) {
+    JW = detX;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) JW *= S.ax[d].w[el[d] * nq[d] + il[d]] * S.ax[d].J[el[d]];
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) G[a * 3 + i] = E1[a * 3 + i] / S.ax[a].J[el[a]];      // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+  PtView p; p.x = x; p.u = u; p.ut = ut; p.gu = gu; p.hu = hu; p.G = G; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
+  p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+  double Cq[DOF][10];
+#pragma unroll
+  for (int f = 0; f < DOF; ++f)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) Cq[f][k] = 0.0;
+#pragma unroll
+  for (int tf = 0; tf < NFS; ++tf) {
+    double e[NFS], R[DOF];
+#pragma unroll
+    for (int g = 0; g < NFS; ++g) e[g] = (g == tf) ? 1.0 : 0.0;
+    Form::vec(p, e, R);
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) {
+      const double r = ispoint ? R[f] * JW : 0.0;      // (a padded lane evaluates vec() on zeros: its value may not even be finite)
+      if (tf == 0) Cq[f][0] += r;
+      else if (tf < 4) {      // physical gradient component tf-1 -> parametric: d_i R_a = sum_b E1[b][i] d_b R_a
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Cq[f][1 + b] += E1[b * 3 + (tf - 1)] * r;
+      } else {                // second-order test feature (a, b): identity geometry (physical = parametric)
+        const int a = (tf - 4) / 3, b = (tf - 4) % 3;
+        Cq[f][k2(a, b)] += r;
+      }
+    }
+  }
+  // rational test functions: R_a = w_a N_a / W, d_b R_a = (w_a / W) (d_b N_a - N_a W_b / W): the coefficients of the polynomial basis
+  if (rat) {
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) {
+      const double c0 = Cq[f][0] - (Cq[f][1] * o1[0] + Cq[f][2] * o1[1] + Cq[f][3] * o1[2]);
+      Cq[f][0] = c0 * iw; Cq[f][1] *= iw; Cq[f][2] *= iw; Cq[f][3] *= iw;
+    }
+  }
+  // ---- backward, IGAElementFixFunction (src/petigaelem.c:1449-1461), IGAElementAssembleVec
+#pragma unroll
+  for (int f = 0; f < DOF; ++f) {
+    double F = SECOND_T ? vs_backward<2>(Cq[f], buf, tab0, tab1, tab2, lane) : vs_backward<1>(Cq[f], buf, tab0, tab1, tab2, lane);
+    F *= wgt;
+    if (isnode) {
+      if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
+      if (F != 0.0) out.vec[row * DOF + f] += F;
+    }
+  }
+}
+#undef VS_SYNC
+
+// dim 3, at most 4 basis functions and 4 points per axis; vector-only drivers; no boundary loads (Function / IFunction subtract
+// their lumped flux per element), no boundary-form passes; second-order test features only on the identity geometry
+template <class Form>
+static bool vec_sumfact_covers(const Space &s, const OutDev &out) {
+  if constexpr (nscalar_of<Form>::v > 0 || has_boundary_of<Form>::v) return false;
+  else {
+    if (s.env.vec_sumfact == 0) return false;
+    if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION) return false;
+    if (s.dim != 3 || s.dof != Form::DOF || (s.nsd != 0 && s.nsd != 3)) return false;
+    if (shape_order_of<Form>::v >= 2 && (s.nsd != 0 || s.rational)) return false;
+    for (int d = 0; d < 3; ++d) {
+      if (s.basis[d].nen > 4 || s.basis[d].nqp > 4) return false;
+      for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && s.load[d][sd].count) return false; }
+    }
+    return true;
+  }
+}
+
+template <class Form>
+static int try_vec_sumfact(const Space &s, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, hipStream_t stream, std::string &kname, int &launches, bool &done) {
+  done = false;
+  if constexpr (nscalar_of<Form>::v > 0 || has_boundary_of<Form>::v) return 0;
+  else {
+  if (!vec_sumfact_covers<Form>(s, out)) return 0;
+  launches = 0;
+  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+      int first = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = first; cr.step[d] = L.p + 1; cr.count[d] = count;
+    }
+    if (empty) continue;
+    const long long nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
+    hipLaunchKernelGGL(vec_sumfact<Form>, dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    launches++;
+  }
+  if (hipGetLastError() != hipSuccess) return IGX_ERR_LIB;
+  kname = "vec_sumfact(vector only: sum factorisation forward and backward, one wavefront per element)";
+  done = true;
+  return 0;
+  }
+}
+
+}  // namespace igx

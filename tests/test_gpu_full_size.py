@@ -213,7 +213,7 @@ def test_navier_stokes_vms_one_gpu_share_properties():
     U = g.create_vec().set(np.tile([0.3, -0.2, 0.5, 0.0], nn))
     V = g.create_vec().set(np.zeros(4 * nn))
     g.compute_ifunction(2.0 / dt, V, 0.0, U, b); g.synchronize()
-    assert "feature_assemble" in g.kernel_name()
+    assert "vec_sumfact" in g.kernel_name()
     assert np.abs(b.get()).max() <= 1e-12
     del g, b, U, V
     # --- walls, random state

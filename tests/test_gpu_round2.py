@@ -57,7 +57,7 @@ def test_navier_stokes_vms_p3(geo, kernel_family):
     Uv, Vv, F, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec(), eng.create_mat()
     eng.compute_ifunction(shift, Vv, 0.0, Uv, F)
     if kernel_family == "auto":
-        assert "feature_assemble" in eng.kernel_name()
+        assert "vec_sumfact" in eng.kernel_name()
     eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
     eng.synchronize()
     if kernel_family == "auto":
