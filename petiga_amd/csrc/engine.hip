@@ -1062,7 +1062,17 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
       if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid = true; g->slab_A = A; g->slab_b = b; }
     };
-    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done);
+    // the Tangent of a nonlinear scalar form without a geometry walks the same pencils (gram_mfma.hpp: state_pencil)
+    PencilModule st; memset(&st.prm, 0, sizeof(st.prm));
+    if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 0 && s.env.state_pencil && (g->kernel_choice == 0 || g->kernel_choice == 2)) {
+      const int deg = s.axis[0].p;
+      if (s.form == IGX_FORM_CAHNHILLIARD && (deg == 2 || deg == 3)) {
+        st.kfn = deg == 2 ? state_pencil<2, FormCahnHilliard<3>> : state_pencil<3, FormCahnHilliard<3>>; st.name = "CahnHilliard";
+        st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * (deg + 1) * (deg + 1) * (deg + 1) * (deg + 1);
+      }
+      if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes(); for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
+    }
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done, st.kfn ? &st : nullptr);
     if (rc) return rc;
   }
   if (!done) {

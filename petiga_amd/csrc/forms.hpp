@@ -165,6 +165,24 @@ template <int DIM> struct FormCahnHilliard {
     Kab += lapNa * (k.dM * k.lap * Nb[0] + k.M * lapNb);
     T[0] = Kab;
   }
+  // The Tangent on the pencil walk (gram_mfma.hpp, state_pencil): k_q[a][b] = sum_f A_f(a) B_f(b) with the test-side features
+  // A = (N, d0 N, d1 N, d2 N, lap N) -- plain tensor products of the 1-D rows -- and the trial side carrying the point's
+  // coefficients: B_0 = JW shift N, B_{1+i} = JW t1 d_i N + d_i c (JW s N + JW dM lap N), B_4 = JW dM lap(c) N + JW M lap N (DIM = 3).
+  static constexpr int PENCIL_NFEAT = 2 + DIM, PENCIL_NC = 6 + DIM;
+  static __device__ __forceinline__ void pencil_coef(const PtView &p, double JW, double *c) {
+    const Coef k = coef(p);
+    c[0] = JW * p.shift; c[1] = JW * k.t1; c[2] = JW * (k.dM * k.dmu + k.M * k.d2mu + k.d2M * k.lap); c[3] = JW * k.dM;
+    c[4] = JW * (k.dM * k.lap); c[5] = JW * k.M;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) c[6 + i] = p.gu[i];
+  }
+  static __device__ __forceinline__ void pencil_trial(const double *c, double N, const double *g, double lap, double *B) {
+    const double h = c[2] * N + c[3] * lap;
+    B[0] = c[0] * N;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) B[1 + i] = c[1] * g[i] + c[6 + i] * h;
+    B[1 + DIM] = c[4] * N + c[5] * lap;
+  }
 };
 
 // demo/Bratu.c + demo/BratuFJ.F90:23-176 (Function / Jacobian and IFunction / IJacobian, Galerkin branches); params {lambda}.

@@ -449,7 +449,10 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
 // left 1..P steps ago (K_e is symmetric, only tiles ta <= tb are computed): each leaving row parks its tiles
 // (0,1..P) transposed in a per-wavefront LDS area, [P(P+1)/2 slots][4 r][HOLD_LD lanes], until the partner
 // row leaves (distance d uses d slots, keyed by the column layer mod d).
-template <bool SYSTEM, int P, bool FIXT = false>
+// NONSYM (state_pencil: a Tangent is not symmetric): all (P+1)^2 tiles are computed; the lower half is parked as it is -- tile (dd,0),
+// rows of layer lay+dd x columns of layer lay, is final when layer lay leaves and belongs to the same lane that will write the row.
+// BCMAT: the Dirichlet fix-up of the band row without a right-hand side (IGAElementFixJacobian, src/petigaelem.c:1425-1447).
+template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem,
@@ -488,7 +491,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
     // IGAElementFixSystem (src/petigaelem.c:1377-1387) on the combined band row: F_i -= sum_k K_ik v_k over fixed
     // columns (linear, so it commutes with the sum over elements), fixed rows / columns become 0, the diagonal of
     // a fixed row becomes the number of elements of this pencil that hold the node (each sets K_kk = 1, F_k = v)
-    const bool bcrow = SYSTEM && bc.any && (bc.xlo || bc.xhi || bc.ylo || bc.yhi || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
+    const bool bcrow = BCMAT && bc.any && (bc.xlo || bc.xhi || bc.ylo || bc.yhi || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
     if (bcrow) {
       double corr[NB];
 #pragma unroll
@@ -553,7 +556,14 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   }
   // park the transposes of tiles (0,1..P): entry (row lay ; a, r') x (col lay+dd ; b1, b2) of this lane is entry
   // (row lay+dd ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
-  if (b2 < NB) {
+  if constexpr (NONSYM) {
+#pragma unroll
+    for (int dd = 1; dd <= P; ++dd) {
+      const int slot = dd * (dd - 1) / 2 + ((lay % dd) + dd) % dd;
+#pragma unroll
+      for (int r = 0; r < NB; ++r) hold[(slot * 4 + r) * HOLD_LD + ls] = acc[dd][0][r];
+    }
+  } else if (b2 < NB) {
 #pragma unroll
     for (int dd = 1; dd <= P; ++dd) {
       const int slot = dd * (dd - 1) / 2 + ((lay % dd) + dd) % dd;
@@ -564,7 +574,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       }
     }
   }
-  pencil_shift<true, NB>(acc, Facc, L.fslot);
+  pencil_shift<!NONSYM, NB>(acc, Facc, L.fslot);
 }
 
 // leaving layer `lay` (always tile slot 0): add its 7 tiles and its F entries to the global arrays.
@@ -884,6 +894,112 @@ __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, cons
   return s;
 }
 
+// ---- Tangents of nonlinear scalar forms on this walk (state_pencil below; SURVEY 8a rows 15, 17: IGAPointFormValue/Grad/Hess
+// fused with the contraction).  A form opts in with PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial (forms.hpp): its Tangent
+// at a point is sum_f A_f(a) B_f(b) with A = (N, d_w N, d_x N, d_y N[, lap N]) -- tensor products of the three 1-D rows, built in
+// registers like the Gram operands -- and B = pencil_trial(c_q, features of b), c_q = pencil_coef(state at the point, JW).
+// No geometry (x = the parametric point: physical derivatives are the rows' own).  Per element the wavefront gathers the (P+1)^3
+// coefficients of U, sums u, grad u and the diagonal of hess u at its (P+1)^3 points by sum factorisation across the lanes
+// (three LDS exchanges) and leaves PENCIL_NC numbers per point where the metric of a mapped geometry would be.
+template <class Form, class = void> struct pencil_state_of { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
+template <class Form> struct pencil_state_of<Form, decltype((void)Form::PENCIL_NFEAT)> { static constexpr bool v = true; static constexpr int nfeat = Form::PENCIL_NFEAT, nc = Form::PENCIL_NC; };
+constexpr int STATE_D2 = 48;      // per-wavefront second derivatives of the 1-D rows: X [q][a], Y [a][q], walk axis [q][a] (zero padded 4 x 4)
+__host__ __device__ static inline size_t pencil_state_bytes() { return (size_t)8 * STATE_D2 * 8; }
+
+// lane = (aw, ay, ax) holds ucoef, the coefficient of U at its node (the Dirichlet value there: IGAElementFixValues,
+// src/petigaelem.c:1334-1358); on return geo[point * NC + k] holds the point coefficients (zeros on the padding)
+template <int P, class Form>
+__device__ __forceinline__ void pencil_state_eval(double *geo, const double *d2w, int lane, const double *uxr, const double *vyr, const double *ztg,
+                                                  double wj, double ucoef, const double *prm, double shift, double tt, const double (&xpar)[3]) {
+  constexpr int NB = P + 1, NC = Form::PENCIL_NC;
+  static_assert(NC * 64 <= 64 + 192 + 320, "point coefficients fit the scratch they replace");
+  double *C0 = geo, *T1 = geo + 64, *T2 = geo + 256;
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous element's readers are done
+  C0[lane] = ucoef;
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  {   // axis X: lane (qx = i0, ay = i1, aw = i2)
+    double tv = 0, td = 0, t2 = 0;
+#pragma unroll
+    for (int ax = 0; ax < NB; ++ax) { const double C = C0[(i2 * 4 + i1) * 4 + ax]; tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1]; t2 += C * d2w[i0 * 4 + ax]; }
+    T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td; T1[((2 * 4 + i1) * 4 + i2) * 4 + i0] = t2;
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  {   // axis Y: lane (qx = i0, qy = i1, aw = i2): (value, value), (d/dX, value), (value, d/dY), (d2/dX2, value), (value, d2/dY2)
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+#pragma unroll
+    for (int ay = 0; ay < NB; ++ay) {
+      const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0], e = T1[((2 * 4 + ay) * 4 + i2) * 4 + i0];
+      const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1], y2 = d2w[16 + ay * 4 + i1];
+      m0 += a * yv; m1 += d * yv; m2 += a * yd; m3 += e * yv; m4 += a * y2;
+    }
+    T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
+    T2[((3 * 4 + i2) * 4 + i1) * 4 + i0] = m3; T2[((4 * 4 + i2) * 4 + i1) * 4 + i0] = m4;
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double c[NC];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) c[k] = 0.0;
+  {   // walk axis: lane = point (qx = i0, qy = i1, qw = i2)
+    double u = 0, gu[3] = {0, 0, 0}, hu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int aw = 0; aw < NB; ++aw) {
+      const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
+      const double t3 = T2[((3 * 4 + aw) * 4 + i1) * 4 + i0], t4 = T2[((4 * 4 + aw) * 4 + i1) * 4 + i0];
+      const double zv = ztg[(i2 * 4 + aw) * 2 + 0], zd = ztg[(i2 * 4 + aw) * 2 + 1], z2 = d2w[32 + i2 * 4 + aw];
+      u += t0 * zv; gu[0] += t0 * zd; gu[1] += t1 * zv; gu[2] += t2 * zv; hu[0] += t0 * z2; hu[4] += t3 * zv; hu[8] += t4 * zv;
+    }
+    if (i0 < NB && i1 < NB && i2 < NB) {
+      PtView p; p.x = xpar; p.u = &u; p.ut = nullptr; p.gu = gu; p.hu = hu; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
+      p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+      Form::pencil_coef(p, wj, c);
+    }
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // every lane has read the partial sums
+#pragma unroll
+  for (int k = 0; k < NC; ++k) geo[lane * NC + k] = c[k];
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// the MFMAs of one element of a Tangent: k-step (qw, qy, feature), k slot = qx (lane>>4); all (P+1)^2 tiles
+template <int NB, class Form>
+__device__ __forceinline__ void pencil_mfma_state(d4_t (&acc)[4][4], double u0, double u1, double u2, const double *vy, const double *vy2,
+                                                  const double *ztg, const double *zt2, const double *coef, int lane) {
+  constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+  constexpr bool LAP = NF > 4;
+  const int qx = lane >> 4;
+#pragma unroll 1
+  for (int qw = 0; qw < NB; ++qw) {
+    double z0[NB], z1[NB], z2[NB];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * 4 + t) * 2 + 0]; z1[t] = ztg[(qw * 4 + t) * 2 + 1]; z2[t] = LAP ? zt2[qw * 4 + t] : 0.0; }
+#pragma unroll
+    for (int qy = 0; qy < NB; ++qy) {
+      const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
+      const double *cp = coef + ((qw * 4 + qy) * 4 + qx) * NC;
+      double c[NC];
+#pragma unroll
+      for (int k = 0; k < NC; ++k) c[k] = cp[k];
+      const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1, a_l = LAP ? u2 * vy0 + u0 * vy2[qy] : 0.0;
+      double A[NF][NB], B[NB][NF];
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        A[0][t] = a_n * z0[t]; A[1][t] = a_n * z1[t]; A[2][t] = a_x * z0[t]; A[3][t] = a_y * z0[t];
+        double lap = 0.0;
+        if constexpr (LAP) { lap = a_n * z2[t] + a_l * z0[t]; A[NF - 1][t] = lap; }
+        const double g[3] = {A[1][t], A[2][t], A[3][t]};
+        Form::pencil_trial(c, A[0][t], g, lap, B[t]);
+      }
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int ta = 0; ta < NB; ++ta)
+#pragma unroll
+          for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][ta], B[tb][f], acc[ta][tb], 0, 0, 0);
+    }
+  }
+}
+
 template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
@@ -893,6 +1009,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   constexpr int NB = P + 1, BW = 2 * P + 1;
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
+  constexpr bool STATE = pencil_state_of<Form>::v;             // a Tangent: all tiles, point coefficients from the state (state_pencil)
+  static_assert(!STATE || (IDENT && !SYSTEM), "a Tangent on the walk: no geometry, matrix only");
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -942,6 +1060,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const long long rs[3] = {1, (long long)S.ax[0].nrow, (long long)S.ax[0].nrow * S.ax[1].nrow};
 
   PencilLane L;
+  double *d2w = nullptr; double u2 = 0;      // STATE: second derivatives of the 1-D rows (LDS, per wavefront); this lane's X-row entry
   {
     const double *__restrict__ TX = AX.tab + (size_t)elx * (NB * NB * NDER);
     const double *__restrict__ TY = AY.tab + (size_t)ely * (NB * NB * NDER);
@@ -961,6 +1080,12 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         const int l2 = lane - 32, qq = l2 >> 3, aa = (l2 >> 1) & 3, kk = l2 & 1;
         vyw[8 * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] : 0.0;
       }
+    }
+    if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
+      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P) + pencil_geo_bytes()) + wave * STATE_D2;
+      if (lane < 16) { const int qq = lane >> 2, aa = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TX[(qq * NB + aa) * NDER + 2] : 0.0; }
+      else if (lane < 32) { const int aa = (lane - 16) >> 2, qq = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TY[(qq * NB + aa) * NDER + 2] : 0.0; }
+      if (qx < NB && ix < NB) u2 = TX[(qx * NB + ix) * NDER + 2];
     }
     // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
     const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
@@ -1013,14 +1138,41 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     const int gqx = lane & 3, gqy = (lane >> 2) & 3;
     if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
   }
+  PencilBC bc; bc.any = false; bc.xlo = bc.xhi = bc.ylo = bc.yhi = false; bc.wlo = bc.whi = -1000;
+  bc.vwlo = bc.vwhi = bc.vxlo = bc.vxhi = bc.vylo = bc.vyhi = 0;
+  if (W == 0 && (SYSTEM || STATE)) {
+    bc.xlo = !AX.periodic && S.bcv[X][0].count > 0 && elx + AX.estart == 0;              bc.vxlo = S.bcv[X][0].value[0];
+    bc.xhi = !AX.periodic && S.bcv[X][1].count > 0 && elx + AX.estart == AX.esizes - 1;  bc.vxhi = S.bcv[X][1].value[0];
+    bc.ylo = !AY.periodic && S.bcv[Y][0].count > 0 && ely + AY.estart == 0;              bc.vylo = S.bcv[Y][0].value[0];
+    bc.yhi = !AY.periodic && S.bcv[Y][1].count > 0 && ely + AY.estart == AY.esizes - 1;  bc.vyhi = S.bcv[Y][1].value[0];
+    if (!AW.periodic && S.bcv[W][0].count > 0 && AW.estart == 0) { bc.wlo = AW.off[0]; bc.vwlo = S.bcv[W][0].value[0]; }
+    if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
+    bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
+  }
   auto geometry = [&](int ei) {   // control points, NURBS weights of the lane's basis functions and the metric of element wh + ei
     if constexpr (GEO) {
       // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
       // there stalls the in-order MFMA issue for its whole latency)
       if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
+      if constexpr (STATE) { if (lane >= 32 && lane < 48) { const int l2 = lane - 32, q = l2 >> 2, a = l2 & 3; d2w[lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + 2] : 0.0; } }
       if constexpr (!IDENT) pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
       else { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }     // (the walk-axis rows above)
       const int gqw = lane >> 4;
+      if constexpr (STATE) {
+        // this lane's node (aw, ay, ax) = (lane>>4, (lane>>2)&3, lane&3): coefficient of U, or the Dirichlet value there
+        const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+        double uc = 0.0;
+        if (aw < NB && ay < NB && ax < NB) {
+          const int li = AW.off[wh + ei] + aw - T.lay0;
+          uc = out.U[(long long)T.rho[li] * rs[W] + rs[X] * AX.rowmap[offx + ax] + rs[Y] * AY.rowmap[offy + ay]];
+          double fv = 0;
+          if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = fv;
+        }
+        double xpar[3] = {0, 0, 0};
+        const int gqx = lane & 3, gqy = (lane >> 2) & 3;
+        if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[(wh + ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
+        pencil_state_eval<P, Form>(geo, d2w, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
+      } else
       if constexpr (is_builtin_gram<Form>::v) pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
       else {
         double xpar[3] = {0, 0, 0};
@@ -1034,17 +1186,6 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   };
   geometry(0);
 
-  PencilBC bc; bc.any = false; bc.xlo = bc.xhi = bc.ylo = bc.yhi = false; bc.wlo = bc.whi = -1000;
-  bc.vwlo = bc.vwhi = bc.vxlo = bc.vxhi = bc.vylo = bc.vyhi = 0;
-  if (W == 0 && SYSTEM) {
-    bc.xlo = !AX.periodic && S.bcv[X][0].count > 0 && elx + AX.estart == 0;              bc.vxlo = S.bcv[X][0].value[0];
-    bc.xhi = !AX.periodic && S.bcv[X][1].count > 0 && elx + AX.estart == AX.esizes - 1;  bc.vxhi = S.bcv[X][1].value[0];
-    bc.ylo = !AY.periodic && S.bcv[Y][0].count > 0 && ely + AY.estart == 0;              bc.vylo = S.bcv[Y][0].value[0];
-    bc.yhi = !AY.periodic && S.bcv[Y][1].count > 0 && ely + AY.estart == AY.esizes - 1;  bc.vyhi = S.bcv[Y][1].value[0];
-    if (!AW.periodic && S.bcv[W][0].count > 0 && AW.estart == 0) { bc.wlo = AW.off[0]; bc.vwlo = S.bcv[W][0].value[0]; }
-    if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
-    bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
-  }
   PencilFix<FIXT> fxt;
   if constexpr (FIXT) { fxt.table = S.fixtable; fxt.rmx = AX.rowmap + offx; fxt.rmy = AY.rowmap + offy; fxt.sx = rs[X]; fxt.sy = rs[Y]; fxt.rho = T.rho; fxt.lay0 = T.lay0; fxt.nl = nl; }
   int held[4] = {0, 0, 0, 0};   // elements walked so far that hold the layer in window slot t
@@ -1073,7 +1214,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
       Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
     }
-    if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
+    if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
+    else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM && !GEO) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
@@ -1090,7 +1232,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -1110,7 +1252,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
-        pencil0_leave<SYSTEM, P, FIXT>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
         held[NB - 1] = 0;
@@ -1131,6 +1273,13 @@ form_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
   gram_pencil_body<SYSTEM, 0, P, true, RAT, false, Form, IDENT>(S, out, pa, prm.v);
 }
 
+// the walk for the Tangent of a nonlinear scalar form without a geometry (pencil_state_eval / pencil_mfma_state above)
+template <int P, class Form>
+__global__ void __launch_bounds__(512, 2)
+state_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  gram_pencil_body<false, 0, P, true, false, false, Form, true>(S, out, pa, prm.v);
+}
+
 #ifndef IGX_RTC
 // ------------------------------------------------------------------ dispatch
 
@@ -1149,7 +1298,9 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 }
 
 // a run-time form's instantiation of the walk (rtc.hpp): the module function for this driver / degree / geometry, its parameters
-struct PencilModule { hipFunction_t fn; ParamsDev prm; std::string name; };
+// ... or a compiled-in instantiation for a built-in form (state_pencil: kfn, its extra LDS, flops per element for the roofline line)
+typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
+struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0; };
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 
@@ -1179,7 +1330,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       long long best = -1; int best_n = nseg;
       for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
         const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
-        const size_t lds_n = pencil_lds_bytes(len + 3, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
+        const size_t lds_n = pencil_lds_bytes(len + 3, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);
         // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
         if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
         const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
@@ -1199,8 +1350,11 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0);
-    if (mod) {      // form_pencil<SYSTEM, P, IDENT, RAT, UserForm> of a run-time form: a module function (rtc.hpp)
+    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);
+    if (mod && mod->kfn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mod->kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(mod->kfn, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa, mod->prm);
+    } else if (mod) {      // form_pencil<SYSTEM, P, IDENT, RAT, UserForm> of a run-time form: a module function (rtc.hpp)
       struct { SpaceDev S; OutDev out; PencilArgs pa; ParamsDev prm; } args;
       memset(&args, 0, sizeof(args));
       args.S = S; args.out = out; args.pa = pa; args.prm = mod->prm;
@@ -1394,10 +1548,13 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
   if (!mod && s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
-  if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return no("only System / Matrix drivers");
+  const bool state = mod && mod->state;       // a Tangent (state_pencil): Jacobian / IJacobian drivers, no geometry
+  if (state ? (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) : (out.op != OP_SYSTEM && out.op != OP_MATRIX)) return no("only System / Matrix drivers (a Tangent: Jacobian / IJacobian)");
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
   const bool geo = s.nsd != 0;
   if (geo && s.nsd != 3) return no("mapped geometry of another dimension");
+  if (state && geo) return no("a Tangent on the walk needs the identity geometry");
+  if (state && S.fixtable) return no("a Tangent on the walk with a fix table");
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
   const int deg = s.axis[0].p;
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");
@@ -1489,10 +1646,11 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       run(rest, ft_rest);
     } else run(P, nullptr);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
-    dom.name = std::string(mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
+    dom.name = std::string(state ? "state_pencil<walk=" : mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
     dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 27 * 6);
+    if (state) dom.flop_per_element = mod->flop_per_element;
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
       Box b = all;
@@ -1501,7 +1659,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = (mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;

@@ -1,0 +1,86 @@
+"""GPU parity of state_pencil (petiga_amd/csrc/gram_mfma.hpp): the Tangent of demo/CahnHilliard3D.c:111-179 through
+IGAComputeIJacobian (src/petigats.c:112-170) on the axis-0 pencil walk -- the state's value, gradient and Laplacian at the Gauss
+points by sum factorisation across the wavefront, all (p+1)^2 tile pairs (the Tangent is not symmetric), band rows written once
+per pencil.  Engine vs oracle on identical inputs: pattern bit-exact, values to 1e-11 of max|K| over the rows without a Dirichlet
+condition; a NaN-poisoned matrix comes back with the same bits (first-touch stores reach every entry)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+from common import compare_mats, make_pair
+
+pytestmark = pytest.mark.gpu
+
+CH = (1.5, 200.0, 0.63, 1.0, 1.0 / 48.0, 1.0)
+
+
+def _poison(mat):
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    _, _, val = mat.device_ptrs()
+    assert hip.hipMemset(val, 0xFF, mat.nblocks * mat.bs * mat.bs * 8) == 0
+    assert hip.hipDeviceSynchronize() == 0
+
+
+@pytest.mark.parametrize("p,N,periodic,bc,nseg", [
+    (2, (9, 4, 5), (False, False, False), False, 0),        # demo/CahnHilliard3D.c at p = 2 (config 4's discretisation)
+    (2, (12, 3, 4), (False, False, False), True, 0),        # Dirichlet values on four faces: FixValues + FixJacobian inside the walk
+    (2, (17, 4, 3), (False, False, False), True, 3),        # three segments along the walk
+    (2, (8, 5, 6), (False, True, True), False, 0),          # the demo's periodic box on the two axes the walk does not follow
+    (3, (9, 4, 4), (False, False, False), False, 0),
+    (3, (10, 3, 5), (False, False, True), True, 2),
+])
+def test_cahn_hilliard_tangent_vs_oracle(p, N, periodic, bc, nseg, monkeypatch):
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
+    if bc:
+        for g in (orc, eng):
+            g.set_boundary_value(0, 0, 0, 0.6)
+            g.set_boundary_value(0, 1, 0, 0.66)
+            g.set_boundary_value(1, 1, 0, 0.61)
+            if not periodic[2]:
+                g.set_boundary_value(2, 0, 0, 0.65)
+    ctx = O.CahnHilliardCtx(*CH)
+    rng = np.random.default_rng(3)
+    n = orc.global_size()
+    U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+    eng.set_form("cahnhilliard", CH)
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    _poison(J)
+    eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "state_pencil<CahnHilliard>" in eng.kernel_name(), eng.kernel_name()
+    J_o = orc.compute_ijacobian("orc_form_ch_tangent", ctx, 250.0, V, 0.0, U)
+    compare_mats(J, J_o, 1e-11)
+    rows, cols, vals = J.to_coo_global()
+    _poison(J)
+    eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J)
+    assert np.array_equal(J.to_coo_global()[2], vals)
+
+
+def test_switch_and_fallbacks(monkeypatch):
+    """IGX_STATE_PENCIL=0, a walk axis wrapped inside the rank, a short walk axis and a mapped geometry keep the feature kernel"""
+    from common import warped_geometry
+    ctx = O.CahnHilliardCtx(*CH)
+    for tag, N, periodic, env, geo in (("off", (9, 4, 4), (False,) * 3, "0", False), ("wrapped", (9, 4, 4), (True, False, False), None, False),
+                                       ("short", (5, 4, 4), (False,) * 3, None, False), ("mapped", (9, 4, 4), (False,) * 3, None, True)):
+        if env is None:
+            monkeypatch.delenv("IGX_STATE_PENCIL", raising=False)
+        else:
+            monkeypatch.setenv("IGX_STATE_PENCIL", env)
+        orc, eng = make_pair(3, 1, 2, list(N), periodic=list(periodic))
+        if geo:
+            X, W = warped_geometry(orc, 3, seed=4, rational=False, amp=0.05)
+            orc.set_geometry(X, W); eng.set_geometry(X, W)
+        rng = np.random.default_rng(5)
+        n = orc.global_size()
+        U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+        eng.set_form("cahnhilliard", CH)
+        Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+        eng.compute_ijacobian(10.0, Vv, 0.0, Uv, J)
+        eng.synchronize()
+        assert "state_pencil" not in eng.kernel_name(), (tag, eng.kernel_name())
+        compare_mats(J, orc.compute_ijacobian("orc_form_ch_tangent", ctx, 10.0, V, 0.0, U), 1e-11)
