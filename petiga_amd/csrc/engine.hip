@@ -1068,7 +1068,11 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       const int deg = s.axis[0].p;
       if (s.form == IGX_FORM_CAHNHILLIARD && (deg == 2 || deg == 3)) {
         st.kfn = deg == 2 ? state_pencil<2, FormCahnHilliard<3>> : state_pencil<3, FormCahnHilliard<3>>; st.name = "CahnHilliard";
-        st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * (deg + 1) * (deg + 1) * (deg + 1) * (deg + 1);
+        st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * (deg == 2 ? 7 * 9 : 16 * 16);     // executed: k-steps x tiles x features
+      }
+      if (s.form == IGX_FORM_BRATU && (deg == 2 || deg == 3)) {
+        st.kfn = deg == 2 ? state_pencil<2, FormBratu<3>> : state_pencil<3, FormBratu<3>>; st.name = "Bratu";
+        st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * (deg == 2 ? 7 * 9 : 16 * 16);
       }
       if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes(); for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
     }

@@ -202,6 +202,14 @@ template <int DIM> struct FormBratu {
     for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i];
     T[0] = p.shift * Na[0] * Nb[0] + s - Na[0] * Nb[0] * p.prm[0] * exp(p.u[0]);
   }
+  // the Jacobian on the pencil walk (gram_mfma.hpp, state_pencil): A = (N, grad N), B = (JW (shift - lambda e^u) N, JW grad N)
+  static constexpr int PENCIL_NFEAT = 1 + DIM, PENCIL_NC = 2;
+  static __device__ __forceinline__ void pencil_coef(const PtView &p, double JW, double *c) { c[0] = JW * (p.shift - p.prm[0] * exp(p.u[0])); c[1] = JW; }
+  static __device__ __forceinline__ void pencil_trial(const double *c, double N, const double *g, double, double *B) {
+    B[0] = c[0] * N;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) B[1 + i] = c[1] * g[i];
+  }
 };
 
 // demo/NavierStokesVMS.c:9-244 (Tau, FineScale, Residual, Tangent); params {nu, fx, fy, fz, dt}

@@ -1000,6 +1000,45 @@ __device__ __forceinline__ void pencil_mfma_state(d4_t (&acc)[4][4], double u0, 
   }
 }
 
+// p = 2: the 27 points of an element fill 7 k-steps of 4 (the loop above leaves the fourth k slot of each of its 9 steps empty:
+// 405 MFMAs); point = 4 * step + (lane>>4), so every row is this lane's own LDS read
+template <class Form>
+__device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
+                                                     const double *coef, int lane) {
+  constexpr int NB = 3, NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+  constexpr bool LAP = NF > 4;
+  const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
+#pragma unroll 1
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0, u2 = (on && LAP) ? d2w[qx * 4 + ix] : 0.0;
+    const double vy0 = vyr[(iy * 4 + qy) * 2 + 0], vy1 = vyr[(iy * 4 + qy) * 2 + 1], vy2 = LAP ? d2w[16 + iy * 4 + qy] : 0.0;
+    const double *cp = coef + ((qw * 4 + qy) * 4 + qx) * NC;
+    double c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = cp[k];
+    const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1, a_l = LAP ? u2 * vy0 + u0 * vy2 : 0.0;
+    double A[NF][NB], B[NB][NF];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
+      A[0][t] = a_n * z0; A[1][t] = a_n * z1; A[2][t] = a_x * z0; A[3][t] = a_y * z0;
+      double lap = 0.0;
+      if constexpr (LAP) { lap = a_n * d2w[32 + qw * 4 + t] + a_l * z0; A[NF - 1][t] = lap; }
+      const double g[3] = {A[1][t], A[2][t], A[3][t]};
+      Form::pencil_trial(c, A[0][t], g, lap, B[t]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int ta = 0; ta < NB; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][ta], B[tb][f], acc[ta][tb], 0, 0, 0);
+  }
+}
+
 template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
@@ -1214,7 +1253,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
       Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
     }
-    if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
+    if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
+    else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();

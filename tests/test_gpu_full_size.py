@@ -158,7 +158,7 @@ def test_cahn_hilliard_full_size_properties():
     shift = 250.0
     g.compute_ifunction(shift, V, 0.0, U, b)
     g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
-    assert "feature_assemble" in g.kernel_name()
+    assert "state_pencil" in g.kernel_name()
     w = _int1d(p, N)
     bN = (w[None, None, :] * w[None, :, None] * w[:, None, None]).reshape(-1)
     F = b.get()

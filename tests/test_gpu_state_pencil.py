@@ -61,6 +61,36 @@ def test_cahn_hilliard_tangent_vs_oracle(p, N, periodic, bc, nseg, monkeypatch):
     assert np.array_equal(J.to_coo_global()[2], vals)
 
 
+@pytest.mark.parametrize("p,N,periodic,driver", [
+    (2, (9, 5, 4), (False, False, False), "jacobian"),      # demo/Bratu.c: Dirichlet u = 0 on every face, Jacobian (SNES) driver
+    (3, (8, 4, 5), (False, False, False), "ijacobian"),
+    (2, (11, 4, 6), (False, False, True), "ijacobian"),
+])
+def test_bratu_jacobian_vs_oracle(p, N, periodic, driver):
+    orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
+    for g in (orc, eng):
+        for d in range(3):
+            if not periodic[d]:
+                for side in range(2):
+                    g.set_boundary_value(d, side, 0, 0.1 * d * side)
+    lam = C.c_double(3.5)
+    rng = np.random.default_rng(8)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n)
+    eng.set_form("bratu", (3.5,))
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    _poison(J)
+    if driver == "jacobian":
+        eng.compute_jacobian(Uv, J)
+        J_o = orc.compute_jacobian("orc_form_bratu_jacobian", lam, U)
+    else:
+        eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J)
+        J_o = orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U)
+    eng.synchronize()
+    assert "state_pencil<Bratu>" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-12)
+
+
 def test_switch_and_fallbacks(monkeypatch):
     """IGX_STATE_PENCIL=0, a walk axis wrapped inside the rank, a short walk axis and a mapped geometry keep the feature kernel"""
     from common import warped_geometry
