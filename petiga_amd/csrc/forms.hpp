@@ -125,6 +125,7 @@ template <int DIM> struct FormCahnHilliard {
   static constexpr unsigned hess_diag_mask() { unsigned m = 0; for (int i = 0; i < DIM; ++i) m |= 1u << (1 + DIM + i * (DIM + 1)); return m; }
   static constexpr unsigned MAT_TEST_MASK = 1u | (((1u << DIM) - 1u) << 1) | hess_diag_mask();   // N, grad N, diagonal of hess N (Laplacian)
   static constexpr unsigned PHI_MASK = MAT_TEST_MASK;   // Residual, Tangent and the field values read nothing else (hu: its diagonal)
+  static constexpr unsigned VEC_TEST_MASK = MAT_TEST_MASK;   // the Residual reads the same test features
   static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU;
   struct Coef { double M, dM, d2M, dmu, d2mu, lap, t1; };
   static __device__ __forceinline__ Coef coef(const PtView &p) {

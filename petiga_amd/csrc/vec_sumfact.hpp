@@ -126,10 +126,13 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
   return f;
 }
 
-template <class Form>
+// GEO: a mapped geometry and / or NURBS weights; without them the geometry chain is the identity at compile time (no E1 / E2
+// products, no quotient rule) and the kernel needs half the registers
+template <class Form, bool GEO>
 __global__ void __launch_bounds__(256)
 vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nelem) {
   constexpr int DOF = Form::DOF;
+  constexpr unsigned VMASK = vec_test_mask_of<Form>::v;                  // test features vec() reads (bit f)
   constexpr bool SECOND_T = shape_order_of<Form>::v >= 2;                // second-order test features (identity geometry only)
   constexpr bool NEEDHU = (Form::NEED & NEED_HU) != 0, NEEDGU = (Form::NEED & (NEED_GU | NEED_HU)) != 0;
   constexpr int UORD = NEEDHU ? 2 : (NEEDGU ? 1 : 0);                    // derivative order of the state
@@ -149,7 +152,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
   const int il[3] = {i0, i1, i2};
   const int op = out.op;
-  const bool geo = S.nsd > 0, rat = S.rational != 0;
+  const bool geo = GEO && S.nsd > 0, rat = GEO && S.rational != 0;
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
   int nb[3], nq[3], off[3];
 #pragma unroll
@@ -198,7 +201,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   x[0] = ispoint ? S.ax[0].pt[el[0] * nq[0] + i0] : 0.0; x[1] = ispoint ? S.ax[1].pt[el[1] * nq[1] + i1] : 0.0; x[2] = ispoint ? S.ax[2].pt[el[2] * nq[2] + i2] : 0.0;
   // index of the second derivative (a, b) among the 10
   auto k2 = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
-  if (geo || rat) {
+  if constexpr (GEO) if (geo || rat) {
     double Dw[10], Dx[3][10];
     if (UORD == 2) vs_forward<2>(wgt, buf, tab0, tab1, tab2, lane, Dw); else vs_forward<1>(wgt, buf, tab0, tab1, tab2, lane, Dw);
     const double W0 = ispoint ? Dw[0] : 1.0;
@@ -261,6 +264,10 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       double D[10];
       vs_forward<UORD>((fixed[f] ? ufix[f] : Uv[f]) * wgt, buf, tab0, tab1, tab2, lane, D);
       u[f] = D[0] * iw;
+      if constexpr (!GEO) {
+        if (UORD >= 1) for (int a = 0; a < 3; ++a) gu[f * 3 + a] = D[1 + a];
+        if (UORD == 2) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) hu[f * 9 + a * 3 + b] = D[k2(a, b)];
+      } else
       if (UORD >= 1) {
         double u1[3], u2[9];
 #pragma unroll
@@ -318,6 +325,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
     for (int k = 0; k < 10; ++k) Cq[f][k] = 0.0;
 #pragma unroll
   for (int tf = 0; tf < NFS; ++tf) {
+    if (!((VMASK >> tf) & 1u)) continue;
     double e[NFS], R[DOF];
 #pragma unroll
     for (int g = 0; g < NFS; ++g) e[g] = (g == tf) ? 1.0 : 0.0;
@@ -327,8 +335,11 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       const double r = ispoint ? R[f] * JW : 0.0;      // (a padded lane evaluates vec() on zeros: its value may not even be finite)
       if (tf == 0) Cq[f][0] += r;
       else if (tf < 4) {      // physical gradient component tf-1 -> parametric: d_i R_a = sum_b E1[b][i] d_b R_a
+        if constexpr (!GEO) Cq[f][tf] += r;
+        else {
 #pragma unroll
-        for (int b = 0; b < 3; ++b) Cq[f][1 + b] += E1[b * 3 + (tf - 1)] * r;
+          for (int b = 0; b < 3; ++b) Cq[f][1 + b] += E1[b * 3 + (tf - 1)] * r;
+        }
       } else {                // second-order test feature (a, b): identity geometry (physical = parametric)
         const int a = (tf - 4) / 3, b = (tf - 4) % 3;
         Cq[f][k2(a, b)] += r;
@@ -394,7 +405,8 @@ static int try_vec_sumfact(const Space &s, const SpaceDev &S, const ParamsDev &p
     }
     if (empty) continue;
     const long long nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
-    hipLaunchKernelGGL(vec_sumfact<Form>, dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    if (s.nsd > 0 || s.rational) hipLaunchKernelGGL((vec_sumfact<Form, true>), dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    else hipLaunchKernelGGL((vec_sumfact<Form, false>), dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
     launches++;
   }
   if (hipGetLastError() != hipSuccess) return IGX_ERR_LIB;

@@ -16,7 +16,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC, DST = "gpurun_out/prof", "profiles"
 SIZES = {"poisson": 256, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96}
-KEY = {"poisson": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "feature_assemble", "nsvms": "feature_assemble"}
+KEY = {"poisson": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<"}
 
 
 def pmc(dirs):
