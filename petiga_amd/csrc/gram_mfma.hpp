@@ -1008,7 +1008,7 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
   constexpr int NB = 3, NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < 7; ++j) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
