@@ -289,7 +289,7 @@ __device__ __forceinline__ PencilLds pencil_lds_carve(double *sm, int ne_max, bo
 __host__ __device__ static inline size_t pencil_lds_bytes(int ne_max, bool geo = false) {
   const int nl = ne_max + 3;
   const size_t tables = (size_t)((geo ? 0 : ne_max * 32) + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
-  return ((tables + 15) & ~(size_t)15) + (geo ? 2 : 1) * 8 * 32 * 8;   // + per-wavefront Y-axis (geo: and X-axis) basis rows [8 waves][4 a][4 q][2]
+  return ((tables + 15) & ~(size_t)15) + 2 * 8 * 32 * 8;   // + per-wavefront Y-axis and X-axis basis rows [8 waves][4 a][4 q][2]
 }
 // mapped geometry: per-wavefront [64 points][7] (JW * F^-1 F^-T: 00,01,02,11,12,22; forcing * JW / W) + [64][4] (1/W, dW/W);
 // the element's control points (homogeneous, [aw][ay][ax][4]) are staged at its start and overwritten by the results
@@ -325,6 +325,31 @@ __device__ __forceinline__ void pencil_mfma(d4_t (&acc)[4][4], const PencilLane 
             acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[ta], op[tb], acc[ta][tb], 0, 0, 0);
       }
     }
+  }
+}
+
+// p = 2: the k-step (qw, qy, alpha) with k slot qx leaves one slot in four empty (27 x 6 = 162 MFMAs per element); numbering the 27
+// points 4 per k-step -- point = 4 * step + (lane>>4), every row value the lane's own LDS read -- takes 7 x 3 x 6 = 126
+__device__ __forceinline__ void pencil_mfma_p2(d4_t (&acc)[4][4], const double *uxs /*LDS [q][a][2], pre-scaled*/, const double *vy /*this lane's [q][2]*/,
+                                               const double *zt /*LDS [q][a][2], pre-scaled*/, int lane) {
+  const int ks = lane >> 4, ix = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double u0 = on ? uxs[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxs[(qx * 4 + ix) * 2 + 1] : 0.0;
+    const double v0 = vy[qy * 2 + 0], v1 = vy[qy * 2 + 1];
+    const double cw = u0 * v0, cx = u1 * v0, cy = u0 * v1;
+    double op[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { const double z0 = zt[(qw * 4 + t) * 2 + 0], z1 = zt[(qw * 4 + t) * 2 + 1]; op[0][t] = cw * z1; op[1][t] = cx * z0; op[2][t] = cy * z0; }
+#pragma unroll
+    for (int al = 0; al < 3; ++al)
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[al][ta], op[al][tb], acc[ta][tb], 0, 0, 0);
   }
 }
 
@@ -873,6 +898,48 @@ __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, do
   }
 }
 
+// p = 2 on a mapped geometry: 27 points in 7 k-steps (see pencil_mfma_p2): 126 MFMAs per element instead of 162
+template <bool RAT>
+__device__ __forceinline__ void pencil_mfma_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vy, const double *ztg,
+                                                   const double *geo, int lane, const double (&wt)[4]) {
+  const int ks = lane >> 4, ix = lane & 3;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0;
+    const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
+    const int p = (qw * 4 + qy) * 4 + qx;
+    const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
+    const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
+    const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
+    double g0[3], g1[3], g2[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      const double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
+      g0[t] = a_n * z1; g1[t] = a_x * z0; g2[t] = a_y * z0;
+      if (RAT) {
+        const double n = a_n * z0, sc = wt[t] * Rp[0];
+        g0[t] = sc * (g0[t] - n * Rp[1]); g1[t] = sc * (g1[t] - n * Rp[2]); g2[t] = sc * (g2[t] - n * Rp[3]);
+      }
+    }
+#pragma unroll
+    for (int be = 0; be < 3; ++be) {
+      const double ma = (be == 0) ? m00 : (be == 1 ? m01 : m02), mb = (be == 0) ? m01 : (be == 1 ? m11 : m12), mc = (be == 0) ? m02 : (be == 1 ? m12 : m22);
+      double B[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) B[t] = ma * g0[t] + mb * g1[t] + mc * g2[t];
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta) {
+        const double A = (be == 0) ? g0[ta] : (be == 1 ? g1[ta] : g2[ta]);
+#pragma unroll
+        for (int tb = ta; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B[tb], acc[ta][tb], 0, 0, 0);
+      }
+    }
+  }
+}
+
 // F_a += w_a sum_q (forcing JW / W)_q N_a(q) for the F lane (fx, fy, slot): the sum factorises over the axes
 template <int NB>
 __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, const double *uxr, const double *vyr, const double *ztg) {
@@ -1109,15 +1176,15 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     L.u0 = 0; L.u1 = 0;
     if (qx < NB && ix < NB) { const double sx = GEO ? 1.0 : sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * NB + ix) * NDER + 0] * sx; L.u1 = TX[(qx * NB + ix) * NDER + 1] * sx; }
     {   // Y-axis rows of this pencil -> LDS [a][q][2] (zero padded); a lane later reads its own row (a = iy) one q at a time
-      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max, GEO) - (GEO ? 2 : 1) * 8 * 32 * 8))) + wave * 32;
+      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max, GEO) - 2 * 8 * 32 * 8))) + wave * 32;
       if (lane < 32) {
         const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1;
         vyw[lane] = (aa < NB && qq < NB) ? TY[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WYq[qq] * AY.J[ely])) : 0.0;
       }
       L.vy = vyw + iy * 8;
-      if (GEO && lane >= 32) {   // X-axis rows [q][a][2], unscaled, for the geometry evaluation and F
+      if (lane >= 32) {   // X-axis rows [q][a][2]: GEO unscaled, for the geometry evaluation and F; else scaled like u0 / u1 (p = 2: packed k-steps)
         const int l2 = lane - 32, qq = l2 >> 3, aa = (l2 >> 1) & 3, kk = l2 & 1;
-        vyw[8 * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] : 0.0;
+        vyw[8 * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WX[qq] * AX.J[elx])) : 0.0;
       }
     }
     if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
@@ -1255,7 +1322,9 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     }
     if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
+    else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
     else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
+    else if constexpr (P == 2 && W == 0) pencil_mfma_p2(acc, L.vy - ((lane >> 2) & 3) * 8 + 8 * 32, L.vy, zt, lane);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM && !GEO) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
@@ -1689,7 +1758,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     dom.name = std::string(state ? "state_pencil<walk=" : mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
-    dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 27 * 6);
+    dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 21 * 6);
     if (state) dom.flop_per_element = mod->flop_per_element;
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
