@@ -143,7 +143,13 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * walk of the headline kernel in 3-D at p = 2, 3 (form_pencil<MyForm>: combined band rows, first-touch stores, the Dirichlet
  * fix-up inside the walk, identity or mapped / NURBS geometry) instead of the element mode: IGXSetKernel(2) insists on it.
  *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
- *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only */
+ *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only
+ * Boundary-form passes (IGXSetBoundaryForm; `if (p->atboundary)` in the reference's callback, e.g. demo/NitscheMethod.c:69-110): a
+ * struct that declares
+ *       static constexpr bool HAS_BOUNDARY = true;
+ *       static __device__ void bmat(const PtView &p,const double *Na,const double *Nb,double *T);   // the integrands at a point of a
+ *       static __device__ void bvec(const PtView &p,const double *Na,double *R);                    // visited face (p.normal, p.boundary_id)
+ * is integrated with bmat / bvec over the visited faces; a struct without them with its ordinary mat / vec, as the reference would. */
 int IGXSetFormSource(IGX iga,const char *source,const char *struct_name,const double params[],int nparams);
 
 /* On-disk formats (PETSc binary, big-endian): the discretisation + NURBS control net written by IGAWrite / igakit,
@@ -241,6 +247,13 @@ int IGXComputeIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXMat J);  
  * Sums are formed in a fixed order: bitwise repeatable. */
 typedef enum { IGX_SCALAR_VOLUME = 1, IGX_SCALAR_X2ERR = 2, IGX_SCALAR_ERRNORM = 3 } IGXScalarKind;
 int IGXComputeScalar(IGX iga,IGXVec U,int kind,const double params[],int nparams,int n,double S[]);
+/* ... with the user's own point functional (IGAFormScalar, include/petiga.h:188-191; IGAComputeScalar's `Scalar` argument,
+ * src/petigacomp.c:35) given as HIP source and compiled at run time like a form of IGXSetFormSource: a struct with
+ *   static constexpr int DOF, ORDER, NSCALAR (= n); static constexpr unsigned NEED;
+ *   static __device__ void scalar(const igx::PtView &p, double *S);     // un-weighted integrand values at the point
+ * p carries x, u, grad u, hess u as NEED asks, prm = params, and atboundary / normal / boundary_id on the passes over faces marked
+ * with IGXSetBoundaryForm (an error norm is this with |Exact(x) - u|^2: IGAComputeErrorNorm, src/petigacomp.c:122-186). */
+int IGXComputeScalarSource(IGX iga,IGXVec U,const char *source,const char *struct_name,const double params[],int nparams,int n,double S[]);
 
 /* engine controls */
 int IGXSetStream(IGX iga,void *hipStream);      /* hipStream_t; NULL = default stream            */

@@ -72,6 +72,7 @@ def lib(build_if_needed=False):
         "IGXAxisInitUniform": [V, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], "IGXAxisSetKnots": [V, C.c_int, C.c_int, _dp],
         "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp],
         "IGXComputeScalar": [V, V, C.c_int, _dp, C.c_int, C.c_int, _dp],
+        "IGXComputeScalarSource": [V, V, C.c_char_p, C.c_char_p, _dp, C.c_int, C.c_int, _dp],
         "IGXRead": [V, C.c_char_p], "IGXWrite": [V, C.c_char_p], "IGXWriteVec": [V, V, C.c_char_p], "IGXReadVec": [V, V, C.c_char_p],
         "IGXSetBoundaryValue": [V, C.c_int, C.c_int, C.c_int, C.c_double], "IGXSetBoundaryLoad": [V, C.c_int, C.c_int, C.c_int, C.c_double],
         "IGXClearBoundary": [V], "IGXSetBoundaryForm": [V, C.c_int, C.c_int, C.c_int], "IGXSetFixTable": [V, V], "IGXSetForm": [V, C.c_int, _dp, C.c_int],
@@ -344,6 +345,14 @@ class IGX:
         out = np.zeros(n)
         p = np.ascontiguousarray(params, dtype=np.float64)
         _ck(lib().IGXComputeScalar(self.h, U.h if U is not None else None, k, p.ctypes.data_as(_dp) if p.size else None, p.size, n, out.ctypes.data_as(_dp)))
+        return out
+
+    def compute_scalar_source(self, source, struct_name, n, U=None, params=()):
+        """IGAComputeScalar with the user's point functional as HIP source (a struct with NSCALAR = n and scalar(p, S))."""
+        out = np.zeros(n)
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        _ck(lib().IGXComputeScalarSource(self.h, U.h if U is not None else None, source.encode(), struct_name.encode(),
+                                         p.ctypes.data_as(_dp) if p.size else None, p.size, n, out.ctypes.data_as(_dp)))
         return out
 
     def element_count(self): return lib().IGXGetElementCount(self.h)

@@ -226,7 +226,7 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const
   const double *zt = rec + 64 * NPD, *wts = zt + 32;
   const int qx = lane >> 4;
   const double wa = RAT ? wts[ta * 16 + (lane & 15)] : 1.0, wb = RAT ? wts[tb * 16 + (lane & 15)] : 1.0;
-#pragma unroll 1
+#pragma unroll 2
   for (int qw = 0; qw < 4; ++qw) {
     const double zA0 = zt[(qw * 4 + ta) * 2 + 0], zA1 = zt[(qw * 4 + ta) * 2 + 1];
     const double zB0 = zt[(qw * 4 + tb) * 2 + 0], zB1 = zt[(qw * 4 + tb) * 2 + 1];

@@ -81,6 +81,7 @@ struct _p_IGX {
   // ranks): IGXReduceGhostRows starts the messages of that face behind it, under the launches of the other elements
   hipEvent_t slab_ev = nullptr; bool slab_valid = false; IGXMat slab_A = nullptr; IGXVec slab_b = nullptr;
   std::shared_ptr<RtcForm> rtc; std::string rtc_source, rtc_name;   // run-time compiled user form (rtc.hpp)
+  std::shared_ptr<RtcForm> rtc_scalar;                              // ... and the last user functional (IGXComputeScalarSource)
 };
 
 struct _p_IGXMat {

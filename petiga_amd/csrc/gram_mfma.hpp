@@ -858,7 +858,7 @@ template <int NB, bool RAT>
 __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *ztg,
                                                 const double *geo, int lane, const double (&wt)[4]) {
   const int qx = lane >> 4;
-#pragma unroll 1
+#pragma unroll 2
   for (int qw = 0; qw < NB; ++qw) {
     double z0[NB], z1[NB];
 #pragma unroll

@@ -330,6 +330,37 @@ static int launch_feature_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
       launches++;
     }
   }
+  // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447), as launch_feature_plan makes them for a built-in form: the
+  // elements of this rank on a visited face, one point layer at the face, added to what the interior pass left (no first touch)
+  for (int bid = 0; bid < 2 * DIM; ++bid) {
+    const int ax = bid / 2, sd = bid % 2;
+    if (!s.visit[ax][sd]) continue;
+    const int eface = sd ? s.elem_sizes[ax] - 1 : 0;
+    if (eface < s.elem_start[ax] || eface >= s.elem_start[ax] + s.elem_width[ax]) continue;   // the face is on another rank
+    RtcFeatArgs fa = args; fa.out.bid = bid; fa.out.first_touch = 0;
+    int nc2[3] = {nc[0], nc[1], nc[2]}; nc2[ax] = 1;
+    for (int c2 = 0; c2 < nc2[2]; ++c2) for (int c1 = 0; c1 < nc2[1]; ++c1) for (int c0 = 0; c0 < nc2[0]; ++c0) {
+      const int cc[3] = {c0, c1, c2};
+      ColorRange cr; bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        if (d == ax) { cr.start[d] = eface - s.elem_start[ax]; cr.step[d] = 1; cr.count[d] = 1; continue; }
+        const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+        int firstel = -1, count = 0;
+        for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (firstel < 0) firstel = e; count++; }
+        if (count == 0) { empty = true; break; }
+        cr.start[d] = firstel; cr.step[d] = L.p + 1; cr.count[d] = count;
+      }
+      if (empty) continue;
+      fa.cr = cr;
+      const size_t nblocks = (size_t)cr.count[0] * cr.count[1] * cr.count[2];
+      for (hipFunction_t fn : K->func) {
+        size_t asz = sizeof(fa);
+        void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &fa, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+        HIPCK(hipModuleLaunchKernel(fn, (unsigned)nblocks, 1, 1, (unsigned)(64 * NW), 1, 1, (unsigned)lds_bytes, g->stream, nullptr, cfg));
+        launches++;
+      }
+    }
+  }
   g->last_launches = launches;
   if (g->dom.launches == 0) {
     if (g->timing && g->dom.ev1) (void)hipEventRecord(g->dom.ev1, g->stream);
@@ -390,6 +421,7 @@ static int launch_pencil_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev 
   return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
 }
 
+static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out);
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
@@ -400,10 +432,9 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   }
   RtcForm &F = *g->rtc;
   if (int rc = rtc_load(g, F)) return rc;
-  const int DOF = F.meta[0], DIM = s.dim; const bool SECOND = F.meta[1] >= 2; const unsigned NEED = (unsigned)F.meta[2];
-  if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "run-time forms are matrix / vector forms (no scalar functionals)");
+  const int DOF = F.meta[0];
+  if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "a struct with NSCALAR is a functional: IGXComputeScalarSource");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
-  for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return fail(IGX_ERR_SUP, "boundary-form passes are not available for run-time forms");
   if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // scalar symmetric gradient forms: the pencil walk (combine before write)
     bool done = false;
     if (int rc = launch_pencil_rtc(g, F, S, out, done)) return rc;
@@ -416,8 +447,16 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64; nen <= 128 with dof <= 2 and nen <= 256 with dof 1 in 3-D, no MAT_PAIR_MASK there)");
   }
-  const int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   if (g->zero_matrix) g->zero_matrix();
+  return rtc_generic_launch(g, F, S, out);
+}
+
+// the point-form kernel of a run-time struct: matrix / vector forms (coloured sweeps + boundary-form passes) and functionals
+// (NSCALAR > 0: one sweep, a row of partial sums per element, as launch_generic does for the built-in ones)
+static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out) {
+  Space &s = g->s;
+  const int DOF = F.meta[0], DIM = s.dim, NS = F.meta[3]; const bool SECOND = F.meta[1] >= 2; const unsigned NEED = (unsigned)F.meta[2];
+  const int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
   const bool fields = (NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
@@ -431,7 +470,7 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.G = take((NEED & NEED_G) ? NQ * D2 : 0);
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((NEED & NEED_HU) ? NQ * DOF * D2 : 0);
-  cv.lift = take(out.op == OP_SYSTEM ? NQ * DOF * NF : 0);
+  cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
   cv.nrm = take(NQ * DIM);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   const size_t lds_limit = 64 * 1024;   // as launch_generic: beyond it Phi goes to an HBM slice and two workgroups share a CU
@@ -447,18 +486,10 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   size_t max_blocks = phi_in_lds ? ((size_t)1 << 30) : scratch_cap / (phi_doubles * sizeof(double));
   if (max_blocks < 1) max_blocks = 1;
   int launches = 0;
-  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
-  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
-    const int cc[3] = {c0, c1, c2};
-    ColorRange cr; bool empty = false;
-    for (int d = 0; d < 3; ++d) {
-      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
-      int first = -1, count = 0;
-      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
-      if (count == 0) { empty = true; break; }
-      cr.start[d] = first; cr.step[d] = L.p + 1; cr.count[d] = count;
-    }
-    if (empty) continue;
+  int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  if (NS > 0) nc[0] = nc[1] = nc[2] = 1;   // nothing is scattered: every element in one sweep
+  int64_t elem_base = 0;
+  auto sweep = [&](ColorRange cr, int bid) -> int {      // one colour (or face layer), split along axis 2 under the scratch cap
     const size_t per2 = (size_t)cr.count[0] * cr.count[1];
     const int chunk2 = (int)std::max<size_t>(1, std::min<size_t>((size_t)cr.count[2], max_blocks / std::max<size_t>(per2, 1)));
     if (!phi_in_lds && per2 > max_blocks) return fail(IGX_ERR_SUP, "scratch too small for one element layer");
@@ -469,11 +500,50 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
         const size_t need = nblocks * phi_doubles * sizeof(double);
         if (g->scratch.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->scratch.alloc(need)) return fail(IGX_ERR_MEM, "scratch allocation failed"); }
       }
-      args.cr = sub; args.phi_global = g->scratch.as<double>();
+      args.cr = sub; args.phi_global = g->scratch.as<double>(); args.out.bid = bid; args.out.elem_base = elem_base; elem_base += (int64_t)nblocks;
       size_t asz = sizeof(args);
       void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
       HIPCK(hipModuleLaunchKernel(F.func, (unsigned)nblocks, 1, 1, 256, 1, 1, (unsigned)lds_bytes, g->stream, nullptr, cfg));
       launches++;
+    }
+    return 0;
+  };
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+      int first = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+      if (NS > 0) { first = 0; count = nel; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = first; cr.step[d] = (NS > 0) ? 1 : L.p + 1; cr.count[d] = count;
+    }
+    if (empty) continue;
+    if (int rc = sweep(cr, -1)) return rc;
+  }
+  // boundary-form passes (IGAElementNextForm, src/petigaelem.c:427-447): the elements of this rank on a visited face, one point
+  // layer at the face; a struct with an atboundary branch supplies bmat / bvec (HAS_BOUNDARY), any other is integrated over the face
+  for (int bid = 0; bid < 2 * DIM; ++bid) {
+    const int ax = bid / 2, sd = bid % 2;
+    if (!s.visit[ax][sd]) continue;
+    const int eface = sd ? s.elem_sizes[ax] - 1 : 0;
+    if (eface < s.elem_start[ax] || eface >= s.elem_start[ax] + s.elem_width[ax]) continue;   // the face is on another rank
+    int nc2[3] = {nc[0], nc[1], nc[2]}; nc2[ax] = 1;
+    for (int c2 = 0; c2 < nc2[2]; ++c2) for (int c1 = 0; c1 < nc2[1]; ++c1) for (int c0 = 0; c0 < nc2[0]; ++c0) {
+      const int cc[3] = {c0, c1, c2};
+      ColorRange cr; bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        if (d == ax) { cr.start[d] = eface - s.elem_start[ax]; cr.step[d] = 1; cr.count[d] = 1; continue; }
+        const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+        int first = -1, count = 0;
+        for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+        if (NS > 0) { first = 0; count = nel; }
+        if (count == 0) { empty = true; break; }
+        cr.start[d] = first; cr.step[d] = (NS > 0) ? 1 : L.p + 1; cr.count[d] = count;
+      }
+      if (empty) continue;
+      if (int rc = sweep(cr, bid)) return rc;
     }
   }
   g->last_launches = launches;
@@ -490,6 +560,59 @@ extern "C" int IGXSetFormSource(IGX g, const char *source, const char *struct_na
   if (int rc = rtc_compile(g, source, struct_name, g->s.dim, f)) return rc;     // compile errors surface here, with the log
   g->rtc = f; g->rtc_source = source; g->rtc_name = struct_name;
   g->s.form = IGX_FORM_SOURCE; g->s.params.assign(params ? params : nullptr, params ? params + nparams : nullptr);
+  return 0;
+}
+
+// IGAComputeScalar (src/petigacomp.c:35-98) with the user's point functional given as source: a struct with DOF, ORDER, NEED,
+// NSCALAR = n and scalar(p, S) -- the un-weighted integrand values at a point (IGAFormScalar, include/petiga.h:188-191); the
+// engine multiplies by JW and sums over the rank's elements and, for visited faces, over their boundary passes (p.atboundary).
+extern "C" int IGXComputeScalarSource(IGX g, IGXVec U, const char *source, const char *struct_name, const double params[], int nparams, int n, double S[]) {
+  NEEDIGA(g);
+  if (!source || !struct_name || !*struct_name) return fail(IGX_ERR_ARG_WRONG, "null source / struct name");
+  if (!S || n < 1) return fail(IGX_ERR_ARG_WRONG, "null result array");
+  if (nparams < 0 || nparams > MAXPARAM || (nparams && !params)) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad parameter list");
+  if (int rc = ensure_device(g)) return rc;
+  Space &s = g->s;
+  if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
+  // (one compiled functional is kept per IGX: the same source and struct are not compiled twice)
+  if (!g->rtc_scalar || g->rtc_scalar->source != source || g->rtc_scalar->name != struct_name || g->rtc_scalar->dim != s.dim) {
+    std::shared_ptr<RtcForm> f;
+    if (int rc = rtc_compile(g, source, struct_name, s.dim, f)) return rc;
+    g->rtc_scalar = f;
+  }
+  RtcForm &F = *g->rtc_scalar;
+  if (int rc = rtc_load(g, F)) return rc;
+  const int ns = F.meta[3];
+  if (ns < 1) return fail(IGX_ERR_ARG_WRONG, "the struct is not a functional (no NSCALAR)");
+  if (n != ns) return fail(IGX_ERR_ARG_WRONG, "this functional returns " + std::to_string(ns) + " scalars");
+  if (F.meta[0] != s.dof) return fail(IGX_ERR_ARG_WRONG, "functional does not match the number of fields (dof)");
+  if (((unsigned)F.meta[2] & (NEED_U | NEED_GU | NEED_HU)) && !U) return fail(IGX_ERR_ARG_WRONG, "the functional reads the state: null vector");
+  int64_t nel = (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
+  for (int a = 0; a < s.dim; ++a) for (int sd = 0; sd < 2; ++sd) {   // one more partial row per element of a visited face
+    const int eface = sd ? s.elem_sizes[a] - 1 : 0;
+    if (s.visit[a][sd] && eface >= s.elem_start[a] && eface < s.elem_start[a] + s.elem_width[a]) nel += (int64_t)s.elem_width[0] * s.elem_width[1] * s.elem_width[2] / s.elem_width[a];
+  }
+  const int nblk = (int)std::min<int64_t>(1024, (nel + 255) / 256);
+  const int64_t chunk = (nel + nblk - 1) / nblk;
+  const size_t need = ((size_t)nel + nblk + 1) * ns * sizeof(double);
+  if (g->partials.bytes < need) { HIPCK(hipStreamSynchronize(g->stream)); if (g->partials.alloc(need)) return fail(IGX_ERR_MEM, "partial-sum buffer allocation failed"); }
+  double *part = g->partials.as<double>(), *stage = part + (size_t)nel * ns, *res = stage + (size_t)nblk * ns;
+  HIPCK(hipMemsetAsync(part, 0, (size_t)nel * ns * sizeof(double), g->stream));
+  OutDev out; memset(&out, 0, sizeof(out));
+  out.op = OP_SCALAR; out.bid = -1; out.errflag = g->errflag.as<int>(); out.vec = part; out.U = U ? U->a.as<double>() : nullptr;
+  const SpaceDev Sd = make_spacedev(g);
+  const std::vector<double> keep = s.params;
+  s.params.assign(params ? params : nullptr, params ? params + nparams : nullptr);
+  const int rc = rtc_generic_launch(g, F, Sd, out);
+  s.params = keep;
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_partials, dim3(nblk), dim3(256), 0, g->stream, part, nel, ns, stage, chunk);
+  hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, g->stream, stage, (int64_t)nblk, ns, res, (int64_t)nblk);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(S, res, ns * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+  HIPCK(hipStreamSynchronize(g->stream));
+  int flag = 0; HIPCK(hipMemcpy(&flag, g->errflag.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) { HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); return fail(flag, "Non-positive det(Jacobian) of the geometry mapping"); }
   return 0;
 }
 

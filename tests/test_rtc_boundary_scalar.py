@@ -1,0 +1,215 @@
+"""Run-time forms to parity with the built-in ones: boundary-form passes (IGAElementNextForm,
+src/petigaelem.c:427-447; `if (p->atboundary)` in the callback) and user functionals (IGAComputeScalar's `Scalar` argument,
+src/petigacomp.c:35-98) for structs given as HIP source.  demo/NitscheMethod.c and demo/BoundaryIntegral.c as source against
+the oracle's restatement of the same callbacks, on both device kernels; the functionals of test/IGAFixTable.c (ErrorSqr) and
+test/IGAGeometryMap.c (volume / area) as source against the oracle and the built-in kinds."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+from common import compare_mats, make_pair, rel_err, warped_geometry
+
+NITSCHE = r"""
+// demo/NitscheMethod.c:69-110 as user source: Poisson inside (f = -2 dim), u = sum x_i^2 imposed weakly on the visited faces;
+// params = {k = max degree}
+template <int DIM> struct UserNitsche {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_X | NEED_G;
+  static constexpr bool HAS_BOUNDARY = true;
+  static __device__ void mat(const PtView &, const double *Na, const double *Nb, double *T) {
+    double s = 0; for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i];
+    T[0] = s;
+  }
+  static __device__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0] * (-2.0 * DIM); }
+  static __device__ double alpha(const PtView &p) {      // C / h with h = NormalMeshSize (:57-66)
+    double s = 0;
+    for (int i = 0; i < DIM; ++i) { double Ni = 0; for (int j = 0; j < DIM; ++j) Ni += p.G[i * DIM + j] * p.normal[j]; s += Ni * Ni; }
+    return 5 * (p.prm[0] + 1) / (2 / sqrt(s));
+  }
+  static __device__ void bmat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double dna = 0, dnb = 0;
+    for (int i = 0; i < DIM; ++i) { dna += Na[1 + i] * p.normal[i]; dnb += Nb[1 + i] * p.normal[i]; }
+    T[0] = -Na[0] * dnb - Nb[0] * dna + alpha(p) * Na[0] * Nb[0];
+  }
+  static __device__ void bvec(const PtView &p, const double *Na, double *R) {
+    double g = 0, dna = 0;
+    for (int i = 0; i < DIM; ++i) { g += p.x[i] * p.x[i]; dna += Na[1 + i] * p.normal[i]; }
+    R[0] = -dna * g + alpha(p) * Na[0] * g;
+  }
+};
+"""
+
+BOUNDARY_INTEGRAL = r"""
+// demo/BoundaryIntegral.c:26-56 as user source: Laplace inside (F = 0), Neumann data 1 on the visited faces
+template <int DIM> struct UserBoundaryIntegral {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr bool HAS_BOUNDARY = true;
+  static __device__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { double s = 0; for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i]; T[0] = s; }
+  static __device__ void vec(const PtView &, const double *, double *R) { R[0] = 0.0; }
+  static __device__ void bmat(const PtView &, const double *, const double *, double *T) { T[0] = 0.0; }
+  static __device__ void bvec(const PtView &, const double *Na, double *R) { R[0] = Na[0]; }
+};
+"""
+
+PLAIN_MASS = r"""
+// no atboundary branch: the ordinary integrand is integrated over the visited faces too (test/IGACreate.c:45-63 System)
+struct UserMass {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;
+  static __device__ void mat(const PtView &, const double *Na, const double *Nb, double *T) { T[0] = Na[0] * Nb[0]; }
+  static __device__ void vec(const PtView &, const double *Na, double *R) { R[0] = Na[0]; }
+};
+"""
+
+FUNCTIONALS = r"""
+// test/IGAFixTable.c:66 + src/petigacomp.c:102 (ErrorSqr): |sum x_i^2 - u|^2
+template <int DIM> struct UserX2Err {
+  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 1; static constexpr unsigned NEED = NEED_X | NEED_U;
+  static __device__ void scalar(const PtView &p, double *S) { double g = 0; for (int i = 0; i < DIM; ++i) g += p.x[i] * p.x[i]; const double e = fabs(g - p.u[0]); S[0] = e * e; }
+};
+// test/IGAGeometryMap.c:383-389: volume inside, area on the visited faces; a third number with the state and a parameter:
+// int (prm0 u^2 + |grad u|^2) over the domain
+template <int DIM> struct UserMeasures {
+  static constexpr int DOF = 1, ORDER = 1, NSCALAR = 3; static constexpr unsigned NEED = NEED_U | NEED_GU;
+  static __device__ void scalar(const PtView &p, double *S) {
+    S[0] = p.atboundary ? 0.0 : 1.0; S[1] = p.atboundary ? 1.0 : 0.0;
+    double g2 = 0; for (int i = 0; i < DIM; ++i) g2 += p.gu[i] * p.gu[i];
+    S[2] = p.atboundary ? 0.0 : p.prm[0] * p.u[0] * p.u[0] + g2;
+  }
+};
+"""
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+def test_boundary_structs_compile_without_a_gpu(dim):
+    """IGXSetFormSource + IGXCheckFormSource: the point-form and the matrix-core instantiations with the bmat / bvec branch"""
+    import petiga_amd as P
+    g = P.IGX(dim, 1)
+    for i in range(dim):
+        g.axis_uniform(i, 2, 4)
+    g.set_form_source(NITSCHE, "UserNitsche<%d>" % dim, (2.0,))
+    g.check_form_source(True, False)
+    g.check_form_source(False, False)
+
+
+def _faces(objs, dim, faces=None):
+    for g in objs:
+        for a in range(dim):
+            for s in range(2):
+                if faces is None or (a, s) in faces:
+                    g.set_boundary_form(a, s, True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("dim,p,N,geo", [(1, 2, 8, None), (2, 2, 9, None), (2, 3, 5, "nurbs"), (3, 2, 4, None), (3, 3, 3, "nurbs"), (3, 4, 2, "poly")])
+def test_nitsche_as_source_matches_oracle(dim, p, N, geo, kernel):
+    orc, eng = make_pair(dim, 1, p, N)
+    eng.set_kernel(kernel)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=4, rational=(geo == "nurbs"), amp=0.1)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    _faces((orc, eng), dim)
+    Ao, bo = orc.compute_system("orc_form_nitsche", C.c_int(p))
+    eng.set_form_source(NITSCHE, "UserNitsche<%d>" % dim, (float(p),))
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "hiprtc" in eng.kernel_name() and (("generic_assemble" in eng.kernel_name()) == (kernel == 1 or dim == 1))
+    compare_mats(A, Ao, 1e-11)
+    assert rel_err(b.get(), bo) < 1e-11
+    # the drivers that apply no Dirichlet fix-up make the same passes
+    eng.compute_matrix(A); eng.compute_vector(b); eng.synchronize()
+    compare_mats(A, Ao, 1e-11)
+    assert rel_err(b.get(), bo) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+@pytest.mark.parametrize("dim,axis,side,geo", [(2, 0, 1, None), (2, 1, 0, "nurbs"), (3, 2, 1, None), (3, 0, 0, "poly")])
+def test_boundary_integral_as_source_matches_oracle(dim, axis, side, geo, kernel):
+    orc, eng = make_pair(dim, 1, 2, 6 if dim == 2 else 4)
+    eng.set_kernel(kernel)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=9, rational=(geo == "nurbs"), amp=0.1)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    for g in (orc, eng):
+        g.set_boundary_value(axis, 1 - side, 0, 1.0)      # demo/BoundaryIntegral.c:172-176
+        g.set_boundary_form(axis, side, True)
+    Ao, bo = orc.compute_system("orc_form_boundary_integral")
+    eng.set_form_source(BOUNDARY_INTEGRAL, "UserBoundaryIntegral<%d>" % dim)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    compare_mats(A, Ao, 1e-12)
+    assert rel_err(b.get(), bo) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_struct_without_a_boundary_branch_is_integrated_over_the_face(kernel):
+    """src/petigaelem.c:427-447: the same callback is called on the face; only `atboundary` tells it"""
+    orc, eng = make_pair(3, 1, 2, [3, 4, 3])
+    eng.set_kernel(kernel)
+    X, W = warped_geometry(orc, 3, seed=2, rational=True, amp=0.08)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    _faces((orc, eng), 3, {(0, 1), (2, 0)})
+    Ao, bo = orc.compute_system("orc_form_mass")
+    eng.set_form_source(PLAIN_MASS, "UserMass")
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    compare_mats(A, Ao, 1e-12)
+    assert rel_err(b.get(), bo) < 1e-12
+
+
+@pytest.mark.gpu
+def test_pencil_walk_declines_a_visited_face():
+    """a run-time form that would take the pencil walk stays on the element kernels when a face is visited"""
+    from test_rtc_forms import USER_POISSON
+    orc, eng = make_pair(3, 1, 2, [8, 3, 3])
+    _faces((orc, eng), 3, {(1, 0)})
+    Ao, bo = orc.compute_system("orc_form_poisson")
+    eng.set_form_source(USER_POISSON, "UserPoisson", (1.0,))
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "form_pencil" not in eng.kernel_name()
+    compare_mats(A, Ao, 1e-12)
+    assert rel_err(b.get(), bo) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,p,geo", [(1, 2, None), (2, 2, "nurbs"), (3, 3, "poly"), (3, 2, "nurbs")])
+def test_user_functionals_match_oracle_and_builtin(dim, p, geo):
+    orc, eng = make_pair(dim, 1, p, 5 if dim < 3 else 3)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=6, rational=(geo == "nurbs"), amp=0.1)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    rng = np.random.default_rng(dim)
+    U = rng.standard_normal(orc.global_size())
+    Uv = eng.create_vec().set(U)
+    s_o = orc.compute_scalar("orc_scalar_x2err", 1, U=U)
+    s_b = eng.compute_scalar("x2err", Uv)
+    s_u = eng.compute_scalar_source(FUNCTIONALS, "UserX2Err<%d>" % dim, 1, Uv)
+    assert abs(s_u[0] - s_o[0]) <= 1e-12 * abs(s_o[0]) and abs(s_u[0] - s_b[0]) <= 1e-13 * abs(s_b[0])
+    # volume / area with two visited faces, and a functional of u and grad u with a parameter
+    faces = {(0, 1)} if dim == 1 else {(0, 1), (dim - 1, 0)}
+    _faces((orc, eng), dim, faces)
+    v_o = orc.compute_scalar("orc_scalar_volume", 2, full=True)
+    v_b = eng.compute_scalar("volume")
+    m = eng.compute_scalar_source(FUNCTIONALS, "UserMeasures<%d>" % dim, 3, Uv, (0.75,))
+    assert np.abs(m[:2] - v_o).max() <= 1e-12 * np.abs(v_o).max() and np.abs(m[:2] - v_b).max() <= 1e-13 * np.abs(v_b).max()
+    # int (0.75 u^2 + |grad u|^2) = U^T (0.75 M + K) U with the oracle's mass and stiffness matrices (no faces: interior only)
+    orc.clear_boundary()
+    M, _ = orc.compute_system("orc_form_mass")
+    K, _ = orc.compute_system("orc_form_poisson")
+    ref = 0.75 * (U @ (M.scipy() @ U)) + U @ (K.scipy() @ U)
+    assert abs(m[2] - ref) <= 1e-11 * abs(ref)
+    # the same functional twice: same bits; a functional struct is refused as a form and a form struct as a functional
+    assert np.array_equal(m, eng.compute_scalar_source(FUNCTIONALS, "UserMeasures<%d>" % dim, 3, Uv, (0.75,)))
+    import petiga_amd as P
+    with pytest.raises(P.IGXError):
+        eng.compute_scalar_source(PLAIN_MASS, "UserMass", 1, Uv)
+    with pytest.raises(P.IGXError):
+        eng.compute_scalar_source(FUNCTIONALS, "UserMeasures<%d>" % dim, 2, Uv, (0.75,))
