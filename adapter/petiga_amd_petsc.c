@@ -344,4 +344,19 @@ PetscErrorCode IGAComputeIJacobian(IGA iga,PetscReal a,Vec vecV,PetscReal t,Vec 
   PetscCall(IGAAmdHandBackMat(iga,c,matJ));
   PetscFunctionReturn(PETSC_SUCCESS);
 }
+
+/* IGAComputeScalar (src/petigacomp.c:35-98) with the point functional given as device source: the program passes the struct next
+ * to (or instead of) its host `Scalar` callback; the rank-local sums come from the engine, the reduction over the ranks is the
+ * reference's own (:93). */
+PetscErrorCode IGAComputeScalarSourceAMD(IGA iga,Vec vecU,PetscInt n,PetscScalar S[],const char source[],const char struct_name[],const PetscReal params[],PetscInt nparams)
+{
+  double local[64];
+  IGAAMD_BEGIN(iga);
+  PetscCheck(c,comm,PETSC_ERR_ARG_WRONGSTATE,"Must call IGASetFormAMD() or IGASetFormSourceAMD() first");
+  PetscCheck(n >= 1 && n <= 64,comm,PETSC_ERR_ARG_OUTOFRANGE,"Number of scalars must be in range [1,64], got %" PetscInt_FMT,n);
+  if (vecU) PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
+  IGXCHK(comm,IGXComputeScalarSource(c->igx,vecU ? c->U : NULL,source,struct_name,(const double*)params,(int)nparams,(int)n,local));
+  PetscCallMPI(MPIU_Allreduce(local,S,(PetscMPIInt)n,MPIU_SCALAR,MPIU_SUM,comm));
+  PetscFunctionReturn(PETSC_SUCCESS);
+}
 #endif /* PETIGA_HAVE_AMD */

@@ -477,7 +477,9 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
 // NONSYM (state_pencil: a Tangent is not symmetric): all (P+1)^2 tiles are computed; the lower half is parked as it is -- tile (dd,0),
 // rows of layer lay+dd x columns of layer lay, is final when layer lay leaves and belongs to the same lane that will write the row.
 // BCMAT: the Dirichlet fix-up of the band row without a right-hand side (IGAElementFixJacobian, src/petigaelem.c:1425-1447).
-template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM>
+// RB: rows (accumulator registers r) per read-add-write batch of an interior band row: all P+1 at once (one memory round trip), or 2
+// where the registers of the old values are what the kernel spills (System driver on a mapped geometry at p = 3)
+template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM, int RB = P + 1>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem,
@@ -541,29 +543,34 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       Fnew = ff ? (double)nelem * fv : Facc - t;
     }
     if (full) {   // interior row: one BW-entry run per (lane, r)
-      double o[NB][BW];
-      if (lane_ok) {
-#pragma unroll
-        for (int r = 0; r < NB; ++r) {
-          if ((L.stmask >> r) & 1u) {   // first touch: nothing to read
-#pragma unroll
-            for (int k = 0; k < BW; ++k) o[r][k] = 0.0;
-            continue;
-          }
-          const double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
-#pragma unroll
-          for (int k = 0; k < BW / 2; ++k) { const d2u_t x = *reinterpret_cast<const d2u_t *>(p + 2 * k); o[r][2 * k] = x[0]; o[r][2 * k + 1] = x[1]; }
-          o[r][BW - 1] = p[BW - 1];
-        }
-      }
       if (fdo) out.vec[frow] = Fold + Fnew;
-      if (lane_ok) {
 #pragma unroll
-        for (int r = 0; r < NB; ++r) {
-          double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+      for (int r0 = 0; r0 < NB; r0 += RB) {
+        double o[RB][BW];
+        if (lane_ok) {
 #pragma unroll
-          for (int k = 0; k < BW / 2; ++k) { d2u_t x; x[0] = o[r][2 * k] + v[r][2 * k]; x[1] = o[r][2 * k + 1] + v[r][2 * k + 1]; *reinterpret_cast<d2u_t *>(p + 2 * k) = x; }
-          p[BW - 1] = o[r][BW - 1] + v[r][BW - 1];
+          for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr;
+            if (r >= NB) continue;
+            if ((L.stmask >> r) & 1u) {   // first touch: nothing to read
+#pragma unroll
+              for (int k = 0; k < BW; ++k) o[rr][k] = 0.0;
+              continue;
+            }
+            const double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+#pragma unroll
+            for (int k = 0; k < BW / 2; ++k) { const d2u_t x = *reinterpret_cast<const d2u_t *>(p + 2 * k); o[rr][2 * k] = x[0]; o[rr][2 * k + 1] = x[1]; }
+            o[rr][BW - 1] = p[BW - 1];
+          }
+#pragma unroll
+          for (int rr = 0; rr < RB; ++rr) {
+            const int r = r0 + rr;
+            if (r >= NB) continue;
+            double *p = out.val + pencil_pos<0>(L, r, ps0, c0, 0, T0, T10);
+#pragma unroll
+            for (int k = 0; k < BW / 2; ++k) { d2u_t x; x[0] = o[rr][2 * k] + v[r][2 * k]; x[1] = o[rr][2 * k + 1] + v[r][2 * k + 1]; *reinterpret_cast<d2u_t *>(p + 2 * k) = x; }
+            p[BW - 1] = o[rr][BW - 1] + v[r][BW - 1];
+          }
         }
       }
     } else {      // rows next to the mesh ends: some columns do not exist
@@ -1341,7 +1348,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -1361,7 +1368,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
-        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
         held[NB - 1] = 0;
