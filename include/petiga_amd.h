@@ -142,6 +142,8 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * most NEED_X -- demo/Poisson3D.c's System, with any x-dependent or anisotropic diffusion tensor and load -- takes the pencil
  * walk of the headline kernel in 3-D at p = 2, 3 (form_pencil<MyForm>: combined band rows, first-touch stores, the Dirichlet
  * fix-up inside the walk, identity or mapped / NURBS geometry) instead of the element mode: IGXSetKernel(2) insists on it.
+ * The vector-only drivers (Vector / Function / IFunction) of ANY struct without an atboundary branch run on the sum-factorised
+ * kernel in 3-D at p <= 3 (vec_sumfact<MyForm>: nqp evaluations of vec() on unit test features instead of nen x nqp).
  *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
  *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only
  * Boundary-form passes (IGXSetBoundaryForm; `if (p->atboundary)` in the reference's callback, e.g. demo/NitscheMethod.c:69-110): a
@@ -358,8 +360,9 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
  * matrix-core kernel the drivers would launch for the degrees set so far (dim >= 2, (p+1)^dim <= 64; 3-D: <= 256), for the matrix drivers
  * (with_matrix != 0) or the vector-only ones.  gram != 0 when the struct declares MAT_PAIR_MASK (it decides the wave layout at
  * dof = 4; on a GPU the flag is read from the compiled module).  gram == 2: the pencil walk's instantiations instead (form_pencil,
- * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  Returns 0 or IGX_ERR_USER with the
- * compiler's log. */
+ * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  gram == 3: the sum-factorised vector kernel
+ * (vec_sumfact<MyForm>: Vector / Function / IFunction in 3-D at p <= 3) for the current geometry kind.  Returns 0 or IGX_ERR_USER with
+ * the compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
 /* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly

@@ -74,6 +74,7 @@ struct RtcForm {
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
+  std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -126,13 +127,14 @@ static void rtc_cache_store(const std::string &path, const std::vector<char> &co
 
 // compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
 static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
-                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false) {
+                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false, bool with_vecsf = false) {
   std::string src;
   src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
   src += kRtcSrc_igx; src += "\n"; src += kRtcSrc_forms; src += "\n"; src += kRtcSrc_generic; src += "\n";
   if (with_feature) { src += kRtcSrc_feature; src += "\n"; }
   if (with_pencil) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_gram; src += "\n"; }
+  if (with_vecsf) { src += kRtcSrc_vecsf; src += "\n"; }
   src += "using namespace igx;\n#line 1 \"user_form.hip\"\n";
   src += source;
   src += "\n";
@@ -421,6 +423,68 @@ static int launch_pencil_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev 
   return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
 }
 
+// ---- the sum-factorised vector kernel (vec_sumfact.hpp) for a run-time form: Vector / Function / IFunction in 3-D at nen, nqp <= 4
+// per axis; the conditions of vec_sumfact_covers with the struct's constants read from the module
+struct RtcVecArgs { SpaceDev S; ParamsDev prm; OutDev out; ColorRange cr; long long nelem; };
+static bool rtc_vecsf_eligible(const Space &s, const RtcForm &F, const OutDev &out) {
+  if (!s.env.vec_sumfact || s.dim != 3 || F.meta[3] > 0 || F.meta[7]) return false;      // no functionals, no atboundary branch
+  if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION) return false;
+  if (s.dof != F.meta[0] || (s.nsd != 0 && s.nsd != 3)) return false;
+  if (F.meta[4] >= 2 && (s.nsd != 0 || s.rational)) return false;        // second-order test features: identity geometry only
+  for (int d = 0; d < 3; ++d) {
+    if (s.basis[d].nen > 4 || s.basis[d].nqp > 4) return false;
+    for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && s.load[d][sd].count) return false; }
+  }
+  return true;
+}
+static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false) {
+  done = false;
+  const Space &s = g->s;
+  if (!compile_only && !rtc_vecsf_eligible(s, F, out)) return 0;
+  const bool geo = s.nsd > 0 || s.rational;
+  std::shared_ptr<RtcFeature> K;
+  auto it = F.vecsf.find(geo ? 1 : 0);
+  if (it != F.vecsf.end() && (it->second->module || compile_only)) K = it->second;
+  else {
+    K.reset(new RtcFeature());
+    const std::string x = std::string("igx::vec_sumfact<") + F.name + ", " + (geo ? "true" : "false") + ">";
+    const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, long long);\n";
+    if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, false, true)) return rc;
+    if (!compile_only) {
+      HIPCK(hipModuleLoadData(&K->module, K->code.data()));
+      hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
+    }
+    F.vecsf[geo ? 1 : 0] = K;
+  }
+  if (compile_only) { done = true; return 0; }
+  RtcVecArgs args; memset(&args, 0, sizeof(args));
+  args.S = S; args.out = out;
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) args.prm.v[i] = s.params[i];
+  int launches = 0;
+  const int nc[3] = {s.lay[0].ncolors, s.lay[1].ncolors, s.lay[2].ncolors};
+  for (int c2 = 0; c2 < nc[2]; ++c2) for (int c1 = 0; c1 < nc[1]; ++c1) for (int c0 = 0; c0 < nc[0]; ++c0) {
+    const int cc[3] = {c0, c1, c2};
+    ColorRange cr; bool empty = false;
+    for (int d = 0; d < 3; ++d) {
+      const AxisLayout &L = s.lay[d]; const int nel = s.elem_width[d];
+      int first = -1, count = 0;
+      for (int e = 0; e < nel; ++e) if (L.color[e] == cc[d]) { if (first < 0) first = e; count++; }
+      if (count == 0) { empty = true; break; }
+      cr.start[d] = first; cr.step[d] = L.p + 1; cr.count[d] = count;
+    }
+    if (empty) continue;
+    args.cr = cr; args.nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
+    size_t asz = sizeof(args);
+    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+    HIPCK(hipModuleLaunchKernel(K->func[0], (unsigned)((args.nelem + 3) / 4), 1, 1, 256, 1, 1, 0, g->stream, nullptr, cfg));
+    launches++;
+  }
+  g->last_launches = launches;
+  g->last_kernel = std::string("vec_sumfact<") + F.name + ">(hiprtc,vector only: sum factorisation forward and backward, one wavefront per element)";
+  done = true;
+  return 0;
+}
+
 static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out);
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
@@ -435,6 +499,11 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   const int DOF = F.meta[0];
   if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "a struct with NSCALAR is a functional: IGXComputeScalarSource");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
+  if (g->kernel_choice == 0) {   // vector-only drivers in 3-D: sum factorisation both ways (vec_sumfact.hpp)
+    bool done = false;
+    if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+  }
   if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // scalar symmetric gradient forms: the pencil walk (combine before write)
     bool done = false;
     if (int rc = launch_pencil_rtc(g, F, S, out, done)) return rc;
@@ -623,6 +692,11 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   NEEDIGA(g);
   if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
   const Space &s = g->s;
+  if (gram == 3) {           // the sum-factorised vector kernel (vec_sumfact) of the struct, with and without a geometry: compile only
+    if (s.dim != 3) return fail(IGX_ERR_SUP, "the sum-factorised vector kernel needs dim 3");
+    bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
+    return launch_vecsf_rtc(g, *g->rtc, Sd, o, done, true);
+  }
   if (gram == 2) {           // the pencil walk's instantiation (form_pencil) for the current degree / geometry: compile only
     if (s.dim != 3 || (s.axis[0].p != 2 && s.axis[0].p != 3)) return fail(IGX_ERR_SUP, "the pencil walk needs dim 3 and degree 2 or 3");
     bool done = false; OutDev o; memset(&o, 0, sizeof(o));

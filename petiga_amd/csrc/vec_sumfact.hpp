@@ -367,6 +367,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
 }
 #undef VS_SYNC
 
+#ifndef IGX_RTC
 // dim 3, at most 4 basis functions and 4 points per axis; vector-only drivers; no boundary loads (Function / IFunction subtract
 // their lumped flux per element), no boundary-form passes; second-order test features only on the identity geometry
 template <class Form>
@@ -415,5 +416,7 @@ static int try_vec_sumfact(const Space &s, const SpaceDev &S, const ParamsDev &p
   return 0;
   }
 }
+
+#endif   // !IGX_RTC
 
 }  // namespace igx

@@ -2,7 +2,8 @@
 src/petigaelem.c:427-447; `if (p->atboundary)` in the callback) and user functionals (IGAComputeScalar's `Scalar` argument,
 src/petigacomp.c:35-98) for structs given as HIP source.  demo/NitscheMethod.c and demo/BoundaryIntegral.c as source against
 the oracle's restatement of the same callbacks, on both device kernels; the functionals of test/IGAFixTable.c (ErrorSqr) and
-test/IGAGeometryMap.c (volume / area) as source against the oracle and the built-in kinds."""
+test/IGAGeometryMap.c (volume / area) as source against the oracle and the built-in kinds; the vector-only drivers of a user struct
+on the sum-factorised kernel (vec_sumfact.hpp compiled for the struct)."""
 import ctypes as C
 
 import numpy as np
@@ -213,3 +214,62 @@ def test_user_functionals_match_oracle_and_builtin(dim, p, geo):
         eng.compute_scalar_source(PLAIN_MASS, "UserMass", 1, Uv)
     with pytest.raises(P.IGXError):
         eng.compute_scalar_source(FUNCTIONALS, "UserMeasures<%d>" % dim, 2, Uv, (0.75,))
+
+
+BRATU3 = r"""
+// demo/BratuFJ.F90:23-176 as user source in three dimensions; params = {lambda}
+struct UserBratu3 {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU;
+  static __device__ void vec(const PtView &p, const double *Na, double *R) {
+    double s = 0; for (int i = 0; i < 3; ++i) s += Na[1 + i] * p.gu[i];
+    R[0] = Na[0] * p.ut[0] + s - Na[0] * p.prm[0] * exp(p.u[0]);
+  }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double s = 0; for (int i = 0; i < 3; ++i) s += Na[1 + i] * Nb[1 + i];
+    T[0] = p.shift * Na[0] * Nb[0] + s - Na[0] * Nb[0] * p.prm[0] * exp(p.u[0]);
+  }
+};
+"""
+
+
+def test_vector_kernel_of_a_user_struct_compiles_without_a_gpu():
+    """IGXCheckFormSource(gram = 3): vec_sumfact<UserStruct, GEO> for the current geometry kind"""
+    import petiga_amd as P
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, 2, 4)
+    g.set_form_source(BRATU3, "UserBratu3", (3.5,))
+    g.check_form_source(False, 3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,N,geo", [(2, (5, 4, 6), None), (3, (3, 4, 3), "nurbs"), ((1, 2, 3), (4, 3, 3), "poly")])
+def test_user_struct_residual_on_the_sum_factorised_kernel(p, N, geo, monkeypatch):
+    orc, eng = make_pair(3, 1, list(p) if isinstance(p, tuple) else p, list(N))
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=12, rational=(geo == "nurbs"), amp=0.08)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    for g in (orc, eng):
+        for d in range(3):
+            g.set_boundary_value(d, 1, 0, 0.1 * d)
+    lam = C.c_double(3.5)
+    rng = np.random.default_rng(8)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n)
+    eng.set_form_source(BRATU3, "UserBratu3", (3.5,))
+    Uv, Vv, F = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec()
+    eng.compute_function(Uv, F); eng.synchronize()
+    assert "vec_sumfact<UserBratu3>(hiprtc" in eng.kernel_name(), eng.kernel_name()
+    assert rel_err(F.get(), orc.compute_function("orc_form_bratu_function", lam, U)) < 1e-12
+    eng.compute_ifunction(4.0, Vv, 0.0, Uv, F); eng.synchronize()
+    assert "vec_sumfact" in eng.kernel_name()
+    F1 = F.get().copy()
+    assert rel_err(F1, orc.compute_ifunction("orc_form_bratu_ifunction", lam, 4.0, V, 0.0, U)) < 1e-12
+    # the element kernels give the same numbers to rounding; the Jacobian of the same struct stays on them
+    eng.set_kernel(3)
+    eng.compute_ifunction(4.0, Vv, 0.0, Uv, F); eng.synchronize()
+    assert "feature_assemble" in eng.kernel_name() and rel_err(F.get(), F1) < 1e-12
+    eng.set_kernel(0)
+    J = eng.create_mat()
+    eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J); eng.synchronize()
+    compare_mats(J, orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U), 1e-12)
