@@ -144,6 +144,12 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * fix-up inside the walk, identity or mapped / NURBS geometry) instead of the element mode: IGXSetKernel(2) insists on it.
  * The vector-only drivers (Vector / Function / IFunction) of ANY struct without an atboundary branch run on the sum-factorised
  * kernel in 3-D at p <= 3 (vec_sumfact<MyForm>: nqp evaluations of vec() on unit test features instead of nen x nqp).
+ * The Tangent (Jacobian / IJacobian) of a nonlinear scalar struct takes the same pencil walk when the struct splits it as
+ * sum_f A_f(a) B_f(b) with the test side A = (N, dN/dx_0, dN/dx_1, dN/dx_2[, laplacian N]) and the trial side B carrying the point:
+ *       static constexpr int PENCIL_NFEAT = 4 or 5, PENCIL_NC = <numbers per Gauss point, at most 9>;
+ *       static __device__ void pencil_coef(const PtView &p,double JW,double *c);        // from u, grad u, diag hess u, shift, prm
+ *       static __device__ void pencil_trial(const double *c,double N,const double *g,double lap,double *B);   // B[0..PENCIL_NFEAT)
+ * (FormCahnHilliard / FormBratu in petiga_amd/csrc/forms.hpp are written this way; 3-D, p = 2 or 3, no geometry, dof 1.)
  *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
  *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only
  * Boundary-form passes (IGXSetBoundaryForm; `if (p->atboundary)` in the reference's callback, e.g. demo/NitscheMethod.c:69-110): a
@@ -361,8 +367,8 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
  * (with_matrix != 0) or the vector-only ones.  gram != 0 when the struct declares MAT_PAIR_MASK (it decides the wave layout at
  * dof = 4; on a GPU the flag is read from the compiled module).  gram == 2: the pencil walk's instantiations instead (form_pencil,
  * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  gram == 3: the sum-factorised vector kernel
- * (vec_sumfact<MyForm>: Vector / Function / IFunction in 3-D at p <= 3) for the current geometry kind.  Returns 0 or IGX_ERR_USER with
- * the compiler's log. */
+ * (vec_sumfact<MyForm>: Vector / Function / IFunction in 3-D at p <= 3) for the current geometry kind.  gram == 4: state_pencil<p, MyForm>
+ * (the Tangent of a scalar struct with the PENCIL_* hooks, below).  Returns 0 or IGX_ERR_USER with the compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
 /* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly

@@ -450,8 +450,9 @@ class IGX:
         return out
 
     def check_form_source(self, with_matrix=True, gram=False):
-        """Compile-only check of the run-time form against the matrix-core kernel of the current degrees (no GPU needed)."""
-        _ck(lib().IGXCheckFormSource(self.h, 1 if with_matrix else 0, 1 if gram else 0))
+        """Compile-only check of the run-time form against the kernels the drivers would launch for the current degrees (no GPU needed)."""
+        # gram: False / True = the struct declares MAT_PAIR_MASK; 2, 3, 4 = the pencil walk / the vector kernel / state_pencil instead
+        _ck(lib().IGXCheckFormSource(self.h, 1 if with_matrix else 0, int(gram)))
 
     def comm_overlap_ms(self):
         """ms by which the upper face of axis 2 was packed before the end of the assembly in the last reduce_ghost_rows."""

@@ -26,6 +26,12 @@ struct PtView {
   int atboundary, boundary_id;   // IGAPoint::atboundary / boundary_id (include/petiga.h:650-652)
 };
 
+// a form whose Tangent can take the pencil walk with the state summed inside the wavefront (gram_mfma.hpp: state_pencil) says so
+// with PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial (see FormCahnHilliard, FormBratu below)
+template <class Form, class = void> struct pencil_state_of { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
+template <class Form> struct pencil_state_of<Form, decltype((void)Form::PENCIL_NFEAT)> { static constexpr bool v = true; static constexpr int nfeat = Form::PENCIL_NFEAT, nc = Form::PENCIL_NC; };
+template <> struct pencil_state_of<void, void> { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
+
 // demo/Poisson{1,2,3}D.c System (demo/Poisson3D.c:3-23)
 template <int DIM> struct FormPoisson {
   static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = 0;

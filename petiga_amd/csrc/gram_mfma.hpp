@@ -975,8 +975,7 @@ __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, cons
 // No geometry (x = the parametric point: physical derivatives are the rows' own).  Per element the wavefront gathers the (P+1)^3
 // coefficients of U, sums u, grad u and the diagonal of hess u at its (P+1)^3 points by sum factorisation across the lanes
 // (three LDS exchanges) and leaves PENCIL_NC numbers per point where the metric of a mapped geometry would be.
-template <class Form, class = void> struct pencil_state_of { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
-template <class Form> struct pencil_state_of<Form, decltype((void)Form::PENCIL_NFEAT)> { static constexpr bool v = true; static constexpr int nfeat = Form::PENCIL_NFEAT, nc = Form::PENCIL_NC; };
+// (pencil_state_of<Form>: forms.hpp)
 constexpr int STATE_D2 = 48;      // per-wavefront second derivatives of the 1-D rows: X [q][a], Y [a][q], walk axis [q][a] (zero padded 4 x 4)
 __host__ __device__ static inline size_t pencil_state_bytes() { return (size_t)8 * STATE_D2 * 8; }
 
@@ -1393,6 +1392,7 @@ form_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
 template <int P, class Form>
 __global__ void __launch_bounds__(512, 2)
 state_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  static_assert(pencil_state_of<Form>::v, "state_pencil: the form declares PENCIL_NFEAT, PENCIL_NC, pencil_coef and pencil_trial");
   gram_pencil_body<false, 0, P, true, false, false, Form, true>(S, out, pa, prm.v);
 }
 

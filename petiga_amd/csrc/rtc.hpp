@@ -69,12 +69,13 @@ struct RtcForm {
   int dim = 0;
   std::vector<char> code;
   // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch, MAT_TEST_MASK, MAT_SYMMETRIC,
-  // VEC_TEST_MASK, 0 (read from the module)
+  // VEC_TEST_MASK, PENCIL_NFEAT or 0 (read from the module)
   int meta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
+  std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -172,7 +173,7 @@ static int rtc_compile(IGX g, const std::string &source, const std::string &name
   const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
   std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[12] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
                      ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v, (int)igx::mat_test_mask_of<" +
-                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, 0};\n";
+                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, igx::pencil_state_of<" + name + ">::nfeat};\n";
   tail += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
   std::shared_ptr<RtcForm> f(new RtcForm());
   std::vector<std::string> low;
@@ -485,6 +486,39 @@ static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   return 0;
 }
 
+// ---- the Tangent of a nonlinear scalar struct on the pencil walk (gram_mfma.hpp: state_pencil<P, UserStruct>): the struct declares
+// PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial like FormCahnHilliard and FormBratu (forms.hpp); dof 1, dim 3, no geometry,
+// uniform degree 2 or 3, Jacobian / IJacobian drivers.  Everything around the kernel is try_gram_mfma, as for form_pencil.
+static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false) {
+  done = false;
+  const Space &s = g->s;
+  const int deg = s.axis[0].p;
+  if (s.dim != 3 || (deg != 2 && deg != 3)) return 0;
+  // (the struct's constants are read from the loaded module: a compile-only check on a machine without a GPU takes the caller's word)
+  if (!compile_only && (F.meta[11] <= 0 || F.meta[0] != 1 || F.meta[3] > 0 || F.meta[7] || !s.env.state_pencil || s.nsd != 0 || (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN))) return 0;
+  std::shared_ptr<RtcFeature> K;
+  auto it = F.state.find(deg);
+  if (it != F.state.end() && (it->second->module || compile_only)) K = it->second;
+  else {
+    K.reset(new RtcFeature());
+    const std::string x = std::string("igx::state_pencil<") + std::to_string(deg) + ", " + F.name + ">";
+    const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::OutDev, igx::PencilArgs, igx::ParamsDev);\n";
+    if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, true)) return rc;
+    if (!compile_only) {
+      HIPCK(hipModuleLoadData(&K->module, K->code.data()));
+      hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
+    }
+    F.state[deg] = K;
+  }
+  if (compile_only) { done = true; return 0; }
+  PencilModule mod; memset(&mod.prm, 0, sizeof(mod.prm));
+  mod.fn = K->func[0]; mod.name = F.name + ",hiprtc"; mod.state = true; mod.extra_lds = pencil_state_bytes();
+  mod.flop_per_element = 2048.0 * F.meta[11] * (deg == 2 ? 7 * 9 : 16 * 16);
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
+  std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
+  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
+}
+
 static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out);
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
@@ -502,6 +536,11 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   if (g->kernel_choice == 0) {   // vector-only drivers in 3-D: sum factorisation both ways (vec_sumfact.hpp)
     bool done = false;
     if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+  }
+  if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // Tangents of scalar structs that opted in: the pencil walk with the state
+    bool done = false;
+    if (int rc = launch_state_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
   }
   if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // scalar symmetric gradient forms: the pencil walk (combine before write)
@@ -692,6 +731,11 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   NEEDIGA(g);
   if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
   const Space &s = g->s;
+  if (gram == 4) {           // state_pencil of a struct with the PENCIL_* hooks, for the current degree: compile only
+    bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
+    if (int rc = launch_state_rtc(g, *g->rtc, Sd, o, done, true)) return rc;
+    return done ? 0 : fail(IGX_ERR_SUP, "state_pencil needs dim 3, dof 1, degree 2 or 3 and a struct with PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial");
+  }
   if (gram == 3) {           // the sum-factorised vector kernel (vec_sumfact) of the struct, with and without a geometry: compile only
     if (s.dim != 3) return fail(IGX_ERR_SUP, "the sum-factorised vector kernel needs dim 3");
     bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));

@@ -273,3 +273,58 @@ def test_user_struct_residual_on_the_sum_factorised_kernel(p, N, geo, monkeypatc
     J = eng.create_mat()
     eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J); eng.synchronize()
     compare_mats(J, orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U), 1e-12)
+
+
+BRATU3_WALK = BRATU3.replace("struct UserBratu3 {", """struct UserBratu3Walk {
+  // the Jacobian on the pencil walk: A = (N, grad N), B = (JW (shift - lambda e^u) N, JW grad N)
+  static constexpr int PENCIL_NFEAT = 4, PENCIL_NC = 2;
+  static __device__ void pencil_coef(const PtView &p, double JW, double *c) { c[0] = JW * (p.shift - p.prm[0] * exp(p.u[0])); c[1] = JW; }
+  static __device__ void pencil_trial(const double *c, double N, const double *g, double, double *B) { B[0] = c[0] * N; for (int i = 0; i < 3; ++i) B[1 + i] = c[1] * g[i]; }""")
+
+
+@pytest.mark.parametrize("p", [2, 3])
+def test_state_pencil_of_a_user_struct_compiles_without_a_gpu(p):
+    """IGXCheckFormSource(gram = 4): state_pencil<p, UserStruct>"""
+    import petiga_amd as P
+    g = P.IGX(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, p, 8)
+    g.set_form_source(BRATU3_WALK, "UserBratu3Walk", (3.5,))
+    g.check_form_source(True, 4)
+    g.set_form_source(BRATU3, "UserBratu3", (3.5,))      # no hooks: the instantiation does not compile
+    with pytest.raises(P.IGXError):
+        g.check_form_source(True, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p,N,periodic,driver", [(2, (9, 4, 5), (False, False, False), "jacobian"), (3, (8, 4, 4), (False, True, False), "ijacobian")])
+def test_user_struct_tangent_on_the_pencil_walk(p, N, periodic, driver):
+    orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
+    for g in (orc, eng):
+        for d in range(3):
+            if not periodic[d]:
+                g.set_boundary_value(d, 0, 0, 0.2 * d)
+    lam = C.c_double(3.5)
+    rng = np.random.default_rng(8)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n)
+    eng.set_form_source(BRATU3_WALK, "UserBratu3Walk", (3.5,))
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    if driver == "jacobian":
+        eng.compute_jacobian(Uv, J)
+        J_o = orc.compute_jacobian("orc_form_bratu_jacobian", lam, U)
+    else:
+        eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J)
+        J_o = orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U)
+    eng.synchronize()
+    assert "state_pencil<UserBratu3Walk,hiprtc>" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-12)
+    # without the hooks the same Jacobian comes from the element kernel
+    eng.set_form_source(BRATU3, "UserBratu3", (3.5,))
+    if driver == "jacobian":
+        eng.compute_jacobian(Uv, J)
+    else:
+        eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "feature_assemble<UserBratu3>" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-12)
