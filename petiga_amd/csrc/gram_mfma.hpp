@@ -246,6 +246,9 @@ struct PencilArgs {
   int seg_len, nseg;
   int blocks_per_seg;      // ceil(pencils / 8): a workgroup (8 wavefronts = 8 pencils) never straddles segments
   int ne_max;              // LDS capacity: elements (seg_len + 3 halo) ; layers = ne_max + 3
+  int alias0;              // the walk axis is periodic and wrapped inside the rank: elements and node layers modulo its length; every
+                           // segment re-computes the P elements before its start (the first one those at the end of the axis) and
+                           // nobody owns rows beyond its own elements: each band row is still written exactly once per pencil
   int first_touch;         // 1: the matrix was NOT zeroed; the first colour that reaches an entry stores it (walk axis 0 only)
   int nelx, nely;          // local element counts on the two non-walked axes (for the first-touch rule)
   int fty_lo, fty_hi, fty_blocked;   // first-touch rule on the Y axis when the launches of an assembly come in two passes (see launch_pencils)
@@ -1130,25 +1133,28 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 8 + wave;
   const int ws = pa.w_lo + seg * pa.seg_len;
   const int we = min(ws + pa.seg_len, pa.w_hi);
-  const int wh = max(ws - P, pa.w_lo);
+  const bool alias0 = W == 0 && pa.alias0 != 0;
+  const int nelw = pa.w_hi - pa.w_lo;                        // (alias0: the whole axis, w_lo = 0)
+  const int wh = alias0 ? ws - P : max(ws - P, pa.w_lo);     // first element walked (alias0: may be negative = from the end of the axis)
   const int ne = we - wh, nl = ne + P;
   const AxisDev &AW = S.ax[W], &AX = S.ax[X], &AY = S.ax[Y];
+  auto ew = [&](int ei) -> int { int e = wh + ei; if (alias0) { e %= nelw; if (e < 0) e += nelw; } return e; };   // element of walk step ei
 
   // ---- stage the segment's walk-axis tables in LDS (all 512 threads); tables are zero padded to 4 x 4
   PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max, GEO);
-  T.lay0 = AW.off[wh];
+  T.lay0 = alias0 ? AW.off[0] + wh : AW.off[wh];             // (alias0: a virtual layer number; rows and tables are taken modulo the axis)
   {
     const int tid = threadIdx.x;
-    const double *__restrict__ tabw = AW.tab + (size_t)wh * (NB * NB * NDER);
     if (!GEO) for (int i = tid; i < ne * 32; i += 512) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
-      const int e = i >> 5, j = i & 31, q = j >> 3, aa = (j >> 1) & 3, k = j & 1;
-      T.zt[i] = (q < NB && aa < NB) ? tabw[((size_t)e * NB * NB + q * NB + aa) * NDER + k] * sqrt(AW.w[(wh + e) * NB + q] * AW.J[wh + e]) : 0.0;
+      const int e = i >> 5, j = i & 31, q = j >> 3, aa = (j >> 1) & 3, k = j & 1, eg = ew(e);
+      T.zt[i] = (q < NB && aa < NB) ? AW.tab[((size_t)eg * NB * NB + q * NB + aa) * NDER + k] * sqrt(AW.w[eg * NB + q] * AW.J[eg]) : 0.0;
     }
     // (GEO: the weight itself, not its root: the metric carries the whole JW)
-    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3; const double wj = (q < NB) ? AW.w[(wh + e) * NB + q] * AW.J[wh + e] : 0.0; T.wq[i] = GEO ? wj : sqrt(wj); }
-    for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[wh + i];
+    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3, eg = ew(e); const double wj = (q < NB) ? AW.w[eg * NB + q] * AW.J[eg] : 0.0; T.wq[i] = GEO ? wj : sqrt(wj); }
+    for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[ew(i)];
     for (int i = tid; i < nl; i += 512) {
-      const int lay = T.lay0 + i;
+      int lay = T.lay0 + i;
+      if (alias0) { lay = (lay - AW.off[0]) % nelw; if (lay < 0) lay += nelw; lay += AW.off[0]; }
       if (lay < AW.gwidth) {
         const int rho = AW.rowmap[lay];
         T.rho[i] = rho; T.cnt[i] = AW.rcnt[rho]; T.pre[i] = AW.prefix[rho];
@@ -1165,6 +1171,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
   int own_lo = (seg == 0) ? -1 : AW.off[ws];
   int own_hi = (seg == pa.nseg - 1) ? (1 << 30) : AW.off[we];
+  if (alias0) { own_lo = AW.off[0] + ws; own_hi = AW.off[0] + we; }
   if ((kDebug && pa.debug_noflush == 1) || !valid) { own_lo = 1 << 30; own_hi = 1 << 30; }
   const int offx = AX.off[elx], offy = AY.off[ely];
   const long long T0 = S.ax[0].tot, T10 = S.ax[1].tot * S.ax[0].tot;
@@ -1265,9 +1272,9 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if constexpr (GEO) {
       // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
       // there stalls the in-order MFMA issue for its whole latency)
-      if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
-      if constexpr (STATE) { if (lane >= 32 && lane < 48) { const int l2 = lane - 32, q = l2 >> 2, a = l2 & 3; d2w[lane] = (q < NB && a < NB) ? AW.tab[((size_t)(wh + ei) * NB * NB + q * NB + a) * NDER + 2] : 0.0; } }
-      if constexpr (!IDENT) pencil_geo_ctrl<P>(geo, S, lane, AW.off[wh + ei], offx, offy, wt);
+      if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
+      if constexpr (STATE) { if (lane >= 32 && lane < 48) { const int l2 = lane - 32, q = l2 >> 2, a = l2 & 3; d2w[lane] = (q < NB && a < NB) ? AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + 2] : 0.0; } }
+      if constexpr (!IDENT) pencil_geo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, wt);
       else { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }     // (the walk-axis rows above)
       const int gqw = lane >> 4;
       if constexpr (STATE) {
@@ -1275,14 +1282,14 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
         double uc = 0.0;
         if (aw < NB && ay < NB && ax < NB) {
-          const int li = AW.off[wh + ei] + aw - T.lay0;
+          const int li = ei + aw;                 // (one new node layer per element: AW.off[wh + ei] - T.lay0 = ei)
           uc = out.U[(long long)T.rho[li] * rs[W] + rs[X] * AX.rowmap[offx + ax] + rs[Y] * AY.rowmap[offy + ay]];
           double fv = 0;
           if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = fv;
         }
         double xpar[3] = {0, 0, 0};
         const int gqx = lane & 3, gqy = (lane >> 2) & 3;
-        if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[(wh + ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
+        if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[ew(ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
         pencil_state_eval<P, Form>(geo, d2w, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
       } else
       if constexpr (is_builtin_gram<Form>::v) pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
@@ -1290,7 +1297,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         double xpar[3] = {0, 0, 0};
         if constexpr (IDENT) {
           const int gqx = lane & 3, gqy = (lane >> 2) & 3;
-          if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[(wh + ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
+          if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[ew(ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
         }
         pencil_form_eval<P, Form, IDENT>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), rational, out.errflag, prm, out.shift, out.t, xpar);
       }
@@ -1364,7 +1371,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 2, (unsigned long long)ne);
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  if (seg == pa.nseg - 1)       // the last segment also owns what is still in the window
+  if (seg == pa.nseg - 1 && !alias0)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
         pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
@@ -1431,6 +1438,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
   for (int cy = 0; cy < s.lay[Y].ncolors; ++cy) for (int cx = 0; cx < s.lay[X].ncolors; ++cx) {
     PencilArgs pa; pa.forcing = forcing;
     pa.first_touch = (W == 0 && first_touch) ? 1 : 0; pa.nelx = s.elem_width[X]; pa.nely = s.elem_width[Y];
+    pa.alias0 = (W == 0 && s.lay[0].alias) ? 1 : 0;
     pa.fty_lo = fty ? fty[0] : 0; pa.fty_hi = fty ? fty[1] : 0x7fffffff; pa.fty_blocked = fty ? fty[2] : 0x7fffffff;
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
@@ -1450,7 +1458,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
         // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
         if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
         const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
-        const long long cost = ((bps * ns + slots - 1) / slots) * (len + (ns > 1 ? P : 0));
+        const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || (W == 0 && s.lay[0].alias)) ? P : 0));
         if (best < 0 || cost < best) { best = cost; best_n = n; }
       }
       nseg = best_n;
@@ -1684,7 +1692,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   // walk axis: the slowest-varying mesh axis that qualifies keeps axis 0 (contiguous CSR columns) on the lanes
   int walk_axis = -1;
   { const int pref[3] = {s.env.walk_axis, 2, 1};
-    for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k])) walk_axis = pref[k]; }
+    for (int k = 0; k < 3 && walk_axis < 0; ++k) if (pref[k] >= 0 && pref[k] < 3 && axis_walkable(s, pref[k], pref[k] == 0)) walk_axis = pref[k]; }
   const bool walk = walk_axis >= 0;
   if (deg == 2 && walk_axis != 0) return no("p=2 needs a walkable axis 0");
   if ((geo || mod) && walk_axis != 0) return no("a mapped geometry / a run-time form needs a walkable axis 0");

@@ -57,8 +57,10 @@ struct FluxArgs {
 };
 
 #ifndef IGX_RTC
-static bool axis_walkable(const Space &s, int d) {   // one new node layer per element, no wrap inside the rank
-  if (s.lay[d].alias || s.elem_width[d] < 8) return false;
+// one new node layer per element; a periodic axis wrapped inside the rank only where the walk takes it modulo its length (wrap_ok:
+// the axis-0 walk of gram_mfma.hpp)
+static bool axis_walkable(const Space &s, int d, bool wrap_ok = false) {
+  if ((s.lay[d].alias && !wrap_ok) || s.elem_width[d] < 8) return false;
   for (int e = 0; e + 1 < s.elem_width[d]; ++e)
     if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
   return true;

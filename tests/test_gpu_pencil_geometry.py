@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from common import compare_mats, make_pair, warped_geometry
+from common import compare_mats, make_pair, rel_err, warped_geometry
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-11
@@ -104,3 +104,38 @@ def test_repeatable_and_matches_the_feature_kernel_on_a_larger_mesh():
     scale = np.abs(outs[2][0]).max()
     assert np.abs(outs[0][0] - outs[2][0]).max() <= 1e-12 * scale
     assert np.abs(outs[0][1] - outs[2][1]).max() <= 1e-12 * np.abs(outs[2][1]).max()
+
+
+@pytest.mark.parametrize("p,N,periodic,nseg,driver", [
+    (3, (9, 4, 5), (True, False, False), 0, "system"),       # the walk axis periodic and wrapped inside the rank
+    (3, (21, 8, 4), (True, True, False), 3, "system"),       # ... in three segments, a second wrapped axis
+    (2, (8, 5, 7), (True, False, True), 0, "matrix"),
+    (2, (17, 4, 4), (True, False, False), 2, "system"),
+])
+def test_walk_axis_wrapped_inside_the_rank(p, N, periodic, nseg, driver, monkeypatch):
+    """gram_pencil on a periodic axis 0 held by one rank: elements and node layers modulo the axis, every segment re-computes the p
+    elements before its start, each band row written once (first-touch stores on a NaN-poisoned matrix)"""
+    import ctypes as C
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
+    for g in (orc, eng):
+        for d in range(3):
+            if not periodic[d]:
+                g.set_boundary_value(d, 0, 0, 0.5 + d); g.set_boundary_value(d, 1, 0, -1.0)
+    Ao, bo = orc.compute_system("orc_form_poisson")
+    eng.set_form("poisson")
+    A, b = eng.create_mat(), eng.create_vec()
+    hip = C.CDLL("libamdhip64.so"); hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+    assert hip.hipMemset(A.device_ptrs()[2], 0xFF, A.nblocks * 8) == 0 and hip.hipDeviceSynchronize() == 0
+    if driver == "system":
+        eng.compute_system(A, b)
+    else:
+        orc.clear_boundary()
+        Ao, bo = orc.compute_system("orc_form_poisson")
+        eng.compute_matrix(A)
+    eng.synchronize()
+    assert "gram_pencil" in eng.kernel_name() and "walk=0" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(A, Ao, 1e-12)
+    if driver == "system":
+        assert rel_err(b.get(), bo) < 1e-12

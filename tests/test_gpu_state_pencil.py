@@ -31,6 +31,9 @@ def _poison(mat):
     (2, (8, 5, 6), (False, True, True), False, 0),          # the demo's periodic box on the two axes the walk does not follow
     (3, (9, 4, 4), (False, False, False), False, 0),
     (3, (10, 3, 5), (False, False, True), True, 2),
+    (2, (9, 5, 6), (True, True, True), False, 0),           # the demo with -iga_periodic on one rank: the walk axis wrapped inside the rank
+    (2, (19, 5, 5), (True, False, True), True, 3),          # ... in three segments (each re-computes the p elements before its start)
+    (3, (8, 7, 4), (True, True, False), False, 2),
 ])
 def test_cahn_hilliard_tangent_vs_oracle(p, N, periodic, bc, nseg, monkeypatch):
     if nseg:
@@ -38,9 +41,11 @@ def test_cahn_hilliard_tangent_vs_oracle(p, N, periodic, bc, nseg, monkeypatch):
     orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
     if bc:
         for g in (orc, eng):
-            g.set_boundary_value(0, 0, 0, 0.6)
-            g.set_boundary_value(0, 1, 0, 0.66)
-            g.set_boundary_value(1, 1, 0, 0.61)
+            if not periodic[0]:
+                g.set_boundary_value(0, 0, 0, 0.6)
+                g.set_boundary_value(0, 1, 0, 0.66)
+            if not periodic[1]:
+                g.set_boundary_value(1, 1, 0, 0.61)
             if not periodic[2]:
                 g.set_boundary_value(2, 0, 0, 0.65)
     ctx = O.CahnHilliardCtx(*CH)
@@ -92,11 +97,11 @@ def test_bratu_jacobian_vs_oracle(p, N, periodic, driver):
 
 
 def test_switch_and_fallbacks(monkeypatch):
-    """IGX_STATE_PENCIL=0, a walk axis wrapped inside the rank, a short walk axis and a mapped geometry keep the feature kernel"""
+    """IGX_STATE_PENCIL=0, a short walk axis and a mapped geometry keep the feature kernel"""
     from common import warped_geometry
     ctx = O.CahnHilliardCtx(*CH)
-    for tag, N, periodic, env, geo in (("off", (9, 4, 4), (False,) * 3, "0", False), ("wrapped", (9, 4, 4), (True, False, False), None, False),
-                                       ("short", (5, 4, 4), (False,) * 3, None, False), ("mapped", (9, 4, 4), (False,) * 3, None, True)):
+    for tag, N, periodic, env, geo in (("off", (9, 4, 4), (False,) * 3, "0", False), ("short", (5, 4, 4), (False,) * 3, None, False),
+                                       ("short wrapped", (7, 5, 5), (True, False, False), None, False), ("mapped", (9, 4, 4), (False,) * 3, None, True)):
         if env is None:
             monkeypatch.delenv("IGX_STATE_PENCIL", raising=False)
         else:
