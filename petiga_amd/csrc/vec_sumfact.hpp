@@ -80,14 +80,18 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
   }
 }
 
-// backward: F_a = sum_q sum_k C_k(q) D_k N_a(q) at this lane's node; buf: 19 x 64 doubles of this wave
-template <int ORD>
+// backward: F_a = sum_q sum_k C_k(q) D_k N_a(q) at this lane's node; buf: 16 x 64 doubles of this wave
+// KMASK: the derivatives k whose coefficient can be non-zero (the others are neither stored nor summed); Cb holds them back to back
+__device__ __forceinline__ constexpr int vs_popc(unsigned m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
+__device__ __forceinline__ constexpr int vs_kc(unsigned kmask, int k) { return vs_popc(kmask & ((1u << k) - 1u)); }
+template <int ORD, unsigned KMASK>
 __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf, const double *tab0, const double *tab1, const double *tab2, int lane) {
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
-  double *Cb = buf, *S2 = buf + 10 * 64, *S1 = buf + 16 * 64;
+  double *Cb = buf, *S2 = buf + vs_popc(KMASK) * 64, *S1 = buf;      // (S1 takes the place of Cb: nobody reads Cb after the first stage)
+  static_assert(vs_popc(KMASK) >= 3, "S1 fits where Cb was");
   VS_SYNC();
 #pragma unroll
-  for (int k = 0; k < 10; ++k) if (vs_v0(k) + vs_v1(k) + vs_v2(k) <= ORD) Cb[k * 64 + lane] = C[k];
+  for (int k = 0; k < 10; ++k) if (((KMASK >> k) & 1u) && vs_v0(k) + vs_v1(k) + vs_v2(k) <= ORD) Cb[vs_kc(KMASK, k) * 64 + lane] = C[k];
   VS_SYNC();
   {   // axis 2: lane (q0, q1, a2)
     double t[6] = {0, 0, 0, 0, 0, 0};
@@ -95,8 +99,8 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
     for (int q2 = 0; q2 < 4; ++q2) {
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
-        if (vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
-        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[k * 64 + i0 + 4 * i1 + 16 * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
+        if (!((KMASK >> k) & 1u) || vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
+        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + 4 * i1 + 16 * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
       }
     }
 #pragma unroll
@@ -126,6 +130,17 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
   return f;
 }
 
+// identity geometry: test feature tf (0 value, 1..3 gradient, 4 + 3a + b second derivative) -> derivative k of the 10
+__device__ __forceinline__ constexpr unsigned vs_kmask_ident(unsigned vmask) {
+  unsigned m = 0;
+  for (int tf = 0; tf < 13; ++tf) {
+    if (!((vmask >> tf) & 1u)) continue;
+    if (tf < 4) m |= 1u << tf;
+    else { const int a = (tf - 4) / 3, b = (tf - 4) % 3, lo = a < b ? a : b, hi = a < b ? b : a; m |= 1u << (4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5))); }
+  }
+  return m | 0x7u;      // (at least three slots: S1 is laid over them)
+}
+
 // GEO: a mapped geometry and / or NURBS weights; without them the geometry chain is the identity at compile time (no E1 / E2
 // products, no quotient rule) and the kernel needs half the registers
 template <class Form, bool GEO>
@@ -137,11 +152,15 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   constexpr bool NEEDHU = (Form::NEED & NEED_HU) != 0, NEEDGU = (Form::NEED & (NEED_GU | NEED_HU)) != 0;
   constexpr int UORD = NEEDHU ? 2 : (NEEDGU ? 1 : 0);                    // derivative order of the state
   constexpr int NFS = SECOND_T ? 13 : 4;
-  __shared__ double sm_all[4][19 * 64 + 3 * 48];
+  // derivatives of the test functions that can carry a coefficient: without a geometry feature tf maps to one of them; with one, the
+  // inverse Jacobian mixes the three first derivatives and the rational correction reaches the value
+  constexpr unsigned KMASK = GEO ? 0xFu : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
+  constexpr int NBACK = vs_popc(KMASK) + (SECOND_T ? 6 : 3), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
+  __shared__ double sm_all[4][NBUF * 64 + 3 * 48];      // Cahn-Hilliard: 31 KB per workgroup, five workgroups (20 wavefronts) per CU
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long w = (long long)blockIdx.x * 4 + wave;
   if (w >= nelem) return;
-  double *buf = sm_all[wave], *tab0 = buf + 19 * 64, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
+  double *buf = sm_all[wave], *tab0 = buf + NBUF * 64, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
   int el[3];
   {
     long long b = w;
@@ -357,7 +376,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // ---- backward, IGAElementFixFunction (src/petigaelem.c:1449-1461), IGAElementAssembleVec
 #pragma unroll
   for (int f = 0; f < DOF; ++f) {
-    double F = SECOND_T ? vs_backward<2>(Cq[f], buf, tab0, tab1, tab2, lane) : vs_backward<1>(Cq[f], buf, tab0, tab1, tab2, lane);
+    double F = SECOND_T ? vs_backward<2, KMASK>(Cq[f], buf, tab0, tab1, tab2, lane) : vs_backward<1, KMASK>(Cq[f], buf, tab0, tab1, tab2, lane);
     F *= wgt;
     if (isnode) {
       if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
