@@ -1283,9 +1283,10 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         double uc = 0.0;
         if (aw < NB && ay < NB && ax < NB) {
           const int li = ei + aw;                 // (one new node layer per element: AW.off[wh + ei] - T.lay0 = ei)
-          uc = out.U[(long long)T.rho[li] * rs[W] + rs[X] * AX.rowmap[offx + ax] + rs[Y] * AY.rowmap[offy + ay]];
+          const long long urow = (long long)T.rho[li] * rs[W] + rs[X] * AX.rowmap[offx + ax] + rs[Y] * AY.rowmap[offy + ay];
+          uc = out.U[urow];
           double fv = 0;
-          if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = fv;
+          if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = S.fixtable ? S.fixtable[urow] : fv;     // (IGASetFixTable: the value by row)
         }
         double xpar[3] = {0, 0, 0};
         const int gqx = lane & 3, gqy = (lane >> 2) & 3;
@@ -1678,7 +1679,6 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   const bool geo = s.nsd != 0;
   if (geo && s.nsd != 3) return no("mapped geometry of another dimension");
   if (state && geo) return no("a Tangent on the walk needs the identity geometry");
-  if (state && S.fixtable) return no("a Tangent on the walk with a fix table");
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
   const int deg = s.axis[0].p;
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");

@@ -155,3 +155,31 @@ def test_switch_and_kernel_choice(monkeypatch):
     assert "vec_sumfact" in res["sumfact"][1] and "vec_sumfact" not in res["off"][1] and "vec_sumfact" not in res["generic"][1]
     for tag in ("off", "generic"):
         _close(res[tag][0], res["sumfact"][0], 1e-12)
+
+
+@pytest.mark.parametrize("geo", [None, "nurbs"])
+def test_fix_table_values_in_function_and_jacobian(geo):
+    """IGASetFixTable (src/petigaform.c:273-298): the value of a fixed dof comes from a row-indexed table; IGAElementFixValues puts
+    it into the state, FixFunction subtracts it (src/petigaelem.c:1334-1358, :1449-1461).  The sum-factorised kernel reads the
+    table, and so does the state walk when it gathers the coefficients of U."""
+    from common import compare_mats
+    orc, eng = make_pair(3, 1, 2, [9, 4, 5])
+    _geometry(orc, eng, geo, 3)
+    for g in (orc, eng):
+        for d in range(3):
+            g.set_boundary_value(d, 0, 0, 0.0); g.set_boundary_value(d, 1, 0, 0.0)      # the faces; the values come from the table
+    rng = np.random.default_rng(4)
+    n = orc.global_size()
+    table, U = rng.standard_normal(n) * 0.2, rng.standard_normal(n) * 0.3
+    orc.set_fixtable(table)
+    eng.set_fixtable(eng.create_vec().set(table))
+    lam = C.c_double(3.5)
+    eng.set_form("bratu", (3.5,))
+    Uv, F, J = eng.create_vec().set(U), eng.create_vec(), eng.create_mat()
+    eng.compute_function(Uv, F); eng.synchronize()
+    assert "vec_sumfact" in eng.kernel_name()
+    _close(F.get(), orc.compute_function("orc_form_bratu_function", lam, U), 1e-12)
+    eng.compute_jacobian(Uv, J); eng.synchronize()
+    assert ("state_pencil" in eng.kernel_name()) == (geo is None), eng.kernel_name()
+    compare_mats(J, orc.compute_jacobian("orc_form_bratu_jacobian", lam, U), 1e-12)
+    orc.set_fixtable(None)
