@@ -142,6 +142,9 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * most NEED_X -- demo/Poisson3D.c's System, with any x-dependent or anisotropic diffusion tensor and load -- takes the pencil
  * walk of the headline kernel in 3-D at p = 2, 3 (form_pencil<MyForm>: combined band rows, first-touch stores, the Dirichlet
  * fix-up inside the walk, identity or mapped / NURBS geometry) instead of the element mode: IGXSetKernel(2) insists on it.
+ * A struct with MAT_PAIR_MASK (and pair_block_mask), 2 or 3 fields and VEC_ZERO -- demo/Elasticity3D.c's System -- takes the band-row
+ * kernel in 3-D at p = 3 on the identity geometry (block_pencil<MyForm>: the element loop turned inside out, each band row written
+ * once per pencil), like the built-in form; IGXSetKernel(4) insists on it.
  * The vector-only drivers (Vector / Function / IFunction) of ANY struct without an atboundary branch run on the sum-factorised
  * kernel in 3-D at p <= 3 (vec_sumfact<MyForm>: nqp evaluations of vec() on unit test features instead of nen x nqp).
  * The Tangent (Jacobian / IJacobian) of a nonlinear scalar struct takes the same pencil walk when the struct splits it as
@@ -368,7 +371,8 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
  * dof = 4; on a GPU the flag is read from the compiled module).  gram == 2: the pencil walk's instantiations instead (form_pencil,
  * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  gram == 3: the sum-factorised vector kernel
  * (vec_sumfact<MyForm>: Vector / Function / IFunction in 3-D at p <= 3) for the current geometry kind.  gram == 4: state_pencil<p, MyForm>
- * (the Tangent of a scalar struct with the PENCIL_* hooks, below).  Returns 0 or IGX_ERR_USER with the compiler's log. */
+ * (the Tangent of a scalar struct with the PENCIL_* hooks, below).  gram == 5: block_pencil<MyForm> (System and Matrix driver) of a
+ * constant-coefficient multi-field struct.  Returns 0 or IGX_ERR_USER with the compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
 /* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly

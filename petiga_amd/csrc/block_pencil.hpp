@@ -23,9 +23,11 @@
 //   2. adds the stage to the matrix with wave-coalesced 16-byte accesses, 126 consecutive lanes per run (first touch: plain stores).
 // Colouring over the pencils' axes 1, 2 as before (16 colours); every entry of a band row is written once per pencil.
 #pragma once
+#ifndef IGX_RTC
 #include <functional>
 #include <string>
 #include <vector>
+#endif
 #include "pencil_common.hpp"
 #include "feature_mfma.hpp"
 
@@ -464,6 +466,7 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
 #undef BP_STAMP
 }
 
+#ifndef IGX_RTC
 // ---- boundary loads of a multi-field form on the identity geometry: gram_mfma.hpp's k_boundary_loads per field
 // (IGAElementBuildFix: AddFlux, src/petigaelem.c:1191-1212; a Dirichlet value on the same dof discards the flux, :1371-1387)
 static __global__ void k_boundary_loads_field(FluxArgs F, int nr0, int nr1, int dof, int field, double *vec) {
@@ -528,21 +531,28 @@ template <class Form> constexpr bool bp_form_ok() {
   return mat_pair_mask_of<Form>::v != 0ull && vec_zero_of<Form>::v && Form::DOF <= 3 && Form::DOF >= 2 && shape_order_of<Form>::v < 2 && Form::ORDER < 2 &&
          !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0;
 }
+static bool block_pencil_covers_space(const Space &s, const SpaceDev &S, const OutDev &out, int dof) {
+  if (s.env.block_pencil == 0) return false;
+  if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return false;
+  if (s.dim != 3 || s.dof != dof || s.nsd != 0 || S.fixtable) return false;
+  for (int d = 0; d < 3; ++d) {
+    if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4 || s.lay[d].alias) return false;
+    for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
+  }
+  if (!axis_walkable(s, 0)) return false;
+  return true;
+}
 template <class Form>
 static bool block_pencil_covers(const Space &s, const SpaceDev &S, const OutDev &out) {
   if constexpr (!bp_form_ok<Form>()) return false;
-  else {
-    if (s.env.block_pencil == 0) return false;
-    if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return false;
-    if (s.dim != 3 || s.dof != Form::DOF || s.nsd != 0 || S.fixtable) return false;
-    for (int d = 0; d < 3; ++d) {
-      if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4 || s.lay[d].alias) return false;
-      for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
-    }
-    if (!axis_walkable(s, 0)) return false;
-    return true;
-  }
+  else return block_pencil_covers_space(s, S, out, Form::DOF);
 }
+
+// the launches of an assembly; `launch(sys, grid, lds_bytes, args)` starts the kernel -- the compiled-in instantiation of a built-in
+// form, or the module function of a run-time struct (rtc.hpp)
+typedef std::function<void(bool, unsigned, size_t, const BlockPencilArgs &)> BlockPencilLaunch;
+static int block_pencil_run(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom,
+                            const std::function<void()> &zero_matrix, const std::function<void()> &slab_done, int DOF, int NP, const BlockPencilLaunch &launch);
 
 template <class Form>
 static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, hipStream_t stream, std::string &kname, int &launches,
@@ -551,8 +561,19 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
   if constexpr (!bp_form_ok<Form>()) return 0;
   else {
   if (!block_pencil_covers<Form>(s, S, out)) return 0;
-  constexpr int P = 3, DOF = Form::DOF;
-  constexpr int NP = fm_popcount(mat_pair_mask_of<Form>::v);
+  return block_pencil_run(s, S, out, stream, kname, launches, err, done, dom, zero_matrix, slab_done, Form::DOF, fm_popcount(mat_pair_mask_of<Form>::v),
+                          [&](bool sys, unsigned grid, size_t lds, const BlockPencilArgs &pa) {
+                            auto kern = sys ? block_pencil<Form, 3, true> : block_pencil<Form, 3, false>;
+                            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                            hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, S, prm, out, pa);
+                          });
+  }
+}
+
+static int block_pencil_run(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom,
+                            const std::function<void()> &zero_matrix, const std::function<void()> &slab_done, int DOF, int NP, const BlockPencilLaunch &launch) {
+  {
+  constexpr int P = 3;
   const bool sys = out.op == OP_SYSTEM;
   const bool first_touch = !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
   if (!first_touch) { if (zero_matrix) zero_matrix(); }
@@ -588,9 +609,7 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
       const size_t lds = (size_t)bp_carve(pa.seg_len, DOF).total * sizeof(double);
-      auto kern = sys ? block_pencil<Form, P, true> : block_pencil<Form, P, false>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(512), lds, stream, S, prm, out, pa);
+      launch(sys, (unsigned)(pencils * pa.nseg), lds, pa);
       launches++;
     }
   };
@@ -616,5 +635,7 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
   return 0;
   }
 }
+
+#endif   // !IGX_RTC
 
 }  // namespace igx

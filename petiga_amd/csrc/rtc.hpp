@@ -70,12 +70,14 @@ struct RtcForm {
   std::vector<char> code;
   // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch, MAT_TEST_MASK, MAT_SYMMETRIC,
   // VEC_TEST_MASK, PENCIL_NFEAT or 0 (read from the module)
-  int meta[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  // [12] number of Gram pairs (bits of MAT_PAIR_MASK), [13] VEC_ZERO, [14], [15] 0
+  int meta[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
   std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P
+  std::map<int, std::shared_ptr<RtcFeature>> block;     // block_pencil instantiations; key: SYSTEM
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -128,7 +130,7 @@ static void rtc_cache_store(const std::string &path, const std::vector<char> &co
 
 // compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
 static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
-                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false, bool with_vecsf = false) {
+                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false, bool with_vecsf = false, bool with_block = false) {
   std::string src;
   src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
@@ -136,6 +138,7 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   if (with_feature) { src += kRtcSrc_feature; src += "\n"; }
   if (with_pencil) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_gram; src += "\n"; }
   if (with_vecsf) { src += kRtcSrc_vecsf; src += "\n"; }
+  if (with_block) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_block; src += "\n"; }
   src += "using namespace igx;\n#line 1 \"user_form.hip\"\n";
   src += source;
   src += "\n";
@@ -171,9 +174,9 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
 
 static int rtc_compile(IGX g, const std::string &source, const std::string &name, int dim, std::shared_ptr<RtcForm> &out) {
   const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
-  std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[12] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
+  std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[16] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
                      ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v, (int)igx::mat_test_mask_of<" +
-                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, igx::pencil_state_of<" + name + ">::nfeat};\n";
+                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, igx::pencil_state_of<" + name + ">::nfeat, igx::fm_popcount(igx::mat_pair_mask_of<" + name + ">::v), igx::vec_zero_of<" + name + ">::v, 0, 0};\n";
   tail += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
   std::shared_ptr<RtcForm> f(new RtcForm());
   std::vector<std::string> low;
@@ -519,6 +522,54 @@ static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
 }
 
+// ---- band rows by node layer (block_pencil.hpp) for a run-time struct: constant-coefficient multi-field forms (MAT_PAIR_MASK, 2 or 3
+// fields, VEC_ZERO, first order, no atboundary branch), the conditions of bp_form_ok / block_pencil_covers with the struct's
+// constants read from the module; colours, segments, first touch, boundary loads and the two-pass assembly are block_pencil_run
+struct RtcBlockArgs { SpaceDev S; ParamsDev prm; OutDev out; BlockPencilArgs pa; };
+static int launch_block_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false, int sys_only = -1) {
+  done = false;
+  const Space &s = g->s;
+  if (s.dim != 3) return 0;
+  if (!compile_only) {
+    const int DOF = F.meta[0];
+    if (F.meta[12] <= 0 || !F.meta[13] || DOF < 2 || DOF > 3 || F.meta[1] >= 2 || F.meta[4] >= 2 || F.meta[7] || F.meta[3] > 0) return 0;
+    if (!block_pencil_covers_space(s, S, out, DOF)) return 0;
+  }
+  const bool sysk = compile_only ? sys_only != 0 : out.op == OP_SYSTEM;
+  auto module_of = [&](bool sys, std::shared_ptr<RtcFeature> &K) -> int {
+    auto it = F.block.find(sys ? 1 : 0);
+    if (it != F.block.end() && (it->second->module || compile_only)) { K = it->second; return 0; }
+    K.reset(new RtcFeature());
+    const std::string x = std::string("igx::block_pencil<") + F.name + ", 3, " + (sys ? "true" : "false") + ">";
+    const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BlockPencilArgs);\n";
+    if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, false, false, true)) return rc;
+    if (!compile_only) {
+      HIPCK(hipModuleLoadData(&K->module, K->code.data()));
+      hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
+    }
+    F.block[sys ? 1 : 0] = K;
+    return 0;
+  };
+  std::shared_ptr<RtcFeature> K;
+  if (int rc = module_of(sysk, K)) return rc;
+  if (compile_only) { done = true; return 0; }
+  ParamsDev prm; memset(&prm, 0, sizeof(prm));
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+  hipFunction_t fn = K->func[0];
+  hipStream_t stream = g->stream;
+  std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
+  const int rc = block_pencil_run(s, S, out, stream, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, F.meta[0], F.meta[12],
+                                  [&](bool, unsigned grid, size_t lds, const BlockPencilArgs &pa) {
+                                    RtcBlockArgs a; memset(&a, 0, sizeof(a));
+                                    a.S = S; a.prm = prm; a.out = out; a.pa = pa;
+                                    size_t asz = sizeof(a);
+                                    void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+                                    (void)hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg);
+                                  });
+  if (rc == 0 && done) g->last_kernel = std::string("block_pencil<") + F.name + ">(hiprtc,mfma_f64_16x16x4,p=3,dof=" + char('0' + F.meta[0]) + ",band rows by node layer)";
+  return rc;
+}
+
 static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out);
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
@@ -537,6 +588,12 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
     bool done = false;
     if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
+  }
+  if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // constant-coefficient multi-field structs: band rows by node layer
+    bool done = false;
+    if (int rc = launch_block_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+    if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernel does not cover this run-time form / configuration (MAT_PAIR_MASK, 2 or 3 fields, VEC_ZERO, 3-D, p = 3, identity geometry, System / Matrix driver)");
   }
   if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // Tangents of scalar structs that opted in: the pencil walk with the state
     bool done = false;
@@ -731,6 +788,12 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   NEEDIGA(g);
   if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
   const Space &s = g->s;
+  if (gram == 5) {           // block_pencil of a constant-coefficient multi-field struct (System and Matrix driver): compile only
+    bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
+    if (int rc = launch_block_rtc(g, *g->rtc, Sd, o, done, true, 1)) return rc;
+    if (!done) return fail(IGX_ERR_SUP, "block_pencil needs dim 3");
+    return launch_block_rtc(g, *g->rtc, Sd, o, done, true, 0);
+  }
   if (gram == 4) {           // state_pencil of a struct with the PENCIL_* hooks, for the current degree: compile only
     bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
     if (int rc = launch_state_rtc(g, *g->rtc, Sd, o, done, true)) return rc;

@@ -41,7 +41,9 @@ for p, n in ((2, 64), (3, 48)):
     run("Poisson p=%d %d^3 built in (feature kernel)" % (p, n), 1, p, n, lambda g: g.set_form("poisson"), kernel=3)
     run("Poisson p=%d %d^3 from source" % (p, n), 1, p, n, lambda g: g.set_form_source(POISSON, "UserPoisson"))
     run("Poisson p=%d %d^3 from source, point-form kernel" % (p, n), 1, p, n, lambda g: g.set_form_source(POISSON, "UserPoisson"), kernel=1)
-run("Elasticity p=3 48^3 built in (element mode)", 3, 3, 48, lambda g: g.set_form("elasticity", (1.0, 1.0)))
-run("Elasticity p=3 48^3 from source, Gram", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<1>", (1.0, 1.0)))
+run("Elasticity p=3 48^3 built in (band rows)", 3, 3, 48, lambda g: g.set_form("elasticity", (1.0, 1.0)))
+from test_rtc_boundary_scalar import ELASTICITY_BANDS
+run("Elasticity p=3 48^3 from source, band rows", 3, 3, 48, lambda g: g.set_form_source(ELASTICITY_BANDS, "UserElasticityBands", (1.0, 1.0)))
+run("Elasticity p=3 48^3 from source, Gram (element mode)", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<1>", (1.0, 1.0)))
 run("Elasticity p=3 48^3 from source, plain", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<0>", (1.0, 1.0)))
 run("Elasticity p=3 48^3 from source, point-form kernel", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<0>", (1.0, 1.0)), kernel=1)

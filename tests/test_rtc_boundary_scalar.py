@@ -328,3 +328,72 @@ def test_user_struct_tangent_on_the_pencil_walk(p, N, periodic, driver):
     eng.synchronize()
     assert "feature_assemble<UserBratu3>" in eng.kernel_name(), eng.kernel_name()
     compare_mats(J, J_o, 1e-12)
+
+
+ELASTICITY_BANDS = r"""
+// demo/Elasticity3D.c:13-46 as user source (with its :37 quirk); params = {lambda, mu}.  The declarations say what the callback's
+// shape is -- point-independent coefficients on gradient pairs (MAT_PAIR_MASK), which block entries a pair reaches
+// (pair_block_mask), F = 0 (VEC_ZERO) -- and the struct takes the band-row kernel (block_pencil.hpp) like the built-in form.
+struct UserElasticityBands {
+  static constexpr int DOF = 3, ORDER = 1; static constexpr unsigned NEED = 0;
+  static constexpr unsigned MAT_TEST_MASK = 0xEu;
+  static constexpr unsigned long long MAT_PAIR_MASK = (0xEull << 8) | (0xEull << 16) | (0xEull << 24);
+  static constexpr bool VEC_ZERO = true;
+  static constexpr unsigned pair_block_mask(int f, int g) { return f == g ? 0x111u : ((1u << ((f - 1) * 3 + (g - 1))) | (1u << ((g - 1) * 3 + (f - 1)))); }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const double l = p.prm[0], m = p.prm[1];
+    const double ax = Na[1], ay = Na[2], az = Na[3], bx = Nb[1], by = Nb[2], bz = Nb[3];
+    T[0] = ax * bx * (l + 2 * m) + m * (ay * by + az * bz); T[1] = ax * by * l + ay * bx * m; T[2] = ax * bz * l + az * bx * m;
+    T[3] = ax * by * m + ay * bx * l; T[4] = ay * by * (l + 2 * m) + m * (az * bz + ax * bx * m); T[5] = ay * bz * l + az * by * m;
+    T[6] = ax * bz * m + az * bx * l; T[7] = ay * bz * m + az * by * l; T[8] = m * (ax * bx + ay * by) + az * bz * (l + 2 * m);
+  }
+  static __device__ void vec(const PtView &, const double *, double *R) { R[0] = 0; R[1] = 0; R[2] = 0; }
+};
+"""
+
+
+def test_band_row_kernel_of_a_user_struct_compiles_without_a_gpu():
+    """IGXCheckFormSource(gram = 5): block_pencil<UserStruct, 3, SYSTEM> for the System and the Matrix driver"""
+    import petiga_amd as P
+    g = P.IGX(3, 3)
+    for i in range(3):
+        g.axis_uniform(i, 3, 8)
+    g.set_form_source(ELASTICITY_BANDS, "UserElasticityBands", (1.5, 0.8))
+    g.check_form_source(True, 5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,bc,driver", [((9, 4, 4), "clamped", "system"), ((12, 3, 5), "mixed", "system"), ((8, 4, 3), "none", "matrix")])
+def test_user_elasticity_on_the_band_row_kernel(N, bc, driver):
+    orc, eng = make_pair(3, 3, 3, list(N))
+    for g in (orc, eng):
+        if bc == "clamped":       # demo/Elasticity3D.c:100-108: one face clamped, u_x = 1 on the opposite one
+            for f in range(3):
+                g.set_boundary_value(0, 0, f, 0.0)
+            g.set_boundary_value(0, 1, 0, 1.0)
+        elif bc == "mixed":
+            g.set_boundary_value(1, 0, 2, 0.3); g.set_boundary_value(2, 1, 0, -0.2); g.set_boundary_load(0, 1, 1, 0.7)
+    ctx = O.ElasticityCtx(1.5, 0.8)
+    eng.set_form_source(ELASTICITY_BANDS, "UserElasticityBands", (1.5, 0.8))
+    A, b = eng.create_mat(), eng.create_vec()
+    if driver == "system":
+        Ao, bo = orc.compute_system("orc_form_elasticity", ctx)
+        eng.compute_system(A, b)
+    else:
+        orc.clear_boundary()
+        Ao, bo = orc.compute_system("orc_form_elasticity", ctx)
+        eng.compute_matrix(A)
+    eng.synchronize()
+    assert "block_pencil<UserElasticityBands>(hiprtc" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(A, Ao, 1e-12)
+    if driver == "system":
+        assert rel_err(b.get(), bo) < 1e-12
+    # IGX_KERNEL-style choice 3 keeps the element kernel: same numbers to rounding
+    eng.set_kernel(3)
+    if driver == "system":
+        eng.compute_system(A, b)
+    else:
+        eng.compute_matrix(A)
+    eng.synchronize()
+    assert "feature_assemble<UserElasticityBands>" in eng.kernel_name()
+    compare_mats(A, Ao, 1e-12)
