@@ -28,6 +28,12 @@ namespace igx {
 
 template <class F, class = void> struct has_mat_unit { static constexpr bool v = false; };
 template <class F> struct has_mat_unit<F, decltype((void)F::HAS_MAT_UNIT)> { static constexpr bool v = F::HAS_MAT_UNIT; };
+// BAND_NFEAT = 5: the form adds the advective derivative u . grad N as a fifth test feature (band_block_mask, mat_unit5: forms.hpp)
+template <class F, class = void> struct band_nfeat_of { static constexpr int v = 4; };
+template <class F> struct band_nfeat_of<F, decltype((void)F::BAND_NFEAT)> { static constexpr int v = F::BAND_NFEAT; };
+template <class Form> __host__ __device__ constexpr unsigned bpt_mask(int i, int j) {
+  if constexpr (band_nfeat_of<Form>::v == 5) return Form::band_block_mask(i, j); else return fm_block_mask<Form>(i, j);
+}
 template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
 template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
 
@@ -200,10 +206,11 @@ __device__ __forceinline__ int bpt_slot(int eu) { const int m = eu % 5; return m
 
 // the MFMAs of one test feature F at one k-step: B^{ij}_F = mat(e_F, Nb JW)[i][j] for the blocks whose mask names F
 template <class Form, int I0, int DOFI, int F>
-__device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const double *cf, const PtView &p, const double (&na)[4], const double (&nb)[4]) {
+__device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const double *cf, const PtView &p, const double (&na)[5], const double (&nb)[4]) {
   constexpr int DOF = Form::DOF;
   double T[DOF * DOF];
-  if constexpr (has_mat_unit<Form>::v) Form::template mat_unit<F>(cf, p, nb, T);
+  if constexpr (band_nfeat_of<Form>::v == 5) Form::template mat_unit5<F>(cf, p, nb, T);
+  else if constexpr (has_mat_unit<Form>::v) Form::template mat_unit<F>(cf, p, nb, T);
   else {
     double ef[4];
 #pragma unroll
@@ -214,7 +221,7 @@ __device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const
   for (int i = 0; i < DOFI; ++i)
 #pragma unroll
     for (int j = 0; j < DOF; ++j) {
-      if (!((fm_block_mask<Form>(I0 + i, j) >> F) & 1u)) continue;
+      if (!((bpt_mask<Form>(I0 + i, j) >> F) & 1u)) continue;
       acc[i * DOF + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[F], T[(I0 + i) * DOF + j], acc[i * DOF + j], 0, 0, 0);
     }
 }
@@ -243,7 +250,7 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const
         fa[1] = sa * (fa[1] - fa[0] * o0); fa[2] = sa * (fa[2] - fa[0] * o1); fa[3] = sa * (fa[3] - fa[0] * o2); fa[0] *= sa;
         fb[1] = sb * (fb[1] - fb[0] * o0); fb[2] = sb * (fb[2] - fb[0] * o1); fb[3] = sb * (fb[3] - fb[0] * o2); fb[0] *= sb;
       }
-      double na[4] = {fa[0], fa[1], fa[2], fa[3]}, nb[4] = {fb[0], fb[1], fb[2], fb[3]};
+      double na[5] = {fa[0], fa[1], fa[2], fa[3], 0.0}, nb[4] = {fb[0], fb[1], fb[2], fb[3]};
       if (GEO) {      // ShapeFunctions (src/petigamapshf.f90.in:30-58): dN/dx_i = sum_b du_b/dx_i dN/du_b
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -261,6 +268,10 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const
       bpt_feature<Form, I0, DOFI, 1>(acc, cf, p, na, nb);
       bpt_feature<Form, I0, DOFI, 2>(acc, cf, p, na, nb);
       bpt_feature<Form, I0, DOFI, 3>(acc, cf, p, na, nb);
+      if constexpr (band_nfeat_of<Form>::v == 5) {      // the advective derivative of the test function (the state u is in the record)
+        na[4] = pd[14] * na[1] + pd[15] * na[2] + pd[16] * na[3];
+        bpt_feature<Form, I0, DOFI, 4>(acc, cf, p, na, nb);
+      }
     }
   }
 }
@@ -619,7 +630,7 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
   if (hipGetLastError() != hipSuccess) { err = "band_pt kernel launch failed"; return IGX_ERR_LIB; }
   int nm = 0;
-  for (int i = 0; i < Form::DOF; ++i) for (int j = 0; j < Form::DOF; ++j) for (int f = 0; f < 4; ++f) if ((fm_block_mask<Form>(i, j) >> f) & 1u) nm++;
+  for (int i = 0; i < Form::DOF; ++i) for (int j = 0; j < Form::DOF; ++j) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_mask<Form>(i, j) >> f) & 1u) nm++;
   dom.name = "band_pt<p=3>"; dom.launches = launches;
   dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
   dom.flop_per_element = 2048.0 * nm * 16 * 16;

@@ -321,6 +321,20 @@ struct FormNSVMS {
       T[15] = tauM * Nb_[1 + g];
     }
   }
+  // band_pt.hpp: a fifth test feature, the advective derivative u . grad N_a, makes the momentum-pressure blocks rank 2 instead of 3:
+  // T_i3 = -dN_a/dx_i N_b + tauM (u . grad N_a) dN_b/dx_i.  39 (block, feature) products per k-step instead of 42.
+  static constexpr int BAND_NFEAT = 5;
+  static constexpr unsigned band_block_mask(int i, int j) { return (i < 3 && j == 3) ? ((1u << (1 + i)) | (1u << 4)) : block_mask(i, j); }
+  template <int F>
+  static __device__ __forceinline__ void mat_unit5(const double *c, const PtView &p, const double *Nb_, double *T) {
+    if constexpr (F == 4) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) T[i * 4 + 3] = c[0] * Nb_[1 + i];
+    } else {
+      mat_unit<F>(c, p, Nb_, T);
+      if constexpr (F >= 1) T[(F - 1) * 4 + 3] = -Nb_[0];      // (the tauM u_g dN_b/dx_i part of every row went to feature 4)
+    }
+  }
   static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
     const double tauM = c[0], tauC = c[1];
