@@ -425,6 +425,10 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     for (int n = 0; n < HB; ++n) { accA[n] = (d4_t){0, 0, 0, 0}; accB[n] = (d4_t){0, 0, 0, 0}; }
     if (grp == 0) bpt_mfma_phase<Form, GEO, RAT, 0, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
     else bpt_mfma_phase<Form, GEO, RAT, DOFI, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
+    if constexpr (band_nfeat_of<Form>::v == 5) {   // blocks a form accumulates as differences (forms.hpp: band_combine)
+      if (grp == 0) { Form::template band_combine<0>(accA); Form::template band_combine<0>(accB); }
+      else { Form::template band_combine<DOFI>(accA); Form::template band_combine<DOFI>(accB); }
+    }
     __builtin_amdgcn_s_barrier();
 
     // ---- flush phase.  Group 0 first brings the element that enters the window with the next layer into the ring: its slot was

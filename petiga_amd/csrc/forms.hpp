@@ -323,8 +323,13 @@ struct FormNSVMS {
   }
   // band_pt.hpp: a fifth test feature, the advective derivative u . grad N_a, makes the momentum-pressure blocks rank 2 instead of 3:
   // T_i3 = -dN_a/dx_i N_b + tauM (u . grad N_a) dN_b/dx_i.  39 (block, feature) products per k-step instead of 42.
+  // The diagonal momentum blocks share all but one product: T_ii = D + (nu + tauC) dN_a/dx_i dN_b/dx_i.  The rows come in two groups,
+  // {0, 1} and {2, 3}; in the first one block (1,1) accumulates only T_11 - T_00 = (nu + tauC) (d_y N_a d_y N_b - d_x N_a d_x N_b) -- two
+  // products instead of four -- and band_combine() adds block (0,0) to it when the sums are complete: 37 products per k-step.
   static constexpr int BAND_NFEAT = 5;
-  static constexpr unsigned band_block_mask(int i, int j) { return (i < 3 && j == 3) ? ((1u << (1 + i)) | (1u << 4)) : block_mask(i, j); }
+  static constexpr unsigned band_block_mask(int i, int j) {
+    return (i < 3 && j == 3) ? ((1u << (1 + i)) | (1u << 4)) : ((i == 1 && j == 1) ? 0x6u : block_mask(i, j));
+  }
   template <int F>
   static __device__ __forceinline__ void mat_unit5(const double *c, const PtView &p, const double *Nb_, double *T) {
     if constexpr (F == 4) {
@@ -333,8 +338,13 @@ struct FormNSVMS {
     } else {
       mat_unit<F>(c, p, Nb_, T);
       if constexpr (F >= 1) T[(F - 1) * 4 + 3] = -Nb_[0];      // (the tauM u_g dN_b/dx_i part of every row went to feature 4)
+      if constexpr (F == 1) T[5] = -(p.prm[0] + c[1]) * Nb_[1];
+      if constexpr (F == 2) T[5] = (p.prm[0] + c[1]) * Nb_[2];
     }
   }
+  // acc: the block entries (i - I0) * 4 + j of one band tile for the row fields I0, I0 + 1
+  template <int I0, class V, int N>
+  static __device__ __forceinline__ void band_combine(V (&acc)[N]) { if constexpr (I0 == 0) acc[1 * 4 + 1] += acc[0]; }
   static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
     const double tauM = c[0], tauC = c[1];
