@@ -36,6 +36,7 @@ struct EnvSwitches {
   int no_first_touch = 0;    // IGX_NO_FIRST_TOUCH: MatZeroEntries + read-modify-write everywhere
   int feature_lds_kb = 0;    // IGX_FEATURE_LDS_KB: LDS target of the feature kernel
   int block_pencil = 1;      // IGX_BLOCK_PENCIL=0: constant-coefficient multi-field forms stay on the feature kernel (block_pencil.hpp)
+  int no_vec_pairs = 0;      // IGX_NO_VEC_PAIRS=1: vec_sumfact keeps one element per wavefront at p <= 2
   int state_pencil = 1;      // IGX_STATE_PENCIL=0: Tangents of scalar forms stay on the feature kernel (gram_mfma.hpp: state_pencil)
   int vec_sumfact = 1;       // IGX_VEC_SUMFACT=0: the vector-only drivers stay on the feature kernel (vec_sumfact.hpp)
   int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)

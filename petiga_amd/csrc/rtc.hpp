@@ -446,19 +446,22 @@ static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   const Space &s = g->s;
   if (!compile_only && !rtc_vecsf_eligible(s, F, out)) return 0;
   const bool geo = s.nsd > 0 || s.rational;
+  bool three = !s.env.no_vec_pairs;      // p <= 2: two elements per wavefront
+  for (int d = 0; d < 3; ++d) three = three && s.axis[d].p >= 1 && s.axis[d].p <= 2 && (compile_only || (s.basis[d].nen <= 3 && s.basis[d].nqp <= 3));
+  const int key = (geo ? 1 : 0) | (three ? 2 : 0);
   std::shared_ptr<RtcFeature> K;
-  auto it = F.vecsf.find(geo ? 1 : 0);
+  auto it = F.vecsf.find(key);
   if (it != F.vecsf.end() && (it->second->module || compile_only)) K = it->second;
   else {
     K.reset(new RtcFeature());
-    const std::string x = std::string("igx::vec_sumfact<") + F.name + ", " + (geo ? "true" : "false") + ">";
+    const std::string x = std::string("igx::vec_sumfact<") + F.name + ", " + (geo ? "true" : "false") + ", " + (three ? "3" : "4") + ">";
     const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, long long);\n";
     if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, false, true)) return rc;
     if (!compile_only) {
       HIPCK(hipModuleLoadData(&K->module, K->code.data()));
       hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
     }
-    F.vecsf[geo ? 1 : 0] = K;
+    F.vecsf[key] = K;
   }
   if (compile_only) { done = true; return 0; }
   RtcVecArgs args; memset(&args, 0, sizeof(args));
@@ -480,11 +483,11 @@ static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
     args.cr = cr; args.nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
     size_t asz = sizeof(args);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    HIPCK(hipModuleLaunchKernel(K->func[0], (unsigned)((args.nelem + 3) / 4), 1, 1, 256, 1, 1, 0, g->stream, nullptr, cfg));
+    HIPCK(hipModuleLaunchKernel(K->func[0], (unsigned)((args.nelem + (three ? 7 : 3)) / (three ? 8 : 4)), 1, 1, 256, 1, 1, 0, g->stream, nullptr, cfg));
     launches++;
   }
   g->last_launches = launches;
-  g->last_kernel = std::string("vec_sumfact<") + F.name + ">(hiprtc,vector only: sum factorisation forward and backward, one wavefront per element)";
+  g->last_kernel = std::string("vec_sumfact<") + F.name + ">(hiprtc,vector only: sum factorisation forward and backward, " + (three ? "two elements per wavefront)" : "one wavefront per element)");
   done = true;
   return 0;
 }

@@ -12,7 +12,8 @@
 //             vec() on the unit test features -- nqp evaluations instead of nen * nqp;
 //   backward  F_a = w_a sum_q sum_k C_k(q) D_k N_a(q) over the 10 parametric derivatives D_k up to order 2: the transpose of the
 //             forward contractions.
-// One wavefront per element (4 x 4 x 4 lanes = nodes = points; smaller degrees leave lanes idle), no matrix cores (there is no
+// One wavefront per element (4 x 4 x 4 lanes = nodes = points), two elements per wavefront when no axis has more than three basis
+// functions or points (p <= 2: 2 x 27 of the 64 lanes), no matrix cores (there is no
 // dense contraction left: the work per element drops from ~nen * nqp * features to ~(nen + nqp) * (p+1) * components), coloured
 // scatter (conflict-free, fixed order: bitwise repeatable).  dim 3, nen <= 4 and nqp <= 4 per axis; first-order test features on
 // any geometry, second-order test features (Cahn-Hilliard's Laplacian) on the identity geometry; no boundary loads, no boundary
@@ -35,18 +36,23 @@ __device__ __forceinline__ constexpr int vs_mv1(int m) { return (m == 2 || m == 
 
 // forward: D[k] = sum_a coef_a D_k N_a(q) at this lane's point; ORD = highest derivative order wanted.  buf: 10 x 64 doubles of this
 // wave; tab[d]: [q][a][3] (value, first, second derivative), zero padded to 4 x 4.
-template <int ORD>
-__device__ __forceinline__ void vs_forward(double coef, double *buf, const double *tab0, const double *tab1, const double *tab2, int lane, double (&D)[10]) {
-  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
-  double *in = buf, *T1 = buf + 64, *T2 = buf + 4 * 64;
+// NS: lanes per axis -- 4: one element per wavefront; 3 (nen, nqp <= 3 on every axis): two elements per wavefront, lanes 0..26 and
+// 27..53.  L: this lane's (i0, i1, i2) and the first lane of its element.
+struct VsLane { int i0, i1, i2, base; };
+template <int ORD, int NS>
+__device__ __forceinline__ void vs_forward(double coef, double *buf, const double *tab0, const double *tab1, const double *tab2, int lane, const VsLane &L, double (&D)[10]) {
+  const int i0 = L.i0, i1 = L.i1, i2 = L.i2;
+  constexpr int S1 = NS, S2 = NS * NS;
+  double *in = buf + L.base, *T1 = buf + 64 + L.base, *T2 = buf + 4 * 64 + L.base;
+  lane -= L.base;
   VS_SYNC();
   in[lane] = coef;
   VS_SYNC();
   {   // axis 0: lane (q0, a1, a2)
     double t[3] = {0, 0, 0};
 #pragma unroll
-    for (int a0 = 0; a0 < 4; ++a0) {
-      const double c = in[a0 + 4 * i1 + 16 * i2];
+    for (int a0 = 0; a0 < NS; ++a0) {
+      const double c = in[a0 + S1 * i1 + S2 * i2];
 #pragma unroll
       for (int v = 0; v <= ORD; ++v) t[v] += c * tab0[(i0 * 4 + a0) * 3 + v];
     }
@@ -57,11 +63,11 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
   {   // axis 1: lane (q0, q1, a2)
     double t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int a1 = 0; a1 < 4; ++a1) {
+    for (int a1 = 0; a1 < NS; ++a1) {
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
-        t[m] += T1[vs_mv0(m) * 64 + i0 + 4 * a1 + 16 * i2] * tab1[(i1 * 4 + a1) * 3 + vs_mv1(m)];
+        t[m] += T1[vs_mv0(m) * 64 + i0 + S1 * a1 + S2 * i2] * tab1[(i1 * 4 + a1) * 3 + vs_mv1(m)];
       }
     }
 #pragma unroll
@@ -71,11 +77,11 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
 #pragma unroll
   for (int k = 0; k < 10; ++k) D[k] = 0.0;
 #pragma unroll
-  for (int a2 = 0; a2 < 4; ++a2) {
+  for (int a2 = 0; a2 < NS; ++a2) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       if (vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
-      D[k] += T2[vs_m(vs_v0(k), vs_v1(k)) * 64 + i0 + 4 * i1 + 16 * a2] * tab2[(i2 * 4 + a2) * 3 + vs_v2(k)];
+      D[k] += T2[vs_m(vs_v0(k), vs_v1(k)) * 64 + i0 + S1 * i1 + S2 * a2] * tab2[(i2 * 4 + a2) * 3 + vs_v2(k)];
     }
   }
 }
@@ -84,10 +90,12 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
 // KMASK: the derivatives k whose coefficient can be non-zero (the others are neither stored nor summed); Cb holds them back to back
 __device__ __forceinline__ constexpr int vs_popc(unsigned m) { int n = 0; for (; m; m &= m - 1) ++n; return n; }
 __device__ __forceinline__ constexpr int vs_kc(unsigned kmask, int k) { return vs_popc(kmask & ((1u << k) - 1u)); }
-template <int ORD, unsigned KMASK>
-__device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf, const double *tab0, const double *tab1, const double *tab2, int lane) {
-  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
-  double *Cb = buf, *S2 = buf + vs_popc(KMASK) * 64, *S1 = buf;      // (S1 takes the place of Cb: nobody reads Cb after the first stage)
+template <int ORD, unsigned KMASK, int NS>
+__device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf, const double *tab0, const double *tab1, const double *tab2, int lane, const VsLane &L) {
+  const int i0 = L.i0, i1 = L.i1, i2 = L.i2;
+  constexpr int T1s = NS, T2s = NS * NS;
+  double *Cb = buf + L.base, *S2 = buf + vs_popc(KMASK) * 64 + L.base, *S1 = buf + L.base;      // (S1 takes the place of Cb: nobody reads Cb after the first stage)
+  lane -= L.base;
   static_assert(vs_popc(KMASK) >= 3, "S1 fits where Cb was");
   VS_SYNC();
 #pragma unroll
@@ -96,11 +104,11 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
   {   // axis 2: lane (q0, q1, a2)
     double t[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int q2 = 0; q2 < 4; ++q2) {
+    for (int q2 = 0; q2 < NS; ++q2) {
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
         if (!((KMASK >> k) & 1u) || vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
-        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + 4 * i1 + 16 * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
+        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + T1s * i1 + T2s * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
       }
     }
 #pragma unroll
@@ -110,11 +118,11 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
   {   // axis 1: lane (q0, a1, a2)
     double t[3] = {0, 0, 0};
 #pragma unroll
-    for (int q1 = 0; q1 < 4; ++q1) {
+    for (int q1 = 0; q1 < NS; ++q1) {
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
-        t[vs_mv0(m)] += S2[m * 64 + i0 + 4 * q1 + 16 * i2] * tab1[(q1 * 4 + i1) * 3 + vs_mv1(m)];
+        t[vs_mv0(m)] += S2[m * 64 + i0 + T1s * q1 + T2s * i2] * tab1[(q1 * 4 + i1) * 3 + vs_mv1(m)];
       }
     }
 #pragma unroll
@@ -123,9 +131,9 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
   VS_SYNC();
   double f = 0;
 #pragma unroll
-  for (int q0 = 0; q0 < 4; ++q0) {
+  for (int q0 = 0; q0 < NS; ++q0) {
 #pragma unroll
-    for (int v = 0; v <= ORD; ++v) f += S1[v * 64 + q0 + 4 * i1 + 16 * i2] * tab0[(q0 * 4 + i0) * 3 + v];
+    for (int v = 0; v <= ORD; ++v) f += S1[v * 64 + q0 + T1s * i1 + T2s * i2] * tab0[(q0 * 4 + i0) * 3 + v];
   }
   return f;
 }
@@ -143,9 +151,10 @@ __device__ __forceinline__ constexpr unsigned vs_kmask_ident(unsigned vmask) {
 
 // GEO: a mapped geometry and / or NURBS weights; without them the geometry chain is the identity at compile time (no E1 / E2
 // products, no quotient rule) and the kernel needs half the registers
-template <class Form, bool GEO>
+template <class Form, bool GEO, int NS = 4>
 __global__ void __launch_bounds__(256)
 vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nelem) {
+  constexpr int EPW = NS == 3 ? 2 : 1, NL = NS * NS * NS;               // elements per wavefront, lanes per element
   constexpr int DOF = Form::DOF;
   constexpr unsigned VMASK = vec_test_mask_of<Form>::v;                  // test features vec() reads (bit f)
   constexpr bool SECOND_T = shape_order_of<Form>::v >= 2;                // second-order test features (identity geometry only)
@@ -156,19 +165,24 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // inverse Jacobian mixes the three first derivatives and the rational correction reaches the value
   constexpr unsigned KMASK = GEO ? 0xFu : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
   constexpr int NBACK = vs_popc(KMASK) + (SECOND_T ? 6 : 3), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
-  __shared__ double sm_all[4][NBUF * 64 + 3 * 48];      // Cahn-Hilliard: 31 KB per workgroup, five workgroups (20 wavefronts) per CU
+  __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard: 33 KB per workgroup, four workgroups per CU, two elements per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long w = (long long)blockIdx.x * 4 + wave;
-  if (w >= nelem) return;
-  double *buf = sm_all[wave], *tab0 = buf + NBUF * 64, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
-  int el[3];
-  {
-    long long b = w;
+  const int esub = (EPW == 2 && lane >= NL) ? 1 : 0;                    // which of the wavefront's elements this lane works on
+  const long long w0 = ((long long)blockIdx.x * 4 + wave) * EPW, w = w0 + esub;
+  if (w0 >= nelem) return;
+  const bool live = lane < EPW * NL && w < nelem;                       // (an odd count leaves the second half of the last wavefront idle)
+  double *buf = sm_all[wave], *tab0 = buf + NBUF * 64 + esub * 144, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
+  auto element_of = [&](long long ww, int (&e3)[3]) {
+    long long b = ww < nelem ? ww : w0;
     const int t0 = (int)(b % cr.count[0]); b /= cr.count[0];
     const int t1 = (int)(b % cr.count[1]); b /= cr.count[1];
-    el[0] = cr.start[0] + t0 * cr.step[0]; el[1] = cr.start[1] + t1 * cr.step[1]; el[2] = cr.start[2] + (int)b * cr.step[2];
-  }
-  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+    e3[0] = cr.start[0] + t0 * cr.step[0]; e3[1] = cr.start[1] + t1 * cr.step[1]; e3[2] = cr.start[2] + (int)b * cr.step[2];
+  };
+  int el[3];
+  element_of(w, el);
+  const int ll = lane < EPW * NL ? lane - esub * NL : 0;                 // (the lanes beyond the last element idle on lane 0's indices)
+  const int i0 = NS == 4 ? (ll & 3) : ll % 3, i1 = NS == 4 ? ((ll >> 2) & 3) : (ll / 3) % 3, i2 = NS == 4 ? (ll >> 4) : ll / 9;
+  const VsLane VL = {i0, i1, i2, esub * NL};
   const int il[3] = {i0, i1, i2};
   const int op = out.op;
   const bool geo = GEO && S.nsd > 0, rat = GEO && S.rational != 0;
@@ -176,14 +190,15 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   int nb[3], nq[3], off[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) { nb[d] = S.ax[d].nen; nq[d] = S.ax[d].nqp; off[d] = S.ax[d].off[el[d]]; }
-  // 1-D rows of the element, [q][a][3], zero padded to 4 x 4
-  for (int i = lane; i < 3 * 48; i += 64) {
-    const int d = i / 48, j = i - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
-    tab0[i] = (q < nq[d] && a < nb[d]) ? S.ax[d].tab[((size_t)el[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v] : 0.0;
+  // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4
+  for (int i = lane; i < EPW * 3 * 48; i += 64) {
+    const int es = i / 144, r = i - es * 144, d = r / 48, j = r - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
+    int e3[3]; element_of(w0 + es, e3);
+    buf[NBUF * 64 + i] = (q < nq[d] && a < nb[d]) ? S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v] : 0.0;
   }
   // this lane's node: control point, state, Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
-  const bool isnode = i0 < nb[0] && i1 < nb[1] && i2 < nb[2];
-  const bool ispoint = i0 < nq[0] && i1 < nq[1] && i2 < nq[2];
+  const bool isnode = live && i0 < nb[0] && i1 < nb[1] && i2 < nb[2];
+  const bool ispoint = live && i0 < nq[0] && i1 < nq[1] && i2 < nq[2];
   size_t row = 0; double Xw[3] = {0, 0, 0}, wgt = 0.0, Uv[DOF], Vv[DOF], ufix[DOF]; bool fixed[DOF];
 #pragma unroll
   for (int f = 0; f < DOF; ++f) { Uv[f] = 0; Vv[f] = 0; ufix[f] = 0; fixed[f] = false; }
@@ -222,7 +237,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   auto k2 = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
   if constexpr (GEO) if (geo || rat) {
     double Dw[10], Dx[3][10];
-    if (UORD == 2) vs_forward<2>(wgt, buf, tab0, tab1, tab2, lane, Dw); else vs_forward<1>(wgt, buf, tab0, tab1, tab2, lane, Dw);
+    if (UORD == 2) vs_forward<2, NS>(wgt, buf, tab0, tab1, tab2, lane, VL, Dw); else vs_forward<1, NS>(wgt, buf, tab0, tab1, tab2, lane, VL, Dw);
     const double W0 = ispoint ? Dw[0] : 1.0;
     iw = 1.0 / W0;
 #pragma unroll
@@ -234,7 +249,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
         for (int b = 0; b < 3; ++b) o2[a * 3 + b] = Dw[k2(a, b)] * iw;
     if (geo) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { if (UORD == 2) vs_forward<2>(Xw[c], buf, tab0, tab1, tab2, lane, Dx[c]); else vs_forward<1>(Xw[c], buf, tab0, tab1, tab2, lane, Dx[c]); }
+      for (int c = 0; c < 3; ++c) { if (UORD == 2) vs_forward<2, NS>(Xw[c], buf, tab0, tab1, tab2, lane, VL, Dx[c]); else vs_forward<1, NS>(Xw[c], buf, tab0, tab1, tab2, lane, VL, Dx[c]); }
       double X1[9], X2[27];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {      // quotient rule on A = sum w X N, W = sum w N (src/petigarat.f90.in + petigamapgeo.f90.in)
@@ -281,7 +296,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
     for (int i = 0; i < 9; ++i) hu[f * 9 + i] = 0;
     if ((Form::NEED & (NEED_U | NEED_GU | NEED_HU)) && useU) {
       double D[10];
-      vs_forward<UORD>((fixed[f] ? ufix[f] : Uv[f]) * wgt, buf, tab0, tab1, tab2, lane, D);
+      vs_forward<UORD, NS>((fixed[f] ? ufix[f] : Uv[f]) * wgt, buf, tab0, tab1, tab2, lane, VL, D);
       u[f] = D[0] * iw;
       if constexpr (!GEO) {
         if (UORD >= 1) for (int a = 0; a < 3; ++a) gu[f * 3 + a] = D[1 + a];
@@ -320,7 +335,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
     }
     if ((Form::NEED & NEED_UT) && useV) {
       double D[10];
-      vs_forward<0>((fixed[f] ? 0.0 : Vv[f]) * wgt, buf, tab0, tab1, tab2, lane, D);
+      vs_forward<0, NS>((fixed[f] ? 0.0 : Vv[f]) * wgt, buf, tab0, tab1, tab2, lane, VL, D);
       ut[f] = D[0] * iw;
     }
   }
@@ -376,7 +391,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // ---- backward, IGAElementFixFunction (src/petigaelem.c:1449-1461), IGAElementAssembleVec
 #pragma unroll
   for (int f = 0; f < DOF; ++f) {
-    double F = SECOND_T ? vs_backward<2, KMASK>(Cq[f], buf, tab0, tab1, tab2, lane) : vs_backward<1, KMASK>(Cq[f], buf, tab0, tab1, tab2, lane);
+    double F = SECOND_T ? vs_backward<2, KMASK, NS>(Cq[f], buf, tab0, tab1, tab2, lane, VL) : vs_backward<1, KMASK, NS>(Cq[f], buf, tab0, tab1, tab2, lane, VL);
     F *= wgt;
     if (isnode) {
       if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
@@ -425,12 +440,28 @@ static int try_vec_sumfact(const Space &s, const SpaceDev &S, const ParamsDev &p
     }
     if (empty) continue;
     const long long nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
-    if (s.nsd > 0 || s.rational) hipLaunchKernelGGL((vec_sumfact<Form, true>), dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
-    else hipLaunchKernelGGL((vec_sumfact<Form, false>), dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    // at most three basis functions and points per axis (p <= 2): two elements per wavefront (54 of 64 lanes instead of 27)
+    bool three = !s.env.no_vec_pairs;
+    for (int d = 0; d < 3; ++d) three = three && s.basis[d].nen <= 3 && s.basis[d].nqp <= 3;
+    const bool g1 = s.nsd > 0 || s.rational;
+    if (three) {
+      const unsigned grid = (unsigned)((nelem + 7) / 8);
+      if (g1) hipLaunchKernelGGL((vec_sumfact<Form, true, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
+      else hipLaunchKernelGGL((vec_sumfact<Form, false, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    } else {
+      const unsigned grid = (unsigned)((nelem + 3) / 4);
+      if (g1) hipLaunchKernelGGL((vec_sumfact<Form, true, 4>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
+      else hipLaunchKernelGGL((vec_sumfact<Form, false, 4>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
+    }
     launches++;
   }
   if (hipGetLastError() != hipSuccess) return IGX_ERR_LIB;
-  kname = "vec_sumfact(vector only: sum factorisation forward and backward, one wavefront per element)";
+  {
+    bool three = !s.env.no_vec_pairs;
+    for (int d = 0; d < 3; ++d) three = three && s.basis[d].nen <= 3 && s.basis[d].nqp <= 3;
+    kname = three ? "vec_sumfact(vector only: sum factorisation forward and backward, two elements per wavefront)"
+                  : "vec_sumfact(vector only: sum factorisation forward and backward, one wavefront per element)";
+  }
   done = true;
   return 0;
   }
