@@ -101,6 +101,43 @@ def cpu_baseline(form, degree, seconds_target=15.0):
                        "one core alone %.1f s, pool wall %.1f s" % (what, m, cores, wall, t1, time.time() - t0))
 
 
+def live_traffic(child_args, dom_name, timeout=300):
+    """HBM bytes per launch of the dominant kernel, measured now: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each with
+    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) around a one-step child run of this same script.
+    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KB and gfx950 reports half of a wide coalesced read.
+    Returns (bytes_per_launch or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "rocprofv3 not found"
+    key = dom_name.split("<")[0].split("(")[0]          # gram_pencil, block_pencil, state_pencil, band_pt, form_pencil, feature_assemble
+    mean = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="igx_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__)] + child_args
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout, env=dict(os.environ, TMPDIR="/tmp"), cwd=ROOT)
+            per = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and ("igx::" + key) in r["Kernel_Name"]:
+                        per.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
+            if not per:
+                return None, "no %s samples of %s" % (counter, key)
+            name = max(per, key=lambda k: sum(per[k]))       # (two-assembly steps: the IJacobian's kernel carries the traffic)
+            mean[counter] = sum(per[name]) / len(per[name])
+        except Exception as e:                              # a missing counter, a time-out: the line falls back to the replayed figure
+            return None, "rocprofv3 pass failed: %r" % (e,)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0, \
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each around a one-step child run of this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch"
+
+
 def _bench_geometry(p, size, periodic):
     """The smooth rational map of `--geometry` (config 5's premise): the same control net for the engine and the oracle."""
     import numpy as np
@@ -261,6 +298,7 @@ def main():
     ap.add_argument("--source", action="store_true", help="poisson only: the form is given as run-time source (IGXSetFormSource), not as the built-in struct")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic (N = 1); replay profiles/traffic.json instead")
     args = ap.parse_args()
     wl = WORKLOADS[args.form]
     # (NavierStokesVMS at 192^3 is an 8-GPU configuration -- 313 GB of matrix values; on fewer than 4 GPUs the default mesh is
@@ -439,6 +477,14 @@ def main():
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % ent.get("round", tj.get("round"))
         except Exception:
             traffic = None
+    if world == 1 and rank == 0 and not args.no_live_traffic and dom_launches > 0:
+        child = ["--form", args.form, "--size", str(size), "--degree", str(args.degree), "--kernel", str(args.kernel), "--steps", "1", "--warmup", "0",
+                 "--no-cpu-baseline", "--no-live-traffic"] + (["--geometry"] if args.geometry else []) + (["--source"] if args.source else [])
+        lt, note = live_traffic(child, dom_name)
+        if lt is not None:
+            traffic, traffic_source = lt, note
+        elif traffic_source:
+            traffic_source += " [live measurement unavailable: %s]" % note
     # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (the headline kernel skips the
     # 6 mirror tiles of the symmetric K_e: 10 of 16), so frac <= 1 is the fp64 MFMA-pipe fraction; the ALGORITHMIC rate
     # (SURVEY 8d / BASELINE.md 3 flop per element) is kept next to it.  For the two-assembly steps (IFunction + IJacobian) the

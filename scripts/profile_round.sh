@@ -11,13 +11,13 @@ rm -rf $OUT; mkdir -p $OUT
 FORMS="${FORMS:-poisson elasticity cahnhilliard nsvms}"
 for f in $FORMS; do
   python3 bench.py --form $f --steps 5 --warmup 1 > $OUT/line_$f.json 2> $OUT/line_$f.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$f -o kt -- python3 bench.py --form $f --steps 3 --warmup 1 --no-cpu-baseline > $OUT/kt_$f.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt_$f -o kt -- python3 bench.py --form $f --steps 3 --warmup 1 --no-cpu-baseline --no-live-traffic > $OUT/kt_$f.log 2>&1
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${f}_$c -o p -- python3 bench.py --form $f --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_${f}_$c.log 2>&1
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_${f}_$c -o p -- python3 bench.py --form $f --steps 1 --warmup 0 --no-cpu-baseline --no-live-traffic > $OUT/pmc_${f}_$c.log 2>&1
   done
-  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${f}_SQ -o p -- python3 bench.py --form $f --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_${f}_SQ.log 2>&1
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${f}_SQ -o p -- python3 bench.py --form $f --steps 1 --warmup 0 --no-cpu-baseline --no-live-traffic > $OUT/pmc_${f}_SQ.log 2>&1
 done
-rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_poisson_LDS -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline > $OUT/pmc_poisson_LDS.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_poisson_LDS -o p -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-live-traffic > $OUT/pmc_poisson_LDS.log 2>&1
 # secondary timings (one assembly each, current kernels)
 BENCH_COMPACT=1 python3 scripts/bench_configs.py c1 c2 full3 full4 full5 c5r c5g c6 c6b c6m c6p c7 > $OUT/configs.txt 2> $OUT/configs.err
 python3 scripts/bench_rtc.py > $OUT/rtc.txt 2> $OUT/rtc.err
