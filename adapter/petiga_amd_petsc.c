@@ -192,7 +192,7 @@ static PetscErrorCode IGAAmdSetState(IGA iga,IGAAmdCtx *c,Vec vecU,IGXVec U)
   /* IGAGetLocalVecArray = IGAGetLocalVec + DMGlobalToLocal + VecGetArrayRead (src/petigavec.c:256-269); the array is taken with
      its memory type instead, so that a device Vec's values never visit the host */
   PetscCall(IGAGetLocalVec(iga,&localU));
-  PetscCall(IGAGlobalToLocal(iga,vecU,localU));
+  PetscCall(IGAGlobalToLocal(iga,vecU,localU,INSERT_VALUES));      /* (src/petigavec.c:266) */
   PetscCall(VecGetArrayReadAndMemType(localU,&arrayU,&mtype));
   IGXCHK(PetscObjectComm((PetscObject)iga),IGXVecCopyFromGhosted(U,(const double*)arrayU,PetscMemTypeDevice(mtype) ? 1 : 0));
   /* a device copy is a kernel on the engine's stream: done before PETSc gets its array back (include/petiga_amd.h) */
@@ -356,7 +356,7 @@ PetscErrorCode IGAComputeScalarSourceAMD(IGA iga,Vec vecU,PetscInt n,PetscScalar
   PetscCheck(n >= 1 && n <= 64,comm,PETSC_ERR_ARG_OUTOFRANGE,"Number of scalars must be in range [1,64], got %" PetscInt_FMT,n);
   if (vecU) PetscCall(IGAAmdSetState(iga,c,vecU,c->U));
   IGXCHK(comm,IGXComputeScalarSource(c->igx,vecU ? c->U : NULL,source,struct_name,(const double*)params,(int)nparams,(int)n,local));
-  PetscCallMPI(MPIU_Allreduce(local,S,(PetscMPIInt)n,MPIU_SCALAR,MPIU_SUM,comm));
+  PetscCallMPI(MPI_Allreduce(local,S,(PetscMPIInt)n,MPIU_SCALAR,MPIU_SUM,comm));      /* as src/petigacomp.c:84 (MPIU_Allreduce returns a PetscErrorCode before PETSc 3.22) */
   PetscFunctionReturn(PETSC_SUCCESS);
 }
 #endif /* PETIGA_HAVE_AMD */

@@ -3,7 +3,9 @@
 (BASELINE.json metric), one process per GPU.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+  N>1: either way works -- `python bench.py --gpus N ...` starts its own N ranks (launch_ranks: children of a process that has
+  not touched the GPU) and relays rank 0's line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+  the ranks are the launcher's.
 
 A step = one complete IGAComputeSystem-equivalent: zero A and b, form every local element's K_e/F_e,
 apply the Dirichlet fix-up, scatter into the device CSR, and (N>1) reduce the ghost rows to their
@@ -285,6 +287,40 @@ def build_problem(P, name, size, degree, world, rank, kernel, geometry, source=F
     return g, A, b, U, V, p
 
 
+def launch_ranks(n):
+    """Starts the n ranks of `bench.py --gpus n` as children of this (GPU-free, torch-free) process: the same command line with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set, rank 0's stdout relayed, the others' kept on stderr.
+    Returns the worst exit code; a rank that fails takes the others down after a grace period (exact PIDs), nothing is retried."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:               # a free rendezvous port on the loop-back interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen(cmd, env=env, cwd=os.getcwd(), stdout=None if r == 0 else sys.stderr))
+    worst, t_fail = 0, None
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            rc = pr.poll()
+            if rc is not None:
+                live.remove(pr)
+                if rc != 0:
+                    worst = worst or (rc if rc > 0 else 128 - rc)
+                    t_fail = t_fail or time.time()
+        if t_fail and live and time.time() - t_fail > 30.0:      # the others may sit in a rendezvous / collective for ever
+            for pr in live:
+                pr.kill()
+            t_fail = time.time() + 1e9
+        time.sleep(0.05)
+    return worst
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,16 +342,25 @@ def main():
     size = args.size or (wl["size"] if (args.form != "nsvms" or args.gpus >= 4) else 96)
     geometry = args.geometry or args.form == "nsvms"
 
+    # `python bench.py --gpus N` without a launcher: this process starts the N ranks itself and relays rank 0's line.  It has
+    # not imported torch and never touches the GPU (a process that has initialised the GPU must not exec or be replaced).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     os.environ.setdefault("IGX_CLOCK_PROBE", "1")   # read at IGXCreate: three stores by one lane per launch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (start it as `python bench.py --gpus N`, or through torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
     # IGX_BENCH_BACKEND=gloo is a test transport (ranks may then share one GPU); the product transport is RCCL
     backend = os.environ.get("IGX_BENCH_BACKEND", "nccl")
-    torch.cuda.set_device(local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local)
+    ndev = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if backend == "nccl" and ndev < world:    # every rank sees the same count and leaves before any rendezvous: rc != 0, no hang
+        sys.exit("bench.py: --gpus %d over RCCL needs %d GPUs, this box shows %d (IGX_BENCH_BACKEND=gloo is the test transport for ranks sharing one GPU)" % (world, world, ndev))
+    torch.cuda.set_device(local % max(ndev, 1) if backend != "nccl" else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -325,6 +370,8 @@ def main():
     assert not args.source or args.form == "poisson", "--source is the metric configuration's form given as source"
     g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry, args.source)
     transport = exchange.init_comm(g) if world > 1 else None      # the library's own exchange: RCCL (or the gloo test transport)
+    # what the transport itself reports: ncclCommCount of the library's communicator ("did RCCL see N ranks")
+    comm_kind, comm_ranks = g.comm_ranks() if world > 1 else (None, None)
     tangent = wl["op"] == "tangent"
     shift = 1.0e3
 
@@ -357,12 +404,24 @@ def main():
     fence()
     t0 = time.perf_counter()
     dom_ms, dom_launches, dom_elems, dom_name, dom_flop = 0.0, 0, 0, "none", 0.0
+    step_ms, step_dom_ms, step_mhz, step_ticks = [], [], [], []
+    t_prev = t0
     for _ in range(args.steps):
         step()
         # HIP events recorded on the engine's own stream around the launches of the dominant kernel of this step
         d = g.dominant_kernel()
         dom_ms += d["ms"]; dom_launches += d["launches"]; dom_elems += d["elements"]
         dom_name, dom_flop = d["name"], d["executed_flop_per_element"]
+        # per step: the shader clock the pencil kernel saw in THIS step (the probe's sums are read and cleared behind the step's
+        # last launch), and the host clock at that point -- box variance and clock dips show up as spread, a slower kernel as a
+        # shift of min / median / max together
+        try:
+            mhz, ticks = g.clock_probe()
+        except Exception:
+            mhz, ticks = None, 0
+        t_now = time.perf_counter()
+        step_ms.append((t_now - t_prev) * 1e3); step_dom_ms.append(d["ms"]); step_mhz.append(mhz); step_ticks.append(ticks)
+        t_prev = t_now
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -450,10 +509,8 @@ def main():
     # 1/2/4/8 GPUs"); rank 0's block is the line's `roofline`, the others travel in `roofline_per_rank`
     # shader clock the chip sustained while the pencil kernel ran (s_memtime ticks per 100 MHz s_memrealtime tick of the first
     # and last workgroup of every timed launch, IGXGetClockProbe): `peak` stays the nominal 2.4 GHz figure, this says how much of the gap is clock
-    try:
-        clock_mhz = g.clock_probe()[0]
-    except Exception:
-        clock_mhz = None
+    good = [(m, w) for m, w in zip(step_mhz, step_ticks) if m]
+    clock_mhz = (sum(m * max(w, 1) for m, w in good) / sum(max(w, 1) for m, w in good)) if good else None
     if args.form == "poisson":
         flop, cbytes = FLOP_PER_ELEM.get(args.degree, 2 * (args.degree + 1) ** 9 * 3), BYTES_PER_ELEM.get(args.degree)
     else:
@@ -509,7 +566,11 @@ def main():
         line = {
             "metric": wl["metric"],
             "value": value, "unit": "elements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_min": min(step_ms), "ms_per_step_median": sorted(step_ms)[len(step_ms) // 2], "ms_per_step_max": max(step_ms),
+            "per_step": {"ms": [round(x, 3) for x in step_ms], "dominant_kernel_ms": [round(x, 3) for x in step_dom_ms],
+                         "shader_clock_mhz": [round(x, 1) if x else None for x in step_mhz]},
+            "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%s: p=%d C%d, %d^3 elements, dof=%d, Gauss %d^3%s%s"
                                    % (wl["ref"], p, p - 1, size, wl["dof"], p + 1, ", Dirichlet u=1 on 6 faces" if args.form == "poisson" else "",
@@ -517,7 +578,8 @@ def main():
                                    (" (one GPU's share of the 192^3 configuration)" if (args.form == "nsvms" and size == 96 and not args.size) else "") +
                                    (" -- the form given as run-time source (IGXSetFormSource)" if args.source else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
-                       "transport": transport, "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
+                       "transport": transport, "rccl_ranks": comm_ranks if comm_kind == "rccl" else None, "transport_ranks": comm_ranks,
+                       "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
             "roofline": roof,
             "device": P.device_info(),
         }

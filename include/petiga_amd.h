@@ -333,6 +333,10 @@ int IGXRefreshGhosts(IGX iga,IGXVec v);
 int IGXCommGetLastBytes(IGX iga,int64_t *bytes_sent);      /* of the last exchange */
 /* one rank sends n doubles to itself through the RCCL path (binding, communicator, streams and events on a single GPU) */
 int IGXCommLoopbackTest(IGX iga,int64_t n,double *maxdiff);
+/* What the bound transport itself reports: kind 1 = RCCL, 2 = host callback (0: none bound); ranks = ncclCommCount of the RCCL
+ * communicator (the number of ranks RCCL actually connected; MPI_Comm_size of the reference's communicator, src/petiga.c:1111),
+ * the size given to IGXSetComm for a host transport. */
+int IGXCommGetRanks(IGX iga,int *kind,int *ranks);
 
 /* ------------------------------------------------------------------------------------------
  * Hand-back to PETSc (used by adapter/petiga_amd_petsc.c).  PETSc assembles device matrices from coordinate

@@ -52,6 +52,8 @@ def lib(build_if_needed=False):
     if _LIB is not None:
         return _LIB
     so = os.path.join(_HERE, "libpetiga_amd_debug.so" if os.environ.get("IGX_USE_DEBUG_LIB") else "libpetiga_amd.so")   # the -DIGX_DEBUG experiment build
+    if os.environ.get("IGX_LIB"):      # another build of this same library (A/B measurements, scripts/headline_ab.py)
+        so = os.path.abspath(os.environ["IGX_LIB"])
     if build_if_needed:
         so = _build.build()
     if not os.path.exists(so):
@@ -99,10 +101,12 @@ def lib(build_if_needed=False):
         "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
         "IGXCommDestroy": [V], "IGXReduceGhostRows": [V, V, V], "IGXRefreshGhosts": [V, V], "IGXCommGetLastBytes": [V, C.POINTER(C.c_int64)],
-        "IGXCommLoopbackTest": [V, C.c_int64, _dp],
+        "IGXCommLoopbackTest": [V, C.c_int64, _dp], "IGXCommGetRanks": [V, C.POINTER(C.c_int), C.POINTER(C.c_int)],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
+        if os.environ.get("IGX_LIB") and not hasattr(L, name):      # an older build of the library under A/B: it lacks newer entry points
+            continue
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
@@ -431,6 +435,12 @@ class IGX:
         n = C.c_int64()
         _ck(lib().IGXCommGetLastBytes(self.h, C.byref(n)))
         return n.value
+
+    def comm_ranks(self):
+        """(transport kind: "rccl" / "host" / None, ranks the transport itself reports: ncclCommCount for RCCL)."""
+        k, n = C.c_int(0), C.c_int(0)
+        _ck(lib().IGXCommGetRanks(self.h, C.byref(k), C.byref(n)))
+        return {0: None, 1: "rccl", 2: "host"}[k.value], n.value
 
     def comm_loopback_test(self, n=1 << 20):
         d = C.c_double()

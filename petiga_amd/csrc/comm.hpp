@@ -19,6 +19,7 @@ struct RcclApi {
   int (*GetUniqueId)(void *) = nullptr;                                           // ncclGetUniqueId(ncclUniqueId*)
   int (*CommInitRank)(void **, int, IGXUniqueId, int) = nullptr;                  // ncclCommInitRank(comm*, nranks, id (by value), rank)
   int (*CommDestroy)(void *) = nullptr;
+  int (*CommCount)(void *, int *) = nullptr;                                      // ncclCommCount(comm, int*)
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;     // ncclSend(buf, count, datatype, peer, comm, stream)
@@ -42,6 +43,7 @@ static int load_rccl(RcclApi &api, const char *path, std::string &err) {
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));
   api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
   api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
   api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
   api.Send = reinterpret_cast<decltype(api.Send)>(sym("ncclSend"));
@@ -224,6 +226,18 @@ extern "C" int IGXCommGetOverlap(IGX g, double *ms) {
   float t = 0;
   HIPCK(hipEventElapsedTime(&t, c.packed1, c.ready));
   *ms = t;
+  return 0;
+}
+extern "C" int IGXCommGetRanks(IGX g, int *kind, int *ranks) {
+  NEEDIGA(g);
+  if (kind) *kind = g->comm ? g->comm->kind : 0;
+  if (ranks) {
+    *ranks = g->comm ? g->s.comm_size : 0;
+    if (g->comm && g->comm->kind == 1) {
+      if (!rccl_api().CommCount) return fail(IGX_ERR_LIB, "librccl.so lacks ncclCommCount");
+      NCCLCK(rccl_api().CommCount(g->comm->nccl, ranks));
+    }
+  }
   return 0;
 }
 extern "C" int IGXCommGetLastBytes(IGX g, int64_t *bytes) { NEEDIGA(g); if (bytes) *bytes = g->comm ? g->comm->last_bytes : 0; return 0; }

@@ -546,7 +546,6 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
       Fnew = ff ? (double)nelem * fv : Facc - t;
     }
     if (full) {   // interior row: one BW-entry run per (lane, r)
-      if (fdo) out.vec[frow] = Fold + Fnew;
 #pragma unroll
       for (int r0 = 0; r0 < NB; r0 += RB) {
         double o[RB][BW];
@@ -565,6 +564,11 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
             for (int k = 0; k < BW / 2; ++k) { const d2u_t x = *reinterpret_cast<const d2u_t *>(p + 2 * k); o[rr][2 * k] = x[0]; o[rr][2 * k + 1] = x[1]; }
             o[rr][BW - 1] = p[BW - 1];
           }
+        }
+        // F behind the first batch's loads: its store needs Fold, and a wait for that load ahead of the band row's loads would put
+        // one more memory round trip into every flush (round 3 had it there: +1.7 % shader cycles per launch of the headline kernel)
+        if (r0 == 0 && fdo) out.vec[frow] = Fold + Fnew;
+        if (lane_ok) {
 #pragma unroll
           for (int rr = 0; rr < RB; ++rr) {
             const int r = r0 + rr;
@@ -1115,7 +1119,9 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
   }
 }
 
-template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT>
+// ALIAS: the wrapped walk axis (PencilArgs::alias0) known at compile time -- 0: not wrapped, 1: wrapped, -1: read from the arguments.
+// The identity-geometry Gram instantiations come in both fixed flavours, so the headline kernel carries none of the modulo logic.
+template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
   static_assert(is_builtin_gram<Form>::v || (GEO && !FIXT), "a run-time form takes the metric path");
@@ -1133,7 +1139,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 8 + wave;
   const int ws = pa.w_lo + seg * pa.seg_len;
   const int we = min(ws + pa.seg_len, pa.w_hi);
-  const bool alias0 = W == 0 && pa.alias0 != 0;
+  static_assert(ALIAS <= 0 || W == 0, "only the axis-0 walk wraps");
+  const bool alias0 = ALIAS >= 0 ? ALIAS == 1 : (W == 0 && pa.alias0 != 0);
   const int nelw = pa.w_hi - pa.w_lo;                        // (alias0: the whole axis, w_lo = 0)
   const int wh = alias0 ? ws - P : max(ws - P, pa.w_lo);     // first element walked (alias0: may be negative = from the end of the axis)
   const int ne = we - wh, nl = ne + P;
@@ -1383,10 +1390,10 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     }
 }
 
-template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
+template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false, int ALIAS = -1>
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
-  gram_pencil_body<SYSTEM, W, P, GEO, RAT, FIXT, void, false>(S, out, pa, nullptr);
+  gram_pencil_body<SYSTEM, W, P, GEO, RAT, FIXT, void, false, ALIAS>(S, out, pa, nullptr);
 }
 
 // the same walk for a run-time scalar form (rtc.hpp compiles this instantiation with hiprtc; IDENT: no geometry)
@@ -1487,7 +1494,8 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
       (void)hipModuleLaunchKernel(mod->fn, (unsigned)(pa.blocks_per_seg * pa.nseg), 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg);
     } else {
-    auto kern = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
+    void (*kern)(SpaceDev, OutDev, PencilArgs) = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
+    if constexpr (W == 0 && !GEO) kern = pa.alias0 ? gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 1> : gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 0>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
     }
