@@ -16,9 +16,15 @@
 //      stream costs about one MFMA per instruction: a tabulation inside this kernel's flush phase would cost more than the
 //      contraction it feeds.)
 //
-// dof = 4: a block is 128 bytes; the row fields come in two groups ({0,1}, {2,3}: 8 of the 16 entries of a block, 128 accumulator
-// registers for a wave's two band tiles) and the two wave groups of the workgroup take one group each of the SAME layer, half a
-// period apart; a flush adds 64-byte half blocks.  The stage holds half of the rows of the band row at a time (57 KB).
+// Round 4 layout (dof = 4: a block is 128 bytes).  A wavefront holds ONE band tile at a time with ALL 16 entries of its blocks
+// (16, or 17 with the part the diagonal momentum blocks share, accumulators of 8 registers): the features of a k-step are built
+// once (round 3 built them in two wave groups, one per pair of row fields), the shared part of the diagonal blocks is summed once
+// (34 instead of 37 products per k-step), and a lane ends up with whole 128-byte blocks -- its read-add-write goes from the
+// accumulators straight to the matrix, one cache line per (lane, row slot): no LDS stage, no arrival counters.  Workgroup = one
+// pencil, FOUR wavefronts (band tiles d = {0}, {+1,-3}, {-1,+3}, {+2,-2}: four tile products each), two workgroups per CU: the two
+// wavefronts of a SIMD belong to different pencils and nothing synchronises them -- while one waits for its old values the
+// other one streams MFMAs.  The next element's record enters the ring through global_load_lds (no registers, one barrier per
+// layer).
 // Periodic axes wrapped inside the rank (config 5 on one GPU) are taken on the walk axis (layers and elements modulo nel) and on
 // axis 2 (its column positions come from the per-axis table); axis 1 must have consecutive positions.
 #pragma once
@@ -37,15 +43,28 @@ template <class Form> __host__ __device__ constexpr unsigned bpt_mask(int i, int
 template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
 template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
 
-// element record (doubles): 64 points x NPD, then the element's walk-axis rows [q][a][2], then its 64 NURBS weights
-template <class Form> constexpr int bpt_npd() { return 1 + 9 + 4 + Form::DOF + Form::NCOEF; }     // JW | E1[b][c] | 1/W, dW_b/W | u | coefficients
-template <class Form> constexpr int bpt_rec() { return 64 * bpt_npd<Form>() + 32 + 64; }
+// BAND_NACC / band_acc_mask / mat_acc / band_finish: the form names its accumulators itself (more than dof^2 when blocks share
+// a part: forms.hpp, FormNSVMS); otherwise one accumulator per block entry with the masks above
+template <class F, class = void> struct band_nacc_of { static constexpr int v = F::DOF * F::DOF; static constexpr bool own = false; };
+template <class F> struct band_nacc_of<F, decltype((void)F::BAND_NACC)> { static constexpr int v = F::BAND_NACC; static constexpr bool own = true; };
+template <class Form> __host__ __device__ constexpr unsigned bpt_acc_mask(int n) {
+  if constexpr (band_nacc_of<Form>::own) return Form::band_acc_mask(n); else return bpt_mask<Form>(n / Form::DOF, n % Form::DOF);
+}
+
+// element record (doubles): 64 points x NPD, then the element's walk-axis rows [q][a][2], then its 64 NURBS weights; padded to
+// whole KB (global_load_lds moves 64 lanes x 16 bytes per instruction).  Per point: JW | the map from the parametric value and
+// gradient (n, d_0, d_1, d_2) of w_a N_a to the physical ones: R = g0 n, d_i R = h_i n + sum_b Gm[i][b] d_b, with g0 = 1/W,
+// Gm[i][b] = du_b/dx_i / W, h_i = -sum_b Gm[i][b] dW_b/W (Rationalize + ShapeFunctions, src/petigarat.f90.in:3-57,
+// petigamapshf.f90.in:30-58, in one 4 x 4 matrix) | u | the form's point coefficients
+template <class Form> constexpr int bpt_npd() { return 1 + 13 + Form::DOF + Form::NCOEF; }
+template <class Form> constexpr int bpt_rec() { return (64 * bpt_npd<Form>() + 32 + 64 + 127) / 128 * 128; }
 
 struct BandArgs {
   int ex_start, ex_step, ex_count, ey_start, ey_step, ey_count;
   int nel0, alias0;                  // elements on axis 0; axis 0 periodic and wrapped inside the rank
   int seg_len, nseg;                 // node layers per segment
   int first_touch, nelx, nely, fty_lo, fty_hi, fty_blocked;
+  int wrap2;                         // axis 2 periodic and wrapped inside the rank (first-touch rule without clipping)
   double *pts;                       // element records of this launch: [pencil][element on axis 0][bpt_rec]
   int debug, dbg_block;
 };
@@ -161,11 +180,15 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     }
     const double Jw = AW.J[e0], Jx = AX.J[elx], Jy = AY.J[ely];
     rec[0] = det * (AW.w[e0 * NB + i2] * Jw) * (AX.w[elx * NB + i0] * Jx) * (AY.w[ely * NB + i1] * Jy);
+    const double g0 = rat ? iw : 1.0;
+    rec[1] = g0;
 #pragma unroll
-    for (int b = 0; b < 3; ++b)
+    for (int i = 0; i < 3; ++i) {
+      double h = 0.0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) rec[1 + b * 3 + c] = E[b][c];
-    rec[10] = iw; rec[11] = H[3][1] * iw; rec[12] = H[3][2] * iw; rec[13] = H[3][3] * iw;
+      for (int b = 0; b < 3; ++b) { const double gm = g0 * E[b][i]; rec[2 + i * 3 + b] = gm; h -= gm * (H[3][1 + b] * iw); }
+      rec[11 + i] = rat ? h : 0.0;
+    }
     double u[DOF];
 #pragma unroll
     for (int f = 0; f < DOF; ++f) { u[f] = H[4 + f][0] * iw; rec[14 + f] = u[f]; }
@@ -185,18 +208,18 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   for (int k = 0; k < NPD; ++k) dst[lane * NPD + k] = rec[k];
   if (lane < 32) dst[64 * NPD + lane] = ztg[lane];
   dst[64 * NPD + 32 + lane] = coef[lane * NC + 3];      // weight of control point (aw, ay, ax) = lane
+  if (64 * NPD + 96 + lane < REC) dst[64 * NPD + 96 + lane] = 0.0;      // (the padding travels into LDS: keep it defined)
 }
 
 // offsets (doubles) into the dynamic LDS block of band_pt
-struct BptCarve { int stage, ring, pre, cnt, rho, P, pen, uv, bc, arrive, total; };
+struct BptCarve { int ring, pre, cnt, rho, P, pen, uv, bc, total; };
 template <class Form>
 __host__ __device__ static inline BptCarve bpt_carve(int seg_len) {
   BptCarve c; int pos = 0;
   auto take = [&](int n) { const int o = pos; pos += (n + 1) & ~1; return o; };
-  c.stage = take(8 * 4 * 4 * 7 * (Form::DOF * Form::DOF / 2));      // half of the rows of a band row, half blocks
   c.ring = take(5 * bpt_rec<Form>());
   c.pre = take(seg_len); c.cnt = take((seg_len + 1) / 2); c.rho = take((seg_len + 1) / 2); c.P = take(seg_len * 4);
-  c.pen = take(64); c.uv = take(64); c.bc = take(6 + 6 * 4); c.arrive = take(2);
+  c.pen = take(64); c.uv = take(64); c.bc = take(6 + 6 * 4);
   c.total = pos;
   return c;
 }
@@ -204,12 +227,13 @@ __host__ __device__ static inline BptCarve bpt_carve(int seg_len) {
 // ring slot of the element with the (unwrapped) index eu = layer - slot: five slots, a window holds four
 __device__ __forceinline__ int bpt_slot(int eu) { const int m = eu % 5; return m < 0 ? m + 5 : m; }
 
-// the MFMAs of one test feature F at one k-step: B^{ij}_F = mat(e_F, Nb JW)[i][j] for the blocks whose mask names F
-template <class Form, int I0, int DOFI, int F>
-__device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const double *cf, const PtView &p, const double (&na)[5], const double (&nb)[4]) {
-  constexpr int DOF = Form::DOF;
-  double T[DOF * DOF];
-  if constexpr (band_nfeat_of<Form>::v == 5) Form::template mat_unit5<F>(cf, p, nb, T);
+// the MFMAs of one test feature F at one k-step: the trial-side values of the accumulators whose mask names F
+template <class Form, int F>
+__device__ __forceinline__ void bpt_feature(d4_t (&acc)[band_nacc_of<Form>::v], const double *cf, const PtView &p, const double (&na)[5], const double (&nb)[4]) {
+  constexpr int NACC = band_nacc_of<Form>::v;
+  double T[NACC];
+  if constexpr (band_nacc_of<Form>::own) Form::template mat_acc<F>(cf, p, nb, T);
+  else if constexpr (band_nfeat_of<Form>::v == 5) Form::template mat_unit5<F>(cf, p, nb, T);
   else if constexpr (has_mat_unit<Form>::v) Form::template mat_unit<F>(cf, p, nb, T);
   else {
     double ef[4];
@@ -218,99 +242,67 @@ __device__ __forceinline__ void bpt_feature(d4_t (&acc)[DOFI * Form::DOF], const
     Form::mat_c(cf, p, ef, nb, T);
   }
 #pragma unroll
-  for (int i = 0; i < DOFI; ++i)
-#pragma unroll
-    for (int j = 0; j < DOF; ++j) {
-      if (!((bpt_mask<Form>(I0 + i, j) >> F) & 1u)) continue;
-      acc[i * DOF + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[F], T[(I0 + i) * DOF + j], acc[i * DOF + j], 0, 0, 0);
-    }
+  for (int n = 0; n < NACC; ++n) {
+    if (!((bpt_acc_mask<Form>(n) >> F) & 1u)) continue;
+    acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[F], T[n], acc[n], 0, 0, 0);
+  }
 }
 
-// one tile product of a row-field group: acc[(i - I0) DOF + j] += A_f(e, ta)^T B^{ij}_f(e, tb) over the element's 64 points
-template <class Form, bool GEO, bool RAT, int I0, int DOFI>
-__device__ __forceinline__ void bpt_product(d4_t (&acc)[DOFI * Form::DOF], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
+// one tile product: acc[n] += A_F(e, ta)^T B^n_F(e, tb) over the element's 64 points; k-step (qw, qy), k slot qx = lane >> 4
+template <class Form, bool GEO, bool RAT>
+__device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
   constexpr int DOF = Form::DOF, NPD = bpt_npd<Form>();
   const double *zt = rec + 64 * NPD, *wts = zt + 32;
   const int qx = lane >> 4;
   const double wa = RAT ? wts[ta * 16 + (lane & 15)] : 1.0, wb = RAT ? wts[tb * 16 + (lane & 15)] : 1.0;
-#pragma unroll 2
+#pragma unroll 1
   for (int qw = 0; qw < 4; ++qw) {
-    const double zA0 = zt[(qw * 4 + ta) * 2 + 0], zA1 = zt[(qw * 4 + ta) * 2 + 1];
-    const double zB0 = zt[(qw * 4 + tb) * 2 + 0], zB1 = zt[(qw * 4 + tb) * 2 + 1];
+    // the walk-axis rows of the row (A) and column (B) basis function, with the NURBS weight of the control point
+    const double zA0 = zt[(qw * 4 + ta) * 2 + 0] * wa, zA1 = zt[(qw * 4 + ta) * 2 + 1] * wa;
+    const double zB0 = zt[(qw * 4 + tb) * 2 + 0] * wb, zB1 = zt[(qw * 4 + tb) * 2 + 1] * wb;
 #pragma unroll
     for (int qy = 0; qy < 4; ++qy) {
       const double *pd = rec + ((qw * 4 + qy) * 4 + qx) * NPD;
       const double jw = pd[0];
-      // parametric value and gradient of the row (A) and column (B) basis function at the point: n, d/du0, d/du1, d/du2
-      double fa[4] = {zA0 * uxy[qy][0], zA1 * uxy[qy][0], zA0 * uxy[qy][1], zA0 * uxy[qy][2]};
-      double fb[4] = {zB0 * uxy[qy][0], zB1 * uxy[qy][0], zB0 * uxy[qy][1], zB0 * uxy[qy][2]};
-      if (RAT) {      // Rationalize (src/petigarat.f90.in:3-57): R = w N / W, dR = (w / W) (dN - N dW / W)
-        const double ri = pd[10], o0 = pd[11], o1 = pd[12], o2 = pd[13];
-        const double sa = wa * ri, sb = wb * ri;
-        fa[1] = sa * (fa[1] - fa[0] * o0); fa[2] = sa * (fa[2] - fa[0] * o1); fa[3] = sa * (fa[3] - fa[0] * o2); fa[0] *= sa;
-        fb[1] = sb * (fb[1] - fb[0] * o0); fb[2] = sb * (fb[2] - fb[0] * o1); fb[3] = sb * (fb[3] - fb[0] * o2); fb[0] *= sb;
-      }
+      // parametric value and gradient at the point: n, d/du0, d/du1, d/du2 (the trial side carries JW: mat() is linear in it)
+      const double fa[4] = {zA0 * uxy[qy][0], zA1 * uxy[qy][0], zA0 * uxy[qy][1], zA0 * uxy[qy][2]};
+      const double zj0 = zB0 * jw, zj1 = zB1 * jw;
+      const double fb[4] = {zj0 * uxy[qy][0], zj1 * uxy[qy][0], zj0 * uxy[qy][1], zj0 * uxy[qy][2]};
       double na[5] = {fa[0], fa[1], fa[2], fa[3], 0.0}, nb[4] = {fb[0], fb[1], fb[2], fb[3]};
-      if (GEO) {      // ShapeFunctions (src/petigamapshf.f90.in:30-58): dN/dx_i = sum_b du_b/dx_i dN/du_b
+      if (GEO) {      // Rationalize + ShapeFunctions as one matrix of the point (band_points)
+        if (RAT) { na[0] = pd[1] * fa[0]; nb[0] = pd[1] * fb[0]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          na[1 + i] = pd[1 + 0 * 3 + i] * fa[1] + pd[1 + 1 * 3 + i] * fa[2] + pd[1 + 2 * 3 + i] * fa[3];
-          nb[1 + i] = pd[1 + 0 * 3 + i] * fb[1] + pd[1 + 1 * 3 + i] * fb[2] + pd[1 + 2 * 3 + i] * fb[3];
+          double a = pd[2 + i * 3 + 0] * fa[1] + pd[2 + i * 3 + 1] * fa[2] + pd[2 + i * 3 + 2] * fa[3];
+          double b = pd[2 + i * 3 + 0] * fb[1] + pd[2 + i * 3 + 1] * fb[2] + pd[2 + i * 3 + 2] * fb[3];
+          if (RAT) { a += pd[11 + i] * fa[0]; b += pd[11 + i] * fb[0]; }
+          na[1 + i] = a; nb[1 + i] = b;
         }
       }
       PtView p; p.x = nullptr; p.u = pd + 14; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = 0.0;
       p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
       const double *cf = pd + 14 + DOF;
-      // mat() is linear in the trial features: the weight goes onto them once instead of onto every block entry
-#pragma unroll
-      for (int g = 0; g < 4; ++g) nb[g] *= jw;
-      bpt_feature<Form, I0, DOFI, 0>(acc, cf, p, na, nb);
-      bpt_feature<Form, I0, DOFI, 1>(acc, cf, p, na, nb);
-      bpt_feature<Form, I0, DOFI, 2>(acc, cf, p, na, nb);
-      bpt_feature<Form, I0, DOFI, 3>(acc, cf, p, na, nb);
+      bpt_feature<Form, 0>(acc, cf, p, na, nb);
+      bpt_feature<Form, 1>(acc, cf, p, na, nb);
+      bpt_feature<Form, 2>(acc, cf, p, na, nb);
+      bpt_feature<Form, 3>(acc, cf, p, na, nb);
       if constexpr (band_nfeat_of<Form>::v == 5) {      // the advective derivative of the test function (the state u is in the record)
         na[4] = pd[14] * na[1] + pd[15] * na[2] + pd[16] * na[3];
-        bpt_feature<Form, I0, DOFI, 4>(acc, cf, p, na, nb);
+        bpt_feature<Form, 4>(acc, cf, p, na, nb);
       }
     }
   }
 }
 
-// the MFMA phase of one wave for one layer and one group of row fields, then the deposit; shared by the two instantiations
-template <class Form, bool GEO, bool RAT, int I0, int DOFI>
-__device__ __forceinline__ void bpt_mfma_phase(d4_t (&accA)[DOFI * Form::DOF], d4_t (&accB)[DOFI * Form::DOF], const double *ring, int li, int nel0, bool alias0,
-                                               bool act, int dA, int dB, bool hasB, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
-  constexpr int P = 3;
-  if (!act) return;
-#pragma unroll 1
-  for (int ta = 0; ta <= P; ++ta) {
-    const int tb = ta + dA;
-    if (tb < 0 || tb > P) continue;
-    const int eu = li - ta;        // (unwrapped: the ring slot follows it, the element itself is eu modulo nel on a wrapped axis)
-    if (!alias0 && (eu < 0 || eu >= nel0)) continue;
-    bpt_product<Form, GEO, RAT, I0, DOFI>(accA, ring + bpt_slot(eu) * bpt_rec<Form>(), ta, tb, uxy, lane, prm, shift);
-  }
-  if (hasB) {
-#pragma unroll 1
-    for (int ta = 0; ta <= P; ++ta) {
-      const int tb = ta + dB;
-      if (tb < 0 || tb > P) continue;
-      const int eu = li - ta;
-      if (!alias0 && (eu < 0 || eu >= nel0)) continue;
-      bpt_product<Form, GEO, RAT, I0, DOFI>(accB, ring + bpt_slot(eu) * bpt_rec<Form>(), ta, tb, uxy, lane, prm, shift);
-    }
-  }
-}
-
 template <class Form, bool GEO, bool RAT>
-__global__ void __launch_bounds__(512, 2)
+__global__ void __launch_bounds__(256, 2)
 band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
-  constexpr int P = 3, NB = 4, BW = 7, DOF = Form::DOF, BS = DOF * DOF, DOFI = DOF / 2, HB = DOFI * DOF, REC = bpt_rec<Form>();
-  static_assert(DOF == 4 && has_point_coef<Form>::v, "two groups of two row fields; the form separates its point coefficients (NCOEF, point_coef, mat_c)");
+  constexpr int P = 3, NB = 4, BW = 7, DOF = Form::DOF, BS = DOF * DOF, NACC = band_nacc_of<Form>::v, REC = bpt_rec<Form>();
+  static_assert(DOF == 4 && has_point_coef<Form>::v, "128-byte blocks; the form separates its point coefficients (NCOEF, point_coef, mat_c)");
+  static_assert(NACC >= BS && NACC <= 20, "accumulators: the block entries first, shared parts behind them");
   extern __shared__ __attribute__((aligned(16))) double bpt_sm[];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, role = wave & 3;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int npen = pa.ex_count * pa.ey_count;
   const int seg = blockIdx.x / npen, pencil = blockIdx.x - seg * npen;
   const int tx = pencil % pa.ex_count, ty = pencil / pa.ex_count;
@@ -323,26 +315,27 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   const int lay_first = AW.off[0];
   const int offx = AX.off[elx], offy = AY.off[ely];
   const BptCarve cv = bpt_carve<Form>(pa.seg_len);
-  double *stage = bpt_sm + cv.stage, *ring = bpt_sm + cv.ring, *uvs = bpt_sm + cv.uv;
+  double *ring = bpt_sm + cv.ring, *uvs = bpt_sm + cv.uv;
   long long *Lpre = reinterpret_cast<long long *>(bpt_sm + cv.pre);
-  int *Lcnt = reinterpret_cast<int *>(bpt_sm + cv.cnt), *Lrho = reinterpret_cast<int *>(bpt_sm + cv.rho), *LP = reinterpret_cast<int *>(bpt_sm + cv.P);
+  int *Lcnt = reinterpret_cast<int *>(bpt_sm + cv.cnt), *LP = reinterpret_cast<int *>(bpt_sm + cv.P);
   BpPencil *pen = reinterpret_cast<BpPencil *>(bpt_sm + cv.pen);
   unsigned *bcm = reinterpret_cast<unsigned *>(bpt_sm + cv.bc);
   double *bcv = bpt_sm + cv.bc + 6;
-  int *arrive = reinterpret_cast<int *>(bpt_sm + cv.arrive) + grp * 2;
-  if (tid < 4) reinterpret_cast<int *>(bpt_sm + cv.arrive)[tid] = 0;
   const double *recs = pa.pts + (size_t)pencil * pa.nel0 * REC;      // this pencil's element records
 
-  auto load_element = [&](int eu, int nt) {     // record of element eu (modulo nel on a wrapped axis) -> its ring slot, by threads 0 .. nt
+  // record of element eu (modulo nel on a wrapped axis) -> its ring slot: REC / 128 pieces of 1 KB, wave w moves the pieces
+  // w, w + 4, ... (global_load_lds: 64 lanes x 16 bytes, no registers; done when vmcnt says so -- the barrier below)
+  auto load_element = [&](int eu) {
     int e = eu;
     if (alias0) { e %= pa.nel0; if (e < 0) e += pa.nel0; } else if (e < 0 || e >= pa.nel0) return;
     const double *src = recs + (size_t)e * REC; double *dst = ring + bpt_slot(eu) * REC;
-    for (int i = tid; i < REC / 2; i += nt) *reinterpret_cast<bp_d2_t *>(dst + 2 * i) = *reinterpret_cast<const bp_d2_t *>(src + 2 * i);
+    for (int c = role; c < REC / 128; c += 4)
+      __builtin_amdgcn_global_load_lds(src + c * 128 + lane * 2, (__attribute__((address_space(3))) void *)(dst + c * 128), 16, 0, 0);
   };
   {   // tables of the segment and of the pencil; the window of the first layer
-    for (int i = tid; i < nlay; i += 512) {
+    for (int i = tid; i < nlay; i += 256) {
       const int lay = lay_first + li_lo + i, rho = AW.rowmap[lay];
-      Lrho[i] = rho; Lcnt[i] = AW.rcnt[rho]; Lpre[i] = AW.prefix[rho];
+      Lcnt[i] = AW.rcnt[rho]; Lpre[i] = AW.prefix[rho];
       for (int d = 0; d < BW; ++d) LP[i * 8 + d] = AW.P[lay * BW + d];
     }
     if (tid < 4) {
@@ -357,7 +350,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       if (pa.first_touch)
         for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
           if (first_touch_axis<P>(elx, a, b, pa.nelx)) fx |= 1u << (a * 4 + b);
-          if (first_touch_axis<P>(ely, a, b, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) fy |= 1u << (a * 4 + b);
+          if (pa.wrap2 ? first_touch_axis_wrapped<P>(ely, a, b) : first_touch_axis<P>(ely, a, b, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) fy |= 1u << (a * 4 + b);
         }
       pen->ftx = fx; pen->fty = fy;
     }
@@ -378,7 +371,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       bcm[k] = m;
     }
     // elements li_lo - P .. li_lo of the first layer's window (periodic: modulo nel)
-    for (int t = 0; t <= P; ++t) load_element(li_lo - t, 512);
+    for (int t = 0; t <= P; ++t) load_element(li_lo - t);
   }
   __syncthreads();
 
@@ -398,139 +391,79 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       uxy[qy][0] = u0 * v0; uxy[qy][1] = u1 * v0; uxy[qy][2] = u0 * v1;
     }
   }
-  const int dA = (role == 0) ? 0 : (role == 1 ? 1 : (role == 2 ? -1 : 2));
-  const int dB = (role == 1) ? -3 : (role == 2 ? 3 : -2);
-  const bool hasB = role != 0;
   const long long T0 = S.ax[0].tot, T10 = S.ax[1].tot * S.ax[0].tot;
-  // read-add-write runs: sub-round s covers the rows a2 in {2s, 2s+1}; wave `role` takes a2 = 2s + (role >> 1), a1 in {2 (role & 1), +1}:
-  // 8 runs (a1, b2); lane ru < 8 holds what does not depend on the layer, for both sub-rounds
-  long long run_base[2], run_cc[2]; int run_pp[2];
+  // block position of this lane's entry (row slots a1 = lane >> 4 on axis 1, a2 = r on axis 2; column slots b1, b2; column layer
+  // lay + d): pos = base[r] + cc[r] * prefix0(lay) + pp[r] * count0(lay) + P0(lay, d)   (axis 1 has consecutive positions)
+  const int a1 = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+  long long pbase[4]; int pcc[4], ppp[4]; unsigned ftm = 0;
 #pragma unroll
-  for (int sb = 0; sb < 2; ++sb) {
-    const int ru = lane & 7, a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3, a2 = 2 * sb + (role >> 1);
-    const long long c1 = pen->c1[a1], c2 = pen->c2[a2];
-    run_base[sb] = pen->ps2[a2] * T10 + c2 * (pen->ps1[a1] * T0);
-    run_cc[sb] = c2 * c1;
-    run_pp[sb] = (int)(pen->P2[a2 * 4 + b2] * c1 + pen->P1_0[a1]);
+  for (int r = 0; r < 4; ++r) {
+    const long long c1 = pen->c1[a1], c2 = pen->c2[r];
+    pbase[r] = pen->ps2[r] * T10 + c2 * (pen->ps1[a1] * T0);
+    pcc[r] = (int)(c2 * c1);
+    ppp[r] = (int)(pen->P2[r * 4 + b2] * c1 + pen->P1_0[a1] + b1);
+    if (((pen->ftx >> (a1 * 4 + b1)) & 1u) && ((pen->fty >> (r * 4 + b2)) & 1u)) ftm |= 1u << r;      // first touch: nothing to read
   }
-  const unsigned ftx = (unsigned)__builtin_amdgcn_readfirstlane((int)pen->ftx), fty = (unsigned)__builtin_amdgcn_readfirstlane((int)pen->fty);
-  const int I0 = grp * DOFI;          // this group's row fields
 
-  // both groups take the same layer, group 1 half a period behind group 0
-  if (grp == 1) __builtin_amdgcn_s_barrier();
   for (int it = 0; it < nlay; ++it) {
     const int li = li_lo + it, lay = lay_first + li;
-    d4_t accA[HB], accB[HB];
-#pragma unroll
-    for (int n = 0; n < HB; ++n) { accA[n] = (d4_t){0, 0, 0, 0}; accB[n] = (d4_t){0, 0, 0, 0}; }
-    if (grp == 0) bpt_mfma_phase<Form, GEO, RAT, 0, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
-    else bpt_mfma_phase<Form, GEO, RAT, DOFI, DOFI>(accA, accB, ring, li, pa.nel0, alias0, !(kDebug && (pa.debug & 2)), dA, dB, hasB, uxy, lane, prm.v, out.shift);
-    if constexpr (band_nfeat_of<Form>::v == 5) {   // blocks a form accumulates as differences (forms.hpp: band_combine)
-      if (grp == 0) { Form::template band_combine<0>(accA); Form::template band_combine<0>(accB); }
-      else { Form::template band_combine<DOFI>(accA); Form::template band_combine<DOFI>(accB); }
-    }
-    __builtin_amdgcn_s_barrier();
-
-    // ---- flush phase.  Group 0 first brings the element that enters the window with the next layer into the ring: its slot was
-    // last read two phases ago (element li - 4, by group 1's MFMA phase of layer li - 1).
-    __builtin_amdgcn_s_setprio(3);
-    if (grp == 0 && it + 1 < nlay) load_element(li + 1, 256);
+    // the element that enters the window with the next layer: its slot was last read in layer li - 1, which every wave has left
+    if (it + 1 < nlay) load_element(li + 1);
     const int c0 = __builtin_amdgcn_readfirstlane(Lcnt[it]);
     const int held = alias0 ? P + 1 : (min(li, pa.nel0 - 1) - max(li - P, 0) + 1);
     const bool bcrow = bc.any && (bc.on[2] || bc.on[3] || bc.on[4] || bc.on[5] || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
     const long long ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(Lpre[it] >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(Lpre[it] & 0xffffffffll));
-    const int runlen = 4 * c0 * HB;            // doubles of a run in the stage (dense); in the matrix the half blocks sit BS apart
-    const bool dowrite = !(kDebug && (pa.debug & 1));
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+      // band tiles of this wave: d = {0}, {+1, -3}, {-1, +3}, {+2, -2}: four tile products per wave and layer
+      if (half == 1 && role == 0) break;
+      const int d = half == 0 ? ((role == 0) ? 0 : (role == 1 ? 1 : (role == 2 ? -1 : 2))) : ((role == 1) ? -3 : (role == 2 ? 3 : -2));
+      const int p0d = __builtin_amdgcn_readfirstlane(LP[it * 8 + d + P]);
+      if (p0d < 0) continue;          // the column layer does not exist (ends of a non-periodic axis)
+      d4_t acc[NACC];
 #pragma unroll
-    for (int sb = 0; sb < 2; ++sb) {
-      {   // deposit the rows a2 = r in {2 sb, 2 sb + 1}: IGAElementFixJacobian on the combined blocks (src/petigaelem.c:1463-1490)
-        const int a1 = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
-        auto deposit = [&](const d4_t (&acc)[HB], int d) {
-          const int p0d = __builtin_amdgcn_readfirstlane(LP[it * 8 + d + P]);
-          if (p0d < 0) return;
-#pragma unroll
-          for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * sb + rr;
-            double K[HB];
-#pragma unroll
-            for (int n = 0; n < HB; ++n) K[n] = acc[n][r];
-            if (bcrow) {
-#pragma unroll
-              for (int i = 0; i < DOFI; ++i)
-#pragma unroll
-                for (int j = 0; j < DOF; ++j) {
-                  double va = 0, vb = 0;
-                  const bool fa = bp_fixed<P>(bc, a1, r, lay, I0 + i, va), fb = bp_fixed<P>(bc, b1, b2, lay + d, j, vb);
-                  if (fa || fb) K[i * DOF + j] = (d == 0 && a1 == b1 && r == b2 && I0 + i == j) ? (double)held : 0.0;
-                }
-            }
-            double *sp = stage + ((size_t)(((a1 + 4 * rr) * 4 + b2) * 4 + b1) * c0 + p0d) * HB;
-#pragma unroll
-            for (int n = 0; n < HB; n += 2) { bp_d2_t t; t[0] = K[n]; t[1] = K[n + 1]; *reinterpret_cast<bp_d2_t *>(sp + n) = t; }
-          }
-        };
-        deposit(accA, dA);
-        if (hasB) deposit(accB, dB);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      // the old values of this wave's 8 runs: a half block = HB / 2 pieces of 16 bytes, the blocks of a run BS doubles apart
-      const long long mypos = run_base[sb] + run_cc[sb] * ps0 + (long long)run_pp[sb] * c0;
-      const int npiece = 4 * c0 * (HB / 2);      // pieces of a run
-      double *gp[8]; d2u_t oldv[8][2];
-      const int a2 = 2 * sb + (role >> 1);
-#pragma unroll
-      for (int ru = 0; ru < 8; ++ru) {
-        const int a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3;
-        const long long pos = ((long long)__builtin_amdgcn_readlane((int)(mypos >> 32), ru) << 32) | (unsigned int)__builtin_amdgcn_readlane((int)(mypos & 0xffffffffll), ru);
-        gp[ru] = out.val + pos * BS + I0 * DOF;
-        const bool ally = (fty >> (a2 * 4 + b2)) & 1u, allx = ((ftx >> (a1 * 4)) & 0xfu) == 0xfu;
-        const bool ld = dowrite && !(ally && allx);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int pc = lane + 64 * h;
-          oldv[ru][h] = (d2u_t){0.0, 0.0};
-          if (ld && pc < npiece) oldv[ru][h] = *reinterpret_cast<const d2u_t *>(gp[ru] + (pc / (HB / 2)) * BS + (pc % (HB / 2)) * 2);
+      for (int n = 0; n < NACC; ++n) acc[n] = (d4_t){0, 0, 0, 0};
+      if (!(kDebug && (pa.debug & 2))) {
+#pragma unroll 1
+        for (int ta = 0; ta <= P; ++ta) {
+          const int tb = ta + d;
+          if (tb < 0 || tb > P) continue;
+          const int eu = li - ta;        // (unwrapped: the ring slot follows it, the element itself is eu modulo nel on a wrapped axis)
+          if (!alias0 && (eu < 0 || eu >= pa.nel0)) continue;
+          bpt_product<Form, GEO, RAT>(acc, ring + bpt_slot(eu) * REC, ta, tb, uxy, lane, prm.v, out.shift);
         }
       }
-      {   // every wave of this group has deposited this sub-round
-        const int target = 4 * (2 * it + sb + 1);
-        while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
-      }
-      if (dowrite) {
-        const int blk = c0 * (HB / 2);          // pieces per b1 group
+      if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc);
+      else if constexpr (band_nfeat_of<Form>::v == 5) Form::template band_combine<0>(acc);
+      if (kDebug && (pa.debug & 1)) continue;
+      // ---- read-add-write of the lane's four blocks (r = row slot on axis 2): a block is one 128-byte line
 #pragma unroll
-        for (int ru = 0; ru < 8; ++ru) {
-          const int a1 = 2 * (role & 1) + (ru >> 2), b2 = ru & 3, rr = role >> 1;
-          const double *sp = stage + (size_t)((a1 + 4 * rr) * 4 + b2) * runlen;
-          const bool fy1 = (fty >> (a2 * 4 + b2)) & 1u;
-          const unsigned fxm = fy1 ? ((ftx >> (a1 * 4)) & 0xfu) : 0u;
+      for (int r = 0; r < 4; ++r) {
+        const long long pos = pbase[r] + (long long)pcc[r] * ps0 + (long long)ppp[r] * c0 + p0d;
+        double *gp = out.val + pos * BS;
+        const bool first = (ftm >> r) & 1u;
+        bp_d2_t oldv[BS / 2];
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int pc = lane + 64 * h;
-            if (pc < npiece) {
-              const bp_d2_t nv = *reinterpret_cast<const bp_d2_t *>(sp + 2 * pc);
-              d2u_t ov = oldv[ru][h];
-              if (fxm) { const int g0 = (pc >= blk) + (pc >= 2 * blk) + (pc >= 3 * blk); if ((fxm >> g0) & 1u) { ov[0] = 0.0; ov[1] = 0.0; } }
-              d2u_t w; w[0] = ov[0] + nv[0]; w[1] = ov[1] + nv[1];
-              *reinterpret_cast<d2u_t *>(gp[ru] + (pc / (HB / 2)) * BS + (pc % (HB / 2)) * 2) = w;
+        for (int k = 0; k < BS / 2; ++k) oldv[k] = first ? (bp_d2_t){0.0, 0.0} : *reinterpret_cast<const bp_d2_t *>(gp + 2 * k);
+        double K[BS];
+#pragma unroll
+        for (int n = 0; n < BS; ++n) K[n] = acc[n][r];
+        if (bcrow) {      // IGAElementFixJacobian on the combined blocks (src/petigaelem.c:1463-1490)
+#pragma unroll
+          for (int i = 0; i < DOF; ++i)
+#pragma unroll
+            for (int j = 0; j < DOF; ++j) {
+              double va = 0, vb = 0;
+              const bool fa = bp_fixed<P>(bc, a1, r, lay, i, va), fb = bp_fixed<P>(bc, b1, b2, lay + d, j, vb);
+              if (fa || fb) K[i * DOF + j] = (d == 0 && a1 == b1 && r == b2 && i == j) ? (double)held : 0.0;
             }
-          }
         }
-      }
-      if (sb == 0) {   // the stage is written again: every wave of the group is done reading it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_fetch_add(arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        const int target = 4 * (it + 1);
-        while (__hip_atomic_load(arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(2);
-        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < BS / 2; ++k) { bp_d2_t w; w[0] = oldv[k][0] + K[2 * k]; w[1] = oldv[k][1] + K[2 * k + 1]; *reinterpret_cast<bp_d2_t *>(gp + 2 * k) = w; }
       }
     }
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_s_barrier();
+    __syncthreads();      // the next element's record is in the ring (vmcnt(0) before the barrier), nobody reads layer li's window any more
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
 }
 
 // ---- host side
@@ -571,7 +504,9 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (!band_pt_covers<Form>(s, S, out)) return 0;
   constexpr int P = 3;
   const bool alias0 = s.lay[0].alias != 0;
-  const bool first_touch = !s.env.no_first_touch && out.val && !alias0 && axis_first_touch_ok(s, 1) && axis_first_touch_ok(s, 2);
+  // (the walk axis needs no rule: a pencil writes every block of its band rows exactly once, wrapped or not)
+  const bool wrap2 = axis_first_touch_wrapped_ok(s, 2);
+  const bool first_touch = !s.env.no_first_touch && out.val && axis_first_touch_ok(s, 1) && (axis_first_touch_ok(s, 2) || wrap2);
   if (!first_touch) { if (zero_matrix) zero_matrix(); }
   else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);
   launches = 0;
@@ -588,18 +523,18 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       if (!color_range(s.lay[1], cx, bx.lo[1], bx.hi[1], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
       if (!color_range(s.lay[2], cy, bx.lo[2], bx.hi[2], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
       // (irregular colours of a wrapped axis hold single elements: color_range gives start / count with the regular step)
-      pa.nel0 = s.elem_width[0]; pa.alias0 = alias0 ? 1 : 0;
+      pa.nel0 = s.elem_width[0]; pa.alias0 = alias0 ? 1 : 0; pa.wrap2 = wrap2 ? 1 : 0;
       const long long pencils = (long long)pa.ex_count * pa.ey_count;
-      // One workgroup per CU (LDS): a launch takes ceil(workgroups / CUs) rounds of one segment each.  Segments cost a window of
-      // element records and one idle half period: the count with the fewest rounds x (layers + 1), at least 8 layers each
-      // (96^3 on 256 CUs: 576 pencils in one piece are 3 rounds of 96 layers, in four pieces 9 rounds of 24)
+      // Two four-wave workgroups per CU (registers, LDS): a launch takes ceil(workgroups / (2 CUs)) rounds of one segment each.
+      // A segment costs a window of element records at its start: the count with the fewest rounds x (layers + 1), at least 8
+      // layers each (96^3 on 256 CUs: 576 pencils in 8 pieces are 9 rounds of 12 layers)
       const int max_len = 64;
       int nseg = (NL + max_len - 1) / max_len;
       {
         long long best = -1; int best_n = nseg;
         for (int n = nseg; n <= std::max(nseg, NL / 8); ++n) {
           const int len = (NL + n - 1) / n, ns = (NL + len - 1) / len;
-          const long long cost = ((pencils * ns + ncu - 1) / ncu) * (len + 1);
+          const long long cost = ((pencils * ns + 2 * ncu - 1) / (2 * ncu)) * (len + 1);
           if (best < 0 || cost < best) { best = cost; best_n = n; }
         }
         nseg = best_n;
@@ -614,7 +549,7 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       const size_t lds = (size_t)bpt_carve<Form>(pa.seg_len).total * sizeof(double);
       auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(512), lds, stream, S, prm, out, pa);
+      hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(256), lds, stream, S, prm, out, pa);
       (void)hipFreeAsync(pa.pts, stream);
       launches++;
     }
@@ -633,12 +568,12 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (rc) return rc;
   if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
   if (hipGetLastError() != hipSuccess) { err = "band_pt kernel launch failed"; return IGX_ERR_LIB; }
-  int nm = 0;
-  for (int i = 0; i < Form::DOF; ++i) for (int j = 0; j < Form::DOF; ++j) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_mask<Form>(i, j) >> f) & 1u) nm++;
+  int nm = 0;      // MFMAs per k-step: one per (accumulator, test feature) product
+  for (int n = 0; n < band_nacc_of<Form>::v; ++n) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_acc_mask<Form>(n) >> f) & 1u) nm++;
   dom.name = "band_pt<p=3>"; dom.launches = launches;
   dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
   dom.flop_per_element = 2048.0 * nm * 16 * 16;
-  kname = std::string("band_pt(mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
+  kname = std::string("band_pt(mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
   done = true;
   return 0;
   }

@@ -49,4 +49,14 @@ static bool axis_first_touch_ok(const Space &s, int d) {
   return true;
 }
 
+// a periodic axis wrapped inside the rank: the rule holds without clipping when the colours run e mod (p+1) across the seam
+static bool axis_first_touch_wrapped_ok(const Space &s, int d) {
+  const int nb = s.axis[d].p + 1;
+  if (!s.lay[d].alias || s.elem_width[d] % nb != 0 || s.elem_width[d] < 2 * nb || s.axis[d].nnp < 2 * s.axis[d].p + 1) return false;
+  for (int e = 0; e + 1 < s.elem_width[d]; ++e)
+    if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
+  for (int e = 0; e < s.elem_width[d]; ++e) if (s.lay[d].color[e] != e % nb) return false;
+  return true;
+}
+
 }  // namespace igx

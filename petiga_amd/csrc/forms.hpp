@@ -345,6 +345,48 @@ struct FormNSVMS {
   // acc: the block entries (i - I0) * 4 + j of one band tile for the row fields I0, I0 + 1
   template <int I0, class V, int N>
   static __device__ __forceinline__ void band_combine(V (&acc)[N]) { if constexpr (I0 == 0) acc[1 * 4 + 1] += acc[0]; }
+  // band_pt.hpp, round 4: a wave holds ALL 16 entries of a block, so the part the three diagonal momentum blocks share,
+  // D = N_a S + grad N_a . (nu grad N_b) + tauM (u . grad N_a) S with S = shift N_b + u . grad N_b, is accumulated ONCE, in a 17th
+  // accumulator, and added to them when the sums are complete (band_finish).  Products per k-step = the ranks of what is left:
+  // D 4 (features N, d_g: nu d_g N_b + tauM u_g S), T_ii - D 1 each, T_ij 2 each, T_i3 2 each (d_i and the advective feature),
+  // T_3j 2 each, T_33 3: 4 + 3 + 12 + 6 + 6 + 3 = 34 (round 3: 37 with the row fields in two wave groups).
+  static constexpr int BAND_NACC = 17;
+  static constexpr unsigned band_acc_mask(int n) {
+    if (n == 16) return 0xFu;
+    const int i = n / 4, j = n % 4;
+    if (i < 3 && j < 3) return (i == j) ? (1u << (1 + i)) : ((1u << (1 + i)) | (1u << (1 + j)));
+    if (i < 3) return (1u << (1 + i)) | (1u << 4);
+    if (j < 3) return 0x1u | (1u << (1 + j));
+    return 0xEu;
+  }
+  // the trial-side value of accumulator n for the unit test feature F (0: N, 1 + g: d_g N, 4: u . grad N); Nb_ carries JW
+  template <int F>
+  static __device__ __forceinline__ void mat_acc(const double *c, const PtView &p, const double *Nb_, double *T) {
+    const double nu = p.prm[0], tauM = c[0], tauC = c[1];
+    const double Nb = Nb_[0];
+    const double S = p.shift * Nb + (p.u[0] * Nb_[1] + p.u[1] * Nb_[2] + p.u[2] * Nb_[3]);
+    if constexpr (F == 0) {
+      T[16] = S; T[12] = Nb_[1]; T[13] = Nb_[2]; T[14] = Nb_[3];
+    } else if constexpr (F == 4) {
+      T[3] = tauM * Nb_[1]; T[7] = tauM * Nb_[2]; T[11] = tauM * Nb_[3];
+    } else {
+      constexpr int g = F - 1;
+      const double tS = tauM * S;
+      T[16] = nu * Nb_[1 + g] + p.u[g] * tS;
+      T[g * 4 + g] = (nu + tauC) * Nb_[1 + g];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k == g) continue;
+        T[g * 4 + k] = tauC * Nb_[1 + k];      // block (g, k), test feature d_g: tauC d_g N_a d_k N_b
+        T[k * 4 + g] = nu * Nb_[1 + k];        // block (k, g), test feature d_g: nu d_g N_a d_k N_b
+      }
+      T[g * 4 + 3] = -Nb;
+      T[12 + g] = tS;
+      T[15] = tauM * Nb_[1 + g];
+    }
+  }
+  template <class V, int N>
+  static __device__ __forceinline__ void band_finish(V (&acc)[N]) { acc[0] += acc[16]; acc[5] += acc[16]; acc[10] += acc[16]; }
   static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
     const double tauM = c[0], tauC = c[1];

@@ -33,6 +33,16 @@ __device__ __forceinline__ bool first_touch_axis(int e, int a, int b, int nel, i
   return (c0 <= hi) ? (e % NB == 0) : (e == lo);
 }
 
+// The same rule on a periodic axis wrapped inside the rank whose element count is a multiple of P+1 (colours stay e mod (P+1) across
+// the seam): the range is not clipped, its elements are taken modulo the axis.
+template <int P>
+__device__ __forceinline__ bool first_touch_axis_wrapped(int e, int a, int b) {
+  constexpr int NB = P + 1;
+  const int lo = e + (a > b ? a : b) - P, hi = e + (a < b ? a : b);
+  const int c0 = ((lo + NB + NB - 1) / NB) * NB - NB;       // smallest multiple of NB >= lo (lo >= -P)
+  return (c0 <= hi) ? (e % NB == 0) : (e == lo);
+}
+
 #ifndef IGX_RTC
 struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
 
