@@ -29,6 +29,9 @@
 // axis 2 (its column positions come from the per-axis table); axis 1 must have consecutive positions.
 #pragma once
 #include "block_pencil.hpp"
+#ifndef IGX_RTC
+#include <climits>
+#endif
 
 namespace igx {
 
@@ -56,7 +59,11 @@ template <class Form> __host__ __device__ constexpr unsigned bpt_acc_mask(int n)
 // gradient (n, d_0, d_1, d_2) of w_a N_a to the physical ones: R = g0 n, d_i R = h_i n + sum_b Gm[i][b] d_b, with g0 = 1/W,
 // Gm[i][b] = du_b/dx_i / W, h_i = -sum_b Gm[i][b] dW_b/W (Rationalize + ShapeFunctions, src/petigarat.f90.in:3-57,
 // petigamapshf.f90.in:30-58, in one 4 x 4 matrix) | u | the form's point coefficients
-template <class Form> constexpr int bpt_npd() { return 1 + 13 + Form::DOF + Form::NCOEF; }
+template <class F, class = void> struct band_ncoef_of { static constexpr int v = F::NCOEF; };
+template <class F> struct band_ncoef_of<F, decltype((void)F::BAND_NCOEF)> { static constexpr int v = F::BAND_NCOEF; };      // (band_coef instead of point_coef)
+template <class F, class = void> struct band_neg5_of { static constexpr bool v = false; };
+template <class F> struct band_neg5_of<F, decltype((void)F::BAND_NEG_FEAT5)> { static constexpr bool v = F::BAND_NEG_FEAT5; };
+template <class Form> constexpr int bpt_npd() { return 1 + 13 + Form::DOF + band_ncoef_of<Form>::v; }
 template <class Form> constexpr int bpt_rec() { return (64 * bpt_npd<Form>() + 32 + 64 + 127) / 128 * 128; }
 
 struct BandArgs {
@@ -67,6 +74,7 @@ struct BandArgs {
   int wrap2;                         // axis 2 periodic and wrapped inside the rank (first-touch rule without clipping)
   double *pts;                       // element records of this launch: [pencil][element on axis 0][bpt_rec]
   int debug, dbg_block;
+  long long *dbg_buf;                // -DIGX_DEBUG builds, IGX_DEBUG_TIMING: cycle stamps [workgroup][wave][layer][6]
 };
 
 // ---- the point tabulation: one wavefront per element
@@ -201,7 +209,7 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       for (int i = 0; i < 3; ++i) G[a * 3 + i] = E[a][i] / L3[a];
     PtView p; p.x = nullptr; p.u = u; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = G; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
     p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
-    Form::point_coef(p, rec + 14 + DOF);
+    if constexpr (band_nacc_of<Form>::own) Form::band_coef(p, rec + 14 + DOF); else Form::point_coef(p, rec + 14 + DOF);
   }
   double *dst = pa.pts + (size_t)elem * REC;
 #pragma unroll
@@ -264,21 +272,27 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
     for (int qy = 0; qy < 4; ++qy) {
       const double *pd = rec + ((qw * 4 + qy) * 4 + qx) * NPD;
       const double jw = pd[0];
-      // parametric value and gradient at the point: n, d/du0, d/du1, d/du2 (the trial side carries JW: mat() is linear in it)
-      const double fa[4] = {zA0 * uxy[qy][0], zA1 * uxy[qy][0], zA0 * uxy[qy][1], zA0 * uxy[qy][2]};
+      // value and gradient of the row (A) and column (B) basis function at the point (the trial side carries JW: mat() is linear
+      // in it).  Parametric: n = z0 (u0 v0), d/du0 = z1 (u0 v0), d/du1 = z0 (u1 v0), d/du2 = z0 (u0 v1).  On a geometry the map to
+      // the physical ones is the point's matrix (band_points): d_i = z1 P_i + z0 Q_i with P_i = Gm[i][0] u0v0 and
+      // Q_i = Gm[i][1] u1v0 + Gm[i][2] u0v1 + h_i u0v0 -- P, Q serve both sides
       const double zj0 = zB0 * jw, zj1 = zB1 * jw;
-      const double fb[4] = {zj0 * uxy[qy][0], zj1 * uxy[qy][0], zj0 * uxy[qy][1], zj0 * uxy[qy][2]};
-      double na[5] = {fa[0], fa[1], fa[2], fa[3], 0.0}, nb[4] = {fb[0], fb[1], fb[2], fb[3]};
-      if (GEO) {      // Rationalize + ShapeFunctions as one matrix of the point (band_points)
-        if (RAT) { na[0] = pd[1] * fa[0]; nb[0] = pd[1] * fb[0]; }
+      double na[5], nb[4];
+      if (GEO) {
+        const double n0 = RAT ? pd[1] * uxy[qy][0] : uxy[qy][0];
+        na[0] = zA0 * n0; nb[0] = zj0 * n0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-          double a = pd[2 + i * 3 + 0] * fa[1] + pd[2 + i * 3 + 1] * fa[2] + pd[2 + i * 3 + 2] * fa[3];
-          double b = pd[2 + i * 3 + 0] * fb[1] + pd[2 + i * 3 + 1] * fb[2] + pd[2 + i * 3 + 2] * fb[3];
-          if (RAT) { a += pd[11 + i] * fa[0]; b += pd[11 + i] * fb[0]; }
-          na[1 + i] = a; nb[1 + i] = b;
+          const double Pi = pd[2 + i * 3 + 0] * uxy[qy][0];
+          double Qi = pd[2 + i * 3 + 1] * uxy[qy][1] + pd[2 + i * 3 + 2] * uxy[qy][2];
+          if (RAT) Qi += pd[11 + i] * uxy[qy][0];
+          na[1 + i] = zA1 * Pi + zA0 * Qi; nb[1 + i] = zj1 * Pi + zj0 * Qi;
         }
+      } else {
+        na[0] = zA0 * uxy[qy][0]; na[1] = zA1 * uxy[qy][0]; na[2] = zA0 * uxy[qy][1]; na[3] = zA0 * uxy[qy][2];
+        nb[0] = zj0 * uxy[qy][0]; nb[1] = zj1 * uxy[qy][0]; nb[2] = zj0 * uxy[qy][1]; nb[3] = zj0 * uxy[qy][2];
       }
+      na[4] = 0.0;
       PtView p; p.x = nullptr; p.u = pd + 14; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = 0.0;
       p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
       const double *cf = pd + 14 + DOF;
@@ -287,7 +301,8 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
       bpt_feature<Form, 2>(acc, cf, p, na, nb);
       bpt_feature<Form, 3>(acc, cf, p, na, nb);
       if constexpr (band_nfeat_of<Form>::v == 5) {      // the advective derivative of the test function (the state u is in the record)
-        na[4] = pd[14] * na[1] + pd[15] * na[2] + pd[16] * na[3];
+        if constexpr (band_neg5_of<Form>::v) na[4] = (-pd[14]) * na[1] + (-pd[15]) * na[2] + (-pd[16]) * na[3];
+        else na[4] = pd[14] * na[1] + pd[15] * na[2] + pd[16] * na[3];
         bpt_feature<Form, 4>(acc, cf, p, na, nb);
       }
     }
@@ -322,6 +337,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   unsigned *bcm = reinterpret_cast<unsigned *>(bpt_sm + cv.bc);
   double *bcv = bpt_sm + cv.bc + 6;
   const double *recs = pa.pts + (size_t)pencil * pa.nel0 * REC;      // this pencil's element records
+  const long long tw_wg = (kDebug && pa.dbg_buf) ? wall_clock64() : 0;
 
   // record of element eu (modulo nel on a wrapped axis) -> its ring slot: REC / 128 pieces of 1 KB, wave w moves the pieces
   // w, w + 4, ... (global_load_lds: 64 lanes x 16 bytes, no registers; done when vmcnt says so -- the barrier below)
@@ -405,6 +421,9 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     if (((pen->ftx >> (a1 * 4 + b1)) & 1u) && ((pen->fty >> (r * 4 + b2)) & 1u)) ftm |= 1u << r;      // first touch: nothing to read
   }
 
+  long long tk0 = 0, tw0 = 0;
+  if (out.clk) { tk0 = __builtin_readcyclecounter(); tw0 = wall_clock64(); }
+  const long long tw_loop = (kDebug && pa.dbg_buf) ? wall_clock64() : 0;
   for (int it = 0; it < nlay; ++it) {
     const int li = li_lo + it, lay = lay_first + li;
     // the element that enters the window with the next layer: its slot was last read in layer li - 1, which every wave has left
@@ -413,6 +432,8 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     const int held = alias0 ? P + 1 : (min(li, pa.nel0 - 1) - max(li - P, 0) + 1);
     const bool bcrow = bc.any && (bc.on[2] || bc.on[3] || bc.on[4] || bc.on[5] || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
     const long long ps0 = ((long long)__builtin_amdgcn_readfirstlane((int)(Lpre[it] >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)(Lpre[it] & 0xffffffffll));
+    long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    if (kDebug && pa.dbg_buf) stamp[0] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
       // band tiles of this wave: d = {0}, {+1, -3}, {-1, +3}, {+2, -2}: four tile products per wave and layer
@@ -433,8 +454,9 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
           bpt_product<Form, GEO, RAT>(acc, ring + bpt_slot(eu) * REC, ta, tb, uxy, lane, prm.v, out.shift);
         }
       }
-      if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc);
+      if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc, prm.v);
       else if constexpr (band_nfeat_of<Form>::v == 5) Form::template band_combine<0>(acc);
+      if (kDebug && pa.dbg_buf) stamp[1 + 2 * half] = __builtin_readcyclecounter();
       if (kDebug && (pa.debug & 1)) continue;
       // ---- read-add-write of the lane's four blocks (r = row slot on axis 2): a block is one 128-byte line
 #pragma unroll
@@ -461,8 +483,25 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
 #pragma unroll
         for (int k = 0; k < BS / 2; ++k) { bp_d2_t w; w[0] = oldv[k][0] + K[2 * k]; w[1] = oldv[k][1] + K[2 * k + 1]; *reinterpret_cast<bp_d2_t *>(gp + 2 * k) = w; }
       }
+      if (kDebug && pa.dbg_buf) stamp[2 + 2 * half] = __builtin_readcyclecounter();
     }
+    if (kDebug && pa.dbg_buf) stamp[5] = __builtin_readcyclecounter();
     __syncthreads();      // the next element's record is in the ring (vmcnt(0) before the barrier), nobody reads layer li's window any more
+    if (kDebug && pa.dbg_buf && lane == 0 && it < 64) {
+      long long *d = pa.dbg_buf + (((size_t)blockIdx.x * 4 + role) * 64 + it) * 8;
+      for (int k = 0; k < 6; ++k) d[k] = stamp[k];
+      d[6] = __builtin_readcyclecounter(); d[7] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4);      // after the barrier; HW_ID
+    }
+  }
+  if (kDebug && pa.dbg_buf && tid == 0) {      // workgroup record behind the layer stamps: start / end on the 100 MHz clock, HW_ID, XCC_ID
+    long long *w = pa.dbg_buf + (size_t)gridDim.x * 4 * 64 * 8 + (size_t)blockIdx.x * 4;
+    w[0] = tw_wg; w[1] = wall_clock64(); pa.dbg_buf[(((size_t)blockIdx.x * 4 + 1) * 64 + 63) * 8] = tw_loop - tw_wg; w[2] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4); w[3] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);
+  }
+  if (out.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && tid == 0) {
+    // IGX_CLOCK_PROBE: s_memtime against the 100 MHz s_memrealtime over the segment, first and last workgroup of every launch
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk), (unsigned long long)(__builtin_readcyclecounter() - tk0));
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 1, (unsigned long long)(wall_clock64() - tw0));
+    atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 2, (unsigned long long)nlay);
   }
 }
 
@@ -502,6 +541,7 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if constexpr (!bpt_form_ok<Form>()) return 0;
   else {
   if (!band_pt_covers<Form>(s, S, out)) return 0;
+  if constexpr (band_nacc_of<Form>::own) { if (!Form::band_params_ok(prm.v)) return 0; }
   constexpr int P = 3;
   const bool alias0 = s.lay[0].alias != 0;
   // (the walk axis needs no rule: a pencil writes every block of its band rows exactly once, wrapped or not)
@@ -525,20 +565,13 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       // (irregular colours of a wrapped axis hold single elements: color_range gives start / count with the regular step)
       pa.nel0 = s.elem_width[0]; pa.alias0 = alias0 ? 1 : 0; pa.wrap2 = wrap2 ? 1 : 0;
       const long long pencils = (long long)pa.ex_count * pa.ey_count;
-      // Two four-wave workgroups per CU (registers, LDS): a launch takes ceil(workgroups / (2 CUs)) rounds of one segment each.
-      // A segment costs a window of element records at its start: the count with the fewest rounds x (layers + 1), at least 8
-      // layers each (96^3 on 256 CUs: 576 pencils in 8 pieces are 9 rounds of 12 layers)
+      // Two four-wave workgroups per CU (registers, LDS).  A segment costs nothing but the window of element records at its start
+      // (no halo is recomputed, and the SIMD gives its older wavefront priority: the partner workgroup keeps the pipe busy through a
+      // newcomer's prologue), so short segments win: they even out the end of a launch.  Measured at 64^3 / 96^3 / 128^3 on a NURBS
+      // map (IGX_NSEG sweeps, profiles/r04_nsvms_segments.txt): four layers per segment is the best length at every size (96^3:
+      // 277.5 ms against 283 at two layers, 285 at eight, 289 at twelve).
       const int max_len = 64;
-      int nseg = (NL + max_len - 1) / max_len;
-      {
-        long long best = -1; int best_n = nseg;
-        for (int n = nseg; n <= std::max(nseg, NL / 8); ++n) {
-          const int len = (NL + n - 1) / n, ns = (NL + len - 1) / len;
-          const long long cost = ((pencils * ns + 2 * ncu - 1) / (2 * ncu)) * (len + 1);
-          if (best < 0 || cost < best) { best = cost; best_n = n; }
-        }
-        nseg = best_n;
-      }
+      int nseg = (NL + 3) / 4;
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
@@ -549,7 +582,55 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       const size_t lds = (size_t)bpt_carve<Form>(pa.seg_len).total * sizeof(double);
       auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      static int dbg_done = 0;
+      const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
+      const size_t dbg_n = (size_t)pencils * pa.nseg * 4 * 64 * 8 + (size_t)pencils * pa.nseg * 4;
+      if (dbg_t) { (void)hipMalloc((void **)&pa.dbg_buf, dbg_n * 8); (void)hipMemset(pa.dbg_buf, 0, dbg_n * 8); }
       hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(256), lds, stream, S, prm, out, pa);
+      if (dbg_t) {   // IGX_DEBUG_TIMING=1: where a layer's cycles go, per role, over the workgroups of the first launch (diagnostic only)
+        dbg_done = 1;
+        (void)hipStreamSynchronize(stream);
+        std::vector<long long> h(dbg_n);
+        (void)hipMemcpy(h.data(), pa.dbg_buf, dbg_n * 8, hipMemcpyDeviceToHost);
+        double sum[4][6] = {{0}}; long long cnt[4] = {0}; long long odd = 0, tot = 0;
+        for (size_t b = 0; b < (size_t)pencils * pa.nseg; ++b) for (int w = 0; w < 4; ++w) for (int l = 1; l + 1 < pa.seg_len && l < 63; ++l) {
+          const long long *d = &h[((b * 4 + w) * 64 + l) * 8], *dn = d + 8;
+          if (!d[0] || !dn[0]) continue;
+          const long long d3 = d[3] ? d[3] : d[2], d4 = d[4] ? d[4] : d3;      // (role 0 has one band tile)
+          sum[w][0] += (double)(d[1] - d[0]); sum[w][1] += (double)(d[2] - d[1]); sum[w][2] += (double)(d3 - d[2]); sum[w][3] += (double)(d4 - d3);
+          sum[w][4] += (double)(d[6] - d[5]); sum[w][5] += (double)(dn[0] - d[0]); cnt[w]++;
+          if (w == 0 && l == 1) { tot++; odd += d[7] & 1; }
+        }
+        for (int w = 0; w < 4; ++w) if (cnt[w]) fprintf(stderr, "[igx band_pt timing] role %d n=%lld cycles: tile A products %.0f | rmw %.0f | tile B products %.0f | rmw %.0f | barrier %.0f | layer %.0f\n",
+                                                         w, cnt[w], sum[w][0] / cnt[w], sum[w][1] / cnt[w], sum[w][2] / cnt[w], sum[w][3] / cnt[w], sum[w][4] / cnt[w], sum[w][5] / cnt[w]);
+        {   // the schedule: per XCC the span of its workgroups, the sum of their durations, the latest start
+          const long long *wg = &h[(size_t)pencils * pa.nseg * 4 * 64 * 8]; const size_t nwg = (size_t)pencils * pa.nseg;
+          long long t0 = LLONG_MAX, t1 = 0; for (size_t b = 0; b < nwg; ++b) { t0 = std::min(t0, wg[b * 4]); t1 = std::max(t1, wg[b * 4 + 1]); }
+          double pro = 0; for (size_t b = 0; b < nwg; ++b) pro += (double)h[((b * 4 + 1) * 64 + 63) * 8];
+          fprintf(stderr, "[igx band_pt schedule] %zu workgroups, launch span %.1f us, mean prologue (tables, window, stagger) %.1f us\n", nwg, (t1 - t0) / 100.0, pro / nwg / 100.0);
+          for (int x = 0; x < 8; ++x) {
+            long long n = 0, first_end = LLONG_MAX, last_end = 0, last_start = 0; double dur = 0; long long cus[64] = {0};
+            for (size_t b = 0; b < nwg; ++b) if ((wg[b * 4 + 3] & 15) == x) {
+              n++; dur += (double)(wg[b * 4 + 1] - wg[b * 4]); last_end = std::max(last_end, wg[b * 4 + 1]); last_start = std::max(last_start, wg[b * 4]);
+              const long long hw = wg[b * 4 + 2]; cus[((hw >> 8) & 15) + 16 * ((hw >> 12) & 1) + 32 * ((hw >> 13) & 1)]++;      // CU_ID, SH_ID, SE_ID (low bit)
+            }
+            long long cmin = LLONG_MAX, cmax = 0; int ncus = 0; for (int c = 0; c < 64; ++c) if (cus[c]) { ncus++; cmin = std::min(cmin, cus[c]); cmax = std::max(cmax, cus[c]); }
+            if (n) fprintf(stderr, "[igx band_pt schedule] xcc %d: %lld workgroups, mean duration %.1f us, last start %.1f us, last end %.1f us; %d CU ids, workgroups per id %lld..%lld\n",
+                           x, n, dur / n / 100.0, (last_start - t0) / 100.0, (last_end - t0) / 100.0, ncus, cmin, cmax);
+          }
+        }
+        {   // per layer index of a segment: cycles from the start of the layer to the start of the next one (role 0)
+          fprintf(stderr, "[igx band_pt timing] layer periods by index:");
+          for (int l = 0; l < pa.seg_len && l < 63; ++l) {
+            double sm = 0; long long n = 0;
+            for (size_t b = 0; b < (size_t)pencils * pa.nseg; ++b) { const long long *d = &h[((b * 4 + 0) * 64 + l) * 8]; if (d[0] && d[6]) { sm += (double)((l + 1 < pa.seg_len && d[8]) ? d[8] - d[0] : d[6] - d[0]); n++; } }
+            if (n) fprintf(stderr, " %.0f", sm / n);
+          }
+          fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[igx band_pt timing] workgroups in an odd wave slot: %lld of %lld; seg_len %d nseg %d\n", odd, tot, pa.seg_len, pa.nseg);
+        (void)hipFree(pa.dbg_buf);
+      }
       (void)hipFreeAsync(pa.pts, stream);
       launches++;
     }

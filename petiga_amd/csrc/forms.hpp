@@ -350,7 +350,13 @@ struct FormNSVMS {
   // accumulator, and added to them when the sums are complete (band_finish).  Products per k-step = the ranks of what is left:
   // D 4 (features N, d_g: nu d_g N_b + tauM u_g S), T_ii - D 1 each, T_ij 2 each, T_i3 2 each (d_i and the advective feature),
   // T_3j 2 each, T_33 3: 4 + 3 + 12 + 6 + 6 + 3 = 34 (round 3: 37 with the row fields in two wave groups).
-  static constexpr int BAND_NACC = 17;
+  // What a constant or a sign can do is left to band_finish as well (fp64 VALU work shares the pipe with the MFMAs): the momentum
+  // blocks are summed as T_ij / nu -- d_j N_a d_i N_b + (tauC / nu) d_i N_a d_j N_b -- and the momentum-pressure blocks as -T_i3, with
+  // the advective feature negated: 52 instead of 64 multiply-adds per k-step.
+  static constexpr int BAND_NACC = 17, BAND_NCOEF = 3;
+  static constexpr bool BAND_NEG_FEAT5 = true;
+  static bool band_params_ok(const double *prm) { return prm[0] > 0.0; }      // (the scaling by 1 / nu; an inviscid flow stays on the feature kernel)
+  static __device__ __forceinline__ void band_coef(const PtView &p, double *c) { double tM, tC; tau(p, tM, tC); c[0] = tM; c[1] = tC / p.prm[0]; c[2] = 1.0 + c[1]; }
   static constexpr unsigned band_acc_mask(int n) {
     if (n == 16) return 0xFu;
     const int i = n / 4, j = n % 4;
@@ -359,10 +365,10 @@ struct FormNSVMS {
     if (j < 3) return 0x1u | (1u << (1 + j));
     return 0xEu;
   }
-  // the trial-side value of accumulator n for the unit test feature F (0: N, 1 + g: d_g N, 4: u . grad N); Nb_ carries JW
+  // the trial-side value of accumulator n for the unit test feature F (0: N, 1 + g: d_g N, 4: -(u . grad N)); Nb_ carries JW
   template <int F>
   static __device__ __forceinline__ void mat_acc(const double *c, const PtView &p, const double *Nb_, double *T) {
-    const double nu = p.prm[0], tauM = c[0], tauC = c[1];
+    const double nu = p.prm[0], tauM = c[0], rC = c[1], rC1 = c[2];
     const double Nb = Nb_[0];
     const double S = p.shift * Nb + (p.u[0] * Nb_[1] + p.u[1] * Nb_[2] + p.u[2] * Nb_[3]);
     if constexpr (F == 0) {
@@ -373,20 +379,29 @@ struct FormNSVMS {
       constexpr int g = F - 1;
       const double tS = tauM * S;
       T[16] = nu * Nb_[1 + g] + p.u[g] * tS;
-      T[g * 4 + g] = (nu + tauC) * Nb_[1 + g];
+      T[g * 4 + g] = rC1 * Nb_[1 + g];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (k == g) continue;
-        T[g * 4 + k] = tauC * Nb_[1 + k];      // block (g, k), test feature d_g: tauC d_g N_a d_k N_b
-        T[k * 4 + g] = nu * Nb_[1 + k];        // block (k, g), test feature d_g: nu d_g N_a d_k N_b
+        T[g * 4 + k] = rC * Nb_[1 + k];        // block (g, k), test feature d_g: (tauC / nu) d_g N_a d_k N_b
+        T[k * 4 + g] = Nb_[1 + k];             // block (k, g), test feature d_g: d_g N_a d_k N_b
       }
-      T[g * 4 + 3] = -Nb;
+      T[g * 4 + 3] = Nb;
       T[12 + g] = tS;
       T[15] = tauM * Nb_[1 + g];
     }
   }
   template <class V, int N>
-  static __device__ __forceinline__ void band_finish(V (&acc)[N]) { acc[0] += acc[16]; acc[5] += acc[16]; acc[10] += acc[16]; }
+  static __device__ __forceinline__ void band_finish(V (&acc)[N], const double *prm) {
+    const double nu = prm[0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i * 4 + j] *= nu;
+      acc[i * 4 + i] += acc[16];
+      acc[i * 4 + 3] = -acc[i * 4 + 3];
+    }
+  }
   static __device__ __forceinline__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
     const double nu = p.prm[0], shift = p.shift;
     const double tauM = c[0], tauC = c[1];
