@@ -363,6 +363,18 @@ def main():
     torch.cuda.set_device(local % max(ndev, 1) if backend != "nccl" else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # A collective that never completes (a peer died, a link is down) must end the run with an exit code, not hang it: every
+        # rank arms a watchdog that leaves the process when the whole measurement has not finished in time (IGX_BENCH_TIMEOUT_S).
+        import threading
+        limit = float(os.environ.get("IGX_BENCH_TIMEOUT_S", "1500"))
+
+        def _expired():
+            sys.stderr.write("bench.py: rank %d of %d did not finish within %.0f s (IGX_BENCH_TIMEOUT_S): leaving with exit code 124\n" % (rank, world, limit))
+            sys.stderr.flush()
+            os._exit(124)
+        wd = threading.Timer(limit, _expired)
+        wd.daemon = True
+        wd.start()
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     import petiga_amd as P

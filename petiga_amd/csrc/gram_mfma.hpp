@@ -252,6 +252,7 @@ struct PencilArgs {
   int first_touch;         // 1: the matrix was NOT zeroed; the first colour that reaches an entry stores it (walk axis 0 only)
   int nelx, nely;          // local element counts on the two non-walked axes (for the first-touch rule)
   int fty_lo, fty_hi, fty_blocked;   // first-touch rule on the Y axis when the launches of an assembly come in two passes (see launch_pencils)
+  int free_run;            // 1: no s_barrier ping-pong between the two wave groups: the SIMD's own arbitration interleaves MFMA and flush phases (IGX_FREE_RUN; default: p = 2 on the identity geometry)
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
   long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
 };
@@ -1325,7 +1326,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int grp = wave >> 2;
   long long tk0 = 0, tw0 = 0;
   if (out.clk) { tk0 = __builtin_readcyclecounter(); tw0 = wall_clock64(); }
-  if (grp == 1) __builtin_amdgcn_s_barrier();
+  const bool pingpong = pa.free_run == 0;
+  if (grp == 1 && pingpong) __builtin_amdgcn_s_barrier();
   int lay = T.lay0;
   for (int ei = 0; ei < ne; ++ei) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
@@ -1355,7 +1357,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       for (int q = 0; q < NB; ++q) sw += wqs[q] * zt[(q * 4 + fs) * 2];
       if (L.fslot < NB) Facc += L.sxy * sw;
     }
-    __builtin_amdgcn_s_barrier();
+    if (pingpong) __builtin_amdgcn_s_barrier();
     if (kDebug && pa.debug_buf) tq2 = __builtin_readcyclecounter();
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
@@ -1370,7 +1372,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
     __builtin_amdgcn_s_setprio(0);
     if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
-    __builtin_amdgcn_s_barrier();
+    if (pingpong) __builtin_amdgcn_s_barrier();
   }
   if (out.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && wave == 0 && lane == 0) {
     // IGX_CLOCK_PROBE: s_memtime against the 100 MHz s_memrealtime over the walk, first and last workgroup of every launch
@@ -1378,7 +1380,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 1, (unsigned long long)(wall_clock64() - tw0));
     atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 2, (unsigned long long)ne);
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
+  if (grp == 0 && pingpong) __builtin_amdgcn_s_barrier();
   if (seg == pa.nseg - 1 && !alias0)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
@@ -1477,6 +1479,10 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.blocks_per_seg = (int)((pencils + 7) / 8);
     pa.ne_max = pa.seg_len + 3;
     pa.debug_noflush = s.env.debug_noflush;
+    // p = 2 on the identity geometry: the flush is the longer phase and the rigid ping-pong makes the MFMA wave wait for it; left to
+    // the SIMD's own arbitration the walk gains 5 % (128^3: 166.7 -> 175.3 M el/s).  Everything at p = 3, mapped geometries and
+    // Tangents lose 6-8 % without the barriers (256^3: 64.8 -> 59.5).  IGX_FREE_RUN=0/1 overrides.
+    pa.free_run = s.env.free_run >= 0 ? s.env.free_run : ((P == 2 && !GEO && !(mod && mod->state)) ? 1 : 0);
     pa.debug_buf = nullptr;
     static int dbg_done = 0;
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
