@@ -376,7 +376,9 @@ int IGXChecksum(IGX iga,IGXMat A,IGXVec b,double S[4]);
  * System and Matrix driver, for the current degree and geometry; dim 3, p = 2 or 3).  gram == 3: the sum-factorised vector kernel
  * (vec_sumfact<MyForm>: Vector / Function / IFunction in 3-D at p <= 3) for the current geometry kind.  gram == 4: state_pencil<p, MyForm>
  * (the Tangent of a scalar struct with the PENCIL_* hooks, below).  gram == 5: block_pencil<MyForm> (System and Matrix driver) of a
- * constant-coefficient multi-field struct.  Returns 0 or IGX_ERR_USER with the compiler's log. */
+ * constant-coefficient multi-field struct.  gram == 6: band_points + band_pt<MyForm> (Matrix / Jacobian / IJacobian of a four-field
+ * struct that separates its point coefficients: NCOEF, point_coef, mat_c), without a geometry and on a NURBS map.
+ * Returns 0 or IGX_ERR_USER with the compiler's log. */
 int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
 
 /* Evidence of the overlap of the ghost-row exchange with the assembly: after IGXReduceGhostRows of an assembly

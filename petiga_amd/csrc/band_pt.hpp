@@ -43,8 +43,6 @@ template <class F> struct band_nfeat_of<F, decltype((void)F::BAND_NFEAT)> { stat
 template <class Form> __host__ __device__ constexpr unsigned bpt_mask(int i, int j) {
   if constexpr (band_nfeat_of<Form>::v == 5) return Form::band_block_mask(i, j); else return fm_block_mask<Form>(i, j);
 }
-template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
-template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
 
 // BAND_NACC / band_acc_mask / mat_acc / band_finish: the form names its accumulators itself (more than dof^2 when blocks share
 // a part: forms.hpp, FormNSVMS); otherwise one accumulator per block entry with the masks above
@@ -221,11 +219,10 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
 
 // offsets (doubles) into the dynamic LDS block of band_pt
 struct BptCarve { int ring, pre, cnt, rho, P, pen, uv, bc, total; };
-template <class Form>
-__host__ __device__ static inline BptCarve bpt_carve(int seg_len) {
+__host__ __device__ static inline BptCarve bpt_carve(int rec, int seg_len) {
   BptCarve c; int pos = 0;
   auto take = [&](int n) { const int o = pos; pos += (n + 1) & ~1; return o; };
-  c.ring = take(5 * bpt_rec<Form>());
+  c.ring = take(5 * rec);
   c.pre = take(seg_len); c.cnt = take((seg_len + 1) / 2); c.rho = take((seg_len + 1) / 2); c.P = take(seg_len * 4);
   c.pen = take(64); c.uv = take(64); c.bc = take(6 + 6 * 4);
   c.total = pos;
@@ -329,7 +326,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   const int nlay = li_hi - li_lo;
   const int lay_first = AW.off[0];
   const int offx = AX.off[elx], offy = AY.off[ely];
-  const BptCarve cv = bpt_carve<Form>(pa.seg_len);
+  const BptCarve cv = bpt_carve(REC, pa.seg_len);
   double *ring = bpt_sm + cv.ring, *uvs = bpt_sm + cv.uv;
   long long *Lpre = reinterpret_cast<long long *>(bpt_sm + cv.pre);
   int *Lcnt = reinterpret_cast<int *>(bpt_sm + cv.cnt), *LP = reinterpret_cast<int *>(bpt_sm + cv.P);
@@ -506,42 +503,49 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
 }
 
 // ---- host side
+// the form qualifies (also evaluated inside a run-time module: rtc.hpp reads it back)
 template <class Form> constexpr bool bpt_form_ok() {
   if constexpr (!has_point_coef<Form>::v) return false;
   else return Form::DOF == 4 && shape_order_of<Form>::v < 2 && !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0 && mat_pair_mask_of<Form>::v == 0ull &&
               (mat_need_of<Form>::v & ~(NEED_U | NEED_G)) == 0u;
 }
+// MFMAs per k-step: one per (accumulator, test feature) product
+template <class Form> constexpr int bpt_products() {
+  int nm = 0;
+  for (int n = 0; n < band_nacc_of<Form>::v; ++n) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_acc_mask<Form>(n) >> f) & 1u) nm++;
+  return nm;
+}
 
-// 3-D, p = 3 with 4 Gauss points per axis, matrix-only drivers (Matrix / Jacobian / IJacobian); axis 0: one new node layer per
-// element (a periodic axis wrapped inside the rank is taken: layers and elements modulo nel, at least 2p+1 of them); axis 1 not
+#ifndef IGX_RTC
+// 3-D, p = 3 with 4 Gauss points per axis, 4 fields, matrix-only drivers (Matrix / Jacobian / IJacobian); axis 0: one new node layer
+// per element (a periodic axis wrapped inside the rank is taken: layers and elements modulo nel, at least 2p+1 of them); axis 1 not
 // wrapped inside the rank; axis 2 either way; any geometry (none / polynomial / NURBS) of dimension 3
+static bool band_pt_covers_space(const Space &s, const SpaceDev &S, const OutDev &out) {
+  if (s.env.block_pencil == 0) return false;
+  if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) return false;
+  if (s.dim != 3 || s.dof != 4 || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
+  for (int d = 0; d < 3; ++d) {
+    if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4) return false;
+    for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
+    if (s.lay[d].alias && s.axis[d].nnp < 7) return false;
+  }
+  if (s.lay[1].alias) return false;
+  if (s.elem_width[0] < 8) return false;
+  for (int e = 0; e + 1 < s.elem_width[0]; ++e) if (s.basis[0].offset[s.elem_start[0] + e + 1] != s.basis[0].offset[s.elem_start[0] + e] + 1) return false;
+  return true;
+}
 template <class Form>
 static bool band_pt_covers(const Space &s, const SpaceDev &S, const OutDev &out) {
   if constexpr (!bpt_form_ok<Form>()) return false;
-  else {
-    if (s.env.block_pencil == 0) return false;
-    if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) return false;
-    if (s.dim != 3 || s.dof != Form::DOF || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
-    for (int d = 0; d < 3; ++d) {
-      if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4) return false;
-      for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
-      if (s.lay[d].alias && s.axis[d].nnp < 7) return false;
-    }
-    if (s.lay[1].alias) return false;
-    if (s.elem_width[0] < 8) return false;
-    for (int e = 0; e + 1 < s.elem_width[0]; ++e) if (s.basis[0].offset[s.elem_start[0] + e + 1] != s.basis[0].offset[s.elem_start[0] + e] + 1) return false;
-    return true;
-  }
+  else return band_pt_covers_space(s, S, out);
 }
 
-template <class Form>
-static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, hipStream_t stream, std::string &kname, int &launches,
-                       std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix, const std::function<void()> &slab_done) {
-  done = false;
-  if constexpr (!bpt_form_ok<Form>()) return 0;
-  else {
-  if (!band_pt_covers<Form>(s, S, out)) return 0;
-  if constexpr (band_nacc_of<Form>::own) { if (!Form::band_params_ok(prm.v)) return 0; }
+// the launches of an assembly; `launch(points, grid, lds_bytes, geo, rat, args)` starts band_points (points = true: 256 threads, four
+// elements per workgroup) or band_pt (256 threads, lds_bytes of dynamic LDS) -- the compiled-in instantiations of a built-in form,
+// or the module functions of a run-time struct (rtc.hpp); rec = bpt_rec<Form>(), products = bpt_products<Form>()
+typedef std::function<void(bool, unsigned, size_t, bool, bool, const BandArgs &)> BandPtLaunch;
+static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom,
+                       const std::function<void()> &zero_matrix, const std::function<void()> &slab_done, int rec, int products, const BandPtLaunch &launch) {
   constexpr int P = 3;
   const bool alias0 = s.lay[0].alias != 0;
   // (the walk axis needs no rule: a pencil writes every block of its band rows exactly once, wrapped or not)
@@ -550,7 +554,6 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (!first_touch) { if (zero_matrix) zero_matrix(); }
   else if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] > 1) zero_neighbour_rows(s, out, stream);
   launches = 0;
-  static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
   const int NL = alias0 ? s.elem_width[0] : s.elem_width[0] + P;
   const bool geo = s.nsd != 0, rat = s.rational != 0;
   int rc = 0;
@@ -568,25 +571,22 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
       // Two four-wave workgroups per CU (registers, LDS).  A segment costs nothing but the window of element records at its start
       // (no halo is recomputed, and the SIMD gives its older wavefront priority: the partner workgroup keeps the pipe busy through a
       // newcomer's prologue), so short segments win: they even out the end of a launch.  Measured at 64^3 / 96^3 / 128^3 on a NURBS
-      // map (IGX_NSEG sweeps, profiles/r04_nsvms_segments.txt): four layers per segment is the best length at every size (96^3:
-      // 277.5 ms against 283 at two layers, 285 at eight, 289 at twelve).
+      // map (IGX_NSEG sweeps, profiles/r04_nsvms_segments.txt): four layers per segment were the best length at every size.
       const int max_len = 64;
       int nseg = (NL + 3) / 4;
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
-      const size_t need = (size_t)pencils * pa.nel0 * bpt_rec<Form>() * sizeof(double);
+      const size_t need = (size_t)pencils * pa.nel0 * rec * sizeof(double);
       if (hipMallocAsync(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
       const long long nelem = pencils * pa.nel0;
-      hipLaunchKernelGGL(band_points<Form>, dim3((unsigned)((nelem + 3) / 4)), dim3(256), 0, stream, S, prm, out, pa);
-      const size_t lds = (size_t)bpt_carve<Form>(pa.seg_len).total * sizeof(double);
-      auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
-      (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      launch(true, (unsigned)((nelem + 3) / 4), 0, geo, rat, pa);
+      const size_t lds = (size_t)bpt_carve(rec, pa.seg_len).total * sizeof(double);
       static int dbg_done = 0;
       const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
       const size_t dbg_n = (size_t)pencils * pa.nseg * 4 * 64 * 8 + (size_t)pencils * pa.nseg * 4;
       if (dbg_t) { (void)hipMalloc((void **)&pa.dbg_buf, dbg_n * 8); (void)hipMemset(pa.dbg_buf, 0, dbg_n * 8); }
-      hipLaunchKernelGGL(kern, dim3((unsigned)(pencils * pa.nseg)), dim3(256), lds, stream, S, prm, out, pa);
+      launch(false, (unsigned)(pencils * pa.nseg), lds, geo, rat, pa);
       if (dbg_t) {   // IGX_DEBUG_TIMING=1: where a layer's cycles go, per role, over the workgroups of the first launch (diagnostic only)
         dbg_done = 1;
         (void)hipStreamSynchronize(stream);
@@ -649,15 +649,31 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (rc) return rc;
   if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
   if (hipGetLastError() != hipSuccess) { err = "band_pt kernel launch failed"; return IGX_ERR_LIB; }
-  int nm = 0;      // MFMAs per k-step: one per (accumulator, test feature) product
-  for (int n = 0; n < band_nacc_of<Form>::v; ++n) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_acc_mask<Form>(n) >> f) & 1u) nm++;
   dom.name = "band_pt<p=3>"; dom.launches = launches;
   dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
-  dom.flop_per_element = 2048.0 * nm * 16 * 16;
+  dom.flop_per_element = 2048.0 * products * 16 * 16;
   kname = std::string("band_pt(mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
   done = true;
   return 0;
+}
+
+template <class Form>
+static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, const OutDev &out, hipStream_t stream, std::string &kname, int &launches,
+                       std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix, const std::function<void()> &slab_done) {
+  done = false;
+  if constexpr (!bpt_form_ok<Form>()) return 0;
+  else {
+  if (!band_pt_covers<Form>(s, S, out)) return 0;
+  if constexpr (band_nacc_of<Form>::own) { if (!Form::band_params_ok(prm.v)) return 0; }
+  return band_pt_run(s, S, out, stream, kname, launches, err, done, dom, zero_matrix, slab_done, bpt_rec<Form>(), bpt_products<Form>(),
+                     [&](bool points, unsigned grid, size_t lds, bool geo, bool rat, const BandArgs &pa) {
+                       if (points) { hipLaunchKernelGGL(band_points<Form>, dim3(grid), dim3(256), 0, stream, S, prm, out, pa); return; }
+                       auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
+                       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                       hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, S, prm, out, pa);
+                     });
   }
 }
+#endif   // !IGX_RTC
 
 }  // namespace igx

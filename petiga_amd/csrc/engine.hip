@@ -20,6 +20,7 @@
 #ifndef IGX_TU_DISPATCH
 #include "gram_mfma.hpp"
 #include "block_pencil.hpp"      // (the host launcher, for run-time forms: rtc.hpp; no kernel of it is instantiated in this unit)
+#include "band_pt.hpp"           // (likewise: band_pt_run)
 #elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)
 #include "block_pencil.hpp"
 #define IGX_HAVE_BLOCK_PENCIL 1

@@ -82,6 +82,9 @@ template <class F> constexpr unsigned fm_block_mask(int i, int j) { if constexpr
 // (Jacobian / IJacobian / Matrix) skip the rest, e.g. the field Hessians NS-VMS needs for its residual alone
 template <class F, class = void> struct mat_need_of { static constexpr unsigned v = F::NEED; };
 template <class F> struct mat_need_of<F, decltype((void)F::MAT_NEED)> { static constexpr unsigned v = F::MAT_NEED; };
+// band_pt.hpp: the form separates what depends on the point alone (NCOEF, point_coef) from what depends on the basis functions (mat_c)
+template <class F, class = void> struct has_point_coef { static constexpr bool v = false; };
+template <class F> struct has_point_coef<F, decltype((void)F::NCOEF)> { static constexpr bool v = true; };
 
 struct FCarve {            // offsets in doubles into the dynamic LDS block
   int t1d[3], w1d[3];

@@ -70,7 +70,7 @@ struct RtcForm {
   std::vector<char> code;
   // DOF, ORDER, NEED, NSCALAR, SHAPE_ORDER, MAT_NEED, MAT_PAIR_MASK != 0, has an atboundary branch, MAT_TEST_MASK, MAT_SYMMETRIC,
   // VEC_TEST_MASK, PENCIL_NFEAT or 0 (read from the module)
-  // [12] number of Gram pairs (bits of MAT_PAIR_MASK), [13] VEC_ZERO, [14], [15] 0
+  // [12] number of Gram pairs (bits of MAT_PAIR_MASK), [13] VEC_ZERO, [14] NCOEF / point_coef declared (band_pt.hpp), [15] 0
   int meta[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   hipModule_t module = nullptr; hipFunction_t func = nullptr;
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
@@ -78,6 +78,7 @@ struct RtcForm {
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
   std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P
   std::map<int, std::shared_ptr<RtcFeature>> block;     // block_pencil instantiations; key: SYSTEM
+  std::map<int, std::shared_ptr<RtcFeature>> band;      // band_points + band_pt instantiations; key: GEO | RAT << 1
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -130,7 +131,7 @@ static void rtc_cache_store(const std::string &path, const std::vector<char> &co
 
 // compiles `tail` behind the library headers and the user's source; returns the code object and the lowered names of `exprs`
 static int rtc_build(const std::string &source, bool with_feature, const std::string &tail, const std::vector<std::string> &exprs,
-                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false, bool with_vecsf = false, bool with_block = false) {
+                     std::vector<char> &code, std::vector<std::string> &lowered, bool with_pencil = false, bool with_vecsf = false, bool with_block = false, bool with_band = false) {
   std::string src;
   src.reserve(source.size() + 400000);
   src += "#define IGX_RTC 1\n";
@@ -138,7 +139,8 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   if (with_feature) { src += kRtcSrc_feature; src += "\n"; }
   if (with_pencil) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_gram; src += "\n"; }
   if (with_vecsf) { src += kRtcSrc_vecsf; src += "\n"; }
-  if (with_block) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_block; src += "\n"; }
+  if (with_block || with_band) { src += kRtcSrc_pencil; src += "\n"; src += kRtcSrc_block; src += "\n"; }
+  if (with_band) { src += kRtcSrc_band; src += "\n"; }
   src += "using namespace igx;\n#line 1 \"user_form.hip\"\n";
   src += source;
   src += "\n";
@@ -176,7 +178,7 @@ static int rtc_compile(IGX g, const std::string &source, const std::string &name
   const std::string expr = "igx::generic_assemble<" + name + ", " + std::to_string(dim) + ">";
   std::string tail = "// what the host-side launcher reads back\n__device__ int igx_user_meta[16] = {" + name + "::DOF, " + name + "::ORDER, (int)" + name + "::NEED, igx::nscalar_of<" + name +
                      ">::v, igx::shape_order_of<" + name + ">::v, (int)igx::mat_need_of<" + name + ">::v, igx::mat_pair_mask_of<" + name + ">::v != 0ull, igx::has_boundary_of<" + name + ">::v, (int)igx::mat_test_mask_of<" +
-                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, igx::pencil_state_of<" + name + ">::nfeat, igx::fm_popcount(igx::mat_pair_mask_of<" + name + ">::v), igx::vec_zero_of<" + name + ">::v, 0, 0};\n";
+                     name + ">::v, igx::mat_symmetric_of<" + name + ">::v, (int)igx::vec_test_mask_of<" + name + ">::v, igx::pencil_state_of<" + name + ">::nfeat, igx::fm_popcount(igx::mat_pair_mask_of<" + name + ">::v), igx::vec_zero_of<" + name + ">::v, igx::has_point_coef<" + name + ">::v, 0};\n";
   tail += "template __global__ void " + expr + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::ColorRange, igx::Carve, double *, size_t);\n";
   std::shared_ptr<RtcForm> f(new RtcForm());
   std::vector<std::string> low;
@@ -575,6 +577,62 @@ static int launch_block_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
 
 static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out);
 // launch_generic (engine.hip) with the form's constants read from the module instead of from a template parameter
+// ---- band rows by node layer with point-dependent coefficients (band_pt.hpp) for a run-time struct: four fields, first order, the
+// point coefficients separated from the basis functions (NCOEF, point_coef, mat_c; optionally mat_unit / BAND_NFEAT / BAND_NACC with
+// their hooks, forms.hpp: FormNSVMS is the model); Matrix / Jacobian / IJacobian drivers.  The conditions of bpt_form_ok are checked
+// on the constants read from the module; colours, segments, first touch and the two-pass assembly are band_pt_run.
+struct RtcBandArgs { SpaceDev S; ParamsDev prm; OutDev out; BandArgs pa; };
+static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false, int geo_only = -1) {
+  done = false;
+  const Space &s = g->s;
+  if (s.dim != 3) return 0;
+  if (!compile_only) {
+    if (!F.meta[14] || F.meta[0] != 4 || F.meta[4] >= 2 || F.meta[7] || F.meta[3] > 0 || F.meta[6] || (F.meta[5] & ~(int)(NEED_U | NEED_G))) return 0;
+    if (!band_pt_covers_space(s, S, out)) return 0;
+  }
+  const bool geo = compile_only ? (geo_only & 1) != 0 : s.nsd != 0, rat = compile_only ? (geo_only & 2) != 0 : s.rational != 0;
+  const int key = (geo ? 1 : 0) | (rat ? 2 : 0);
+  std::shared_ptr<RtcFeature> K;
+  auto it = F.band.find(key);
+  if (it != F.band.end() && (it->second->module || compile_only)) K = it->second;
+  else {
+    K.reset(new RtcFeature());
+    const std::string xp = std::string("igx::band_points<") + F.name + ">";
+    const std::string xb = std::string("igx::band_pt<") + F.name + ", " + (geo ? "true" : "false") + ", " + (rat ? "true" : "false") + ">";
+    const std::string tail = "static_assert(igx::bpt_form_ok<" + F.name + ">(), \"band_pt: four fields, first order, NCOEF / point_coef / mat_c, no atboundary branch\");\n"
+                             "__device__ int igx_band_meta[4] = {igx::bpt_rec<" + F.name + ">(), igx::bpt_products<" + F.name + ">(), 0, 0};\n"
+                             "template __global__ void " + xp + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n"
+                             "template __global__ void " + xb + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n";
+    if (int rc = rtc_build(F.source, true, tail, {xp, xb}, K->code, K->lowered, false, false, false, true)) return rc;
+    if (!compile_only) {
+      HIPCK(hipModuleLoadData(&K->module, K->code.data()));
+      for (int k = 0; k < 2; ++k) { hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[k].c_str())); K->func.push_back(fn); }
+      hipDeviceptr_t p = nullptr; size_t n = 0;
+      HIPCK(hipModuleGetGlobal(&p, &n, K->module, "igx_band_meta"));
+      if (n != sizeof(K->meta)) return fail(IGX_ERR_LIB, "unexpected igx_band_meta size");
+      HIPCK(hipMemcpy(K->meta, p, sizeof(K->meta), hipMemcpyDeviceToHost));
+    }
+    F.band[key] = K;
+  }
+  if (compile_only) { done = true; return 0; }
+  ParamsDev prm; memset(&prm, 0, sizeof(prm));
+  for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
+  hipStream_t stream = g->stream;
+  int lrc = 0;
+  std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
+  const int rc = band_pt_run(s, S, out, stream, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, K->meta[0], K->meta[1],
+                             [&](bool points, unsigned grid, size_t lds, bool, bool, const BandArgs &pa) {
+                               RtcBandArgs a; memset(&a, 0, sizeof(a));
+                               a.S = S; a.prm = prm; a.out = out; a.pa = pa;
+                               size_t asz = sizeof(a);
+                               void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
+                               if (hipModuleLaunchKernel(K->func[points ? 0 : 1], grid, 1, 1, 256, 1, 1, (unsigned)lds, stream, nullptr, cfg) != hipSuccess) lrc = IGX_ERR_LIB;
+                             });
+  if (rc == 0 && lrc) return fail(lrc, "band_pt: launch of the run-time instantiation failed");
+  if (rc == 0 && done) g->last_kernel = std::string("band_pt<") + F.name + ">(hiprtc,mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records)";
+  return rc;
+}
+
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
   if (!g->rtc || g->rtc->dim != s.dim) {
@@ -592,11 +650,16 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
     if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
   }
+  if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // four-field structs with separated point coefficients: band rows by node layer
+    bool done = false;
+    if (int rc = launch_band_rtc(g, F, S, out, done)) return rc;
+    if (done) return 0;
+  }
   if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // constant-coefficient multi-field structs: band rows by node layer
     bool done = false;
     if (int rc = launch_block_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
-    if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernel does not cover this run-time form / configuration (MAT_PAIR_MASK, 2 or 3 fields, VEC_ZERO, 3-D, p = 3, identity geometry, System / Matrix driver)");
+    if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this run-time form / configuration (block_pencil: MAT_PAIR_MASK, 2 or 3 fields, VEC_ZERO, 3-D, p = 3, identity geometry, System / Matrix driver; band_pt: 4 fields, NCOEF / point_coef / mat_c, 3-D, p = 3, matrix-only driver)");
   }
   if (g->kernel_choice == 0 || g->kernel_choice == 2) {   // Tangents of scalar structs that opted in: the pencil walk with the state
     bool done = false;
@@ -791,6 +854,12 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   NEEDIGA(g);
   if (g->s.form != IGX_FORM_SOURCE || !g->rtc) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXSetFormSource() first");
   const Space &s = g->s;
+  if (gram == 6) {           // band_points + band_pt of a four-field struct with separated point coefficients: compile only (no geometry and NURBS)
+    bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
+    if (int rc = launch_band_rtc(g, *g->rtc, Sd, o, done, true, 0)) return rc;
+    if (!done) return fail(IGX_ERR_SUP, "band_pt needs dim 3");
+    return launch_band_rtc(g, *g->rtc, Sd, o, done, true, 3);
+  }
   if (gram == 5) {           // block_pencil of a constant-coefficient multi-field struct (System and Matrix driver): compile only
     bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
     if (int rc = launch_block_rtc(g, *g->rtc, Sd, o, done, true, 1)) return rc;

@@ -1,0 +1,163 @@
+"""Run-time structs on band_pt (petiga_amd/csrc/band_pt.hpp through rtc.hpp): a four-field form with point-dependent coefficients given
+as source -- the reference's callback is an opaque user function (include/petiga.h:153-197); demo/NavierStokesVMS.c:166-244's Tangent
+is the model -- reaches the band-row kernel like the built-in FormNSVMS when it separates what depends on the point alone
+(NCOEF, point_coef) from what depends on the basis functions (mat_c).  Two structs: a plain one (the Tangent written once, in
+mat_c: the kernel applies it to the unit test features) and the built-in struct's own text under another name (all of its hooks:
+unit features, the advective fifth feature, 17 accumulators) -- the latter must run at the built-in's rate."""
+import os
+import re
+import time
+
+import numpy as np
+import pytest
+
+import oracle_api as O
+from common import compare_mats, make_pair, warped_geometry
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NU, FX, DT = 1.472e-4, 3.37204e-3, 1e-2
+
+# the Tangent of demo/NavierStokesVMS.c:166-244 with Tau (:9-46) separated; params = {nu, fx, fy, fz, dt}
+PLAIN_VMS = r"""
+struct UserVMS {
+  static constexpr int DOF = 4, ORDER = 1, SHAPE_ORDER = 1;
+  static constexpr unsigned NEED = NEED_U | NEED_G, MAT_NEED = NEED_U | NEED_G;
+  static constexpr int NCOEF = 2;
+  static __device__ void point_coef(const PtView &p, double *c) {     // tau_M, tau_C from the metric G = J J^T of the scaled inverse map
+    const double *J = p.G; const double nu = p.prm[0], dt = p.prm[4], C_I = 1.0 / 12.0;
+    double G[9], g[3] = {0, 0, 0}, G_G = 0, g_g = 0, u_G_u = 0;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { double s = 0; for (int k = 0; k < 3; ++k) s += J[i * 3 + k] * J[j * 3 + k]; G[i * 3 + j] = s; }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) g[i] += J[i * 3 + j];
+    for (int i = 0; i < 9; ++i) G_G += G[i] * G[i];
+    for (int i = 0; i < 3; ++i) g_g += g[i] * g[i];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) u_G_u += p.u[i] * G[i * 3 + j] * p.u[j];
+    const double tauM = 1.0 / sqrt(4 / (dt * dt) + u_G_u + C_I * nu * nu * G_G);
+    c[0] = tauM; c[1] = 1.0 / (tauM * g_g);
+  }
+  static __device__ void mat_c(const double *c, const PtView &p, const double *Na_, const double *Nb_, double *T) {
+    const double nu = p.prm[0], shift = p.shift, tauM = c[0], tauC = c[1];
+    const double ux = p.u[0], uy = p.u[1], uz = p.u[2];
+    const double Na = Na_[0], Na_x = Na_[1], Na_y = Na_[2], Na_z = Na_[3];
+    const double Nb = Nb_[0], Nb_x = Nb_[1], Nb_y = Nb_[2], Nb_z = Nb_[3];
+    const double adva = ux * Na_x + uy * Na_y + uz * Na_z, advb = ux * Nb_x + uy * Nb_y + uz * Nb_z;
+    const double Tii = shift * Na * Nb + Na * advb + nu * (Na_x * Nb_x + Na_y * Nb_y + Na_z * Nb_z) + tauM * adva * (shift * Nb + advb);
+    T[0] = nu * Na_x * Nb_x + tauC * Na_x * Nb_x + Tii; T[1] = nu * Na_y * Nb_x + tauC * Na_x * Nb_y; T[2] = nu * Na_z * Nb_x + tauC * Na_x * Nb_z;
+    T[4] = nu * Na_x * Nb_y + tauC * Na_y * Nb_x; T[5] = nu * Na_y * Nb_y + tauC * Na_y * Nb_y + Tii; T[6] = nu * Na_z * Nb_y + tauC * Na_y * Nb_z;
+    T[8] = nu * Na_x * Nb_z + tauC * Na_z * Nb_x; T[9] = nu * Na_y * Nb_z + tauC * Na_z * Nb_y; T[10] = nu * Na_z * Nb_z + tauC * Na_z * Nb_z + Tii;
+    T[3] = -Na_x * Nb + tauM * adva * Nb_x; T[7] = -Na_y * Nb + tauM * adva * Nb_y; T[11] = -Na_z * Nb + tauM * adva * Nb_z;
+    T[12] = Na * Nb_x + tauM * Na_x * (shift * Nb + advb); T[13] = Na * Nb_y + tauM * Na_y * (shift * Nb + advb); T[14] = Na * Nb_z + tauM * Na_z * (shift * Nb + advb);
+    T[15] = tauM * (Na_x * Nb_x + Na_y * Nb_y + Na_z * Nb_z);
+  }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { double c[2]; point_coef(p, c); mat_c(c, p, Na, Nb, T); }
+  static __device__ void vec(const PtView &, const double *, double *R) { R[0] = 0; R[1] = 0; R[2] = 0; R[3] = 0; }
+};
+"""
+
+
+def builtin_text_as_source(name="UserNSVMSFull"):
+    """struct FormNSVMS of petiga_amd/csrc/forms.hpp, renamed: what a user who wants the built-in's rate writes"""
+    text = open(os.path.join(ROOT, "petiga_amd", "csrc", "forms.hpp")).read()
+    i = text.index("struct FormNSVMS {")
+    j = text.index("\n};", i) + 3
+    return re.sub(r"\bFormNSVMS\b", name, text[i:j]), name
+
+
+def _problem(N, periodic, geo, objs_only=False):
+    orc, eng = make_pair(3, 4, 3, list(N), periodic=list(periodic))
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=sum(N), rational=(geo == "nurbs"), amp=0.08)
+        orc.set_geometry(X, W)
+        eng.set_geometry(X, W)
+    for g in (orc, eng):
+        for side in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, side, f, 0.0)
+    return orc, eng
+
+
+def test_band_structs_compile_without_a_gpu():
+    """IGXCheckFormSource(gram = 6): band_points + band_pt of both structs, without a geometry and on a NURBS map"""
+    import petiga_amd as P
+    full, name = builtin_text_as_source()
+    for src, nm in ((PLAIN_VMS, "UserVMS"), (full, name)):
+        g = P.IGX(3, 4)
+        for i in range(3):
+            g.axis_uniform(i, 3, 8)
+        g.set_form_source(src, nm, (NU, FX, 0.0, 0.0, DT))
+        g.check_form_source(True, 6)
+
+
+def test_a_struct_without_point_coefficients_does_not_compile_for_band_pt():
+    import petiga_amd as P
+    src = PLAIN_VMS.replace("static constexpr int NCOEF = 2;", "").replace("UserVMS", "UserVMSNoCoef")
+    g = P.IGX(3, 4)
+    for i in range(3):
+        g.axis_uniform(i, 3, 8)
+    g.set_form_source(src, "UserVMSNoCoef", (NU, FX, 0.0, 0.0, DT))
+    with pytest.raises(P.IGXError) as e:
+        g.check_form_source(True, 6)
+    assert "band_pt" in str(e.value)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["plain", "full"])
+@pytest.mark.parametrize("N,periodic,geo", [((8, 4, 4), (False, False, False), None), ((9, 3, 8), (True, False, True), "nurbs"), ((10, 4, 5), (False, False, False), "poly")])
+def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo):
+    orc, eng = _problem(N, periodic, geo)
+    ctx, params = O.NSVMSCtx(NU, FX, 0.0, 0.0, DT), (NU, FX, 0.0, 0.0, DT)
+    rng = np.random.default_rng(31)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n) * 0.1
+    shift = 2.0 / DT
+    J_o = orc.compute_ijacobian("orc_form_ns_tangent", ctx, shift, V, 0.0, U)
+    src, name = (PLAIN_VMS, "UserVMS") if which == "plain" else builtin_text_as_source()
+    eng.set_form_source(src, name, params)
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert ("band_pt<%s>(hiprtc" % name) in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-11)
+    eng.set_kernel(3)      # the element mode of the feature kernel: same numbers to rounding
+    eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert ("feature_assemble<%s>" % name) in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-11)
+
+
+@pytest.mark.gpu
+def test_the_builtin_struct_given_as_source_runs_at_the_builtin_rate():
+    """demo/NavierStokesVMS.c's Tangent as source at 48^3 on a NURBS map: within 5 % of the built-in form (min of 4 assemblies each)"""
+    import petiga_amd as P
+    times, mats = {}, {}
+    for kind in ("builtin", "source"):
+        g = P.IGX(3, 4)
+        for i, per in enumerate((True, False, True)):
+            g.axis_uniform(i, 3, 48, periodic=per)
+        g.setup()
+        import bench
+        X, W = bench._bench_geometry(3, 48, [True, False, True])
+        g.set_geometry(X, W)
+        for side in range(2):
+            for f in range(3):
+                g.set_boundary_value(1, side, f, 0.0)
+        if kind == "builtin":
+            g.set_form("nsvms", (NU, FX, 0.0, 0.0, DT))
+        else:
+            src, name = builtin_text_as_source()
+            g.set_form_source(src, name, (NU, FX, 0.0, 0.0, DT))
+        J = g.create_mat()
+        rng = np.random.default_rng(5)
+        U, V = g.create_vec().set(0.1 + 0.05 * rng.standard_normal(J.nbrows * 4)), g.create_vec().set(np.zeros(J.nbrows * 4))
+        ts = []
+        for _ in range(5):
+            g.synchronize()
+            t = time.perf_counter()
+            g.compute_ijacobian(2.0 / DT, V, 0.0, U, J)
+            g.synchronize()
+            ts.append(time.perf_counter() - t)
+        times[kind] = min(ts[1:])
+        mats[kind] = (J.host(True), g.kernel_name())
+    assert "band_pt(" in mats["builtin"][1] and "band_pt<UserNSVMSFull>(hiprtc" in mats["source"][1], (mats["builtin"][1], mats["source"][1])
+    scale = np.abs(mats["builtin"][0]).max()
+    assert np.abs(mats["builtin"][0] - mats["source"][0]).max() <= 1e-13 * scale
+    assert times["source"] <= 1.05 * times["builtin"], times
