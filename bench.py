@@ -30,7 +30,7 @@ ALG = {"elasticity": (4718592, 25400), "cahnhilliard": (790000, 1009), "nsvms": 
 NOMINAL_MHZ = 2400.0
 FP64_PEAK_TFLOPS = 78.6                        # MI355X fp64 vector = matrix peak (256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-KERNEL_TAG = "r03"                             # profiles/traffic.json must describe this round's kernel to be quoted
+KERNEL_TAG = "r04"                             # profiles/traffic.json must describe this round's kernel to be quoted
 
 
 def physical_cores():
@@ -104,10 +104,11 @@ def cpu_baseline(form, degree, seconds_target=15.0):
 
 
 def live_traffic(child_args, dom_name, timeout=300):
-    """HBM bytes per launch of the dominant kernel, measured now: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each with
-    --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) around a one-step child run of this same script.
-    bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KB and gfx950 reports half of a wide coalesced read.
-    Returns (bytes_per_launch or None, note)."""
+    """HBM-side bytes per launch of the dominant kernel, measured now: two rocprofv3 passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE, each
+    with --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) around a one-step child run of this same script.
+    The kernel instantiation is picked ONCE (from the FETCH pass: the one that fetched most in total) and the WRITE pass reads the
+    same name.  Returns (dict or None, note): raw FETCH_SIZE / WRITE_SIZE in bytes per launch and the guide's corrected figure
+    (2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies a 128-byte read request as 64 bytes)."""
     import csv
     import glob
     import shutil
@@ -117,7 +118,7 @@ def live_traffic(child_args, dom_name, timeout=300):
     if not exe:
         return None, "rocprofv3 not found"
     key = dom_name.split("<")[0].split("(")[0]          # gram_pencil, block_pencil, state_pencil, band_pt, form_pencil, feature_assemble
-    mean = {}
+    mean, name = {}, None
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="igx_pmc_", dir="/tmp")
         try:
@@ -126,18 +127,25 @@ def live_traffic(child_args, dom_name, timeout=300):
             per = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and ("igx::" + key) in r["Kernel_Name"]:
+                    if r["Counter_Name"] == counter and ("igx::" + key + "<") in r["Kernel_Name"]:
                         per.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
             if not per:
                 return None, "no %s samples of %s" % (counter, key)
-            name = max(per, key=lambda k: sum(per[k]))       # (two-assembly steps: the IJacobian's kernel carries the traffic)
+            if name is None:
+                name = max(per, key=lambda k: sum(per[k]))       # (two-assembly steps: the IJacobian's kernel carries the traffic)
+            if name not in per:
+                return None, "the %s pass has no samples of %s" % (counter, name)
             mean[counter] = sum(per[name]) / len(per[name])
         except Exception as e:                              # a missing counter, a time-out: the line falls back to the replayed figure
             return None, "rocprofv3 pass failed: %r" % (e,)
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    return (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0, \
-        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each around a one-step child run of this command; (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch"
+    fetch, write = mean["FETCH_SIZE"] * 1024.0, mean["WRITE_SIZE"] * 1024.0
+    return dict(corrected=2.0 * fetch + write, fetch_raw=fetch, write_raw=write, kernel=name.replace("void igx::", "")), \
+        "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE, one pass each around a one-step child run of this command; " \
+        "traffic = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 bytes per launch (the guide's gfx950 correction: a 128-byte read request is tallied as 64 bytes -- it holds " \
+        "for the kernels of this library that read whole 128-byte lines, band_pt's blocks among them: reads + point records = 2 x FETCH_SIZE to 2 % there; " \
+        "traffic_raw_fetch / traffic_raw_write are the uncorrected counters)"
 
 
 def _bench_geometry(p, size, periodic):
@@ -534,7 +542,7 @@ def main():
     # HBM bytes per launch of the dominant kernel come from rocprofv3 --pmc passes of this same command
     # (scripts/profile_round.sh), committed as profiles/traffic.json: they are NOT measured inside this run, so the
     # line names the file; null when the file does not describe this configuration (form, size, degree, ranks, round).
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_raw = None, None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):
         try:
@@ -551,7 +559,7 @@ def main():
                  "--no-cpu-baseline", "--no-live-traffic"] + (["--geometry"] if args.geometry else []) + (["--source"] if args.source else [])
         lt, note = live_traffic(child, dom_name)
         if lt is not None:
-            traffic, traffic_source = lt, note
+            traffic, traffic_source, traffic_raw = lt["corrected"], note, lt
         elif traffic_source:
             traffic_source += " [live measurement unavailable: %s]" % note
     # Dominant kernel.  `achieved` / `frac` count the flops the kernel EXECUTES on the matrix cores (the headline kernel skips the
@@ -562,6 +570,8 @@ def main():
             "frac": executed / FP64_PEAK_TFLOPS,
             "achieved_algorithmic": achieved, "frac_algorithmic": (achieved / FP64_PEAK_TFLOPS) if achieved else None,
             "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_raw_fetch": traffic_raw["fetch_raw"] if traffic_raw else None, "traffic_raw_write": traffic_raw["write_raw"] if traffic_raw else None,
+            "traffic_kernel": traffic_raw["kernel"] if traffic_raw else None,
             "hbm_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and avg_launch_s > 0) else None,
             "shader_clock_mhz": clock_mhz, "nominal_clock_mhz": NOMINAL_MHZ,
             "frac_at_measured_clock": (executed / (FP64_PEAK_TFLOPS * clock_mhz / NOMINAL_MHZ)) if clock_mhz else None,

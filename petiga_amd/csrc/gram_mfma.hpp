@@ -1436,6 +1436,9 @@ typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
 struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0; };
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
+// a launch that could not be made (the LDS of the chosen segments beyond the device's, a module launch refused): try_gram_mfma
+// reports it instead of the generic "kernel launch failed" of a later call
+inline const char *&pencil_launch_error() { static thread_local const char *e = nullptr; return e; }
 
 template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
 // fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
@@ -1489,6 +1492,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);
+    if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the pencil walk's tables do not fit the 160 KB of LDS for any segment length"; return; }
     if (mod && mod->kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mod->kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(mod->kfn, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa, mod->prm);
@@ -1498,7 +1502,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       args.S = S; args.out = out; args.pa = pa; args.prm = mod->prm;
       size_t asz = sizeof(args);
       void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-      (void)hipModuleLaunchKernel(mod->fn, (unsigned)(pa.blocks_per_seg * pa.nseg), 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg);
+      if (hipModuleLaunchKernel(mod->fn, (unsigned)(pa.blocks_per_seg * pa.nseg), 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg) != hipSuccess) { pencil_launch_error() = "launch of the run-time instantiation of the pencil walk failed"; return; }
     } else {
     void (*kern)(SpaceDev, OutDev, PencilArgs) = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
     if constexpr (W == 0 && !GEO) kern = pa.alias0 ? gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 1> : gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 0>;
@@ -1799,6 +1803,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     }
     kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
+  if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
   done = true;
   return 0;

@@ -27,6 +27,7 @@ struct HiprtcApi {
   int (*CodeSize)(void *, size_t *) = nullptr;
   int (*Code)(void *, char *) = nullptr;
   int (*Destroy)(void **) = nullptr;
+  int (*Version)(int *, int *) = nullptr;      // hiprtcVersion(major, minor): part of the cache key
 };
 static HiprtcApi &hiprtc_api() { static HiprtcApi a; return a; }
 
@@ -48,6 +49,7 @@ static int load_hiprtc(std::string &err) {
   a.CodeSize = reinterpret_cast<decltype(a.CodeSize)>(sym("hiprtcGetCodeSize"));
   a.Code = reinterpret_cast<decltype(a.Code)>(sym("hiprtcGetCode"));
   a.Destroy = reinterpret_cast<decltype(a.Destroy)>(sym("hiprtcDestroyProgram"));
+  a.Version = reinterpret_cast<decltype(a.Version)>(sym("hiprtcVersion"));
   if (!a.Create || !a.AddName || !a.Compile || !a.LogSize || !a.Log || !a.Lowered || !a.CodeSize || !a.Code || !a.Destroy) { err = "libhiprtc.so lacks the expected API"; a = HiprtcApi(); return IGX_ERR_LIB; }
   return 0;
 }
@@ -88,22 +90,34 @@ static unsigned long long rtc_fnv(const std::string &t, unsigned long long h = 1
   for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; }
   return h;
 }
+// the options every program is compiled with: also part of the cache key
+static const char *kRtcOpts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
+constexpr int kRtcNOpts = 4;
+// key of a program: its whole text, the name expressions, the options above, the HIP this library was built against AND the version
+// the loaded libhiprtc.so reports (it is bound at run time: another ROCm's compiler never finds this one's objects)
+static unsigned long long rtc_program_key(const std::string &src, const std::vector<std::string> &exprs, unsigned long long seed) {
+  std::string tool = "hip " + std::to_string(HIP_VERSION);
+  for (int i = 0; i < kRtcNOpts; ++i) { tool += ' '; tool += kRtcOpts[i]; }
+  { std::string e; int maj = 0, min = 0;
+    if (load_hiprtc(e) == 0 && hiprtc_api().Version && hiprtc_api().Version(&maj, &min) == 0) tool += " hiprtc " + std::to_string(maj) + "." + std::to_string(min);
+    else tool += " hiprtc ?"; }
+  unsigned long long h = rtc_fnv(src, rtc_fnv(tool, seed));
+  for (const std::string &x : exprs) h = rtc_fnv(x, h ^ 0x9e3779b97f4a7c15ull);
+  return h;
+}
 static std::string rtc_cache_path(const std::string &src, const std::vector<std::string> &exprs) {
   const char *dir = getenv("IGX_RTC_CACHE_DIR");
   if (!dir || !*dir) return std::string();
-  // the compiler is part of the key as well: target, options and the HIP runtime this library was built against (a code object of
-  // another ROCm release is never picked up)
-  unsigned long long h = rtc_fnv(src, rtc_fnv(std::string("gfx950 -O3 -std=c++17 -munsafe-fp-atomics hip ") + std::to_string(HIP_VERSION)));
-  for (const std::string &x : exprs) h = rtc_fnv(x, h ^ 0x9e3779b97f4a7c15ull);
-  char name[64]; snprintf(name, sizeof(name), "/igx_%016llx.bin", h);
+  char name[64]; snprintf(name, sizeof(name), "/igx_%016llx.bin", rtc_program_key(src, exprs, 1469598103934665603ull));
   return std::string(dir) + name;
 }
-static bool rtc_cache_load(const std::string &path, size_t nexpr, std::vector<char> &code, std::vector<std::string> &lowered) {
+static bool rtc_cache_load(const std::string &path, size_t nexpr, std::vector<char> &code, std::vector<std::string> &lowered, unsigned long long check) {
   FILE *f = path.empty() ? nullptr : fopen(path.c_str(), "rb");
   if (!f) return false;
   bool ok = false;
-  unsigned n = 0;
-  if (fread(&n, sizeof(n), 1, f) == 1 && n == nexpr) {
+  unsigned n = 0; unsigned long long stored = 0;
+  // (the file starts with a second hash of the program -- another seed than the one in its name: a stale or foreign file is refused)
+  if (fread(&stored, sizeof(stored), 1, f) == 1 && stored == check && fread(&n, sizeof(n), 1, f) == 1 && n == nexpr) {
     lowered.clear(); ok = true;
     for (unsigned i = 0; i < n && ok; ++i) {
       unsigned len = 0;
@@ -117,12 +131,12 @@ static bool rtc_cache_load(const std::string &path, size_t nexpr, std::vector<ch
   fclose(f);
   return ok;
 }
-static void rtc_cache_store(const std::string &path, const std::vector<char> &code, const std::vector<std::string> &lowered) {
+static void rtc_cache_store(const std::string &path, const std::vector<char> &code, const std::vector<std::string> &lowered, unsigned long long check) {
   if (path.empty()) return;
   const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
   FILE *f = fopen(tmp.c_str(), "wb");
   if (!f) return;
-  const unsigned n = (unsigned)lowered.size(); bool ok = fwrite(&n, sizeof(n), 1, f) == 1;
+  const unsigned n = (unsigned)lowered.size(); bool ok = fwrite(&check, sizeof(check), 1, f) == 1 && fwrite(&n, sizeof(n), 1, f) == 1;
   for (const std::string &t : lowered) { const unsigned len = (unsigned)t.size(); ok = ok && fwrite(&len, sizeof(len), 1, f) == 1 && (len == 0 || fwrite(t.data(), 1, len, f) == len); }
   const unsigned long long cs = code.size(); ok = ok && fwrite(&cs, sizeof(cs), 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
   ok = (fclose(f) == 0) && ok;
@@ -146,14 +160,14 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   src += "\n";
   src += tail;
   const std::string cache = rtc_cache_path(src, exprs);
-  if (rtc_cache_load(cache, exprs.size(), code, lowered)) return 0;
+  const unsigned long long check = cache.empty() ? 0ull : rtc_program_key(src, exprs, 0x84222325cbf29ce4ull);
+  if (rtc_cache_load(cache, exprs.size(), code, lowered, check)) return 0;
   std::string e; if (int rc = load_hiprtc(e)) return fail(rc, e);
   HiprtcApi &a = hiprtc_api();
   void *prog = nullptr;
   if (a.Create(&prog, src.c_str(), "igx_user_form.hip", 0, nullptr, nullptr) != 0) return fail(IGX_ERR_LIB, "hiprtcCreateProgram failed");
   for (const std::string &x : exprs) (void)a.AddName(prog, x.c_str());
-  const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics"};
-  const int rc = a.Compile(prog, 4, opts);
+  const int rc = a.Compile(prog, kRtcNOpts, kRtcOpts);
   if (rc != 0) {
     size_t n = 0; (void)a.LogSize(prog, &n); std::string log(n, '\0'); if (n) (void)a.Log(prog, &log[0]);
     (void)a.Destroy(&prog);
@@ -170,7 +184,7 @@ static int rtc_build(const std::string &source, bool with_feature, const std::st
   code.resize(cs);
   if (a.Code(prog, code.data()) != 0) { (void)a.Destroy(&prog); return fail(IGX_ERR_LIB, "hiprtcGetCode failed"); }
   (void)a.Destroy(&prog);
-  rtc_cache_store(cache, code, lowered);
+  rtc_cache_store(cache, code, lowered, check);
   return 0;
 }
 
@@ -563,14 +577,16 @@ static int launch_block_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   hipFunction_t fn = K->func[0];
   hipStream_t stream = g->stream;
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
+  int lrc = 0;
   const int rc = block_pencil_run(s, S, out, stream, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, F.meta[0], F.meta[12],
                                   [&](bool, unsigned grid, size_t lds, const BlockPencilArgs &pa) {
                                     RtcBlockArgs a; memset(&a, 0, sizeof(a));
                                     a.S = S; a.prm = prm; a.out = out; a.pa = pa;
                                     size_t asz = sizeof(a);
                                     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &a, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-                                    (void)hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg);
+                                    if (lds > (size_t)160 * 1024 || hipModuleLaunchKernel(fn, grid, 1, 1, 512, 1, 1, (unsigned)lds, stream, nullptr, cfg) != hipSuccess) lrc = IGX_ERR_LIB;
                                   });
+  if (rc == 0 && lrc) return fail(lrc, "block_pencil: launch of the run-time instantiation failed");
   if (rc == 0 && done) g->last_kernel = std::string("block_pencil<") + F.name + ">(hiprtc,mfma_f64_16x16x4,p=3,dof=" + char('0' + F.meta[0]) + ",band rows by node layer)";
   return rc;
 }
