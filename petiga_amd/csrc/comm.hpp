@@ -145,7 +145,7 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   g->slab_valid = false;
   HIPCK(hipEventRecord(c.ready, g->stream));
   c.last_bytes = 0; c.packed1_valid = false;
-  auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (p.off[2] == 1) == (phase == 1); };   // 0: everything; 1: o2 = 1; 2: o2 = 0
+  auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (p.off[2] >= 1) == (phase == 1); };   // 0: everything; 1: o2 >= 1; 2: o2 = 0
   auto pack = [&](int phase) -> int {
     for (size_t k = 0; k < out_plans.size(); ++k) {
       if (doubles(out_plans[k]) == 0 || !in_phase(out_plans[k], phase)) continue;

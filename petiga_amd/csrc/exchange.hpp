@@ -11,7 +11,7 @@
 
 struct NbrPlan {
   int rank;              // peer
-  int off[3];            // neighbour offset o in {0,1}^3
+  int off[3];            // neighbour offset: ranks above (send) / below (receive) on every axis; 0 or 1 unless ranks are thinner than p elements
   int start[3], count[3];  // local row-index box on this rank
   int64_t mat_doubles, vec_doubles;
 };
@@ -31,39 +31,45 @@ static void axis_ranges_of(const Space &s, int d, int c, int &lstart, int &lwidt
 
 static int rank_of(const Space &s, const int c[3]) { return c[0] + s.proc_sizes[0] * (c[1] + s.proc_sizes[1] * c[2]); }
 
-// build the send list (send=true: to upper neighbours) or the receive list (from lower neighbours)
+// build the send list (send=true: to upper neighbours) or the receive list (from lower neighbours).
+// Per axis the ghost layer of a rank (p node layers on a C^{p-1} axis) belongs to the ranks above it: to the next one alone when
+// that owns at least as many nodes, to several when ranks are thinner than p elements (src/petiga.c:1172-1208 makes no such
+// restriction: PETSc's stash routes every row to its true owner).  So an axis contributes pieces (k, start, count): k = 0 the owned
+// part, k >= 1 the part of the ghost layer that rank me + k owns (send) / the part of rank me - k's ghost layer that I own (receive);
+// a message per offset vector (k0, k1, k2) != 0.  Ranks are taken unwrapped on a periodic axis (rank C + np = rank C, its nodes
+// shifted by the period), so the formulas are the same with and without the wrap.
 static std::vector<NbrPlan> neighbour_plans(const Space &s, bool send) {
   std::vector<NbrPlan> out;
   if (!s.setup) return out;
-  for (int o = 1; o < 8; ++o) {
-    const int od[3] = {o & 1, (o >> 1) & 1, (o >> 2) & 1};
-    NbrPlan pl; bool ok = true; int pc[3];
-    for (int d = 0; d < 3 && ok; ++d) {
-      const int np = s.proc_sizes[d], me = s.proc_ranks[d];
-      if (d >= s.dim) { if (od[d]) ok = false; pc[d] = 0; pl.start[d] = 0; pl.count[d] = 1; continue; }
-      const bool per = s.axis[d].periodic != 0;
-      int peer = send ? me + od[d] : me - od[d];
-      if (od[d]) {
-        if (np == 1) { ok = false; break; }            // single rank on this axis: nothing to exchange (periodic wraps locally)
-        if (peer < 0 || peer >= np) { if (!per) { ok = false; break; } peer = (peer + np) % np; }
-      }
-      pc[d] = peer;
-      // sender's ranges on this axis
-      const int sc = send ? me : peer;
-      int ls, lw, gs, gw; axis_ranges_of(s, d, sc, ls, lw, gs, gw);
-      const int nghost = gw - lw;
-      if (od[d]) {
-        if (nghost <= 0) { ok = false; break; }
-        if (send) { pl.start[d] = lw; pl.count[d] = nghost; }         // my ghost part
-        else { pl.start[d] = 0; pl.count[d] = nghost; }               // my first owned nodes = the sender's ghosts
-      } else {
-        const int lwme = s.node_lwidth[d], gwme = s.node_gwidth[d];
-        pl.start[d] = 0; pl.count[d] = std::min(lwme, gwme);          // owned part (same on both sides)
-      }
+  struct Piece { int k, peer, start, count; };
+  std::vector<Piece> pieces[3];
+  for (int d = 0; d < 3; ++d) {
+    if (d >= s.dim) { pieces[d].push_back({0, 0, 0, 1}); continue; }
+    const int np = s.proc_sizes[d], me = s.proc_ranks[d];
+    const bool per = s.axis[d].periodic != 0;
+    const int period = s.axis[d].nnp;      // distinct nodes of the axis (a periodic axis: its basis functions wrap after this many)
+    pieces[d].push_back({0, me, 0, std::min(s.node_lwidth[d], s.node_gwidth[d])});      // owned part (same on both sides)
+    if (np == 1) continue;                 // single rank on this axis: nothing to exchange (periodic wraps locally)
+    auto mod = [&](int c) { return ((c % np) + np) % np; };
+    auto fdiv = [&](int c) { return (c - mod(c)) / np; };
+    auto unwrapped = [&](int C, int &LS, int &lw, int &gw) { int ls, gs; axis_ranges_of(s, d, mod(C), ls, lw, gs, gw); LS = ls + fdiv(C) * period; };
+    for (int k = 1; k < np; ++k) {
+      const int S = send ? me : me - k, R = send ? me + k : me;      // sender and owner, unwrapped
+      if (!per && (S < 0 || R >= np)) break;
+      int LSs, lws, gws, LSr, lwr, gwr;
+      unwrapped(S, LSs, lws, gws); unwrapped(R, LSr, lwr, gwr);
+      const int a = std::max(LSs + lws, LSr), b = std::min(LSs + gws, LSr + lwr);      // sender's ghost nodes that the owner owns
+      if (LSr >= LSs + gws) break;           // beyond the ghost layer: no further rank holds any of it
+      if (b <= a) continue;
+      pieces[d].push_back({k, mod(send ? R : S), a - (send ? LSs : LSr), b - a});
     }
-    if (!ok) continue;
-    pl.rank = rank_of(s, pc);
-    for (int d = 0; d < 3; ++d) pl.off[d] = od[d];
+  }
+  for (const Piece &p2 : pieces[2]) for (const Piece &p1 : pieces[1]) for (const Piece &p0 : pieces[0]) {
+    if (p0.k == 0 && p1.k == 0 && p2.k == 0) continue;
+    const Piece *pc[3] = {&p0, &p1, &p2};
+    NbrPlan pl; int coords[3];
+    for (int d = 0; d < 3; ++d) { pl.off[d] = pc[d]->k; pl.start[d] = pc[d]->start; pl.count[d] = pc[d]->count; coords[d] = pc[d]->peer; }
+    pl.rank = rank_of(s, coords);
     int64_t t[3];
     for (int d = 0; d < 3; ++d) { t[d] = 0; for (int k = 0; k < pl.count[d]; ++k) t[d] += s.lay[d].rcnt[pl.start[d] + k]; }
     pl.mat_doubles = t[0] * t[1] * t[2] * s.dof * s.dof;

@@ -324,10 +324,13 @@ void stencil(const Axis &ax, int i, int *first, int *last) {
 // least as many nodes as its lower neighbour has ghosts (fewer than p elements per rank breaks it: the reference's PETSc
 // stash would route such rows two ranks up).  Refused by the exchange entry points rather than summed into the wrong rows.
 int exchange_supported(const Space &s, std::string &err) {
+  // Ghost rows go to their true owners however thin the ranks are (exchange.hpp: one message per rank the ghost layer reaches).
+  // What cannot be served: a periodic axis whose ghost layer reaches around to the sender itself (fewer nodes on the other
+  // ranks together than one ghost layer).
   for (int i = 0; i < s.dim; ++i) {
     const Axis &ax = s.axis[i];
     const int np = s.proc_sizes[i], nel = s.elem_sizes[i], p = ax.p;
-    if (np == 1) continue;
+    if (np == 1 || !ax.periodic) continue;
     auto ranges = [&](int c, int &lw, int &gw) {   // node ranges of the rank with coordinate c on this axis (space_setup)
       const int q = nel / np, r = nel % np, ew = q + (r > c ? 1 : 0), es = c * q + std::min(c, r), el = es + ew - 1;
       const int lstart = ax.span[es] - p, gend = ax.span[el] + 1;
@@ -335,10 +338,11 @@ int exchange_supported(const Space &s, std::string &err) {
       lw = (c == np - 1) ? ax.nnp - lstart : lend - lstart; gw = gend - lstart;
     };
     for (int c = 0; c < np; ++c) {
-      if (c == np - 1 && !ax.periodic) continue;
-      int lw, gw, lwn, gwn; ranges(c, lw, gw); ranges((c + 1) % np, lwn, gwn);
-      if (gw - lw > lwn) {
-        err = "axis " + std::to_string(i) + ": a rank owns fewer nodes than its neighbour's ghost layer (fewer than p elements per rank); use fewer processors on this axis";
+      int lw, gw; ranges(c, lw, gw);
+      int others = 0;
+      for (int k = 1; k < np; ++k) { int lwn, gwn; ranges((c + k) % np, lwn, gwn); others += lwn; }
+      if (gw - lw > others) {
+        err = "axis " + std::to_string(i) + ": the ghost layer of a rank reaches around the periodic axis to the rank itself; use fewer processors on this axis";
         return IGX_ERR_SUP;
       }
     }

@@ -119,7 +119,7 @@ struct Space {
 
 int  space_setup(Space &s, std::string &err);          // IGASetUp stages 1+3 (src/petiga.c:1111-1310,1450-1493)
 int  space_layout(Space &s, std::string &err);         // AxisLayout for the three axes
-int  exchange_supported(const Space &s, std::string &err);   // 0, or IGX_ERR_SUP when ghost rows would need a two-rank hop
+int  exchange_supported(const Space &s, std::string &err);   // 0, or IGX_ERR_SUP when a periodic ghost layer would wrap onto its own rank
 
 #endif   // !IGX_RTC
 

@@ -407,7 +407,10 @@ def _rank_matrix_rows(eng, A, b):
                                                              (4, 3, 3, 2, (6, 7, 5), (0, 0, 0), "elasticity+nurbs"), (8, 3, 1, 3, (7, 8, 9), (0, 0, 0), "poisson+nurbs"),
                                                              (3, 2, 1, 3, (11, 4), (0, 0), "poisson+nurbs"),
                                                              # axis 0 long enough for the pencil kernel's mapped-geometry variant on every rank
-                                                             (2, 3, 1, 3, (9, 4, 8), (0, 0, 0), "poisson+nurbs"), (4, 3, 1, 2, (10, 6, 8), (0, 0, 0), "poisson+nurbs")])
+                                                             (2, 3, 1, 3, (9, 4, 8), (0, 0, 0), "poisson+nurbs"), (4, 3, 1, 2, (10, 6, 8), (0, 0, 0), "poisson+nurbs"),
+                                                             # ranks thinner than p elements: a ghost layer reaches two (three) ranks up
+                                                             (5, 1, 1, 3, (10,), (0,), "poisson"), (6, 2, 1, 3, (6, 8), (0, 0), "poisson"), (7, 1, 2, 3, (7,), (0,), "mass"),
+                                                             (27, 3, 1, 2, (3, 4, 3), (0, 0, 0), "poisson"), (12, 3, 1, 3, (4, 6, 5), (0, 0, 0), "poisson+nurbs")])
 def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     """Every rank assembles its own element box, ghost rows are packed / added through the C ABI exactly as
     petiga_amd/exchange.py does between processes; the owned rows of all ranks together must be the
@@ -638,7 +641,8 @@ def test_pencil_first_touch_needs_no_zeroing(p, N, size):
         assert np.abs(A2.host(True) - ref).max() <= TOL * np.abs(ref).max()
 
 
-@pytest.mark.parametrize("size,form,N,periodic", [(4, "ch", (6, 7, 8), (0, 0, 0)), (8, "ch", (8, 8, 8), (0, 0, 0)), (2, "ns", (9, 3, 8), (1, 0, 1)), (4, "ns", (9, 4, 8), (1, 0, 1))])
+@pytest.mark.parametrize("size,form,N,periodic", [(4, "ch", (6, 7, 8), (0, 0, 0)), (8, "ch", (8, 8, 8), (0, 0, 0)), (2, "ns", (9, 3, 8), (1, 0, 1)), (4, "ns", (9, 4, 8), (1, 0, 1)),
+                                                  (27, "ch", (3, 4, 3), (0, 0, 0))])      # one element of degree 2 per rank and axis: ghost values come from two ranks up
 def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic):
     """Nonlinear drivers on a partition (configs 4 and 5 are multi-GPU): every rank knows the state only on the nodes
     it owns, the owner -> ghost refresh (IGXPackOwnerValues / IGXUnpackGhostValues, the reverse of the ghost-row
