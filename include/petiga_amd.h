@@ -386,6 +386,9 @@ int IGXCheckFormSource(IGX iga,int with_matrix,int gram);
  * last launch finished (positive: they travelled under the remaining launches).  PETSC_ERR_ARG_WRONGSTATE when the last
  * reduction did not start early (one rank on axis 2, IGX_OVERLAP=0, another kernel path). */
 int IGXCommGetOverlap(IGX iga,double *ms);
+/* ... and how many of the three phases of that reduction (upper faces of axes 2, 1, 0) were packed behind a face mark of the
+ * assembly instead of its last launch: the pencil walk of a rank with upper neighbours on three axes marks all three. */
+int IGXCommGetEarlyPhases(IGX iga,int *n);
 
 /* Shader clock under load.  With IGX_CLOCK_PROBE=1 in the environment at IGXCreate, the first and the last workgroup of every
  * pencil-kernel launch add their s_memtime ticks and the ticks of the constant 100 MHz s_memrealtime counter over their walk to

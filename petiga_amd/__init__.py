@@ -101,7 +101,7 @@ def lib(build_if_needed=False):
         "IGXVecGetGhostedSize": [V, C.POINTER(C.c_int64)], "IGXVecCopyFromGhosted": [V, V, C.c_int], "IGXVecCopyToGhosted": [V, V, C.c_int],
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
         "IGXCommDestroy": [V], "IGXReduceGhostRows": [V, V, V], "IGXRefreshGhosts": [V, V], "IGXCommGetLastBytes": [V, C.POINTER(C.c_int64)],
-        "IGXCommLoopbackTest": [V, C.c_int64, _dp], "IGXCommGetRanks": [V, C.POINTER(C.c_int), C.POINTER(C.c_int)],
+        "IGXCommLoopbackTest": [V, C.c_int64, _dp], "IGXCommGetRanks": [V, C.POINTER(C.c_int), C.POINTER(C.c_int)], "IGXCommGetEarlyPhases": [V, C.POINTER(C.c_int)],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     for name, args in sig.items():
@@ -469,6 +469,12 @@ class IGX:
         ms = C.c_double(0)
         _ck(lib().IGXCommGetOverlap(self.h, C.byref(ms)))
         return ms.value
+
+    def comm_early_phases(self):
+        """phases (upper faces of axes 2, 1, 0) of the last reduce_ghost_rows that were packed behind a face mark of the assembly"""
+        n = C.c_int(0)
+        _ck(lib().IGXCommGetEarlyPhases(self.h, C.byref(n)))
+        return n.value
 
     def clock_probe(self):
         """(shader MHz, elements walked) over the probe workgroups of the pencil-kernel launches since the last call; needs IGX_CLOCK_PROBE=1 at creation."""

@@ -68,6 +68,7 @@ struct IgxComm {
   hipEvent_t packed1 = nullptr; bool packed1_valid = false;   // exchange stream, after the first phase's messages were packed (IGXCommGetOverlap)
   std::vector<DevBuf> sbuf, rbuf;     // one per neighbour of the larger of the two lists
   int64_t last_bytes = 0;
+  int early_phases = 0;               // phases of the last reduction that started on a face mark of the assembly (IGXCommGetEarlyPhases)
   ~IgxComm() {
     if (xs) (void)hipStreamSynchronize(xs);      // nothing of this communicator is in flight when it goes
     if (nccl && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(nccl);
@@ -136,16 +137,17 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   // marked the moment the rows of that face were complete (slab_ev, engine.hip) starts the first group there, under its
   // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
   // receiver's own launches store into, so it waits for the end of the assembly either way.
-  const bool phased = reduce && g->s.proc_sizes[2] > 1 && g->s.env.overlap;   // (the environment is the same on every rank)
-  // What the marked assembly wrote is face-complete at its mark, and a matrix / vector an EARLIER call wrote was complete before
-  // it (one engine stream).  The mark is only good while it is the last write: every entry point that writes to an IGXMat /
+  const bool phased = reduce && g->s.env.overlap;   // (the environment is the same on every rank)
+  // What the marked assembly wrote is face-complete at its marks, and a matrix / vector an EARLIER call wrote was complete before
+  // them (one engine stream).  A mark is only good while it is the last write: every entry point that writes to an IGXMat /
   // IGXVec afterwards clears it (IGXCompute*, IGXVecCopyFromHost, IGXVecCopyFromGhosted, IGXReadVec, IGXUnpackGhost*, every
   // exchange), and the reduction then packs where the engine stream stands.
-  const bool early = phased && g->slab_valid;
-  g->slab_valid = false;
+  const int marks = phased ? g->slab_valid : 0;      // bit 0: upper face of axis 2, bit 1: axis 1, bit 2: axis 0 (engine.hip)
+  g->slab_valid = 0;
   HIPCK(hipEventRecord(c.ready, g->stream));
-  c.last_bytes = 0; c.packed1_valid = false;
-  auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (p.off[2] >= 1) == (phase == 1); };   // 0: everything; 1: o2 >= 1; 2: o2 = 0
+  c.last_bytes = 0; c.packed1_valid = false; c.early_phases = 0;
+  // phase 1: the messages with o2 >= 1; phase 2: o2 = 0 and o1 >= 1; phase 3: o2 = o1 = 0 (o0 >= 1); phase 0: everything
+  auto in_phase = [&](const NbrPlan &p, int phase) { return phase == 0 || (phase == 1 ? p.off[2] >= 1 : (phase == 2 ? (p.off[2] == 0 && p.off[1] >= 1) : (p.off[2] == 0 && p.off[1] == 0))); };
   auto pack = [&](int phase) -> int {
     for (size_t k = 0; k < out_plans.size(); ++k) {
       if (doubles(out_plans[k]) == 0 || !in_phase(out_plans[k], phase)) continue;
@@ -156,6 +158,10 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   };
   auto move = [&](int phase) -> int {      // the messages of a phase: one RCCL group, or one call of the host transport
     if (c.kind == 1) {
+      bool any = false;
+      for (size_t k = 0; k < in_plans.size() && !any; ++k) any = doubles(in_plans[k]) && in_phase(in_plans[k], phase);
+      for (size_t k = 0; k < out_plans.size() && !any; ++k) any = doubles(out_plans[k]) && in_phase(out_plans[k], phase);
+      if (!any) return 0;
       NCCLCK(rccl_api().GroupStart());
       int rc_ = 0;      // (an error inside the group still closes it: RCCL must not be left with an open group)
       for (size_t k = 0; k < in_plans.size() && !rc_; ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) rc_ = rccl_api().Recv(c.rbuf[k].p, (size_t)doubles(in_plans[k]), kNcclDouble, in_plans[k].rank, c.nccl, c.xs);
@@ -168,27 +174,30 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
     std::vector<int> sp, rp; std::vector<double *> sb, rb; std::vector<int64_t> sn, rn;
     for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) { sp.push_back(out_plans[k].rank); sb.push_back(c.sbuf[k].as<double>()); sn.push_back(doubles(out_plans[k])); }
     for (size_t k = 0; k < in_plans.size(); ++k) if (doubles(in_plans[k]) && in_phase(in_plans[k], phase)) { rp.push_back(in_plans[k].rank); rb.push_back(c.rbuf[k].as<double>()); rn.push_back(doubles(in_plans[k])); }
-    HIPCK(hipStreamSynchronize(c.xs));      // a host transport reads the packed buffers (the engine stream keeps running)
     if (sp.empty() && rp.empty()) return 0;
+    HIPCK(hipStreamSynchronize(c.xs));      // a host transport reads the packed buffers (the engine stream keeps running)
     if (int rc = c.fn(c.fnctx, (int)sp.size(), sp.data(), sb.data(), sn.data(), (int)rp.size(), rp.data(), rb.data(), rn.data())) return fail(IGX_ERR_LIB, "transport callback failed with code " + std::to_string(rc));
     return 0;
   };
   // What the exchange stream waits for.  Only a PACK reads what the engine stream writes; a receive lands in a buffer of the
   // exchange itself.  So a phase in which this rank sends nothing is issued at once -- its receives are posted while the rank
   // still assembles, and the sender's early face message moves under the receiver's remaining launches (in a non-periodic
-  // [1,1,2] / [2,2,2] grid the receiver of the axis-2 face is exactly the rank without an upper neighbour there).  A phase with
-  // sends waits for what it packs: the face mark (phase 1 of a marked assembly) or the assembly's last launch.  Sends and
+  // [1,1,2] / [2,2,2] grid the receiver of a face is exactly the rank without an upper neighbour there).  A phase with
+  // sends waits for what it packs: the face mark of its axis (a marked assembly) or the assembly's last launch.  Sends and
   // receives of a phase stay in ONE group: split into two groups on one stream, two ranks that both receive first would wait
-  // for each other's sends for ever.  The unpack adds into rows the rank's own launches store into: it always waits for c.ready.
+  // for each other's sends for ever.  Every rank issues the phases in the same order.  The unpack adds into rows the rank's own
+  // launches store into: it always waits for c.ready.
   auto sends_in = [&](int phase) { for (size_t k = 0; k < out_plans.size(); ++k) if (doubles(out_plans[k]) && in_phase(out_plans[k], phase)) return true; return false; };
   if (phased) {
-    if (sends_in(1)) HIPCK(hipStreamWaitEvent(c.xs, early ? g->slab_ev : c.ready, 0));
-    if (int rc = pack(1)) return rc;
-    c.packed1_valid = early && sends_in(1) && hipEventRecord(c.packed1, c.xs) == hipSuccess;
-    if (int rc = move(1)) return rc;
-    if (sends_in(2)) HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));      // the assembly's last launch
-    if (int rc = pack(2)) return rc;
-    if (int rc = move(2)) return rc;
+    for (int phase = 1; phase <= 3; ++phase) {
+      const int bit = phase == 1 ? 1 : (phase == 2 ? 2 : 4);
+      hipEvent_t mark = phase == 1 ? g->slab_ev : g->face_ev[phase == 2 ? 1 : 0];
+      const bool early = (marks & bit) != 0 && mark != nullptr;
+      if (sends_in(phase)) { HIPCK(hipStreamWaitEvent(c.xs, early ? mark : c.ready, 0)); if (early) c.early_phases++; }
+      if (int rc = pack(phase)) return rc;
+      if (phase == 1) c.packed1_valid = early && sends_in(1) && hipEventRecord(c.packed1, c.xs) == hipSuccess;
+      if (int rc = move(phase)) return rc;
+    }
   } else {
     // the exchange stream picks up where the engine stream stands (the assembly's last launch)
     if (sends_in(0)) HIPCK(hipStreamWaitEvent(c.xs, c.ready, 0));
@@ -240,6 +249,8 @@ extern "C" int IGXCommGetRanks(IGX g, int *kind, int *ranks) {
   }
   return 0;
 }
+// how many phases of the last IGXReduceGhostRows were packed behind a face mark of the assembly instead of its last launch (0..3)
+extern "C" int IGXCommGetEarlyPhases(IGX g, int *n) { NEEDIGA(g); if (!n) return fail(IGX_ERR_ARG_WRONG, "null result"); *n = g->comm ? g->comm->early_phases : 0; return 0; }
 extern "C" int IGXCommGetLastBytes(IGX g, int64_t *bytes) { NEEDIGA(g); if (bytes) *bytes = g->comm ? g->comm->last_bytes : 0; return 0; }
 
 // RCCL on one rank: n doubles travel to this rank itself through a grouped ncclSend / ncclRecv on the exchange stream

@@ -81,7 +81,10 @@ struct _p_IGX {
   std::shared_ptr<IgxComm> comm;   // transport of the ghost-row exchange (comm.hpp)
   // recorded on the engine stream when the elements next to the upper face of axis 2 have been assembled (pencil kernel, several
   // ranks): IGXReduceGhostRows starts the messages of that face behind it, under the launches of the other elements
-  hipEvent_t slab_ev = nullptr; bool slab_valid = false; IGXMat slab_A = nullptr; IGXVec slab_b = nullptr;
+  // slab_valid: bit 0 = the mark of axis 2 (slab_ev), bit 1 = axis 1, bit 2 = axis 0 (face_ev[1], face_ev[0]: the pencil walk's three passes)
+  hipEvent_t slab_ev = nullptr; int slab_valid = 0; IGXMat slab_A = nullptr; IGXVec slab_b = nullptr;
+  hipEvent_t face_ev[2] = {nullptr, nullptr};
+  std::function<void(int)> face_done;  // marks "upper face of axis 1 / 0 assembled" (gram_mfma.hpp)
   std::shared_ptr<RtcForm> rtc; std::string rtc_source, rtc_name;   // run-time compiled user form (rtc.hpp)
   std::shared_ptr<RtcForm> rtc_scalar;                              // ... and the last user functional (IGXComputeScalarSource)
 };
@@ -105,6 +108,7 @@ extern "C" int IGXDestroy(IGX *iga) {
   (*iga)->comm.reset();       // (synchronises its exchange stream first)
   for (auto &e : (*iga)->ev) if (e) (void)hipEventDestroy(e);
   if ((*iga)->slab_ev) (void)hipEventDestroy((*iga)->slab_ev);
+  for (int k = 0; k < 2; ++k) if ((*iga)->face_ev[k]) (void)hipEventDestroy((*iga)->face_ev[k]);
   delete *iga; *iga = nullptr; return 0;
 }
 #define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
@@ -1060,11 +1064,20 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
   g->dom = DomInfo(); g->dom.ev0 = g->timing ? g->ev[4] : nullptr; g->dom.ev1 = g->timing ? g->ev[5] : nullptr;
   if (g->kernel_choice != 1 && g->kernel_choice != 3 && s.form != IGX_FORM_SOURCE) {   // (a run-time form reaches the pencil walk through rtc.hpp)
     std::function<void()> slab_done;
-    g->slab_valid = false;
-    if (g->comm && s.env.overlap) slab_done = [&]() {
-      if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
-      if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid = true; g->slab_A = A; g->slab_b = b; }
-    };
+    std::function<void(int)> face_done;
+    g->slab_valid = 0;
+    if (g->comm && s.env.overlap) {
+      slab_done = [&]() {
+        if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid |= 1; g->slab_A = A; g->slab_b = b; }
+      };
+      if (s.env.overlap != 2) face_done = [&](int axis) {      // (IGX_OVERLAP=2: the mark of axis 2 alone, as in round 3)
+        if (axis < 0 || axis > 1) return;
+        if (!g->face_ev[axis] && hipEventCreateWithFlags(&g->face_ev[axis], hipEventDisableTiming) != hipSuccess) return;
+        if (hipEventRecord(g->face_ev[axis], g->stream) == hipSuccess) { g->slab_valid |= (axis == 1 ? 2 : 4); g->slab_A = A; g->slab_b = b; }
+      };
+    }
+    g->face_done = face_done;
     // the Tangent of a nonlinear scalar form without a geometry walks the same pencils (gram_mfma.hpp: state_pencil)
     PencilModule st; memset(&st.prm, 0, sizeof(st.prm));
     if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 0 && s.env.state_pencil && (g->kernel_choice == 0 || g->kernel_choice == 2)) {
@@ -1079,18 +1092,24 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       }
       if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes(); for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
     }
-    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done, st.kfn ? &st : nullptr);
+    rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done, st.kfn ? &st : nullptr, face_done);
+    g->face_done = nullptr;
     if (rc) return rc;
   }
   if (!done) {
     g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
-    g->slab_valid = false;
+    g->slab_valid = 0;
     if (g->comm && s.env.overlap) g->slab_done = [&]() {
       if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
-      if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid = true; g->slab_A = A; g->slab_b = b; }
+      if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid |= 1; g->slab_A = A; g->slab_b = b; }
+    };
+    if (g->comm && s.env.overlap) g->face_done = [&](int axis) {      // (run-time forms on the pencil walk: rtc.hpp)
+      if (axis < 0 || axis > 1) return;
+      if (!g->face_ev[axis] && hipEventCreateWithFlags(&g->face_ev[axis], hipEventDisableTiming) != hipSuccess) return;
+      if (hipEventRecord(g->face_ev[axis], g->stream) == hipSuccess) { g->slab_valid |= (axis == 1 ? 2 : 4); g->slab_A = A; g->slab_b = b; }
     };
     rc = (s.form == IGX_FORM_SOURCE) ? launch_generic_rtc(g, S, out) : dispatch_by_dim(g, S, out);
-    g->zero_matrix = nullptr; g->slab_done = nullptr;
+    g->zero_matrix = nullptr; g->slab_done = nullptr; g->face_done = nullptr;
     if (rc) return rc;
   }
   if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }

@@ -251,7 +251,10 @@ struct PencilArgs {
                            // nobody owns rows beyond its own elements: each band row is still written exactly once per pencil
   int first_touch;         // 1: the matrix was NOT zeroed; the first colour that reaches an entry stores it (walk axis 0 only)
   int nelx, nely;          // local element counts on the two non-walked axes (for the first-touch rule)
-  int fty_lo, fty_hi, fty_blocked;   // first-touch rule on the Y axis when the launches of an assembly come in two passes (see launch_pencils)
+  int fty_lo, fty_hi, fty_blocked;   // first-touch rule on the Y axis when the launches of an assembly come in several passes (see launch_pencils)
+  int ftx_lo, ftx_hi, ftx_blocked;   // ... and on the X axis
+  int w_halo_lo;           // lowest element a segment may re-compute as halo (= w_lo unless the walked range is the upper part of the axis: a face pass)
+  int open_hi;             // 1: elements beyond w_hi exist and belong to another pass: the last segment owns no rows past its elements
   int free_run;            // 1: no s_barrier ping-pong between the two wave groups: the SIMD's own arbitration interleaves MFMA and flush phases (IGX_FREE_RUN; default: p = 2 on the identity geometry)
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
   long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
@@ -1143,7 +1146,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   static_assert(ALIAS <= 0 || W == 0, "only the axis-0 walk wraps");
   const bool alias0 = ALIAS >= 0 ? ALIAS == 1 : (W == 0 && pa.alias0 != 0);
   const int nelw = pa.w_hi - pa.w_lo;                        // (alias0: the whole axis, w_lo = 0)
-  const int wh = alias0 ? ws - P : max(ws - P, pa.w_lo);     // first element walked (alias0: may be negative = from the end of the axis)
+  const int wh = alias0 ? ws - P : max(ws - P, pa.w_halo_lo);   // first element walked (alias0: may be negative = from the end of the axis)
   const int ne = we - wh, nl = ne + P;
   const AxisDev &AW = S.ax[W], &AX = S.ax[X], &AY = S.ax[Y];
   auto ew = [&](int ei) -> int { int e = wh + ei; if (alias0) { e %= nelw; if (e < 0) e += nelw; } return e; };   // element of walk step ei
@@ -1177,8 +1180,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int pc = valid ? pencil : 0;
   const int tx = pc % pa.ex_count, ty = pc / pa.ex_count;
   const int elx = pa.ex_start + tx * pa.ex_step, ely = pa.ey_start + ty * pa.ey_step;
-  int own_lo = (seg == 0) ? -1 : AW.off[ws];
-  int own_hi = (seg == pa.nseg - 1) ? (1 << 30) : AW.off[we];
+  int own_lo = (seg == 0 && pa.w_halo_lo == pa.w_lo) ? -1 : AW.off[ws];
+  int own_hi = (seg == pa.nseg - 1 && !pa.open_hi) ? (1 << 30) : AW.off[we];
   if (alias0) { own_lo = AW.off[0] + ws; own_hi = AW.off[0] + we; }
   if ((kDebug && pa.debug_noflush == 1) || !valid) { own_lo = 1 << 30; own_hi = 1 << 30; }
   const int offx = AX.off[elx], offy = AY.off[ely];
@@ -1238,7 +1241,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     L.fslot = lane >> 4;
     L.stmask = 0;
     if (W == 0 && pa.first_touch) {
-      const bool fx1 = first_touch_axis<P>(elx, a < NB ? a : 0, b1 < NB ? b1 : 0, pa.nelx);
+      const bool fx1 = first_touch_axis<P>(elx, a < NB ? a : 0, b1 < NB ? b1 : 0, pa.nelx, pa.ftx_lo, pa.ftx_hi, pa.ftx_blocked);
 #pragma unroll
       for (int r = 0; r < NB; ++r) if (fx1 && first_touch_axis<P>(ely, r, b2 < NB ? b2 : 0, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) L.stmask |= 1u << r;
     }
@@ -1381,7 +1384,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     atomicAdd(reinterpret_cast<unsigned long long *>(out.clk) + 2, (unsigned long long)ne);
   }
   if (grp == 0 && pingpong) __builtin_amdgcn_s_barrier();
-  if (seg == pa.nseg - 1 && !alias0)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
+  if (seg == pa.nseg - 1 && !alias0 && !pa.open_hi)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
         pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
@@ -1433,6 +1436,9 @@ static void launch_elements(const Space &s, const SpaceDev &S, const OutDev &out
 // a run-time form's instantiation of the walk (rtc.hpp): the module function for this driver / degree / geometry, its parameters
 // ... or a compiled-in instantiation for a built-in form (state_pencil: kfn, its extra LDS, flops per element for the roofline line)
 typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
+// one pass of an assembly that comes in several (the elements next to the upper faces first, a mark for the exchange after each):
+// the first-touch rule of axis X (like fty for axis Y), and, when the pass is a part of the walk axis, how its ends join the others
+struct PencilPass { int ftx[3] = {0, 0x7fffffff, 0x7fffffff}; int halo_lo = -1; bool open_hi = false; };
 struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0; };
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
@@ -1444,7 +1450,7 @@ template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FI
 // fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
 // (first_touch_axis); null: one pass over the whole axis
 static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, const Box &bx, double forcing, int &launches, bool first_touch = false, const int *fty = nullptr,
-                           const PencilModule *mod = nullptr) {
+                           const PencilModule *mod = nullptr, const PencilPass *pass = nullptr) {
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return;
   const int nw = bx.hi[W] - bx.lo[W];
@@ -1453,6 +1459,8 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.first_touch = (W == 0 && first_touch) ? 1 : 0; pa.nelx = s.elem_width[X]; pa.nely = s.elem_width[Y];
     pa.alias0 = (W == 0 && s.lay[0].alias) ? 1 : 0;
     pa.fty_lo = fty ? fty[0] : 0; pa.fty_hi = fty ? fty[1] : 0x7fffffff; pa.fty_blocked = fty ? fty[2] : 0x7fffffff;
+    pa.ftx_lo = pass ? pass->ftx[0] : 0; pa.ftx_hi = pass ? pass->ftx[1] : 0x7fffffff; pa.ftx_blocked = pass ? pass->ftx[2] : 0x7fffffff;
+    pa.w_halo_lo = (pass && pass->halo_lo >= 0) ? pass->halo_lo : bx.lo[W]; pa.open_hi = (pass && pass->open_hi) ? 1 : 0;
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
@@ -1471,7 +1479,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
         // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
         if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
         const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
-        const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || (W == 0 && s.lay[0].alias)) ? P : 0));
+        const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W])) ? P : 0));
         if (best < 0 || cost < best) { best = cost; best_n = n; }
       }
       nseg = best_n;
@@ -1687,7 +1695,8 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
 // 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
                          std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix,
-                         const std::function<void()> &slab_done = std::function<void()>(), const PencilModule *mod = nullptr) {
+                         const std::function<void()> &slab_done = std::function<void()>(), const PencilModule *mod = nullptr,
+                         const std::function<void(int)> &face_done = std::function<void(int)>()) {
   done = false;
   auto no = [&](const char *why) { if (forced) { err = std::string("MFMA kernel does not cover this configuration: ") + why; return (int)IGX_ERR_SUP; } return 0; };
   if (!mod && s.form != IGX_FORM_POISSON && s.form != IGX_FORM_POISSON_F) return no("form is not a scalar gradient-Gram form");
@@ -1742,50 +1751,64 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     }
     const int l0 = launches;
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
-    auto run = [&](const Box &P, const int *fty) {
+    auto run = [&](const Box &P, const int *fty, const PencilPass *pp = nullptr) {
     if (geo && fixt) {
       switch ((deg == 2 ? 0 : 2) + (s.rational ? 1 : 0)) {
-      case 0: launch_pencils<true, 0, 2, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 1: launch_pencils<true, 0, 2, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      case 2: launch_pencils<true, 0, 3, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-      default: launch_pencils<true, 0, 3, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+      case 0: launch_pencils<true, 0, 2, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
+      case 1: launch_pencils<true, 0, 2, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
+      case 2: launch_pencils<true, 0, 3, true, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
+      default: launch_pencils<true, 0, 3, true, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
       }
     } else if (geo || mod) {   // metric tensor per Gauss point from the wavefront's own geometry evaluation (a run-time form: its own coefficients)
       const int v = (deg == 2 ? 0 : 4) + (sys ? 2 : 0) + (s.rational ? 1 : 0);
       switch (v) {
-      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
-      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod); break;
+      case 0: launch_pencils<false, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 1: launch_pencils<false, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 2: launch_pencils<true, 0, 2, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 3: launch_pencils<true, 0, 2, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 4: launch_pencils<false, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 5: launch_pencils<false, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      case 6: launch_pencils<true, 0, 3, true, false>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
+      default: launch_pencils<true, 0, 3, true, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, mod, pp); break;
       }
     } else if (fixt) {
-      if (deg == 2) launch_pencils<true, 0, 2, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
-      else launch_pencils<true, 0, 3, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
+      if (deg == 2) launch_pencils<true, 0, 2, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp);
+      else launch_pencils<true, 0, 3, false, false, true>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp);
     } else if (deg == 2) {
-      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty);
+      if (sys) launch_pencils<true, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); else launch_pencils<false, 0, 2>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp);
     } else switch (walk_axis * 2 + (sys ? 1 : 0)) {
-    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
-    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty); break;
+    case 0: launch_pencils<false, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
+    case 1: launch_pencils<true, 0, 3>(s, S, out, stream, P, ga.forcing, launches, first_touch, fty, nullptr, pp); break;
     case 2: launch_pencils<false, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 3: launch_pencils<true, 1, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     case 4: launch_pencils<false, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     default: launch_pencils<true, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     }
     };
-    // Upper face of axis 2 first (multi-rank, axis-0 walk): the elements within p layers of that face in every colour, then a
-    // mark for the exchange (slab_done), then the rest.  The ghost rows of the face get nothing from the second pass.
-    const int n2 = s.elem_width[2];
-    const bool upper2 = s.proc_sizes[2] > 1 && (s.proc_ranks[2] < s.proc_sizes[2] - 1 || s.axis[2].periodic);
-    if (slab_done && walk_axis == 0 && upper2 && n2 >= 2 * (deg + 1) && P.lo[2] == 0 && P.hi[2] == n2) {
-      Box top = P, rest = P; top.lo[2] = n2 - deg; rest.hi[2] = n2 - deg;
-      const int ft_top[3] = {n2 - deg, n2, 0x7fffffff}, ft_rest[3] = {0, n2 - deg, n2 - deg};
-      run(top, ft_top);
-      slab_done();
-      run(rest, ft_rest);
+    // Upper faces first (multi-rank, axis-0 walk): the elements within p layers of the upper face of axis 2 in every colour, a mark
+    // for the exchange (slab_done); of what is left, the elements next to the upper face of axis 1, a mark (face_done(1)); then the
+    // last p elements of every remaining pencil -- the upper face of axis 0: a segment of its own that re-computes p halo elements
+    // and owns the rows from its first layer on -- and a mark (face_done(0)); then the rest, whose last segment owns no row past
+    // its elements.  The ghost rows of a face get nothing from the passes after its mark: its messages travel under them (comm.hpp).
+    // First touch makes the launch order part of the result: per pass the rule applies to the elements of that pass alone, and an
+    // entry an earlier pass reaches as well is only added to (fty / ftx: {lo, hi, blocked}).
+    const int n0 = s.elem_width[0], n1 = s.elem_width[1], n2 = s.elem_width[2];
+    auto upper = [&](int d) { return s.proc_sizes[d] > 1 && (s.proc_ranks[d] < s.proc_sizes[d] - 1 || s.axis[d].periodic); };
+    const bool whole = walk_axis == 0 && P.lo[0] == 0 && P.hi[0] == n0 && P.lo[1] == 0 && P.hi[1] == n1 && P.lo[2] == 0 && P.hi[2] == n2;
+    const bool can2 = slab_done && whole && upper(2) && n2 >= 2 * (deg + 1);
+    const bool can1 = face_done && whole && upper(1) && n1 >= 2 * (deg + 1) && !s.lay[1].alias;
+    const bool can0 = face_done && whole && upper(0) && n0 - deg >= 8 && !s.lay[0].alias;
+    if (can2 || can1 || can0) {
+      Box R = P;
+      auto pass_of = [&](const Box &b, bool face0, bool rest0, int *fty, PencilPass &pp) {
+        fty[0] = b.lo[2]; fty[1] = b.hi[2]; fty[2] = (can2 && b.hi[2] <= n2 - deg) ? n2 - deg : 0x7fffffff;
+        pp.ftx[0] = b.lo[1]; pp.ftx[1] = b.hi[1]; pp.ftx[2] = (can1 && b.hi[1] <= n1 - deg) ? n1 - deg : 0x7fffffff;
+        pp.halo_lo = face0 ? 0 : -1; pp.open_hi = rest0;
+      };
+      if (can2) { Box A = R; A.lo[2] = n2 - deg; R.hi[2] = n2 - deg; int fty[3]; PencilPass pp; pass_of(A, false, false, fty, pp); run(A, fty, &pp); slab_done(); }
+      if (can1) { Box B = R; B.lo[1] = n1 - deg; R.hi[1] = n1 - deg; int fty[3]; PencilPass pp; pass_of(B, false, false, fty, pp); run(B, fty, &pp); face_done(1); }
+      if (can0) { Box C = R; C.lo[0] = n0 - deg; R.hi[0] = n0 - deg; int fty[3]; PencilPass pp; pass_of(C, true, false, fty, pp); run(C, fty, &pp); face_done(0); }
+      { int fty[3]; PencilPass pp; pass_of(R, false, can0, fty, pp); run(R, fty, &pp); }
     } else run(P, nullptr);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
     dom.name = std::string(state ? "state_pencil<walk=" : mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;

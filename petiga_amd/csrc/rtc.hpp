@@ -440,7 +440,7 @@ static int launch_pencil_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev 
   mod.fn = K->func[0]; mod.name = F.name;
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
-  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
+  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod, g->face_done);
 }
 
 // ---- the sum-factorised vector kernel (vec_sumfact.hpp) for a run-time form: Vector / Function / IFunction in 3-D at nen, nqp <= 4
@@ -538,7 +538,7 @@ static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   mod.flop_per_element = 2048.0 * F.meta[11] * (deg == 2 ? 7 * 9 : 16 * 16);
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
-  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod);
+  return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod, g->face_done);
 }
 
 // ---- band rows by node layer (block_pencil.hpp) for a run-time struct: constant-coefficient multi-field forms (MAT_PAIR_MASK, 2 or 3

@@ -105,16 +105,32 @@ def _rank_main(rank, world, port, case, outdir, name=""):
             assert "pencil walk" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16)
         else:
             assert "feature_assemble" in g.kernel_name() and (g.dominant_kernel()["launches"] > ncol) == has_upper
+    faces = None
     if "pencil" in name:
-        # several ranks on axis 2 and a communicator: the elements next to the upper face of axis 2 are assembled first
-        # (all 16 colours), the rest after them: the ghost rows of that face are complete before the second pass starts
+        # a communicator and upper neighbours: the elements next to the upper face of axis 2 are assembled first (all colours), then
+        # those next to the upper face of axis 1, then the last p elements of every remaining pencil (the upper face of axis 0),
+        # then the rest: the ghost rows of a face are complete when its pass ends (gram_mfma.hpp: three marks for the exchange)
         assert "gram_pencil" in g.kernel_name()
-        has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
-        # (the p elements next to the face: p of the p+1 colours of axis 2, times the p+1 of axis 1, then all (p+1)^2)
-        assert g.dominant_kernel()["launches"] == (p + 1) ** 2 + (p * (p + 1) if has_upper else 0)
+        sz = g.sizes()
+        up = [sz["proc_sizes"][d] > 1 and (sz["proc_ranks"][d] < sz["proc_sizes"][d] - 1 or bool(periodic[d])) for d in range(3)]
+        n = sz["elem_width"]
+        can2, can1, can0 = up[2] and n[2] >= 2 * (p + 1), up[1] and n[1] >= 2 * (p + 1), up[0] and n[0] - p >= 8
+        ncol = lambda cnt: min(cnt, p + 1)
+        r1, r2, launches = n[1], n[2], 0
+        if can2:
+            launches += ncol(r1) * ncol(p); r2 = n[2] - p
+        if can1:
+            launches += ncol(p) * ncol(r2); r1 = n[1] - p
+        if can0:
+            launches += ncol(r1) * ncol(r2)
+        launches += ncol(r1) * ncol(r2)
+        assert g.dominant_kernel()["launches"] == launches, (g.dominant_kernel(), launches, up, n)
+        faces = int(can2) + int(can1) + int(can0)
     if "rewrite" in name:     # the vector is written again after the assembly marked its face: the mark no longer stands for it,
         b.set(2.0 * b.get())  # the reduction must pack the NEW values (comm.hpp: every writer clears the mark)
     g.reduce_ghost_rows(A, b)          # enqueued; the copies below wait on the engine stream
+    if faces is not None:              # every face pass of the assembly started its phase of the exchange behind its own mark
+        assert g.comm_early_phases() == (0 if "rewrite" in name else faces), (g.comm_early_phases(), faces)
     if "pencil" in name or "split" in name:
         has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
         if has_upper and "rewrite" not in name:      # the reduction started behind the face mark (on these tiny meshes, with the ranks sharing one GPU, the
@@ -138,6 +154,9 @@ CASES = {
     "poisson-p3-2ranks-pencil-loads": (2, (3, 1, 3, (8, 6, 16), (0, 0, 0), "poisson", ())),
     "poisson-p2-4ranks-pencil-loads": (4, (3, 1, 2, (9, 12, 12), (0, 0, 0), "poisson", ())),
     "poisson-p2-8ranks-pencil": (8, (3, 1, 2, (16, 12, 12), (0, 0, 0), "poisson", ())),      # [2,2,2]: faces, edges and the corner
+    "poisson-p2-8ranks-pencil-faces": (8, (3, 1, 2, (24, 12, 12), (0, 0, 0), "poisson", ())),  # ... long enough on axis 0 for its face pass: three early phases on rank 0
+    "poisson-p3-8ranks-pencil-faces": (8, (3, 1, 3, (24, 16, 16), (0, 0, 0), "poisson", ())),
+    "poisson-p3-4ranks-pencil-faces-periodic": (4, (3, 1, 3, (12, 16, 16), (0, 1, 1), "poisson", ())),
     "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-rewrite": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
