@@ -461,6 +461,10 @@ def main():
         overlap_ms = g.comm_overlap_ms() if world > 1 else None
     except Exception:
         overlap_ms = None
+    try:                       # phases of the last reduction (upper faces of axes 2, 1, 0) that were packed behind a face mark of the assembly
+        early_phases = g.comm_early_phases() if world > 1 else None
+    except Exception:
+        early_phases = None
 
     def assemble(gg, AA, bb, UU, VV):
         if tangent:
@@ -601,7 +605,7 @@ def main():
                                    (" -- the form given as run-time source (IGXSetFormSource)" if args.source else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
                        "transport": transport, "rccl_ranks": comm_ranks if comm_kind == "rccl" else None, "transport_ranks": comm_ranks,
-                       "exchange_started_before_assembly_end_ms": overlap_ms, "checksum": [float(x) for x in cs], "checksum_check": check},
+                       "exchange_started_before_assembly_end_ms": overlap_ms, "exchange_early_phases": early_phases, "checksum": [float(x) for x in cs], "checksum_check": check},
             "roofline": roof,
             "device": P.device_info(),
         }

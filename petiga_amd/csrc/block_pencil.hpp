@@ -619,8 +619,9 @@ static int block_pencil_run(const Space &s, const SpaceDev &S, const OutDev &out
   const int n2 = s.elem_width[2];
   const bool upper2 = s.proc_sizes[2] > 1 && (s.proc_ranks[2] < s.proc_sizes[2] - 1 || s.axis[2].periodic);
   if (slab_done && upper2 && n2 >= 2 * (P + 1)) {
-    Box top = all, rest = all; top.lo[2] = n2 - P; rest.hi[2] = n2 - P;
-    const int ft_top[3] = {n2 - P, n2, 0x7fffffff}, ft_rest[3] = {0, n2 - P, n2 - P};
+    const int c2 = face_cut(n2, P);      // (a thick pass: pencil_common.hpp)
+    Box top = all, rest = all; top.lo[2] = c2; rest.hi[2] = c2;
+    const int ft_top[3] = {c2, n2, 0x7fffffff}, ft_rest[3] = {0, c2, c2};
     run(top, ft_top);
     slab_done();
     run(rest, ft_rest);

@@ -1446,6 +1446,41 @@ static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 // reports it instead of the generic "kernel launch failed" of a later call
 inline const char *&pencil_launch_error() { static thread_local const char *e = nullptr; return e; }
 
+// Segments of one launch (the pencils of one colour, nw walked elements): as few as possible -- every segment re-computes P halo
+// elements -- but enough workgroups for the CUs.  One 8-pencil workgroup per CU at a time (LDS; two where the tables are small), so a
+// launch takes ceil(workgroups / slots) rounds of (segment length + halo): the count with the least rounds x length.  Returns the
+// count; *cost = that product (element-steps of the launch's critical path).
+static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bool walk0, size_t extra_lds, bool halo_always, long long *cost_out = nullptr) {
+  static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  const long long bps = (pencils + 7) / 8;
+  int nseg = std::max(1, (nw + 159) / 160);
+  long long best = -1; int best_n = nseg;
+  for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
+    const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
+    const size_t lds_n = pencil_lds_bytes(len + 3, geo) + (walk0 ? pencil_hold_bytes(P) : 0) + (geo ? pencil_geo_bytes() : 0) + extra_lds;
+    // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
+    if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
+    const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
+    const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || halo_always) ? P : 0));
+    if (best < 0 || cost < best) { best = cost; best_n = n; }
+  }
+  if (cost_out) *cost_out = best < 0 ? 0 : best;
+  return best_n;
+}
+// the same summed over the colour launches of a box of elements (axis-0 walk): what a pass of an assembly costs
+static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always) {
+  long long total = 0;
+  for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return 0;
+  for (int cy = 0; cy < s.lay[2].ncolors; ++cy) for (int cx = 0; cx < s.lay[1].ncolors; ++cx) {
+    int st, sp, nx, ny;
+    if (!color_range(s.lay[1], cx, bx.lo[1], bx.hi[1], st, sp, nx) || !color_range(s.lay[2], cy, bx.lo[2], bx.hi[2], st, sp, ny)) continue;
+    long long c = 0;
+    (void)pencil_segments((long long)nx * ny, bx.hi[0] - bx.lo[0], P, geo, true, extra_lds, halo_always || s.lay[0].alias, &c);
+    total += c;
+  }
+  return total;
+}
+
 template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false>
 // fty (axis-0 walk): {lo, hi, blocked} of the first-touch rule on axis Y when the assembly comes in two passes over that axis
 // (first_touch_axis); null: one pass over the whole axis
@@ -1464,26 +1499,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
-    // Segments: as few as possible (every segment re-computes P halo elements).  Bounds: the LDS tables hold
-    // <= 160 elements, and a launch should fill the 256 CUs (one 8-pencil workgroup each) at least twice.
-    const long long bps = (pencils + 7) / 8;
-    // one 8-pencil workgroup per CU at a time (LDS), so a launch takes ceil(workgroups / CUs) rounds of
-    // (segment length + P halo elements): pick the segment count with the least rounds x length
-    static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-    int nseg = std::max(1, (nw + 159) / 160);
-    {
-      long long best = -1; int best_n = nseg;
-      for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
-        const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
-        const size_t lds_n = pencil_lds_bytes(len + 3, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);
-        // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
-        if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
-        const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
-        const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W])) ? P : 0));
-        if (best < 0 || cost < best) { best = cost; best_n = n; }
-      }
-      nseg = best_n;
-    }
+    int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, mod ? mod->extra_lds : 0, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]));
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
@@ -1785,11 +1801,10 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     default: launch_pencils<true, 2, 3>(s, S, out, stream, P, ga.forcing, launches); break;
     }
     };
-    // Upper faces first (multi-rank, axis-0 walk): the elements within p layers of the upper face of axis 2 in every colour, a mark
-    // for the exchange (slab_done); of what is left, the elements next to the upper face of axis 1, a mark (face_done(1)); then the
-    // last p elements of every remaining pencil -- the upper face of axis 0: a segment of its own that re-computes p halo elements
-    // and owns the rows from its first layer on -- and a mark (face_done(0)); then the rest, whose last segment owns no row past
-    // its elements.  The ghost rows of a face get nothing from the passes after its mark: its messages travel under them (comm.hpp).
+    // Upper faces first (multi-rank, axis-0 walk): the upper half of axis 2 in every colour, a mark for the exchange (slab_done); of
+    // what is left, the upper half of axis 1, a mark (face_done(1)); then the upper half of every remaining pencil -- the upper face
+    // of axis 0: segments of their own, the first of which re-computes p halo elements and owns the rows from its first layer on --
+    // and a mark (face_done(0)); then the rest, whose last segment owns no row past its elements.  The ghost rows of a face get nothing from the passes after its mark: its messages travel under them (comm.hpp).
     // First touch makes the launch order part of the result: per pass the rule applies to the elements of that pass alone, and an
     // entry an earlier pass reaches as well is only added to (fty / ftx: {lo, hi, blocked}).
     const int n0 = s.elem_width[0], n1 = s.elem_width[1], n2 = s.elem_width[2];
@@ -1797,17 +1812,43 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     const bool whole = walk_axis == 0 && P.lo[0] == 0 && P.hi[0] == n0 && P.lo[1] == 0 && P.hi[1] == n1 && P.lo[2] == 0 && P.hi[2] == n2;
     const bool can2 = slab_done && whole && upper(2) && n2 >= 2 * (deg + 1);
     const bool can1 = face_done && whole && upper(1) && n1 >= 2 * (deg + 1) && !s.lay[1].alias;
-    const bool can0 = face_done && whole && upper(0) && n0 - deg >= 8 && !s.lay[0].alias;
-    if (can2 || can1 || can0) {
+    const bool can0 = face_done && whole && upper(0) && n0 >= 16 && !s.lay[0].alias;
+    bool faces_first = can2 || can1 || can0;
+    const int c2 = face_cut(n2, deg), c1 = face_cut(n1, deg), c0 = std::max(8, face_cut(n0, deg));      // (thick passes: pencil_common.hpp)
+    if (faces_first && s.env.overlap < 0) {
+      // IGX_OVERLAP unset: make the passes only when they cost less than what they hide.  Cost: the launcher's own measure (rounds x
+      // segment length, summed over the launches) of the passes against one pass, times the time of an element-step.  Gain: the
+      // largest face message at the link's rate -- the faces travel on different links, at once (IGX_LINK_GBS, default 60 GB/s per
+      // direction).  At 8 ranks of the metric configuration (128^3 per rank) three passes cost 6 ms of a 33 ms assembly and a face
+      // is 141 MB = 2.4 ms: one pass; at 2 ranks (256 x 256 x 128) the pass costs 2.3 ms and the face is 552 MB = 9 ms: faces first
+      // (scripts/time_rank_box.py, profiles/r04_face_passes.txt).
+      const size_t xl = mod ? mod->extra_lds : 0;
+      Box R = P; long long multi = 0;
+      if (can2) { Box A = R; A.lo[2] = c2; R.hi[2] = c2; multi += pencil_box_cost(s, deg, geo || mod, xl, A, false); }
+      if (can1) { Box B = R; B.lo[1] = c1; R.hi[1] = c1; multi += pencil_box_cost(s, deg, geo || mod, xl, B, false); }
+      if (can0) { Box C = R; C.lo[0] = c0; R.hi[0] = c0; multi += pencil_box_cost(s, deg, geo || mod, xl, C, true); }
+      multi += pencil_box_cost(s, deg, geo || mod, xl, R, false);
+      const long long single = pencil_box_cost(s, deg, geo || mod, xl, P, false);
+      const double t_step = (deg == 3 ? 30e-6 : 9e-6) * ((geo || mod) ? 1.4 : 1.0);      // s per element-step of a launch (256^3: 16 ms / (4 rounds x 131))
+      const double cost_s = (double)(multi - single) * t_step;
+      const char *lr = getenv("IGX_LINK_GBS"); const double rate = (lr && atof(lr) > 0 ? atof(lr) : 60.0) * 1e9;
+      double face = 0; const double rowb = 8.0 * (2 * deg + 1) * (2 * deg + 1) * (2 * deg + 1);
+      const double nr[3] = {(double)s.lay[0].nrow, (double)s.lay[1].nrow, (double)s.lay[2].nrow};
+      if (can2) face = std::max(face, deg * nr[0] * nr[1] * rowb);
+      if (can1) face = std::max(face, deg * nr[0] * nr[2] * rowb);
+      if (can0) face = std::max(face, deg * nr[1] * nr[2] * rowb);
+      faces_first = face / rate > cost_s;
+    }
+    if (faces_first) {
       Box R = P;
       auto pass_of = [&](const Box &b, bool face0, bool rest0, int *fty, PencilPass &pp) {
-        fty[0] = b.lo[2]; fty[1] = b.hi[2]; fty[2] = (can2 && b.hi[2] <= n2 - deg) ? n2 - deg : 0x7fffffff;
-        pp.ftx[0] = b.lo[1]; pp.ftx[1] = b.hi[1]; pp.ftx[2] = (can1 && b.hi[1] <= n1 - deg) ? n1 - deg : 0x7fffffff;
+        fty[0] = b.lo[2]; fty[1] = b.hi[2]; fty[2] = (can2 && b.hi[2] <= c2) ? c2 : 0x7fffffff;
+        pp.ftx[0] = b.lo[1]; pp.ftx[1] = b.hi[1]; pp.ftx[2] = (can1 && b.hi[1] <= c1) ? c1 : 0x7fffffff;
         pp.halo_lo = face0 ? 0 : -1; pp.open_hi = rest0;
       };
-      if (can2) { Box A = R; A.lo[2] = n2 - deg; R.hi[2] = n2 - deg; int fty[3]; PencilPass pp; pass_of(A, false, false, fty, pp); run(A, fty, &pp); slab_done(); }
-      if (can1) { Box B = R; B.lo[1] = n1 - deg; R.hi[1] = n1 - deg; int fty[3]; PencilPass pp; pass_of(B, false, false, fty, pp); run(B, fty, &pp); face_done(1); }
-      if (can0) { Box C = R; C.lo[0] = n0 - deg; R.hi[0] = n0 - deg; int fty[3]; PencilPass pp; pass_of(C, true, false, fty, pp); run(C, fty, &pp); face_done(0); }
+      if (can2) { Box A = R; A.lo[2] = c2; R.hi[2] = c2; int fty[3]; PencilPass pp; pass_of(A, false, false, fty, pp); run(A, fty, &pp); slab_done(); }
+      if (can1) { Box B = R; B.lo[1] = c1; R.hi[1] = c1; int fty[3]; PencilPass pp; pass_of(B, false, false, fty, pp); run(B, fty, &pp); face_done(1); }
+      if (can0) { Box C = R; C.lo[0] = c0; R.hi[0] = c0; int fty[3]; PencilPass pp; pass_of(C, true, false, fty, pp); run(C, fty, &pp); face_done(0); }
       { int fty[3]; PencilPass pp; pass_of(R, false, can0, fty, pp); run(R, fty, &pp); }
     } else run(P, nullptr);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);

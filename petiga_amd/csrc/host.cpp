@@ -23,7 +23,7 @@ EnvSwitches read_env_switches() {
   e.state_pencil = num("IGX_STATE_PENCIL", 1);
   e.no_vec_pairs = num("IGX_NO_VEC_PAIRS", 0);
   e.fuse_groups = num("IGX_FUSE_GROUPS", 1);
-  e.overlap = num("IGX_OVERLAP", 1);
+  e.overlap = num("IGX_OVERLAP", -1);
   e.clock_probe = num("IGX_CLOCK_PROBE", 0) != 0;
   e.feature_lds_kb = num("IGX_FEATURE_LDS_KB", 0);
   e.combine = num("IGX_COMBINE", -1);

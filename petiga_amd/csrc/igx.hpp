@@ -31,7 +31,8 @@ struct EnvSwitches {
   int walk_axis = 0;         // IGX_WALK_AXIS: preferred walk axis of the pencil kernel
   int nseg = 0;              // IGX_NSEG: segments per pencil (0 = model)
   int clock_probe = 0;       // IGX_CLOCK_PROBE: the pencil kernel records shader-clock ticks against the 100 MHz wall clock (IGXGetClockProbe)
-  int overlap = 1;           // IGX_OVERLAP=0: no upper-face-first pass, the ghost-row exchange starts after the last launch
+  int overlap = -1;          // IGX_OVERLAP: 0 = no face-first passes, the ghost-row exchange starts after the last launch; 1 = always; 2 = the face of axis 2
+                             // alone (round 3); unset (-1): the pencil walk decides by cost against the size of the faces, the other kernels make their pass
   int fuse_groups = 1;       // IGX_FUSE_GROUPS=0: one launch per group of row fields again (NS-VMS p=3; experiment switch)
   int no_first_touch = 0;    // IGX_NO_FIRST_TOUCH: MatZeroEntries + read-modify-write everywhere
   int feature_lds_kb = 0;    // IGX_FEATURE_LDS_KB: LDS target of the feature kernel

@@ -46,6 +46,12 @@ __device__ __forceinline__ bool first_touch_axis_wrapped(int e, int a, int b) {
 #ifndef IGX_RTC
 struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
 
+// Where a face-first pass cuts an axis of n elements: the elements [cut, n) are assembled first.  The p elements next to the face
+// would do, but a pass that thin fills a quarter of the CUs with one short segment per workgroup (128^3 per rank: +5 ms per face
+// on a 33 ms assembly, scripts/time_rank_box.py); the upper HALF of the axis costs only its segments' halo and still leaves the
+// face's messages half (a quarter, an eighth) of the assembly to travel.  A multiple of p+1, at least p+1 from both ends.
+static inline int face_cut(int n, int p) { const int c = (n / 2) / (p + 1) * (p + 1); return std::max(p + 1, std::min(c, n - (p + 1))); }
+
 // colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element
 static bool color_range(const AxisLayout &L, int c, int lo, int hi, int &start, int &step, int &count) {
   start = -1; count = 0; step = L.p + 1;

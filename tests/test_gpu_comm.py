@@ -41,6 +41,8 @@ def _poisson_loads(g):
 
 def _rank_main(rank, world, port, case, outdir, name=""):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if "pencil" in name:
+        os.environ["IGX_OVERLAP"] = "1"       # the face-first passes whatever their cost (unset, the walk weighs it against the size of the faces: tiny here)
     if "combine" in name:
         os.environ["IGX_COMBINE"] = "1"
     if "split" in name and "block" not in name:
@@ -99,8 +101,8 @@ def _rank_main(rank, world, port, case, outdir, name=""):
     if "split" in name:       # the feature kernel makes the same two passes: more launches than colours on a rank with an upper neighbour
         has_upper = g.sizes()["proc_ranks"][2] < g.sizes()["proc_sizes"][2] - 1 or bool(periodic[2])
         ncol = int(np.prod(g.coloring()))
-        if "block" in name:       # block_pencil.hpp: the same 16 + 12 launches
-            assert "block_pencil" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16), (g.kernel_name(), g.dominant_kernel())
+        if "block" in name:       # block_pencil.hpp: the upper half of axis 2 first, all 16 colours in both passes
+            assert "block_pencil" in g.kernel_name() and g.dominant_kernel()["launches"] == (32 if has_upper else 16), (g.kernel_name(), g.dominant_kernel())
         elif "combine" in name:     # 16 colours over axes 1, 2; the face pass adds 3 of the 4 colours of axis 2
             assert "pencil walk" in g.kernel_name() and g.dominant_kernel()["launches"] == (28 if has_upper else 16)
         else:
@@ -114,13 +116,14 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         sz = g.sizes()
         up = [sz["proc_sizes"][d] > 1 and (sz["proc_ranks"][d] < sz["proc_sizes"][d] - 1 or bool(periodic[d])) for d in range(3)]
         n = sz["elem_width"]
-        can2, can1, can0 = up[2] and n[2] >= 2 * (p + 1), up[1] and n[1] >= 2 * (p + 1), up[0] and n[0] - p >= 8
+        can2, can1, can0 = up[2] and n[2] >= 2 * (p + 1), up[1] and n[1] >= 2 * (p + 1), up[0] and n[0] >= 16
+        cut = lambda m: max(p + 1, min((m // 2) // (p + 1) * (p + 1), m - (p + 1)))      # face_cut (pencil_common.hpp): the upper half goes first
         ncol = lambda cnt: min(cnt, p + 1)
         r1, r2, launches = n[1], n[2], 0
         if can2:
-            launches += ncol(r1) * ncol(p); r2 = n[2] - p
+            launches += ncol(r1) * ncol(n[2] - cut(n[2])); r2 = cut(n[2])
         if can1:
-            launches += ncol(p) * ncol(r2); r1 = n[1] - p
+            launches += ncol(n[1] - cut(n[1])) * ncol(r2); r1 = cut(n[1])
         if can0:
             launches += ncol(r1) * ncol(r2)
         launches += ncol(r1) * ncol(r2)
