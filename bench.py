@@ -66,10 +66,10 @@ def physical_cores():
 
 
 # single-core rates of the oracle (elements/s), only to size the bounded sample
-CPU_RATE_GUESS = {"poisson": 900.0, "elasticity": 160.0, "cahnhilliard": 2500.0, "nsvms": 60.0}
+CPU_RATE_GUESS = {"poisson": 930.0, "elasticity": 350.0, "cahnhilliard": 6600.0, "nsvms": 85.0}      # (measured: profiles/r04_*_line.json)
 
 
-def cpu_baseline(form, degree, seconds_target=15.0):
+def cpu_baseline(form, degree, seconds_target=15.0, geometry=False):
     """Times the CPU oracle (port of the reference loop) on this box's host cores on a bounded sample of the same
     workload.  One worker per PHYSICAL core; every worker assembles its own box of m^3 elements into its own local
     matrix -- what a rank of `mpiexec -n cores` does with its ghosted box (the reference's MatSetValuesLocal works on the
@@ -77,21 +77,21 @@ def cpu_baseline(form, degree, seconds_target=15.0):
     rate and cores x single-core (the no-loss bound); the speed-up quoted next to it uses the larger of the two."""
     import multiprocessing as mp
     cores = physical_cores()
-    rate1 = (900.0 if degree == 3 else 9000.0) if form == "poisson" else CPU_RATE_GUESS[form]
+    rate1 = (CPU_RATE_GUESS["poisson"] if degree == 3 else 16000.0) if form == "poisson" else CPU_RATE_GUESS[form]
     m = int(round((rate1 * seconds_target) ** (1.0 / 3.0)))
-    m = max(8, min(m, 40))
+    m = max(8, min(m, 60))
     # one core alone first (also warms the page cache / builds nothing: the .so is prebuilt)
-    e1, t1 = _cpu_worker((form, degree, m))
+    e1, t1 = _cpu_worker((form, degree, m, geometry))
     t0 = time.time()
     if cores > 1:
         with mp.get_context("spawn").Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(form, degree, m)] * cores)
+            res = pool.map(_cpu_worker, [(form, degree, m, geometry)] * cores)
     else:
         res = [(e1, t1)]
     wall = max(r[1] for r in res)
     elems = sum(r[0] for r in res)
     single = e1 / t1
-    what = {"poisson": "3-D p=%d Poisson System (Dirichlet on 6 faces)" % degree,
+    what = {"poisson": "3-D p=%d Poisson System (Dirichlet on 6 faces%s)" % (degree, ", the bench's rational NURBS map" if geometry else ""),
             "elasticity": "3-D p=3 Elasticity System (orc_form_elasticity; clamped face, u_x = 1 on the opposite one)",
             "cahnhilliard": "3-D p=2 C1 CahnHilliard IFunction + IJacobian (orc_form_ch_residual / orc_form_ch_tangent)",
             "nsvms": "3-D p=3 NavierStokesVMS IFunction + IJacobian on the bench's rational NURBS map (orc_form_ns_residual / orc_form_ns_tangent; axes 0, 2 periodic, no-slip on axis 1)"}[form]
@@ -166,7 +166,7 @@ def _bench_geometry(p, size, periodic):
 
 
 def _cpu_worker(args):
-    form, degree, m = args
+    form, degree, m, with_geo = args
     import numpy as np
     import oracle_api as O
     w = WORKLOADS[form]
@@ -192,6 +192,7 @@ def _cpu_worker(args):
             for f in range(3):
                 g.set_boundary_value(1, s_, f, 0.0)
         ctx = O.NSVMSCtx(1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2)
+    if form == "nsvms" or with_geo:
         X, W = _bench_geometry(p, m, w["periodic"])
         g.set_geometry(X, W)
     A = g.create_mat()
@@ -552,7 +553,7 @@ def main():
         try:
             tj = json.load(open(tf))
             for ent in tj.get("configs", [tj]):
-                if ent.get("form", "poisson") == args.form and ent.get("size") == size and ent.get("degree", p) == p and ent.get("n_gpus") == world and ent.get("kernel_tag") == KERNEL_TAG:
+                if ent.get("form", "poisson") == args.form and ent.get("size") == size and ent.get("degree", p) == p and ent.get("n_gpus") == world and ent.get("kernel_tag") == KERNEL_TAG and bool(ent.get("geometry", args.form == "nsvms")) == bool(geometry):
                     # PMC passes run one step: bytes per launch of the dominant kernel of THIS step shape
                     traffic = ent.get("bytes_per_launch")
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % ent.get("round", tj.get("round"))
@@ -612,7 +613,7 @@ def main():
         if roofs:
             line["roofline_per_rank"] = roofs
         if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.form, args.degree)
+            cb = cpu_baseline(args.form, args.degree, geometry=geometry and args.form != "nsvms")
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = value / max(cb["value"], cb["cores_x_single_core"])
         print(json.dumps(line))

@@ -47,3 +47,38 @@ run("Elasticity p=3 48^3 from source, band rows", 3, 3, 48, lambda g: g.set_form
 run("Elasticity p=3 48^3 from source, Gram (element mode)", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<1>", (1.0, 1.0)))
 run("Elasticity p=3 48^3 from source, plain", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<0>", (1.0, 1.0)))
 run("Elasticity p=3 48^3 from source, point-form kernel", 3, 3, 48, lambda g: g.set_form_source(USER_ELASTICITY, "UserElasticity<0>", (1.0, 1.0)), kernel=1)
+
+
+# NavierStokesVMS Tangent (demo/NavierStokesVMS.c:166-244), 48^3 on the bench's NURBS map, axes 0 and 2 periodic: built in, the built-in
+# struct's text as source, a plain struct (the Tangent written once in mat_c) -- all on band_pt -- and the plain struct on the feature kernel
+def run_vms(label, setform, kernel=0):
+    import bench
+    g = P.IGX(3, 4)
+    for i, per in enumerate((True, False, True)):
+        g.axis_uniform(i, 3, 48, periodic=per)
+    g.setup()
+    g.set_kernel(kernel)
+    X, W = bench._bench_geometry(3, 48, [True, False, True])
+    g.set_geometry(X, W)
+    for side in range(2):
+        for f in range(3):
+            g.set_boundary_value(1, side, f, 0.0)
+    setform(g)
+    J = g.create_mat()
+    rng = np.random.default_rng(5)
+    U, V = g.create_vec().set(0.1 + 0.05 * rng.standard_normal(J.nbrows * 4)), g.create_vec().set(np.zeros(J.nbrows * 4))
+    ts = []
+    for _ in range(4):
+        g.synchronize(); t = time.perf_counter()
+        g.compute_ijacobian(200.0, V, 0.0, U, J); g.synchronize()
+        ts.append(time.perf_counter() - t)
+    print("%-46s first %7.1f ms, then %8.2f ms %7.2f M el/s  %s" % (label, ts[0] * 1e3, min(ts[1:]) * 1e3, 48 ** 3 / min(ts[1:]) / 1e6, g.kernel_name()))
+
+
+from test_rtc_band_pt import PLAIN_VMS, builtin_text_as_source
+VMS = (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2)
+run_vms("NS-VMS Tangent p=3 48^3 NURBS built in", lambda g: g.set_form("nsvms", VMS))
+_src, _name = builtin_text_as_source()
+run_vms("NS-VMS Tangent 48^3 built-in text as source", lambda g: g.set_form_source(_src, _name, VMS))
+run_vms("NS-VMS Tangent 48^3 plain struct as source", lambda g: g.set_form_source(PLAIN_VMS, "UserVMS", VMS))
+run_vms("NS-VMS Tangent 48^3 plain struct, feature", lambda g: g.set_form_source(PLAIN_VMS, "UserVMS", VMS), kernel=3)

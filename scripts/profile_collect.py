@@ -13,10 +13,11 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC, DST = "gpurun_out/prof", "profiles"
-SIZES = {"poisson": 256, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96}
-KEY = {"poisson": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<"}
+SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96}
+KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<"}
+FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson"}
 
 
 def pmc(dirs):
@@ -37,7 +38,7 @@ def write_pmc(path, agg):
 
 
 configs = []
-for form in ("poisson", "elasticity", "cahnhilliard", "nsvms"):
+for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhilliard", "nsvms"):
     lf = "%s/line_%s.json" % (SRC, form)
     if not os.path.exists(lf) or not open(lf).read().strip():
         continue
@@ -56,7 +57,7 @@ for form in ("poisson", "elasticity", "cahnhilliard", "nsvms"):
         k = dom[0]
         mean = lambda c: sum(a[k][c]) / len(a[k][c])
         F, W = mean("FETCH_SIZE"), mean("WRITE_SIZE")
-        ent = dict(form=form, round=int(tag[1:]), kernel_tag=tag, size=SIZES[form], n_gpus=1, kernel=k.replace("void igx::", ""),
+        ent = dict(form=FORM.get(form, form), tag=form, geometry=form.endswith("_nurbs") or form == "nsvms", round=int(tag[1:]), kernel_tag=tag, size=SIZES[form], n_gpus=1, kernel=k.replace("void igx::", ""),
                    launches_per_step=r["launches_per_step"], FETCH_SIZE_KB_per_launch=F, WRITE_SIZE_KB_per_launch=W,
                    raw_bytes_per_launch=(F + W) * 1024, bytes_per_launch=(2 * F + W) * 1024,
                    bytes_per_element=(2 * F + W) * 1024 / max(r["elements_per_launch"], 1),
@@ -64,15 +65,21 @@ for form in ("poisson", "elasticity", "cahnhilliard", "nsvms"):
                    note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (profiles/%s_%s_pmc_summary.csv); bytes = (2 x FETCH_SIZE + "
                         "WRITE_SIZE) x 1024: gfx950 reports half of a wide coalesced read (MI355X_MICROARCH.md, HBM section); mfma_busy_pmc = "
                         "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 128)" % (tag, form))
-        if form == "poisson":
-            ent["degree"] = 3
+        if form.startswith("poisson"):
+            ent["degree"] = 2 if "_p2" in form else 3
         configs.append(ent)
-        line["roofline"]["traffic"] = ent["bytes_per_launch"]
-        line["roofline"]["traffic_source"] = "rocprofv3 --pmc passes of the same command in the same gpurun call (profiles/%s_%s_pmc_summary.csv)" % (tag, form)
+        # (the line keeps the traffic bench.py measured inside its own run; the separate PMC passes of this call go into traffic.json and
+        #  next to it as a cross-check)
+        line["roofline"]["traffic_pmc_passes"] = ent["bytes_per_launch"]
         line["roofline"]["mfma_busy_pmc"] = ent["mfma_busy_pmc"]
-        if r.get("avg_launch_ms"):
-            line["roofline"]["hbm_frac"] = ent["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
+        if line["roofline"].get("traffic") is None:
+            line["roofline"]["traffic"] = ent["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = "rocprofv3 --pmc passes of the same command in the same gpurun call (profiles/%s_%s_pmc_summary.csv)" % (tag, form)
+            if r.get("avg_launch_ms"):
+                line["roofline"]["hbm_frac"] = ent["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
     json.dump(line, open("%s/%s_%s_line.json" % (DST, tag, form), "w"), indent=1)
+if os.path.exists(SRC + "/line_poisson_source.json") and open(SRC + "/line_poisson_source.json").read().strip():
+    shutil.copy(SRC + "/line_poisson_source.json", "%s/%s_poisson_source_line.json" % (DST, tag))
 for src, dst in (("configs.txt", "secondary_configs.txt"), ("rtc.txt", "runtime_forms.txt")):
     if os.path.exists(SRC + "/" + src):
         shutil.copy(SRC + "/" + src, "%s/%s_%s" % (DST, tag, dst))
