@@ -76,10 +76,12 @@ struct BandArgs {
 };
 
 // ---- the point tabulation: one wavefront per element
-template <class Form>
+// (P = 2: the element's 27 functions and points sit in the 4 x 4 x 4 lane slots, the padding carries zeros -- like the headline kernel at p = 2)
+template <class Form, int P = 3>
 __global__ void __launch_bounds__(256)
 band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
-  constexpr int P = 3, NB = 4, DOF = Form::DOF, NC = 4 + DOF, NPD = bpt_npd<Form>(), REC = bpt_rec<Form>();
+  constexpr int NB = P + 1, DOF = Form::DOF, NC = 4 + DOF, NPD = bpt_npd<Form>(), REC = bpt_rec<Form>();
+  static_assert(P == 2 || P == 3, "degrees 2 and 3");
   __shared__ double sm_all[4][64 * NC + 128 + 192 + 96];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long elem = (long long)blockIdx.x * 4 + wave;
@@ -93,11 +95,13 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   const int off0 = AW.off[e0], offx = AX.off[elx], offy = AY.off[ely];
   const bool geo = S.nsd > 0, rat = S.rational != 0;
   {   // control points (homogeneous) and state of the lane's basis function (aw, ay, ax) = (lane >> 4, (lane >> 2) & 3, lane & 3)
-    const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+    const int aw0 = lane >> 4, ay0 = (lane >> 2) & 3, ax0 = lane & 3;
+    const bool vn = aw0 < NB && ay0 < NB && ax0 < NB;      // a basis function of the element (not a padding slot)
+    const int aw = vn ? aw0 : 0, ay = vn ? ay0 : 0, ax = vn ? ax0 : 0;
     const size_t g = (size_t)(off0 + aw) + (size_t)AW.gwidth * ((size_t)(offx + ax) + (size_t)AX.gwidth * (size_t)(offy + ay));
-    const double w = rat ? S.W[g] : 1.0;
+    const double w = vn ? (rat ? S.W[g] : 1.0) : 0.0;
     double c[NC];
-    c[0] = geo ? S.X[g * 3 + 0] * w : 0.0; c[1] = geo ? S.X[g * 3 + 1] * w : 0.0; c[2] = geo ? S.X[g * 3 + 2] * w : 0.0; c[3] = w;
+    c[0] = (geo && vn) ? S.X[g * 3 + 0] * w : 0.0; c[1] = (geo && vn) ? S.X[g * 3 + 1] * w : 0.0; c[2] = (geo && vn) ? S.X[g * 3 + 2] * w : 0.0; c[3] = w;
     const size_t row = (size_t)AW.rowmap[off0 + aw] + (size_t)AW.nrow * ((size_t)AX.rowmap[offx + ax] + (size_t)AX.nrow * (size_t)AY.rowmap[offy + ay]);
     // IGAElementFixValues (src/petigaelem.c:1327-1358): the state at a Dirichlet dof is the boundary value
     const int el3[3] = {e0, elx, ely}, aa[3] = {aw, ax, ay};
@@ -119,11 +123,12 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     for (int k = 0; k < NC; ++k) coef[lane * NC + k] = c[k];
     if (lane < 32) {
       const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1;
-      uxr[lane] = AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k];              // [q][a][2]
-      ztg[lane] = AW.tab[((size_t)e0 * NB * NB + q * NB + a) * NDER + k];               // [q][a][2]
+      const bool ok = q < NB && a < NB;
+      uxr[lane] = ok ? AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k] : 0.0;   // [q][a][2]
+      ztg[lane] = ok ? AW.tab[((size_t)e0 * NB * NB + q * NB + a) * NDER + k] : 0.0;    // [q][a][2]
     } else {
       const int l2 = lane - 32, a = l2 >> 3, q = (l2 >> 1) & 3, k = l2 & 1;
-      vyr[l2] = AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k];                // [a][q][2]
+      vyr[l2] = (q < NB && a < NB) ? AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k] : 0.0;     // [a][q][2]
     }
   }
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -132,7 +137,7 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
   double zv[4], zd[4];
 #pragma unroll
-  for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[(i2 * 4 + aw) * 2 + 0]; zd[aw] = ztg[(i2 * 4 + aw) * 2 + 1]; }
+  for (int aw = 0; aw < 4; ++aw) { zv[aw] = ztg[(i2 * 4 + aw) * 2 + 0]; zd[aw] = ztg[(i2 * 4 + aw) * 2 + 1]; }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     {
@@ -167,9 +172,10 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   // lane = Gauss point (qx, qy, qw) = (i0, i1, i2); record index = lane
   double rec[NPD];
   {
-    const double iw = 1.0 / H[3][0];
+    const bool vq = i0 < NB && i1 < NB && i2 < NB;      // a Gauss point of the element (a padding slot keeps finite numbers and JW = 0)
+    const double iw = vq ? 1.0 / H[3][0] : 1.0;
     double E[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, det = 1.0;
-    if (geo) {
+    if (geo && vq) {
       double F[3][3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -185,7 +191,7 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
     }
     const double Jw = AW.J[e0], Jx = AX.J[elx], Jy = AY.J[ely];
-    rec[0] = det * (AW.w[e0 * NB + i2] * Jw) * (AX.w[elx * NB + i0] * Jx) * (AY.w[ely * NB + i1] * Jy);
+    rec[0] = vq ? det * (AW.w[e0 * NB + i2] * Jw) * (AX.w[elx * NB + i0] * Jx) * (AY.w[ely * NB + i1] * Jy) : 0.0;
     const double g0 = rat ? iw : 1.0;
     rec[1] = g0;
 #pragma unroll
@@ -193,7 +199,7 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       double h = 0.0;
 #pragma unroll
       for (int b = 0; b < 3; ++b) { const double gm = g0 * E[b][i]; rec[2 + i * 3 + b] = gm; h -= gm * (H[3][1 + b] * iw); }
-      rec[11 + i] = rat ? h : 0.0;
+      rec[11 + i] = (rat && vq) ? h : 0.0;
     }
     double u[DOF];
 #pragma unroll
@@ -254,19 +260,19 @@ __device__ __forceinline__ void bpt_feature(d4_t (&acc)[band_nacc_of<Form>::v], 
 }
 
 // one tile product: acc[n] += A_F(e, ta)^T B^n_F(e, tb) over the element's 64 points; k-step (qw, qy), k slot qx = lane >> 4
-template <class Form, bool GEO, bool RAT>
+template <class Form, bool GEO, bool RAT, int NB>
 __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
   constexpr int DOF = Form::DOF, NPD = bpt_npd<Form>();
   const double *zt = rec + 64 * NPD, *wts = zt + 32;
   const int qx = lane >> 4;
   const double wa = RAT ? wts[ta * 16 + (lane & 15)] : 1.0, wb = RAT ? wts[tb * 16 + (lane & 15)] : 1.0;
 #pragma unroll 1
-  for (int qw = 0; qw < 4; ++qw) {
+  for (int qw = 0; qw < NB; ++qw) {
     // the walk-axis rows of the row (A) and column (B) basis function, with the NURBS weight of the control point
     const double zA0 = zt[(qw * 4 + ta) * 2 + 0] * wa, zA1 = zt[(qw * 4 + ta) * 2 + 1] * wa;
     const double zB0 = zt[(qw * 4 + tb) * 2 + 0] * wb, zB1 = zt[(qw * 4 + tb) * 2 + 1] * wb;
 #pragma unroll
-    for (int qy = 0; qy < 4; ++qy) {
+    for (int qy = 0; qy < NB; ++qy) {
       const double *pd = rec + ((qw * 4 + qy) * 4 + qx) * NPD;
       const double jw = pd[0];
       // value and gradient of the row (A) and column (B) basis function at the point (the trial side carries JW: mat() is linear
@@ -306,10 +312,11 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
   }
 }
 
-template <class Form, bool GEO, bool RAT>
+template <class Form, bool GEO, bool RAT, int P = 3>
 __global__ void __launch_bounds__(256, 2)
 band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
-  constexpr int P = 3, NB = 4, BW = 7, DOF = Form::DOF, BS = DOF * DOF, NACC = band_nacc_of<Form>::v, REC = bpt_rec<Form>();
+  constexpr int NB = P + 1, BW = 2 * P + 1, DOF = Form::DOF, BS = DOF * DOF, NACC = band_nacc_of<Form>::v, REC = bpt_rec<Form>();
+  static_assert(P == 2 || P == 3, "degrees 2 and 3 (p = 2 in the 4 x 4 tile slots, zero padded)");
   static_assert(DOF == 4 && has_point_coef<Form>::v, "128-byte blocks; the form separates its point coefficients (NCOEF, point_coef, mat_c)");
   static_assert(NACC >= BS && NACC <= 20, "accumulators: the block entries first, shared parts behind them");
   extern __shared__ __attribute__((aligned(16))) double bpt_sm[];
@@ -352,16 +359,16 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       for (int d = 0; d < BW; ++d) LP[i * 8 + d] = AW.P[lay * BW + d];
     }
     if (tid < 4) {
-      const int a = tid;
+      const int a = tid < NB ? tid : 0;      // (slot 3 at p = 2 is padding: a copy of slot 0, never written from)
       const int ixg = offx + a, rhox = AX.rowmap[ixg], iyg = offy + a, rhoy = AY.rowmap[iyg];
-      pen->ps1[a] = AX.prefix[rhox]; pen->c1[a] = AX.rcnt[rhox]; pen->P1_0[a] = AX.P[ixg * BW + (0 - a + P)]; pen->rmx[a] = rhox;
-      pen->ps2[a] = AY.prefix[rhoy]; pen->c2[a] = AY.rcnt[rhoy]; pen->rmy[a] = rhoy;
-      for (int b = 0; b < 4; ++b) pen->P2[a * 4 + b] = AY.P[iyg * BW + (b - a + P)];
+      pen->ps1[tid] = AX.prefix[rhox]; pen->c1[tid] = AX.rcnt[rhox]; pen->P1_0[tid] = AX.P[ixg * BW + (0 - a + P)]; pen->rmx[tid] = rhox;
+      pen->ps2[tid] = AY.prefix[rhoy]; pen->c2[tid] = AY.rcnt[rhoy]; pen->rmy[tid] = rhoy;
+      for (int b = 0; b < 4; ++b) pen->P2[tid * 4 + b] = AY.P[iyg * BW + ((b < NB ? b : 0) - a + P)];
     }
     if (tid == 64) {
       unsigned fx = 0, fy = 0;
       if (pa.first_touch)
-        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+        for (int a = 0; a < NB; ++a) for (int b = 0; b < NB; ++b) {
           if (first_touch_axis<P>(elx, a, b, pa.nelx)) fx |= 1u << (a * 4 + b);
           if (pa.wrap2 ? first_touch_axis_wrapped<P>(ely, a, b) : first_touch_axis<P>(ely, a, b, pa.nely, pa.fty_lo, pa.fty_hi, pa.fty_blocked)) fy |= 1u << (a * 4 + b);
         }
@@ -369,8 +376,8 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     }
     if (tid >= 128 && tid < 192) {   // per (qx, ix): u0, u1 of axis 1; per (iy, qy): v0, v1 of axis 2 (raw rows)
       const int l2 = tid - 128;
-      if (l2 < 32) { const int q = l2 >> 3, a = (l2 >> 1) & 3, k = l2 & 1; uvs[l2] = AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k]; }            // [q][a][2]
-      else { const int l3 = l2 - 32, a = l3 >> 3, q = (l3 >> 1) & 3, k = l3 & 1; uvs[l2] = AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k]; }       // [a][q][2]
+      if (l2 < 32) { const int q = l2 >> 3, a = (l2 >> 1) & 3, k = l2 & 1; uvs[l2] = (q < NB && a < NB) ? AX.tab[((size_t)elx * NB * NB + q * NB + a) * NDER + k] : 0.0; }            // [q][a][2]
+      else { const int l3 = l2 - 32, a = l3 >> 3, q = (l3 >> 1) & 3, k = l3 & 1; uvs[l2] = (q < NB && a < NB) ? AY.tab[((size_t)ely * NB * NB + q * NB + a) * NDER + k] : 0.0; }       // [a][q][2]
     }
     if (tid >= 192 && tid < 198) {   // Dirichlet faces this pencil can touch (IGAElementFixJacobian; not the Matrix driver)
       const int k = tid - 192, d = k >> 1, sd = k & 1;
@@ -408,6 +415,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
   // block position of this lane's entry (row slots a1 = lane >> 4 on axis 1, a2 = r on axis 2; column slots b1, b2; column layer
   // lay + d): pos = base[r] + cc[r] * prefix0(lay) + pp[r] * count0(lay) + P0(lay, d)   (axis 1 has consecutive positions)
   const int a1 = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
+  const bool lane_ok = a1 < NB && b1 < NB && b2 < NB;      // lanes of the zero padding (p = 2) hold no block
   long long pbase[4]; int pcc[4], ppp[4]; unsigned ftm = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -433,9 +441,11 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     if (kDebug && pa.dbg_buf) stamp[0] = __builtin_readcyclecounter();
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-      // band tiles of this wave: d = {0}, {+1, -3}, {-1, +3}, {+2, -2}: four tile products per wave and layer
-      if (half == 1 && role == 0) break;
-      const int d = half == 0 ? ((role == 0) ? 0 : (role == 1 ? 1 : (role == 2 ? -1 : 2))) : ((role == 1) ? -3 : (role == 2 ? 3 : -2));
+      // band tiles of this wave: d = {0}, {+1, -P}, {-1, +P} and, at p = 3, {+2, -2}: (P + 1) tile products per wave and layer
+      constexpr int NONE = 99;
+      const int d = half == 0 ? ((role == 0) ? 0 : (role == 1 ? 1 : (role == 2 ? -1 : (P == 3 ? 2 : NONE))))
+                              : ((role == 1) ? -P : (role == 2 ? P : ((P == 3 && role == 3) ? -2 : NONE)));
+      if (d == NONE) continue;
       const int p0d = __builtin_amdgcn_readfirstlane(LP[it * 8 + d + P]);
       if (p0d < 0) continue;          // the column layer does not exist (ends of a non-periodic axis)
       d4_t acc[NACC];
@@ -448,7 +458,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
           if (tb < 0 || tb > P) continue;
           const int eu = li - ta;        // (unwrapped: the ring slot follows it, the element itself is eu modulo nel on a wrapped axis)
           if (!alias0 && (eu < 0 || eu >= pa.nel0)) continue;
-          bpt_product<Form, GEO, RAT>(acc, ring + bpt_slot(eu) * REC, ta, tb, uxy, lane, prm.v, out.shift);
+          bpt_product<Form, GEO, RAT, NB>(acc, ring + bpt_slot(eu) * REC, ta, tb, uxy, lane, prm.v, out.shift);
         }
       }
       if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc, prm.v);
@@ -457,7 +467,8 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       if (kDebug && (pa.debug & 1)) continue;
       // ---- read-add-write of the lane's four blocks (r = row slot on axis 2): a block is one 128-byte line
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < NB; ++r) {
+        if (!lane_ok) continue;
         const long long pos = pbase[r] + (long long)pcc[r] * ps0 + (long long)ppp[r] * c0 + p0d;
         double *gp = out.val + pos * BS;
         const bool first = (ftm >> r) & 1u;
@@ -524,10 +535,12 @@ static bool band_pt_covers_space(const Space &s, const SpaceDev &S, const OutDev
   if (s.env.block_pencil == 0) return false;
   if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) return false;
   if (s.dim != 3 || s.dof != 4 || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
+  const int p = s.axis[0].p;
+  if (p != 2 && p != 3) return false;
   for (int d = 0; d < 3; ++d) {
-    if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4) return false;
+    if (s.axis[d].p != p || s.basis[d].nqp != p + 1 || s.basis[d].nen != p + 1) return false;
     for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;
-    if (s.lay[d].alias && s.axis[d].nnp < 7) return false;
+    if (s.lay[d].alias && s.axis[d].nnp < 2 * p + 1) return false;
   }
   if (s.lay[1].alias) return false;
   if (s.elem_width[0] < 8) return false;
@@ -540,13 +553,13 @@ static bool band_pt_covers(const Space &s, const SpaceDev &S, const OutDev &out)
   else return band_pt_covers_space(s, S, out);
 }
 
-// the launches of an assembly; `launch(points, grid, lds_bytes, geo, rat, args)` starts band_points (points = true: 256 threads, four
+// the launches of an assembly; `launch(points, grid, lds_bytes, geo, rat, degree, args)` starts band_points (points = true: 256 threads, four
 // elements per workgroup) or band_pt (256 threads, lds_bytes of dynamic LDS) -- the compiled-in instantiations of a built-in form,
 // or the module functions of a run-time struct (rtc.hpp); rec = bpt_rec<Form>(), products = bpt_products<Form>()
-typedef std::function<void(bool, unsigned, size_t, bool, bool, const BandArgs &)> BandPtLaunch;
+typedef std::function<void(bool, unsigned, size_t, bool, bool, int, const BandArgs &)> BandPtLaunch;
 static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom,
                        const std::function<void()> &zero_matrix, const std::function<void()> &slab_done, int rec, int products, const BandPtLaunch &launch) {
-  constexpr int P = 3;
+  const int P = s.axis[0].p;
   const bool alias0 = s.lay[0].alias != 0;
   // (the walk axis needs no rule: a pencil writes every block of its band rows exactly once, wrapped or not)
   const bool wrap2 = axis_first_touch_wrapped_ok(s, 2);
@@ -580,13 +593,13 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
       const size_t need = (size_t)pencils * pa.nel0 * rec * sizeof(double);
       if (hipMallocAsync(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
       const long long nelem = pencils * pa.nel0;
-      launch(true, (unsigned)((nelem + 3) / 4), 0, geo, rat, pa);
+      launch(true, (unsigned)((nelem + 3) / 4), 0, geo, rat, P, pa);
       const size_t lds = (size_t)bpt_carve(rec, pa.seg_len).total * sizeof(double);
       static int dbg_done = 0;
       const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
       const size_t dbg_n = (size_t)pencils * pa.nseg * 4 * 64 * 8 + (size_t)pencils * pa.nseg * 4;
       if (dbg_t) { (void)hipMalloc((void **)&pa.dbg_buf, dbg_n * 8); (void)hipMemset(pa.dbg_buf, 0, dbg_n * 8); }
-      launch(false, (unsigned)(pencils * pa.nseg), lds, geo, rat, pa);
+      launch(false, (unsigned)(pencils * pa.nseg), lds, geo, rat, P, pa);
       if (dbg_t) {   // IGX_DEBUG_TIMING=1: where a layer's cycles go, per role, over the workgroups of the first launch (diagnostic only)
         dbg_done = 1;
         (void)hipStreamSynchronize(stream);
@@ -650,10 +663,10 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
   if (rc) return rc;
   if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
   if (hipGetLastError() != hipSuccess) { err = "band_pt kernel launch failed"; return IGX_ERR_LIB; }
-  dom.name = "band_pt<p=3>"; dom.launches = launches;
+  dom.name = std::string("band_pt<p=") + char('0' + P) + ">"; dom.launches = launches;
   dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
-  dom.flop_per_element = 2048.0 * products * 16 * 16;
-  kname = std::string("band_pt(mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
+  dom.flop_per_element = 2048.0 * products * (P + 1) * (P + 1) * (P + 1) * (P + 1);      // (P+1)^2 tile products of (P+1)^2 k-steps per layer
+  kname = std::string("band_pt(mfma_f64_16x16x4,p=") + char('0' + P) + std::string(",dof=4,band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
   done = true;
   return 0;
 }
@@ -667,9 +680,10 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   if (!band_pt_covers<Form>(s, S, out)) return 0;
   if constexpr (band_nacc_of<Form>::own) { if (!Form::band_params_ok(prm.v)) return 0; }
   return band_pt_run(s, S, out, stream, kname, launches, err, done, dom, zero_matrix, slab_done, bpt_rec<Form>(), bpt_products<Form>(),
-                     [&](bool points, unsigned grid, size_t lds, bool geo, bool rat, const BandArgs &pa) {
-                       if (points) { hipLaunchKernelGGL(band_points<Form>, dim3(grid), dim3(256), 0, stream, S, prm, out, pa); return; }
-                       auto kern = geo ? (rat ? band_pt<Form, true, true> : band_pt<Form, true, false>) : band_pt<Form, false, false>;
+                     [&](bool points, unsigned grid, size_t lds, bool geo, bool rat, int deg, const BandArgs &pa) {
+                       if (points) { hipLaunchKernelGGL((deg == 2 ? band_points<Form, 2> : band_points<Form, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, pa); return; }
+                       auto kern = deg == 2 ? (geo ? (rat ? band_pt<Form, true, true, 2> : band_pt<Form, true, false, 2>) : band_pt<Form, false, false, 2>)
+                                            : (geo ? (rat ? band_pt<Form, true, true, 3> : band_pt<Form, true, false, 3>) : band_pt<Form, false, false, 3>);
                        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, S, prm, out, pa);
                      });

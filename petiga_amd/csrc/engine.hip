@@ -820,7 +820,9 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   }
 #endif
 #ifdef IGX_HAVE_BAND_PT
-  if constexpr (DIM == 3) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer, point-dependent coefficients (band_pt.hpp)
+  // (p = 2 only on request: the 27-function element in 4 x 4 x 4 tile slots wastes two thirds of the MFMAs there -- NS-VMS 48^3: 7.7 M el/s, the
+  //  feature kernel's 2 x 2 tiles are as fast -- so the automatic choice keeps the feature kernel at p = 2)
+  if constexpr (DIM == 3) if ((g->kernel_choice == 0 && s.axis[0].p == 3) || g->kernel_choice == 4) {   // band rows by node layer, point-dependent coefficients (band_pt.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -828,7 +830,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
   }
 #endif
-  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0; band_pt: 3-D, p = 3, matrix-only driver of a 4-field form with separated point coefficients)");
+  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0; band_pt: 3-D, p = 2 or 3, matrix-only driver of a 4-field form with separated point coefficients)");
   if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;

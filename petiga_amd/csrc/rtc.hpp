@@ -607,14 +607,16 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
     if (!band_pt_covers_space(s, S, out)) return 0;
   }
   const bool geo = compile_only ? (geo_only & 1) != 0 : s.nsd != 0, rat = compile_only ? (geo_only & 2) != 0 : s.rational != 0;
-  const int key = (geo ? 1 : 0) | (rat ? 2 : 0);
+  const int deg = s.axis[0].p;
+  if (deg != 2 && deg != 3) { if (compile_only) return fail(IGX_ERR_SUP, "band_pt needs degree 2 or 3"); return 0; }
+  const int key = (geo ? 1 : 0) | (rat ? 2 : 0) | (deg << 2);
   std::shared_ptr<RtcFeature> K;
   auto it = F.band.find(key);
   if (it != F.band.end() && (it->second->module || compile_only)) K = it->second;
   else {
     K.reset(new RtcFeature());
-    const std::string xp = std::string("igx::band_points<") + F.name + ">";
-    const std::string xb = std::string("igx::band_pt<") + F.name + ", " + (geo ? "true" : "false") + ", " + (rat ? "true" : "false") + ">";
+    const std::string xp = std::string("igx::band_points<") + F.name + ", " + std::to_string(deg) + ">";
+    const std::string xb = std::string("igx::band_pt<") + F.name + ", " + (geo ? "true" : "false") + ", " + (rat ? "true" : "false") + ", " + std::to_string(deg) + ">";
     const std::string tail = "static_assert(igx::bpt_form_ok<" + F.name + ">(), \"band_pt: four fields, first order, NCOEF / point_coef / mat_c, no atboundary branch\");\n"
                              "__device__ int igx_band_meta[4] = {igx::bpt_rec<" + F.name + ">(), igx::bpt_products<" + F.name + ">(), 0, 0};\n"
                              "template __global__ void " + xp + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n"
@@ -637,7 +639,7 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
   int lrc = 0;
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
   const int rc = band_pt_run(s, S, out, stream, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, K->meta[0], K->meta[1],
-                             [&](bool points, unsigned grid, size_t lds, bool, bool, const BandArgs &pa) {
+                             [&](bool points, unsigned grid, size_t lds, bool, bool, int, const BandArgs &pa) {
                                RtcBandArgs a; memset(&a, 0, sizeof(a));
                                a.S = S; a.prm = prm; a.out = out; a.pa = pa;
                                size_t asz = sizeof(a);
@@ -645,7 +647,7 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
                                if (hipModuleLaunchKernel(K->func[points ? 0 : 1], grid, 1, 1, 256, 1, 1, (unsigned)lds, stream, nullptr, cfg) != hipSuccess) lrc = IGX_ERR_LIB;
                              });
   if (rc == 0 && lrc) return fail(lrc, "band_pt: launch of the run-time instantiation failed");
-  if (rc == 0 && done) g->last_kernel = std::string("band_pt<") + F.name + ">(hiprtc,mfma_f64_16x16x4,p=3,dof=4,band rows by node layer,point records)";
+  if (rc == 0 && done) g->last_kernel = std::string("band_pt<") + F.name + ">(hiprtc,mfma_f64_16x16x4,p=" + std::to_string(deg) + ",dof=4,band rows by node layer,point records)";
   return rc;
 }
 
@@ -666,7 +668,7 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
     if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;
   }
-  if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // four-field structs with separated point coefficients: band rows by node layer
+  if ((g->kernel_choice == 0 && s.axis[0].p == 3) || g->kernel_choice == 4) {   // four-field structs with separated point coefficients: band rows by node layer (p = 2 on request)
     bool done = false;
     if (int rc = launch_band_rtc(g, F, S, out, done)) return rc;
     if (done) return 0;

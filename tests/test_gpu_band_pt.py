@@ -38,6 +38,7 @@ def _walls(objs, periodic, kind):
                     g.set_boundary_value(d, 1, 3, -0.2)
 
 
+@pytest.mark.parametrize("p", [3, 2])
 @pytest.mark.parametrize("N,periodic,geo,bc,nseg", [
     ((8, 4, 4), (False, False, False), None, "noslip", 0),
     ((9, 5, 4), (False, False, False), "nurbs", "mixed", 0),
@@ -47,10 +48,10 @@ def _walls(objs, periodic, kind):
     ((11, 4, 7), (True, False, False), "nurbs", "mixed", 2),
     ((8, 5, 9), (False, False, True), "poly", "noslip", 0),
 ])
-def test_ns_vms_tangent_vs_oracle(N, periodic, geo, bc, nseg, monkeypatch):
+def test_ns_vms_tangent_vs_oracle(N, periodic, geo, bc, nseg, p, monkeypatch):
     if nseg:
         monkeypatch.setenv("IGX_NSEG", str(nseg))
-    orc, eng = make_pair(3, 4, 3, list(N), periodic=list(periodic))
+    orc, eng = make_pair(3, 4, p, list(N), periodic=list(periodic))
     if geo:
         X, W = warped_geometry(orc, 3, seed=sum(N), rational=(geo == "nurbs"), amp=0.08)
         orc.set_geometry(X, W)

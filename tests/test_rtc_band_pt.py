@@ -62,8 +62,8 @@ def builtin_text_as_source(name="UserNSVMSFull"):
     return re.sub(r"\bFormNSVMS\b", name, text[i:j]), name
 
 
-def _problem(N, periodic, geo, objs_only=False):
-    orc, eng = make_pair(3, 4, 3, list(N), periodic=list(periodic))
+def _problem(N, periodic, geo, p=3):
+    orc, eng = make_pair(3, 4, p, list(N), periodic=list(periodic))
     if geo:
         X, W = warped_geometry(orc, 3, seed=sum(N), rational=(geo == "nurbs"), amp=0.08)
         orc.set_geometry(X, W)
@@ -79,10 +79,10 @@ def test_band_structs_compile_without_a_gpu():
     """IGXCheckFormSource(gram = 6): band_points + band_pt of both structs, without a geometry and on a NURBS map"""
     import petiga_amd as P
     full, name = builtin_text_as_source()
-    for src, nm in ((PLAIN_VMS, "UserVMS"), (full, name)):
+    for src, nm, deg in ((PLAIN_VMS, "UserVMS", 3), (full, name, 3), (full, name, 2)):
         g = P.IGX(3, 4)
         for i in range(3):
-            g.axis_uniform(i, 3, 8)
+            g.axis_uniform(i, deg, 8)
         g.set_form_source(src, nm, (NU, FX, 0.0, 0.0, DT))
         g.check_form_source(True, 6)
 
@@ -101,9 +101,10 @@ def test_a_struct_without_point_coefficients_does_not_compile_for_band_pt():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("which", ["plain", "full"])
-@pytest.mark.parametrize("N,periodic,geo", [((8, 4, 4), (False, False, False), None), ((9, 3, 8), (True, False, True), "nurbs"), ((10, 4, 5), (False, False, False), "poly")])
-def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo):
-    orc, eng = _problem(N, periodic, geo)
+@pytest.mark.parametrize("N,periodic,geo,p", [((8, 4, 4), (False, False, False), None, 3), ((9, 3, 8), (True, False, True), "nurbs", 3), ((10, 4, 5), (False, False, False), "poly", 3),
+                                              ((9, 4, 6), (True, False, True), "nurbs", 2)])
+def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo, p):
+    orc, eng = _problem(N, periodic, geo, p)
     ctx, params = O.NSVMSCtx(NU, FX, 0.0, 0.0, DT), (NU, FX, 0.0, 0.0, DT)
     rng = np.random.default_rng(31)
     n = orc.global_size()
@@ -112,6 +113,8 @@ def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo):
     J_o = orc.compute_ijacobian("orc_form_ns_tangent", ctx, shift, V, 0.0, U)
     src, name = (PLAIN_VMS, "UserVMS") if which == "plain" else builtin_text_as_source()
     eng.set_form_source(src, name, params)
+    if p == 2:
+        eng.set_kernel(4)      # (the automatic choice keeps the feature kernel at p = 2: as fast there)
     Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
     eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
     eng.synchronize()
