@@ -356,6 +356,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))
 
+    # Libraries write to file descriptor 1 on their own (RCCL's version banner at communicator creation, gloo's connection notes):
+    # everything but the result line goes to stderr, so that stdout carries exactly ONE line.
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     os.environ.setdefault("IGX_CLOCK_PROBE", "1")   # read at IGXCreate: three stores by one lane per launch
@@ -616,7 +622,11 @@ def main():
             cb = cpu_baseline(args.form, args.degree, geometry=geometry and args.form != "nsvms")
             line["cpu_baseline"] = cb
             line["speedup_vs_cpu"] = value / max(cb["value"], cb["cores_x_single_core"])
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
         print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world > 1:
         dist.destroy_process_group()
 

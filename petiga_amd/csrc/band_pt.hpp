@@ -620,7 +620,7 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
           const long long *wg = &h[(size_t)pencils * pa.nseg * 4 * 64 * 8]; const size_t nwg = (size_t)pencils * pa.nseg;
           long long t0 = LLONG_MAX, t1 = 0; for (size_t b = 0; b < nwg; ++b) { t0 = std::min(t0, wg[b * 4]); t1 = std::max(t1, wg[b * 4 + 1]); }
           double pro = 0; for (size_t b = 0; b < nwg; ++b) pro += (double)h[((b * 4 + 1) * 64 + 63) * 8];
-          fprintf(stderr, "[igx band_pt schedule] %zu workgroups, launch span %.1f us, mean prologue (tables, window, stagger) %.1f us\n", nwg, (t1 - t0) / 100.0, pro / nwg / 100.0);
+          fprintf(stderr, "[igx band_pt schedule] %zu workgroups, launch span %.1f us, mean prologue (tables, window) %.1f us\n", nwg, (t1 - t0) / 100.0, pro / nwg / 100.0);
           for (int x = 0; x < 8; ++x) {
             long long n = 0, first_end = LLONG_MAX, last_end = 0, last_start = 0; double dur = 0; long long cus[64] = {0};
             for (size_t b = 0; b < nwg; ++b) if ((wg[b * 4 + 3] & 15) == x) {

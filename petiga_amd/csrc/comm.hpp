@@ -132,11 +132,11 @@ static int comm_exchange(IGX g, IGXMat A, IGXVec b, bool reduce) {
   bool grew = false;
   for (size_t k = 0; k < out_plans.size(); ++k) if (c.sbuf[k].bytes < (size_t)doubles(out_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.sbuf[k].alloc((size_t)doubles(out_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
   for (size_t k = 0; k < in_plans.size(); ++k) if (c.rbuf[k].bytes < (size_t)doubles(in_plans[k]) * 8) { if (!grew) { HIPCK(hipStreamSynchronize(c.xs)); grew = true; } if (c.rbuf[k].alloc((size_t)doubles(in_plans[k]) * 8)) return fail(IGX_ERR_MEM, "exchange buffer allocation failed"); }
-  // Ghost-row reduction in two phases when axis 2 is split over ranks: the messages of the upper face of axis 2
-  // (offsets with o2 = 1) first, the others after them.  Every rank issues the two groups in this order; a rank whose assembly
-  // marked the moment the rows of that face were complete (slab_ev, engine.hip) starts the first group there, under its
-  // remaining launches -- pack and wire time of the largest face leave the critical path.  The unpack adds into rows the
-  // receiver's own launches store into, so it waits for the end of the assembly either way.
+  // Ghost-row reduction in up to three phases: the messages of the upper face of axis 2 (offsets with o2 >= 1) first, then those of
+  // axis 1 (o2 = 0, o1 >= 1), then those of axis 0 alone.  Every rank issues the groups in this order; a rank whose assembly marked
+  // the moment the rows of a face were complete (slab_ev / face_ev, engine.hip) starts that face's group there, under its remaining
+  // launches -- pack and wire time leave the critical path.  The unpack adds into rows the receiver's own launches store into, so it
+  // waits for the end of the assembly either way.
   const bool phased = reduce && g->s.env.overlap;   // (the environment is the same on every rank)
   // What the marked assembly wrote is face-complete at its marks, and a matrix / vector an EARLIER call wrote was complete before
   // them (one engine stream).  A mark is only good while it is the last write: every entry point that writes to an IGXMat /

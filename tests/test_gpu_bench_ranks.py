@@ -18,6 +18,7 @@ def _check_line(r, form, size):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
+    assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]      # stdout carries the line and nothing else (gloo / RCCL notes go to stderr)
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["value"] > 0
     chk = line["config"]["checksum_check"]
