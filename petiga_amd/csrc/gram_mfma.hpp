@@ -872,45 +872,50 @@ __device__ __forceinline__ void pencil_form_eval(double *geo, int lane, const do
 // the MFMAs of one element on a mapped geometry: k-step (qw, qy, beta), k slot = qx (lane>>4); 10 tiles (K_e is symmetric)
 // (the walk-axis point loop stays rolled and the rational branch is a template parameter: fully unrolled with both branches
 // the kernel was 60 KB of code and its MFMA phase took 55k cycles against 31k of MFMA issue: instruction-cache bound)
+// Round 4: what does not depend on the tile slot t is computed once per point.  With the parametric gradient of the lane's basis
+// function g_gamma(t) = w_t / W (z'_t P_gamma + z_t Q_gamma), P = (a_n, 0, 0), Q = (-a_n o_0, a_x - a_n o_1, a_y - a_n o_2) (o = dW / W;
+// a polynomial map: Q = (0, a_x, a_y)), the trial operand B_beta(t) = sum_gamma M_beta,gamma g_gamma(t) is the SAME two-term form
+// with PB_beta = M_beta0 P_0 and QB_beta = sum_gamma M_beta,gamma Q_gamma: 20 point-level + 10 per-slot multiply-adds per (qw, qy) instead
+// of 3 + 20 per slot (NURBS: 83 -> 60 per 30 MFMAs; the fp64 VALU work shares the pipe with them).
 template <int NB, bool RAT>
 __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *ztg,
                                                 const double *geo, int lane, const double (&wt)[4]) {
   const int qx = lane >> 4;
 #pragma unroll 2
   for (int qw = 0; qw < NB; ++qw) {
-    double z0[NB], z1[NB];
+    double z0[NB], z1[NB];      // the walk-axis row of tile slot t, with the NURBS weight of its control point
 #pragma unroll
-    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * 4 + t) * 2 + 0]; z1[t] = ztg[(qw * 4 + t) * 2 + 1]; }
+    for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * 4 + t) * 2 + 0]; z1[t] = ztg[(qw * 4 + t) * 2 + 1]; if (RAT) { z0[t] *= wt[t]; z1[t] *= wt[t]; } }
 #pragma unroll
     for (int qy = 0; qy < NB; ++qy) {
       const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
       const int p = (qw * 4 + qy) * 4 + qx;
       const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
       const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
-      const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
-      double g0[NB], g1[NB], g2[NB];
-#pragma unroll
-      for (int t = 0; t < NB; ++t) { g0[t] = a_n * z1[t]; g1[t] = a_x * z0[t]; g2[t] = a_y * z0[t]; }
+      double P0 = u0 * vy0, Q0 = 0.0, Q1 = u1 * vy0, Q2 = u0 * vy1;
       if (RAT) {
-        const double rinv = Rp[0], o0 = Rp[1], o1 = Rp[2], o2 = Rp[3];
+        const double rinv = Rp[0];
+        Q0 = -P0 * Rp[1]; Q1 -= P0 * Rp[2]; Q2 -= P0 * Rp[3];
+        P0 *= rinv; Q0 *= rinv; Q1 *= rinv; Q2 *= rinv;
+      }
+      const double PB[3] = {m00 * P0, m01 * P0, m02 * P0};
+      double QB[3] = {m01 * Q1 + m02 * Q2, m11 * Q1 + m12 * Q2, m12 * Q1 + m22 * Q2};
+      if (RAT) { QB[0] += m00 * Q0; QB[1] += m01 * Q0; QB[2] += m02 * Q0; }
+      double g[3][NB];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-          const double n = a_n * z0[t], sc = wt[t] * rinv;
-          g0[t] = sc * (g0[t] - n * o0); g1[t] = sc * (g1[t] - n * o1); g2[t] = sc * (g2[t] - n * o2);
-        }
+      for (int t = 0; t < NB; ++t) {
+        g[0][t] = z1[t] * P0; if (RAT) g[0][t] += z0[t] * Q0;
+        g[1][t] = z0[t] * Q1; g[2][t] = z0[t] * Q2;
       }
 #pragma unroll
       for (int be = 0; be < 3; ++be) {
-        const double ma = (be == 0) ? m00 : (be == 1 ? m01 : m02), mb = (be == 0) ? m01 : (be == 1 ? m11 : m12), mc = (be == 0) ? m02 : (be == 1 ? m12 : m22);
         double B[NB];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) B[t] = ma * g0[t] + mb * g1[t] + mc * g2[t];
+        for (int t = 0; t < NB; ++t) B[t] = z1[t] * PB[be] + z0[t] * QB[be];
 #pragma unroll
-        for (int ta = 0; ta < NB; ++ta) {
-          const double A = (be == 0) ? g0[ta] : (be == 1 ? g1[ta] : g2[ta]);
+        for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
-          for (int tb = ta; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B[tb], acc[ta][tb], 0, 0, 0);
-        }
+          for (int tb = ta; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[be][ta], B[tb], acc[ta][tb], 0, 0, 0);
       }
     }
   }
@@ -931,30 +936,31 @@ __device__ __forceinline__ void pencil_mfma_geo_p2(d4_t (&acc)[4][4], const doub
     const int p = (qw * 4 + qy) * 4 + qx;
     const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
     const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
-    const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
-    double g0[3], g1[3], g2[3];
+    double P0 = u0 * vy0, Q0 = 0.0, Q1 = u1 * vy0, Q2 = u0 * vy1;      // (see pencil_mfma_geo: the point-level half of both operands)
+    if (RAT) {
+      const double rinv = Rp[0];
+      Q0 = -P0 * Rp[1]; Q1 -= P0 * Rp[2]; Q2 -= P0 * Rp[3];
+      P0 *= rinv; Q0 *= rinv; Q1 *= rinv; Q2 *= rinv;
+    }
+    const double PB[3] = {m00 * P0, m01 * P0, m02 * P0};
+    double QB[3] = {m01 * Q1 + m02 * Q2, m11 * Q1 + m12 * Q2, m12 * Q1 + m22 * Q2};
+    if (RAT) { QB[0] += m00 * Q0; QB[1] += m01 * Q0; QB[2] += m02 * Q0; }
+    double g[3][3], B[3][3];
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
-      const double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
-      g0[t] = a_n * z1; g1[t] = a_x * z0; g2[t] = a_y * z0;
-      if (RAT) {
-        const double n = a_n * z0, sc = wt[t] * Rp[0];
-        g0[t] = sc * (g0[t] - n * Rp[1]); g1[t] = sc * (g1[t] - n * Rp[2]); g2[t] = sc * (g2[t] - n * Rp[3]);
-      }
+      double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
+      if (RAT) { z0 *= wt[t]; z1 *= wt[t]; }
+      g[0][t] = z1 * P0; if (RAT) g[0][t] += z0 * Q0;
+      g[1][t] = z0 * Q1; g[2][t] = z0 * Q2;
+#pragma unroll
+      for (int be = 0; be < 3; ++be) B[be][t] = z1 * PB[be] + z0 * QB[be];
     }
 #pragma unroll
-    for (int be = 0; be < 3; ++be) {
-      const double ma = (be == 0) ? m00 : (be == 1 ? m01 : m02), mb = (be == 0) ? m01 : (be == 1 ? m11 : m12), mc = (be == 0) ? m02 : (be == 1 ? m12 : m22);
-      double B[3];
+    for (int be = 0; be < 3; ++be)
 #pragma unroll
-      for (int t = 0; t < 3; ++t) B[t] = ma * g0[t] + mb * g1[t] + mc * g2[t];
+      for (int ta = 0; ta < 3; ++ta)
 #pragma unroll
-      for (int ta = 0; ta < 3; ++ta) {
-        const double A = (be == 0) ? g0[ta] : (be == 1 ? g1[ta] : g2[ta]);
-#pragma unroll
-        for (int tb = ta; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A, B[tb], acc[ta][tb], 0, 0, 0);
-      }
-    }
+        for (int tb = ta; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[be][ta], B[be][tb], acc[ta][tb], 0, 0, 0);
   }
 }
 
