@@ -46,6 +46,14 @@ constexpr int IGX_NOT_MINE = -12345;    // a dispatch unit's answer for a form o
 // ------------------------------------------------------------------ objects
 struct DevBuf {
   void *p = nullptr; size_t bytes = 0;
+  DevBuf() = default;
+  // owns its allocation: movable, not copyable (a std::vector<DevBuf> that grows must MOVE its elements -- copied, the old elements'
+  // destructors freed the memory the new ones pointed to: the exchange buffers of a rank whose refresh and reduction lists differ in
+  // length, i.e. 4 and 8 ranks with a nonlinear form, before round 4)
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  DevBuf(DevBuf &&o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+  DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { if (p) (void)hipFree(p); p = o.p; bytes = o.bytes; o.p = nullptr; o.bytes = 0; } return *this; }
   ~DevBuf() { if (p) (void)hipFree(p); }
   int alloc(size_t n) { if (p) { (void)hipFree(p); p = nullptr; } bytes = n; if (!n) return 0; return hipMalloc(&p, n) == hipSuccess ? 0 : 1; }
   template <class T> int upload(const std::vector<T> &v) {

@@ -133,7 +133,9 @@ static int ghost_rows(IGX g, IGXMat A, IGXVec b, int k, double *devbuf, bool sen
   if (mode == 0) hipLaunchKernelGGL(k_ghost_rows<0>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
   else if (mode == 1) hipLaunchKernelGGL(k_ghost_rows<1>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
   else hipLaunchKernelGGL(k_ghost_rows<2>, dim3((unsigned)nrows), dim3(256), 0, st, P, bp, vp, xp, devbuf, matd);
-  HIPCK(hipGetLastError());
+  if (hipError_t e_ = hipGetLastError(); e_ != hipSuccess)
+    return fail(IGX_ERR_LIB, std::string("ghost-row kernel (mode ") + std::to_string(mode) + ", entry " + std::to_string(k) + " of the " + (send_list ? "send" : "receive") + " list, peer " + std::to_string(pl.rank) +
+                ", rows " + std::to_string(pl.count[0]) + " x " + std::to_string(pl.count[1]) + " x " + std::to_string(pl.count[2]) + "): " + hipGetErrorString(e_));
   return 0;
 }
 

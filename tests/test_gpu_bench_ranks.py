@@ -14,19 +14,22 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _check_line(r, form, size):
+GRID = {2: [1, 1, 2], 4: [1, 2, 2], 8: [2, 2, 2]}
+
+
+def _check_line(r, form, size, ranks=2):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     assert len(r.stdout.strip().splitlines()) == 1, r.stdout[-2000:]      # stdout carries the line and nothing else (gloo / RCCL notes go to stderr)
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["value"] > 0
+    assert line["n_gpus"] == ranks and line["value"] > 0
     chk = line["config"]["checksum_check"]
     assert chk is not None and chk["size"] == size and max(chk["rel_diff"]) < 1e-9, chk
-    assert line["config"]["partition"] == [1, 1, 2]
-    assert line["config"]["transport"] == "host" and line["config"]["transport_ranks"] == 2 and line["config"]["rccl_ranks"] is None
+    assert line["config"]["partition"] == GRID[ranks]
+    assert line["config"]["transport"] == "host" and line["config"]["transport_ranks"] == ranks and line["config"]["rccl_ranks"] is None
     per_rank = line["roofline_per_rank"]
-    assert [r_["rank"] for r_ in per_rank] == [0, 1] and sum(r_["local_elements"] for r_ in per_rank) == size ** 3
+    assert [r_["rank"] for r_ in per_rank] == list(range(ranks)) and sum(r_["local_elements"] for r_ in per_rank) == size ** 3
     assert all(r_["frac"] is not None and r_["avg_launch_ms"] > 0 for r_ in per_rank)
     assert line["ms_per_step_min"] <= line["ms_per_step_median"] <= line["ms_per_step_max"] and len(line["per_step"]["ms"]) == line["steps"]
 
@@ -40,6 +43,18 @@ def test_bench_two_ranks_checksums(form, size):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--form", form, "--size", str(size), "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     _check_line(r, form, size)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ranks,form,size", [(8, "cahnhilliard", 48), (4, "nsvms", 32), (8, "poisson", 64)])
+def test_bench_four_and_eight_ranks(ranks, form, size):
+    """[1,2,2] and [2,2,2] as processes sharing the one GPU: the ghost refresh of a nonlinear form (its lists differ in length from the
+    reduction's: the exchange buffers of round 3 did not survive that) and the whole N-rank flow of the driver's SCALE run"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(IGX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--form", form, "--size", str(size), "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    _check_line(r, form, size, ranks)
 
 
 @pytest.mark.gpu

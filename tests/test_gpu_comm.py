@@ -62,6 +62,11 @@ def _rank_main(rank, world, port, case, outdir, name=""):
     for i in range(dim):
         g.axis_uniform(i, p, N[i], periodic=bool(periodic[i]))
     g.setup()
+    if "nurbs" in name:        # the same rational control net on every rank (and in the oracle below); a rank keeps its ghosted box
+        from common import make_pair, warped_geometry
+        orc_geo, _ = make_pair(dim, dof, p, list(N), periodic=[bool(x) for x in periodic], engine=False)
+        X, W = warped_geometry(orc_geo, dim, seed=7, rational=True, amp=0.08)
+        g.set_geometry(X, W)
     if form == "poisson" and "loads" in name:
         _poisson_loads(g)
     elif form == "poisson":
@@ -112,7 +117,7 @@ def _rank_main(rank, world, port, case, outdir, name=""):
         # a communicator and upper neighbours: the elements next to the upper face of axis 2 are assembled first (all colours), then
         # those next to the upper face of axis 1, then the last p elements of every remaining pencil (the upper face of axis 0),
         # then the rest: the ghost rows of a face are complete when its pass ends (gram_mfma.hpp: three marks for the exchange)
-        assert "gram_pencil" in g.kernel_name()
+        assert ("state_pencil" if form == "cahnhilliard" else "gram_pencil") in g.kernel_name(), g.kernel_name()
         sz = g.sizes()
         up = [sz["proc_sizes"][d] > 1 and (sz["proc_ranks"][d] < sz["proc_sizes"][d] - 1 or bool(periodic[d])) for d in range(3)]
         n = sz["elem_width"]
@@ -160,6 +165,8 @@ CASES = {
     "poisson-p2-8ranks-pencil-faces": (8, (3, 1, 2, (24, 12, 12), (0, 0, 0), "poisson", ())),  # ... long enough on axis 0 for its face pass: three early phases on rank 0
     "poisson-p3-8ranks-pencil-faces": (8, (3, 1, 3, (24, 16, 16), (0, 0, 0), "poisson", ())),
     "poisson-p3-4ranks-pencil-faces-periodic": (4, (3, 1, 3, (12, 16, 16), (0, 1, 1), "poisson", ())),
+    "poisson-p3-8ranks-pencil-faces-nurbs": (8, (3, 1, 3, (24, 16, 16), (0, 0, 0), "poisson", ())),        # the mapped-geometry walk in three passes
+    "cahnhilliard-p2-8ranks-pencil-faces": (8, (3, 1, 2, (24, 12, 12), (0, 0, 0), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),   # the Tangent's walk
     "poisson-p3-2ranks-pencil": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-rewrite": (2, (3, 1, 3, (8, 9, 17), (0, 0, 0), "poisson", ())),
     "poisson-p3-2ranks-pencil-periodic": (2, (3, 1, 3, (8, 8, 16), (0, 0, 1), "poisson", ())),
@@ -185,6 +192,10 @@ def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
     port = 29600 + (os.getpid() + hash(name)) % 300
     mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name), nprocs=world, join=True)
     orc, _ = make_pair(dim, dof, p, list(N), periodic=[bool(x) for x in periodic], engine=False)
+    if "nurbs" in name:
+        from common import warped_geometry
+        X, W = warped_geometry(orc, dim, seed=7, rational=True, amp=0.08)
+        orc.set_geometry(X, W)
     if form == "poisson" and "loads" in name:
         _poisson_loads(orc)
         A_o, b_o = orc.compute_system("orc_form_poisson")
