@@ -26,8 +26,17 @@ def test_rccl_binding_loopback():
     uid = P.IGX.comm_unique_id()
     assert len(uid) == 128 and any(uid)
     g.comm_init_rccl(uid)
+    assert g.comm_ranks() == ("rccl", 1)          # ncclCommCount of the library's communicator (bench.py prints it as rccl_ranks)
     assert g.comm_loopback_test(1 << 18) == 0.0
+    # a reduction on the one-rank communicator: no neighbours, the three phases are empty groups that are never opened
+    A, b = g.create_mat(), g.create_vec()
+    g.set_form("poisson")
+    g.compute_system(A, b)
+    g.reduce_ghost_rows(A, b)
+    g.synchronize()
+    assert g.comm_early_phases() == 0
     g.comm_destroy()
+    assert g.comm_ranks() == (None, 0)
 
 
 def _poisson_loads(g):
