@@ -1090,6 +1090,21 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
     g->face_done = face_done;
     // the Tangent of a nonlinear scalar form without a geometry walks the same pencils (gram_mfma.hpp: state_pencil)
     PencilModule st; memset(&st.prm, 0, sizeof(st.prm));
+    if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 3 && s.axis[0].p == 2 && s.env.state_pencil && (g->kernel_choice == 0 || g->kernel_choice == 2)) {
+      // ... and on a mapped geometry at p = 2 (state_pencil_geo: the map's second derivatives and the state's in one sum factorisation)
+      if (s.form == IGX_FORM_CAHNHILLIARD) {
+        st.kfn = s.rational ? state_pencil_geo<2, true, FormCahnHilliard<3>> : state_pencil_geo<2, false, FormCahnHilliard<3>>; st.name = "CahnHilliard";
+        st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 9;
+      }
+      if (s.form == IGX_FORM_BRATU) {
+        st.kfn = s.rational ? state_pencil_geo<2, true, FormBratu<3>> : state_pencil_geo<2, false, FormBratu<3>>; st.name = "Bratu";
+        st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 9;
+      }
+      if (st.kfn) {
+        st.state = true; st.state_geo = true; st.extra_lds = pencil_state_bytes() + pencil_sgeo_bytes() - pencil_geo_bytes();
+        for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i];
+      }
+    }
     if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 0 && s.env.state_pencil && (g->kernel_choice == 0 || g->kernel_choice == 2)) {
       const int deg = s.axis[0].p;
       if (s.form == IGX_FORM_CAHNHILLIARD && (deg == 2 || deg == 3)) {

@@ -1129,6 +1129,249 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
   }
 }
 
+// ---- Tangents on a mapped geometry (p = 2; state_pencil_geo below).  The physical features of a basis function R_a = w_a N_a / W at
+// a Gauss point are LINEAR in the parametric derivatives of the polynomial N_a up to the form's order:
+//   R = n / W,   d_i R = sum_b E_bi (n_b - n o_b) / W                    (E = du/dx, o = dW / W: K3 Rationalize + K5 InverseMap)
+//   lap R = [ sum_bg G_bg n_bg + sum_b (b_b - 2 (G o)_b) n_b + (2 o.G o - b.o - G : d2W / W) n ] / W
+// with G = E E^T and b_b = -sum_c E_bc (G : d2 x_c) the Laplacian of the parametric coordinate u_b (the second-order term of the
+// inverse map: src/petigageo.f90.in GeometryMap order 2, petigabsp/petigarat second derivatives); the factor w_a is the lane's.  So the
+// wavefront leaves, per Gauss point, the form's coefficients c (pencil_coef of the PHYSICAL u, grad u, hess u there) and this map
+// (1 + 9 + 3 [+ 6 + 3 + 1] numbers); the MFMA phase folds the map into the x-y part of the lane's tensor product once per point
+// (23 multiply-adds) and finishes each tile slot with the walk-axis row (10), then pencil_trial as on the identity geometry.
+// The sums over the (p+1)^3 control points -- x, y, z, W and w U, ten derivatives each -- are the sum factorisation of
+// pencil_state_eval with the mixed second derivatives added.  Records are packed [27 points][SGEO_NPD] (stride 34 doubles: the four
+// k slots of an MFMA step read four different records, 16-byte aligned and on different banks).
+constexpr int SGEO_NPD = 34, SGEO_Z = 928, SGEO_DOUBLES = SGEO_Z + 32;
+__host__ __device__ static inline size_t pencil_sgeo_bytes() { return (size_t)8 * SGEO_DOUBLES * 8; }
+
+// stage the element's control points in homogeneous form with the state: lane = (aw, ay, ax) -> [lane][5] = (wX, wY, wZ, w, wU)
+template <int P>
+__device__ __forceinline__ void pencil_sgeo_ctrl(double *geo, const SpaceDev &S, int lane, int off0, int offx, int offy, double ucoef, double (&wt)[4]) {
+  constexpr int NB = P + 1;
+  const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+  double c[5] = {0, 0, 0, 0, 0};
+  if (aw < NB && ay < NB && ax < NB) {
+    const size_t g = (size_t)(off0 + aw) + (size_t)S.ax[0].gwidth * ((size_t)(offx + ax) + (size_t)S.ax[1].gwidth * (size_t)(offy + ay));
+    const double w = S.W ? S.W[g] : 1.0;
+    c[0] = S.X[g * 3 + 0] * w; c[1] = S.X[g * 3 + 1] * w; c[2] = S.X[g * 3 + 2] * w; c[3] = w; c[4] = ucoef * w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous element's readers of this area are done
+#pragma unroll
+  for (int k = 0; k < 5; ++k) geo[lane * 5 + k] = c[k];
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wt[t] = geo[((t * 4 + ((lane >> 2) & 3)) * 4 + (lane & 3)) * 5 + 3];
+}
+
+// lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); rows as in pencil_state_eval; on return geo[point * SGEO_NPD + k],
+// point = (qw (P+1) + qy)(P+1) + qx, holds c[0..NC) | 1/W | E_bi / W [b][i] | -(E^T o)_i / W | (LAP:) m_k G_k / W (ww, wx, wy, xx, xy, yy; m = 2 off
+// the diagonal) | (b - 2 G o)_b / W | the coefficient of n
+template <int P, bool RAT, class Form>
+__device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w, int lane, const double *uxr, const double *vyr, const double *ztg,
+                                                 double wj, const double *prm, double shift, double tt, int *errflag) {
+  constexpr int NB = P + 1, NC = Form::PENCIL_NC;
+  constexpr bool LAP = Form::PENCIL_NFEAT > 4;
+  constexpr int ND = LAP ? 10 : 4;
+  static_assert(NC + 13 + (LAP ? 10 : 0) <= SGEO_NPD && NB * NB * NB * SGEO_NPD <= SGEO_Z, "the point records fit their area");
+  double *C0 = geo, *T1 = geo + 320, *T2 = geo + 512;
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  const bool valid = i0 < NB && i1 < NB && i2 < NB;
+  double zv[NB], zd[NB], z2[NB];
+#pragma unroll
+  for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[((i2 & 3) * 4 + aw) * 2 + 0]; zd[aw] = ztg[((i2 & 3) * 4 + aw) * 2 + 1]; z2[aw] = LAP ? d2w[32 + i2 * 4 + aw] : 0.0; }
+  double H[5][ND];      // derivative slots: value, w, x, y, ww, wx, wy, xx, xy, yy (w = the walk axis = parametric axis 0)
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    if (!RAT && c == 3) {
+#pragma unroll
+      for (int k = 0; k < ND; ++k) H[3][k] = k == 0 ? 1.0 : 0.0;
+      continue;
+    }
+    {   // axis X: lane (qx = i0, ay = i1, aw = i2)
+      double tv = 0, td = 0, t2 = 0;
+#pragma unroll
+      for (int ax = 0; ax < NB; ++ax) {
+        const double C = C0[((i2 * 4 + i1) * 4 + ax) * 5 + c];
+        tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1];
+        if (LAP) t2 += C * d2w[i0 * 4 + ax];
+      }
+      T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td;
+      if (LAP) T1[((2 * 4 + i1) * 4 + i2) * 4 + i0] = t2;
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {   // axis Y: lane (qx = i0, qy = i1, aw = i2): (v,v), (d,v), (v,d), (d2,v), (v,d2), (d,d)
+      double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
+#pragma unroll
+      for (int ay = 0; ay < NB; ++ay) {
+        const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0];
+        const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1];
+        m0 += a * yv; m1 += d * yv; m2 += a * yd;
+        if (LAP) { const double e = T1[((2 * 4 + ay) * 4 + i2) * 4 + i0], y2 = d2w[16 + ay * 4 + i1]; m3 += e * yv; m4 += a * y2; m5 += d * yd; }
+      }
+      T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
+      if (LAP) { T2[((3 * 4 + i2) * 4 + i1) * 4 + i0] = m3; T2[((4 * 4 + i2) * 4 + i1) * 4 + i0] = m4; T2[((5 * 4 + i2) * 4 + i1) * 4 + i0] = m5; }
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    {   // walk axis: lane = point (qx = i0, qy = i1, qw = i2)
+      double h[ND];
+#pragma unroll
+      for (int k = 0; k < ND; ++k) h[k] = 0.0;
+#pragma unroll
+      for (int aw = 0; aw < NB; ++aw) {
+        const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
+        h[0] += t0 * zv[aw]; h[1] += t0 * zd[aw]; h[2] += t1 * zv[aw]; h[3] += t2 * zv[aw];
+        if constexpr (LAP) {
+          const double t3 = T2[((3 * 4 + aw) * 4 + i1) * 4 + i0], t4 = T2[((4 * 4 + aw) * 4 + i1) * 4 + i0], t5 = T2[((5 * 4 + aw) * 4 + i1) * 4 + i0];
+          h[4] += t0 * z2[aw]; h[5] += t1 * zd[aw]; h[6] += t2 * zd[aw]; h[7] += t3 * zv[aw]; h[8] += t5 * zv[aw]; h[9] += t4 * zv[aw];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < ND; ++k) H[c][k] = h[k];
+    }
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  }
+  double rec[SGEO_NPD];
+#pragma unroll
+  for (int k = 0; k < SGEO_NPD; ++k) rec[k] = 0.0;
+  if (valid) {
+    constexpr int PB[6] = {0, 0, 0, 1, 1, 2}, PG[6] = {0, 1, 2, 1, 2, 2};
+    const double iw = 1.0 / H[3][0];
+    double o[3], Wh[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int b = 0; b < 3; ++b) o[b] = H[3][1 + b] * iw;
+    if constexpr (LAP) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Wh[k] = H[3][4 + k] * iw;
+    }
+    // the quotient rule on the homogeneous sums: x_c (c = 0..2) and u (slot 3)
+    double val[4], d1[4][3], d2[4][6];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      const int c = cc < 3 ? cc : 4;
+      val[cc] = H[c][0] * iw;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) d1[cc][b] = H[c][1 + b] * iw - val[cc] * o[b];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) d2[cc][k] = LAP ? H[c][LAP ? 4 + k : 0] * iw - d1[cc][PB[k]] * o[PG[k]] - d1[cc][PG[k]] * o[PB[k]] - val[cc] * Wh[k] : 0.0;
+    }
+    const double (&F)[4][3] = d1;     // F[c][b] = dx_c / du_b for c < 3
+    const double det = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) + F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
+    if (!(det > 0.0)) atomicExch(errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+    const double id = 1.0 / det;
+    double E[3][3];     // E[b][c] = du_b / dx_c
+    E[0][0] = (F[1][1] * F[2][2] - F[1][2] * F[2][1]) * id; E[0][1] = (F[0][2] * F[2][1] - F[0][1] * F[2][2]) * id; E[0][2] = (F[0][1] * F[1][2] - F[0][2] * F[1][1]) * id;
+    E[1][0] = (F[1][2] * F[2][0] - F[1][0] * F[2][2]) * id; E[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id; E[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
+    E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
+    // the state in physical derivatives
+    double u = val[3], gu[3], hu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gu[i] = E[0][i] * d1[3][0] + E[1][i] * d1[3][1] + E[2][i] * d1[3][2];
+    double *Lp = rec + NC;
+    Lp[0] = iw;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Lp[1 + b * 3 + i] = iw * E[b][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Lp[10 + i] = -iw * (E[0][i] * o[0] + E[1][i] * o[1] + E[2][i] * o[2]);
+    if constexpr (LAP) {
+      double G[6], v[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        G[k] = E[PB[k]][0] * E[PG[k]][0] + E[PB[k]][1] * E[PG[k]][1] + E[PB[k]][2] * E[PG[k]][2];
+        v[k] = d2[3][k] - gu[0] * d2[0][k] - gu[1] * d2[1][k] - gu[2] * d2[2][k];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += (PB[k] == PG[k] ? 1.0 : 2.0) * E[PB[k]][i] * E[PG[k]][i] * v[k];
+        hu[i * 4] = s;
+      }
+      double q[3], bb[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s += (PB[k] == PG[k] ? 1.0 : 2.0) * G[k] * d2[c][k];
+        q[c] = s;
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) bb[b] = -(E[b][0] * q[0] + E[b][1] * q[1] + E[b][2] * q[2]);
+      const double Go[3] = {G[0] * o[0] + G[1] * o[1] + G[2] * o[2], G[1] * o[0] + G[3] * o[1] + G[4] * o[2], G[2] * o[0] + G[4] * o[1] + G[5] * o[2]};
+      double gw = 0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { Lp[13 + k] = iw * (PB[k] == PG[k] ? 1.0 : 2.0) * G[k]; gw += (PB[k] == PG[k] ? 1.0 : 2.0) * G[k] * Wh[k]; }
+#pragma unroll
+      for (int b = 0; b < 3; ++b) Lp[19 + b] = iw * (bb[b] - 2.0 * Go[b]);
+      Lp[22] = iw * (2.0 * (o[0] * Go[0] + o[1] * Go[1] + o[2] * Go[2]) - (bb[0] * o[0] + bb[1] * o[1] + bb[2] * o[2]) - gw);
+    }
+    PtView p; p.x = val; p.u = &u; p.ut = nullptr; p.gu = gu; p.hu = hu; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
+    p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+    Form::pencil_coef(p, det * wj, rec);
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // every lane has read the partial sums
+  if (valid) {
+    double *out = geo + ((i2 * NB + i1) * NB + i0) * SGEO_NPD;
+#pragma unroll
+    for (int k = 0; k < SGEO_NPD; ++k) out[k] = rec[k];
+  }
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// the MFMAs of one element of a Tangent on a mapped geometry, p = 2: 7 k-steps of 4 points as in pencil_mfma_state_p2
+template <bool RAT, class Form>
+__device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
+                                                         const double *geo, int lane, const double (&wt)[4]) {
+  constexpr int NB = 3, NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+  constexpr bool LAP = NF > 4;
+  const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0, u2 = (on && LAP) ? d2w[qx * 4 + ix] : 0.0;
+    const double vy0 = vyr[(iy * 4 + qy) * 2 + 0], vy1 = vyr[(iy * 4 + qy) * 2 + 1], vy2 = LAP ? d2w[16 + iy * 4 + qy] : 0.0;
+    const double *rp = geo + pc * SGEO_NPD, *Lp = rp + NC;
+    double c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = rp[k];
+    const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
+    const double PN = Lp[0] * a_n;
+    double PG[3], QG[3], PL = 0, QL = 0, RL = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { PG[i] = Lp[10 + i] * a_n + Lp[4 + i] * a_x + Lp[7 + i] * a_y; QG[i] = Lp[1 + i] * a_n; }
+    if constexpr (LAP) {
+      const double a_xx = u2 * vy0, a_xy = u1 * vy1, a_yy = u0 * vy2;
+      PL = Lp[22] * a_n + Lp[20] * a_x + Lp[21] * a_y + Lp[16] * a_xx + Lp[17] * a_xy + Lp[18] * a_yy;
+      QL = Lp[19] * a_n + Lp[14] * a_x + Lp[15] * a_y;
+      RL = Lp[13] * a_n;
+    }
+    double A[NF][NB], B[NB][NF];
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1], z2 = LAP ? d2w[32 + qw * 4 + t] : 0.0;
+      if (RAT) { z0 *= wt[t]; z1 *= wt[t]; z2 *= wt[t]; }
+      A[0][t] = z0 * PN;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) A[1 + i][t] = z0 * PG[i] + z1 * QG[i];
+      double lap = 0.0;
+      if constexpr (LAP) { lap = z0 * PL + z1 * QL + z2 * RL; A[NF - 1][t] = lap; }
+      const double g[3] = {A[1][t], A[2][t], A[3][t]};
+      Form::pencil_trial(c, A[0][t], g, lap, B[t]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int ta = 0; ta < NB; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][ta], B[tb][f], acc[ta][tb], 0, 0, 0);
+  }
+}
+
 // ALIAS: the wrapped walk axis (PencilArgs::alias0) known at compile time -- 0: not wrapped, 1: wrapped, -1: read from the arguments.
 // The identity-geometry Gram instantiations come in both fixed flavours, so the headline kernel carries none of the modulo logic.
 template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1>
@@ -1141,7 +1384,10 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
   constexpr bool STATE = pencil_state_of<Form>::v;             // a Tangent: all tiles, point coefficients from the state (state_pencil)
-  static_assert(!STATE || (IDENT && !SYSTEM), "a Tangent on the walk: no geometry, matrix only");
+  constexpr bool SGEO = STATE && !IDENT;                       // ... on a mapped geometry (p = 2: pencil_sgeo_eval)
+  static_assert(!STATE || !SYSTEM, "a Tangent on the walk: matrix only");
+  static_assert(!SGEO || P == 2, "a Tangent on a mapped geometry: p = 2");
+  constexpr int GZ = SGEO ? SGEO_Z : GEO_Z, GD = SGEO ? SGEO_DOUBLES : GEO_DOUBLES;      // the per-wavefront metric area and the walk-axis rows behind it
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1218,7 +1464,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       }
     }
     if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
-      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P) + pencil_geo_bytes()) + wave * STATE_D2;
+      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P) + (size_t)8 * GD * 8) + wave * STATE_D2;
       if (lane < 16) { const int qq = lane >> 2, aa = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TX[(qq * NB + aa) * NDER + 2] : 0.0; }
       else if (lane < 32) { const int aa = (lane - 16) >> 2, qq = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TY[(qq * NB + aa) * NDER + 2] : 0.0; }
       if (qx < NB && ix < NB) u2 = TX[(qx * NB + ix) * NDER + 2];
@@ -1269,7 +1515,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
   constexpr bool rational = GEO && RAT;
   if constexpr (GEO) {
-    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GEO_DOUBLES;
+    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GD;
     vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + 8 * 32;
     const int gqx = lane & 3, gqy = (lane >> 2) & 3;
     if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
@@ -1289,10 +1535,10 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if constexpr (GEO) {
       // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
       // there stalls the in-order MFMA issue for its whole latency)
-      if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GEO_Z + lane] = (q < NB && a < NB) ? AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
+      if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; geo[GZ + lane] = (q < NB && a < NB) ? AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + k] : 0.0; }
       if constexpr (STATE) { if (lane >= 32 && lane < 48) { const int l2 = lane - 32, q = l2 >> 2, a = l2 & 3; d2w[lane] = (q < NB && a < NB) ? AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + 2] : 0.0; } }
-      if constexpr (!IDENT) pencil_geo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, wt);
-      else { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }     // (the walk-axis rows above)
+      if constexpr (!IDENT && !SGEO) pencil_geo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, wt);
+      else if constexpr (IDENT) { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }     // (the walk-axis rows above)
       const int gqw = lane >> 4;
       if constexpr (STATE) {
         // this lane's node (aw, ay, ax) = (lane>>4, (lane>>2)&3, lane&3): coefficient of U, or the Dirichlet value there
@@ -1305,10 +1551,15 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
           double fv = 0;
           if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = S.fixtable ? S.fixtable[urow] : fv;     // (IGASetFixTable: the value by row)
         }
+        if constexpr (SGEO) {
+          pencil_sgeo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, uc, wt);
+          pencil_sgeo_eval<P, RAT, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
+        } else {
         double xpar[3] = {0, 0, 0};
         const int gqx = lane & 3, gqy = (lane >> 2) & 3;
         if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[ew(ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
-        pencil_state_eval<P, Form>(geo, d2w, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
+        pencil_state_eval<P, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
+        }
       } else
       if constexpr (is_builtin_gram<Form>::v) pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
       else {
@@ -1343,7 +1594,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
-    const double *ztg = geo + GEO_Z;   // GEO: the element's raw walk-axis rows [q][a][2] (staged with its metric)
+    const double *ztg = geo + GZ;   // GEO: the element's raw walk-axis rows [q][a][2] (staged with its metric)
     if (SYSTEM && GEO) {   // F of this element (its point values are in the metric area).  Here, ahead of this wave's own MFMAs and
       // while the partner wavefront is in its memory-bound flush: fp64 VALU work issued next to the PARTNER's MFMA stream waits
       // about one MFMA (64 cycles) per instruction -- in the flush phase these 64 multiply-adds per lane kept the System driver's
@@ -1352,7 +1603,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
       Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
     }
-    if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
+    if constexpr (SGEO) pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane, wt);
+    else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
     else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
@@ -1422,6 +1674,14 @@ state_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
   gram_pencil_body<false, 0, P, true, false, false, Form, true>(S, out, pa, prm.v);
 }
 
+// ... and on a mapped geometry (p = 2: pencil_sgeo_eval / pencil_mfma_state_geo_p2)
+template <int P, bool RAT, class Form>
+__global__ void __launch_bounds__(512, 2)
+state_pencil_geo(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  static_assert(pencil_state_of<Form>::v, "state_pencil_geo: the form declares PENCIL_NFEAT, PENCIL_NC, pencil_coef and pencil_trial");
+  gram_pencil_body<false, 0, P, true, RAT, false, Form, false>(S, out, pa, prm.v);
+}
+
 #ifndef IGX_RTC
 // ------------------------------------------------------------------ dispatch
 
@@ -1445,7 +1705,8 @@ typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
 // one pass of an assembly that comes in several (the elements next to the upper faces first, a mark for the exchange after each):
 // the first-touch rule of axis X (like fty for axis Y), and, when the pass is a part of the walk axis, how its ends join the others
 struct PencilPass { int ftx[3] = {0, 0x7fffffff, 0x7fffffff}; int halo_lo = -1; bool open_hi = false; };
-struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0; };
+struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0;
+                      bool state_geo = false; };      // state_geo: the instantiation is state_pencil_geo (evaluates the geometry itself)
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 // a launch that could not be made (the LDS of the chosen segments beyond the device's, a module launch refused): try_gram_mfma
@@ -1727,7 +1988,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   if (s.dim != 3 || s.dof != 1) return no("needs dim=3, dof=1");
   const bool geo = s.nsd != 0;
   if (geo && s.nsd != 3) return no("mapped geometry of another dimension");
-  if (state && geo) return no("a Tangent on the walk needs the identity geometry");
+  if (state && geo != mod->state_geo) return no("a Tangent on a mapped geometry takes the walk at p = 2 only");
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) if (s.visit[a][sd]) return no("boundary-form passes");
   const int deg = s.axis[0].p;
   if (deg != 2 && deg != 3) return no("needs p=2 or p=3");

@@ -78,6 +78,11 @@ if "c3" in which:
 if "c4" in which:
     h2 = 1.0 / (3 * 128 * 128)
     run("CahnHilliard3D p=2 128^3 tangent (config 4 is 256^3)", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian")
+if "c4g" in which:
+    h2 = 1.0 / (3 * 128 * 128)
+    run("CahnHilliard3D p=2 128^3 tangent on a NURBS geometry", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian", geo=True)
+    run("CahnHilliard3D p=2 128^3 tangent on a polynomial geometry", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian", geo="poly")
+    run("CahnHilliard3D p=2 128^3 residual on a NURBS geometry", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ifunction", geo=True)
 if "c4r" in which:
     h2 = 1.0 / (3 * 128 * 128)
     run("CahnHilliard3D p=2 128^3 residual", 3, 1, 2, (128,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ifunction")

@@ -96,17 +96,64 @@ def test_bratu_jacobian_vs_oracle(p, N, periodic, driver):
     compare_mats(J, J_o, 1e-12)
 
 
+@pytest.mark.parametrize("form,N,periodic,rational,bc,nseg,amp", [
+    ("ch", (9, 4, 5), (False, False, False), False, False, 0, 0.05),     # a polynomial map
+    ("ch", (9, 4, 5), (False, False, False), True, False, 0, 0.05),      # NURBS: the weights enter the second derivatives (Rationalize at order 2)
+    ("ch", (12, 3, 4), (False, False, False), True, True, 0, 0.08),      # Dirichlet values on four faces
+    ("ch", (17, 4, 3), (False, False, False), True, True, 3, 0.05),      # three segments along the walk
+    ("ch", (8, 5, 6), (False, False, False), False, False, 0, 0.0),      # the identity map given as a geometry (Greville net)
+    ("bratu", (9, 5, 4), (False, False, False), True, True, 0, 0.06),    # a first-order form: no second derivatives summed
+    ("bratu", (11, 4, 6), (False, False, False), False, True, 2, 0.06),
+])
+def test_tangent_on_a_mapped_geometry_vs_oracle(form, N, periodic, rational, bc, nseg, amp, monkeypatch):
+    """state_pencil_geo (p = 2): the Tangent on a mapped geometry -- the physical gradient and Laplacian of the basis functions and of
+    the state need the second derivatives of the map (and of the NURBS weight function): IGAElement's shape functions at order 2,
+    src/petigageo.f90.in + src/petigarat.f90.in.  Engine vs oracle on the same warped net, 1e-10 of max|K|."""
+    from common import warped_geometry
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 1, 2, list(N), periodic=list(periodic))
+    X, W = warped_geometry(orc, 3, seed=6, rational=rational, amp=amp)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    if bc:
+        for g in (orc, eng):
+            g.set_boundary_value(0, 0, 0, 0.6); g.set_boundary_value(0, 1, 0, 0.66)
+            g.set_boundary_value(1, 1, 0, 0.61); g.set_boundary_value(2, 0, 0, 0.65)
+    rng = np.random.default_rng(13)
+    n = orc.global_size()
+    V = rng.standard_normal(n)
+    if form == "ch":
+        U = 0.63 + 0.05 * (2 * rng.random(n) - 1)
+        eng.set_form("cahnhilliard", CH)
+        J_o = orc.compute_ijacobian("orc_form_ch_tangent", O.CahnHilliardCtx(*CH), 250.0, V, 0.0, U)
+    else:
+        U = 0.3 * rng.standard_normal(n)
+        eng.set_form("bratu", (3.5,))
+        J_o = orc.compute_ijacobian("orc_form_bratu_ijacobian", C.c_double(3.5), 250.0, V, 0.0, U)
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    _poison(J)
+    eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "state_pencil<" in eng.kernel_name() and "mapped geometry" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-10)
+    vals = J.to_coo_global()[2]
+    _poison(J)
+    eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J)
+    assert np.array_equal(J.to_coo_global()[2], vals)
+
+
 def test_switch_and_fallbacks(monkeypatch):
-    """IGX_STATE_PENCIL=0, a short walk axis and a mapped geometry keep the feature kernel"""
+    """IGX_STATE_PENCIL=0, a short walk axis and a mapped geometry at p = 3 keep the feature kernel"""
     from common import warped_geometry
     ctx = O.CahnHilliardCtx(*CH)
-    for tag, N, periodic, env, geo in (("off", (9, 4, 4), (False,) * 3, "0", False), ("short", (5, 4, 4), (False,) * 3, None, False),
-                                       ("short wrapped", (7, 5, 5), (True, False, False), None, False), ("mapped", (9, 4, 4), (False,) * 3, None, True)):
+    for tag, N, periodic, env, geo, p in (("off", (9, 4, 4), (False,) * 3, "0", False, 2), ("short", (5, 4, 4), (False,) * 3, None, False, 2),
+                                          ("short wrapped", (7, 5, 5), (True, False, False), None, False, 2), ("mapped", (9, 4, 4), (False,) * 3, None, True, 3),
+                                          ("mapped, off", (9, 4, 4), (False,) * 3, "0", True, 2)):
         if env is None:
             monkeypatch.delenv("IGX_STATE_PENCIL", raising=False)
         else:
             monkeypatch.setenv("IGX_STATE_PENCIL", env)
-        orc, eng = make_pair(3, 1, 2, list(N), periodic=list(periodic))
+        orc, eng = make_pair(3, 1, p, list(N), periodic=list(periodic))
         if geo:
             X, W = warped_geometry(orc, 3, seed=4, rational=False, amp=0.05)
             orc.set_geometry(X, W); eng.set_geometry(X, W)
