@@ -1141,77 +1141,89 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
 // The sums over the (p+1)^3 control points -- x, y, z, W and w U, ten derivatives each -- are the sum factorisation of
 // pencil_state_eval with the mixed second derivatives added.  Records are packed [27 points][SGEO_NPD] (stride 34 doubles: the four
 // k slots of an MFMA step read four different records, 16-byte aligned and on different banks).
-constexpr int SGEO_NPD = 34, SGEO_Z = 928, SGEO_DOUBLES = SGEO_Z + 32;
+constexpr int SGEO_NPD = 34, SGEO_Z = 1216, SGEO_DOUBLES = SGEO_Z + 32 + 32;      // records / scratch | walk-axis rows [32] | NURBS weights of the element's nodes [27]
 __host__ __device__ static inline size_t pencil_sgeo_bytes() { return (size_t)8 * SGEO_DOUBLES * 8; }
 
-// stage the element's control points in homogeneous form with the state: lane = (aw, ay, ax) -> [lane][5] = (wX, wY, wZ, w, wU)
+// stage the element's control points in homogeneous form with the state: lane = (aw, ay, ax) -> [node][5] = (wX, wY, wZ, w, wU),
+// node = (aw (P+1) + ay)(P+1) + ax (packed: the scratch of the sums and the parked second derivatives share the area, see below)
 template <int P>
-__device__ __forceinline__ void pencil_sgeo_ctrl(double *geo, const SpaceDev &S, int lane, int off0, int offx, int offy, double ucoef, double (&wt)[4]) {
+__device__ __forceinline__ void pencil_sgeo_ctrl(double *geo, const SpaceDev &S, int lane, int off0, int offx, int offy, double ucoef) {
   constexpr int NB = P + 1;
   const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
+  const bool valid = aw < NB && ay < NB && ax < NB;
   double c[5] = {0, 0, 0, 0, 0};
-  if (aw < NB && ay < NB && ax < NB) {
+  if (valid) {
     const size_t g = (size_t)(off0 + aw) + (size_t)S.ax[0].gwidth * ((size_t)(offx + ax) + (size_t)S.ax[1].gwidth * (size_t)(offy + ay));
     const double w = S.W ? S.W[g] : 1.0;
     c[0] = S.X[g * 3 + 0] * w; c[1] = S.X[g * 3 + 1] * w; c[2] = S.X[g * 3 + 2] * w; c[3] = w; c[4] = ucoef * w;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous element's readers of this area are done
+  if (valid) {
 #pragma unroll
-  for (int k = 0; k < 5; ++k) geo[lane * 5 + k] = c[k];
+    for (int k = 0; k < 5; ++k) geo[((aw * NB + ay) * NB + ax) * 5 + k] = c[k];
+    geo[SGEO_Z + 32 + (aw * NB + ay) * NB + ax] = c[3];      // (the MFMA phase reads the weight of its lane's basis functions from here)
+  }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-#pragma unroll
-  for (int t = 0; t < 4; ++t) wt[t] = geo[((t * 4 + ((lane >> 2) & 3)) * 4 + (lane & 3)) * 5 + 3];
 }
 
 // lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); rows as in pencil_state_eval; on return geo[point * SGEO_NPD + k],
 // point = (qw (P+1) + qy)(P+1) + qx, holds c[0..NC) | 1/W | E_bi / W [b][i] | -(E^T o)_i / W | (LAP:) m_k G_k / W (ww, wx, wy, xx, xy, yy; m = 2 off
-// the diagonal) | (b - 2 G o)_b / W | the coefficient of n
+// the diagonal) | (b - 2 G o)_b / W | the coefficient of n.
+// Scratch, packed by the (P+1)^3 valid lanes: control points [node][5] | T1 [3][ay][aw][qx] | T2 [6][aw][qy][qx] | the raw second
+// derivatives parked per point [5][6] (in registers the 50 sums of a point next to the walk's accumulators spilled 219 VGPRs)
 template <int P, bool RAT, class Form>
-__device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w, int lane, const double *uxr, const double *vyr, const double *ztg,
+__device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w_, int lane, const double *uxr_, const double *vyr_, const double *ztg_,
                                                  double wj, const double *prm, double shift, double tt, int *errflag) {
-  constexpr int NB = P + 1, NC = Form::PENCIL_NC;
+  constexpr int NB = P + 1, NC = Form::PENCIL_NC, N3 = NB * NB * NB;
   constexpr bool LAP = Form::PENCIL_NFEAT > 4;
   constexpr int ND = LAP ? 10 : 4;
-  static_assert(NC + 13 + (LAP ? 10 : 0) <= SGEO_NPD && NB * NB * NB * SGEO_NPD <= SGEO_Z, "the point records fit their area");
-  double *C0 = geo, *T1 = geo + 320, *T2 = geo + 512;
+  constexpr int OT1 = (N3 * 5 + 1) & ~1, OT2 = (OT1 + 3 * N3 + 1) & ~1, OPK = (OT2 + 6 * N3 + 1) & ~1;
+  static_assert(NC + 13 + (LAP ? 10 : 0) <= SGEO_NPD && N3 * SGEO_NPD <= SGEO_Z && OPK + 30 * N3 <= SGEO_Z, "the point records and the scratch fit the area");
+  double *C0 = geo, *T1 = geo + OT1, *T2 = geo + OT2, *PK = geo + OPK;
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
   const bool valid = i0 < NB && i1 < NB && i2 < NB;
-  double zv[NB], zd[NB], z2[NB];
+  const int j0 = min(i0, NB - 1), j1 = min(i1, NB - 1), j2 = min(i2, NB - 1);      // (padding lanes read in bounds, write nothing)
+  const int pt = (j2 * NB + j1) * NB + j0;
+  // derivative slots: value, w, x, y, ww, wx, wy, xx, xy, yy (w = the walk axis = parametric axis 0); the six second derivatives of the
+  // five components are parked in LDS [point][component][6]
+  double Hx[5][4];
 #pragma unroll
-  for (int aw = 0; aw < NB; ++aw) { zv[aw] = ztg[((i2 & 3) * 4 + aw) * 2 + 0]; zd[aw] = ztg[((i2 & 3) * 4 + aw) * 2 + 1]; z2[aw] = LAP ? d2w[32 + i2 * 4 + aw] : 0.0; }
-  double H[5][ND];      // derivative slots: value, w, x, y, ww, wx, wy, xx, xy, yy (w = the walk axis = parametric axis 0)
+  for (int k = 0; k < 4; ++k) Hx[3][k] = k == 0 ? 1.0 : 0.0;
 #pragma unroll
   for (int c = 0; c < 5; ++c) {
-    if (!RAT && c == 3) {
-#pragma unroll
-      for (int k = 0; k < ND; ++k) H[3][k] = k == 0 ? 1.0 : 0.0;
-      continue;
-    }
+    if (!RAT && c == 3) continue;
+    // (the 1-D rows are re-read per component: hoisted out of this loop they hold 54 VGPRs next to the walk's accumulators)
+    int keep = 0; asm volatile("" : "+v"(keep));
+    const double *uxr = uxr_ + keep, *vyr = vyr_ + keep, *ztg = ztg_ + keep, *d2w = d2w_ + keep;
     {   // axis X: lane (qx = i0, ay = i1, aw = i2)
       double tv = 0, td = 0, t2 = 0;
 #pragma unroll
       for (int ax = 0; ax < NB; ++ax) {
-        const double C = C0[((i2 * 4 + i1) * 4 + ax) * 5 + c];
+        const double C = C0[((j2 * NB + j1) * NB + ax) * 5 + c];
         tv += C * uxr[(i0 * 4 + ax) * 2 + 0]; td += C * uxr[(i0 * 4 + ax) * 2 + 1];
         if (LAP) t2 += C * d2w[i0 * 4 + ax];
       }
-      T1[((0 * 4 + i1) * 4 + i2) * 4 + i0] = tv; T1[((1 * 4 + i1) * 4 + i2) * 4 + i0] = td;
-      if (LAP) T1[((2 * 4 + i1) * 4 + i2) * 4 + i0] = t2;
+      if (valid) {
+        T1[((0 * NB + j1) * NB + j2) * NB + j0] = tv; T1[((1 * NB + j1) * NB + j2) * NB + j0] = td;
+        if (LAP) T1[((2 * NB + j1) * NB + j2) * NB + j0] = t2;
+      }
     }
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     {   // axis Y: lane (qx = i0, qy = i1, aw = i2): (v,v), (d,v), (v,d), (d2,v), (v,d2), (d,d)
       double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0;
 #pragma unroll
       for (int ay = 0; ay < NB; ++ay) {
-        const double a = T1[((0 * 4 + ay) * 4 + i2) * 4 + i0], d = T1[((1 * 4 + ay) * 4 + i2) * 4 + i0];
+        const double a = T1[((0 * NB + ay) * NB + j2) * NB + j0], d = T1[((1 * NB + ay) * NB + j2) * NB + j0];
         const double yv = vyr[(ay * 4 + i1) * 2 + 0], yd = vyr[(ay * 4 + i1) * 2 + 1];
         m0 += a * yv; m1 += d * yv; m2 += a * yd;
-        if (LAP) { const double e = T1[((2 * 4 + ay) * 4 + i2) * 4 + i0], y2 = d2w[16 + ay * 4 + i1]; m3 += e * yv; m4 += a * y2; m5 += d * yd; }
+        if (LAP) { const double e = T1[((2 * NB + ay) * NB + j2) * NB + j0], y2 = d2w[16 + ay * 4 + i1]; m3 += e * yv; m4 += a * y2; m5 += d * yd; }
       }
-      T2[((0 * 4 + i2) * 4 + i1) * 4 + i0] = m0; T2[((1 * 4 + i2) * 4 + i1) * 4 + i0] = m1; T2[((2 * 4 + i2) * 4 + i1) * 4 + i0] = m2;
-      if (LAP) { T2[((3 * 4 + i2) * 4 + i1) * 4 + i0] = m3; T2[((4 * 4 + i2) * 4 + i1) * 4 + i0] = m4; T2[((5 * 4 + i2) * 4 + i1) * 4 + i0] = m5; }
+      if (valid) {
+        T2[((0 * NB + j2) * NB + j1) * NB + j0] = m0; T2[((1 * NB + j2) * NB + j1) * NB + j0] = m1; T2[((2 * NB + j2) * NB + j1) * NB + j0] = m2;
+        if (LAP) { T2[((3 * NB + j2) * NB + j1) * NB + j0] = m3; T2[((4 * NB + j2) * NB + j1) * NB + j0] = m4; T2[((5 * NB + j2) * NB + j1) * NB + j0] = m5; }
+      }
     }
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     {   // walk axis: lane = point (qx = i0, qy = i1, qw = i2)
@@ -1220,43 +1232,51 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w,
       for (int k = 0; k < ND; ++k) h[k] = 0.0;
 #pragma unroll
       for (int aw = 0; aw < NB; ++aw) {
-        const double t0 = T2[((0 * 4 + aw) * 4 + i1) * 4 + i0], t1 = T2[((1 * 4 + aw) * 4 + i1) * 4 + i0], t2 = T2[((2 * 4 + aw) * 4 + i1) * 4 + i0];
-        h[0] += t0 * zv[aw]; h[1] += t0 * zd[aw]; h[2] += t1 * zv[aw]; h[3] += t2 * zv[aw];
+        const double zv = ztg[(i2 * 4 + aw) * 2 + 0], zd = ztg[(i2 * 4 + aw) * 2 + 1];
+        const double t0 = T2[((0 * NB + aw) * NB + j1) * NB + j0], t1 = T2[((1 * NB + aw) * NB + j1) * NB + j0], t2 = T2[((2 * NB + aw) * NB + j1) * NB + j0];
+        h[0] += t0 * zv; h[1] += t0 * zd; h[2] += t1 * zv; h[3] += t2 * zv;
         if constexpr (LAP) {
-          const double t3 = T2[((3 * 4 + aw) * 4 + i1) * 4 + i0], t4 = T2[((4 * 4 + aw) * 4 + i1) * 4 + i0], t5 = T2[((5 * 4 + aw) * 4 + i1) * 4 + i0];
-          h[4] += t0 * z2[aw]; h[5] += t1 * zd[aw]; h[6] += t2 * zd[aw]; h[7] += t3 * zv[aw]; h[8] += t5 * zv[aw]; h[9] += t4 * zv[aw];
+          const double z2 = d2w[32 + i2 * 4 + aw];
+          const double t3 = T2[((3 * NB + aw) * NB + j1) * NB + j0], t4 = T2[((4 * NB + aw) * NB + j1) * NB + j0], t5 = T2[((5 * NB + aw) * NB + j1) * NB + j0];
+          h[4] += t0 * z2; h[5] += t1 * zd; h[6] += t2 * zd; h[7] += t3 * zv; h[8] += t5 * zv; h[9] += t4 * zv;
         }
       }
 #pragma unroll
-      for (int k = 0; k < ND; ++k) H[c][k] = h[k];
+      for (int k = 0; k < 4; ++k) Hx[c][k] = h[k];
+      if constexpr (LAP) {
+        if (valid) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) PK[pt * 30 + c * 6 + k] = h[4 + k];      // (read back by this lane only)
+        }
+      }
     }
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  double rec[SGEO_NPD];
-#pragma unroll
-  for (int k = 0; k < SGEO_NPD; ++k) rec[k] = 0.0;
+  // (every lane is past the sums: the scratch is dead but for the parked values, which their own lane reads before it stores the
+  //  part of its record that follows from them -- program order within the wavefront)
   if (valid) {
     constexpr int PB[6] = {0, 0, 0, 1, 1, 2}, PG[6] = {0, 1, 2, 1, 2, 2};
-    const double iw = 1.0 / H[3][0];
+    double *rec = geo + pt * SGEO_NPD, *Lp = rec + NC;
+    const double (&Hw)[4] = Hx[3], (&Hu)[4] = Hx[4];
+    const double iw = 1.0 / Hw[0];
     double o[3], Wh[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int b = 0; b < 3; ++b) o[b] = H[3][1 + b] * iw;
+    for (int b = 0; b < 3; ++b) o[b] = Hw[1 + b] * iw;
     if constexpr (LAP) {
 #pragma unroll
-      for (int k = 0; k < 6; ++k) Wh[k] = H[3][4 + k] * iw;
+      for (int k = 0; k < 6; ++k) Wh[k] = RAT ? PK[pt * 30 + 3 * 6 + k] * iw : 0.0;
     }
-    // the quotient rule on the homogeneous sums: x_c (c = 0..2) and u (slot 3)
-    double val[4], d1[4][3], d2[4][6];
+    // the quotient rule on the homogeneous sums: x_c (c = 0..2) and u
+    double xv[3], F[3][3], u, du[3];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      const int c = cc < 3 ? cc : 4;
-      val[cc] = H[c][0] * iw;
+    for (int c = 0; c < 3; ++c) {
+      xv[c] = Hx[c][0] * iw;
 #pragma unroll
-      for (int b = 0; b < 3; ++b) d1[cc][b] = H[c][1 + b] * iw - val[cc] * o[b];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) d2[cc][k] = LAP ? H[c][LAP ? 4 + k : 0] * iw - d1[cc][PB[k]] * o[PG[k]] - d1[cc][PG[k]] * o[PB[k]] - val[cc] * Wh[k] : 0.0;
+      for (int b = 0; b < 3; ++b) F[c][b] = Hx[c][1 + b] * iw - xv[c] * o[b];      // F[c][b] = dx_c / du_b
     }
-    const double (&F)[4][3] = d1;     // F[c][b] = dx_c / du_b for c < 3
+    u = Hu[0] * iw;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) du[b] = Hu[1 + b] * iw - u * o[b];
     const double det = F[0][0] * (F[1][1] * F[2][2] - F[1][2] * F[2][1]) - F[0][1] * (F[1][0] * F[2][2] - F[1][2] * F[2][0]) + F[0][2] * (F[1][0] * F[2][1] - F[1][1] * F[2][0]);
     if (!(det > 0.0)) atomicExch(errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
     const double id = 1.0 / det;
@@ -1265,23 +1285,28 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w,
     E[1][0] = (F[1][2] * F[2][0] - F[1][0] * F[2][2]) * id; E[1][1] = (F[0][0] * F[2][2] - F[0][2] * F[2][0]) * id; E[1][2] = (F[0][2] * F[1][0] - F[0][0] * F[1][2]) * id;
     E[2][0] = (F[1][0] * F[2][1] - F[1][1] * F[2][0]) * id; E[2][1] = (F[0][1] * F[2][0] - F[0][0] * F[2][1]) * id; E[2][2] = (F[0][0] * F[1][1] - F[0][1] * F[1][0]) * id;
     // the state in physical derivatives
-    double u = val[3], gu[3], hu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double gu[3], hu[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-    for (int i = 0; i < 3; ++i) gu[i] = E[0][i] * d1[3][0] + E[1][i] * d1[3][1] + E[2][i] * d1[3][2];
-    double *Lp = rec + NC;
-    Lp[0] = iw;
-#pragma unroll
-    for (int b = 0; b < 3; ++b)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) Lp[1 + b * 3 + i] = iw * E[b][i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) Lp[10 + i] = -iw * (E[0][i] * o[0] + E[1][i] * o[1] + E[2][i] * o[2]);
+    for (int i = 0; i < 3; ++i) gu[i] = E[0][i] * du[0] + E[1][i] * du[1] + E[2][i] * du[2];
+    double G[6], Go[3] = {0, 0, 0}, bb[3] = {0, 0, 0}, gw = 0;
     if constexpr (LAP) {
-      double G[6], v[6];
+      double v[6];      // G = E E^T (m_k G_k below); v_k = u_,k - sum_c (d_c u) x_c,k: hess u = E^T v E
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
-        G[k] = E[PB[k]][0] * E[PG[k]][0] + E[PB[k]][1] * E[PG[k]][1] + E[PB[k]][2] * E[PG[k]][2];
-        v[k] = d2[3][k] - gu[0] * d2[0][k] - gu[1] * d2[1][k] - gu[2] * d2[2][k];
+        G[k] = (PB[k] == PG[k] ? 1.0 : 2.0) * (E[PB[k]][0] * E[PG[k]][0] + E[PB[k]][1] * E[PG[k]][1] + E[PB[k]][2] * E[PG[k]][2]);
+        v[k] = PK[pt * 30 + 4 * 6 + k] * iw - du[PB[k]] * o[PG[k]] - du[PG[k]] * o[PB[k]] - u * Wh[k];
+        gw += G[k] * Wh[k];
+      }
+      double q[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          const double xk = PK[pt * 30 + c * 6 + k] * iw - F[c][PB[k]] * o[PG[k]] - F[c][PG[k]] * o[PB[k]] - xv[c] * Wh[k];      // x_c,k
+          s += G[k] * xk; v[k] -= gu[c] * xk;
+        }
+        q[c] = s;
       }
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
@@ -1290,33 +1315,34 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w,
         for (int k = 0; k < 6; ++k) s += (PB[k] == PG[k] ? 1.0 : 2.0) * E[PB[k]][i] * E[PG[k]][i] * v[k];
         hu[i * 4] = s;
       }
-      double q[3], bb[3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        double s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) s += (PB[k] == PG[k] ? 1.0 : 2.0) * G[k] * d2[c][k];
-        q[c] = s;
-      }
 #pragma unroll
       for (int b = 0; b < 3; ++b) bb[b] = -(E[b][0] * q[0] + E[b][1] * q[1] + E[b][2] * q[2]);
-      const double Go[3] = {G[0] * o[0] + G[1] * o[1] + G[2] * o[2], G[1] * o[0] + G[3] * o[1] + G[4] * o[2], G[2] * o[0] + G[4] * o[1] + G[5] * o[2]};
-      double gw = 0;
+      // (G o)_b with the doubled off-diagonal entries halved again
+      Go[0] = G[0] * o[0] + 0.5 * (G[1] * o[1] + G[2] * o[2]); Go[1] = 0.5 * G[1] * o[0] + G[3] * o[1] + 0.5 * G[4] * o[2]; Go[2] = 0.5 * (G[2] * o[0] + G[4] * o[1]) + G[5] * o[2];
+    }
+    // ---- the record (the parked values have been read)
+    {
+      double c[NC];
+      PtView p; p.x = xv; p.u = &u; p.ut = nullptr; p.gu = gu; p.hu = hu; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
+      p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+      Form::pencil_coef(p, det * wj, c);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { Lp[13 + k] = iw * (PB[k] == PG[k] ? 1.0 : 2.0) * G[k]; gw += (PB[k] == PG[k] ? 1.0 : 2.0) * G[k] * Wh[k]; }
+      for (int k = 0; k < NC; ++k) rec[k] = c[k];
+    }
+    Lp[0] = iw;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) Lp[1 + b * 3 + i] = iw * E[b][i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) Lp[10 + i] = -iw * (E[0][i] * o[0] + E[1][i] * o[1] + E[2][i] * o[2]);
+    if constexpr (LAP) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) Lp[13 + k] = iw * G[k];
 #pragma unroll
       for (int b = 0; b < 3; ++b) Lp[19 + b] = iw * (bb[b] - 2.0 * Go[b]);
       Lp[22] = iw * (2.0 * (o[0] * Go[0] + o[1] * Go[1] + o[2] * Go[2]) - (bb[0] * o[0] + bb[1] * o[1] + bb[2] * o[2]) - gw);
     }
-    PtView p; p.x = val; p.u = &u; p.ut = nullptr; p.gu = gu; p.hu = hu; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
-    p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
-    Form::pencil_coef(p, det * wj, rec);
-  }
-  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // every lane has read the partial sums
-  if (valid) {
-    double *out = geo + ((i2 * NB + i1) * NB + i0) * SGEO_NPD;
-#pragma unroll
-    for (int k = 0; k < SGEO_NPD; ++k) out[k] = rec[k];
   }
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -1324,11 +1350,12 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w,
 // the MFMAs of one element of a Tangent on a mapped geometry, p = 2: 7 k-steps of 4 points as in pencil_mfma_state_p2
 template <bool RAT, class Form>
 __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
-                                                         const double *geo, int lane, const double (&wt)[4]) {
+                                                         const double *geo, int lane) {
   constexpr int NB = 3, NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
-#pragma unroll
+  const double *wl = ztg + 32 + min(iy, NB - 1) * NB + min(ix, NB - 1);      // NURBS weights [t][iy][ix] (a padding lane's operands are zero: any finite weight)
+#pragma unroll 1
   for (int j = 0; j < 7; ++j) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
@@ -1354,7 +1381,7 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
       double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1], z2 = LAP ? d2w[32 + qw * 4 + t] : 0.0;
-      if (RAT) { z0 *= wt[t]; z1 *= wt[t]; z2 *= wt[t]; }
+      if (RAT) { const double w = wl[t * NB * NB]; z0 *= w; z1 *= w; z2 *= w; }
       A[0][t] = z0 * PN;
 #pragma unroll
       for (int i = 0; i < 3; ++i) A[1 + i][t] = z0 * PG[i] + z1 * QG[i];
@@ -1552,7 +1579,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
           if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = S.fixtable ? S.fixtable[urow] : fv;     // (IGASetFixTable: the value by row)
         }
         if constexpr (SGEO) {
-          pencil_sgeo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, uc, wt);
+          pencil_sgeo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, uc);
           pencil_sgeo_eval<P, RAT, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
         } else {
         double xpar[3] = {0, 0, 0};
@@ -1603,7 +1630,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
       Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
     }
-    if constexpr (SGEO) pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane, wt);
+    if constexpr (SGEO) pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
