@@ -1168,27 +1168,28 @@ __device__ __forceinline__ void pencil_sgeo_ctrl(double *geo, const SpaceDev &S,
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// lane = Gauss point (qx, qy, qw) = (lane&3, (lane>>2)&3, lane>>4); rows as in pencil_state_eval; on return geo[point * SGEO_NPD + k],
-// point = (qw (P+1) + qy)(P+1) + qx, holds c[0..NC) | 1/W | E_bi / W [b][i] | -(E^T o)_i / W | (LAP:) m_k G_k / W (ww, wx, wy, xx, xy, yy; m = 2 off
-// the diagonal) | (b - 2 G o)_b / W | the coefficient of n.
-// Scratch, packed by the (P+1)^3 valid lanes: control points [node][5] | T1 [3][ay][aw][qx] | T2 [6][aw][qy][qx] | the raw second
-// derivatives parked per point [5][6] (in registers the 50 sums of a point next to the walk's accumulators spilled 219 VGPRs)
+// The sums (flush phase of the previous element: LDS exchanges, 57 multiply-adds per component).  lane = Gauss point (qx, qy, qw) =
+// (lane&3, (lane>>2)&3, lane>>4); rows as in pencil_state_eval.  Scratch, packed by the (P+1)^3 valid lanes: control points [node][5] |
+// T1 [3][ay][aw][qx] | T2 [6][aw][qy][qx] | the raw second derivatives parked per point [5][6] (in registers the 50 sums of a point
+// next to the walk's accumulators spilled 219 VGPRs).  Hx[component][value, d_w, d_x, d_y] stays in registers.
+template <int P, bool LAP> struct SgeoLayout {
+  static constexpr int NB = P + 1, N3 = NB * NB * NB;
+  static constexpr int OT1 = (N3 * 5 + 1) & ~1, OT2 = (OT1 + 3 * N3 + 1) & ~1, OPK = (OT2 + 6 * N3 + 1) & ~1;
+  static_assert(N3 * SGEO_NPD <= SGEO_Z && OPK + 30 * N3 <= SGEO_Z, "the point records and the scratch fit the area");
+};
 template <int P, bool RAT, class Form>
-__device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w_, int lane, const double *uxr_, const double *vyr_, const double *ztg_,
-                                                 double wj, const double *prm, double shift, double tt, int *errflag) {
-  constexpr int NB = P + 1, NC = Form::PENCIL_NC, N3 = NB * NB * NB;
+__device__ __forceinline__ void pencil_sgeo_sums(double *geo, const double *d2w_, int lane, const double *uxr_, const double *vyr_, const double *ztg_, double (&Hx)[5][4]) {
+  constexpr int NB = P + 1;
   constexpr bool LAP = Form::PENCIL_NFEAT > 4;
   constexpr int ND = LAP ? 10 : 4;
-  constexpr int OT1 = (N3 * 5 + 1) & ~1, OT2 = (OT1 + 3 * N3 + 1) & ~1, OPK = (OT2 + 6 * N3 + 1) & ~1;
-  static_assert(NC + 13 + (LAP ? 10 : 0) <= SGEO_NPD && N3 * SGEO_NPD <= SGEO_Z && OPK + 30 * N3 <= SGEO_Z, "the point records and the scratch fit the area");
-  double *C0 = geo, *T1 = geo + OT1, *T2 = geo + OT2, *PK = geo + OPK;
+  using LY = SgeoLayout<P, LAP>;
+  double *C0 = geo, *T1 = geo + LY::OT1, *T2 = geo + LY::OT2, *PK = geo + LY::OPK;
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
   const bool valid = i0 < NB && i1 < NB && i2 < NB;
   const int j0 = min(i0, NB - 1), j1 = min(i1, NB - 1), j2 = min(i2, NB - 1);      // (padding lanes read in bounds, write nothing)
   const int pt = (j2 * NB + j1) * NB + j0;
   // derivative slots: value, w, x, y, ww, wx, wy, xx, xy, yy (w = the walk axis = parametric axis 0); the six second derivatives of the
   // five components are parked in LDS [point][component][6]
-  double Hx[5][4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) Hx[3][k] = k == 0 ? 1.0 : 0.0;
 #pragma unroll
@@ -1252,8 +1253,23 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w_
     }
     __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
-  // (every lane is past the sums: the scratch is dead but for the parked values, which their own lane reads before it stores the
-  //  part of its record that follows from them -- program order within the wavefront)
+}
+
+// The point's record from its sums (at the start of the element's own MFMA phase: 450 fp64 operations per lane, which next to the
+// partner wavefront's MFMA stream -- in the flush phase -- wait for the shared FP64 pipe, ~25 cycles each).  On return
+// geo[point * SGEO_NPD + k], point = (qw (P+1) + qy)(P+1) + qx, holds c[0..NC) | 1/W | E_bi / W [b][i] | -(E^T o)_i / W | (LAP:) m_k G_k / W
+// (ww, wx, wy, xx, xy, yy; m = 2 off the diagonal) | (b - 2 G o)_b / W | the coefficient of n.  The scratch of the sums is dead but for
+// the parked values, which their own lane reads before it stores the part of its record that follows from them (program order
+// within the wavefront).
+template <int P, bool RAT, class Form>
+__device__ __forceinline__ void pencil_sgeo_point(double *geo, int lane, const double (&Hx)[5][4], double wj, const double *prm, double shift, double tt, int *errflag) {
+  constexpr int NB = P + 1, NC = Form::PENCIL_NC;
+  constexpr bool LAP = Form::PENCIL_NFEAT > 4;
+  static_assert(NC + 13 + (LAP ? 10 : 0) <= SGEO_NPD, "the point record fits its stride");
+  const double *PK = geo + SgeoLayout<P, LAP>::OPK;
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  const bool valid = i0 < NB && i1 < NB && i2 < NB;
+  const int pt = (min(i2, NB - 1) * NB + min(i1, NB - 1)) * NB + min(i0, NB - 1);
   if (valid) {
     constexpr int PB[6] = {0, 0, 0, 1, 1, 2}, PG[6] = {0, 1, 2, 1, 2, 2};
     double *rec = geo + pt * SGEO_NPD, *Lp = rec + NC;
@@ -1347,7 +1363,20 @@ __device__ __forceinline__ void pencil_sgeo_eval(double *geo, const double *d2w_
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
-// the MFMAs of one element of a Tangent on a mapped geometry, p = 2: 7 k-steps of 4 points as in pencil_mfma_state_p2
+// the MFMAs of one element of a Tangent on a mapped geometry, p = 2: 7 k-steps of 4 points as in pencil_mfma_state_p2.
+// The loop stays rolled (unrolled, 84 VGPRs spill around it) and is pipelined by hand: a step's point-level operands (P, Q, R and
+// the coefficients c: 19 doubles) are prepared under the MFMAs of the step before -- in program order behind the first feature's nine
+// MFMAs, held there by the scheduling groups below; left to itself the compiler puts the 130 instructions of a step's preparation in
+// front of its first MFMA, where the matrix pipe idles for ~1000 of the step's 3900 cycles.
+template <int M, int N>
+__device__ __forceinline__ void sgeo_sched_groups() {      // one MFMA, then its share of the other instructions (constant arguments only)
+  if constexpr (M < N) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+    if constexpr (M < 9) __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+    else if constexpr (M < 33) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); }
+    sgeo_sched_groups<M + 1, N>();
+  }
+}
 template <bool RAT, class Form>
 __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
                                                          const double *geo, int lane) {
@@ -1355,47 +1384,59 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
   const double *wl = ztg + 32 + min(iy, NB - 1) * NB + min(ix, NB - 1);      // NURBS weights [t][iy][ix] (a padding lane's operands are zero: any finite weight)
-#pragma unroll 1
-  for (int j = 0; j < 7; ++j) {
+  struct Step { double c[NC], PN, PG[3], QG[3], PL, QL, RL; int qw; };
+  auto prep = [&](int j, Step &s) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
     const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
     const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0, u2 = (on && LAP) ? d2w[qx * 4 + ix] : 0.0;
     const double vy0 = vyr[(iy * 4 + qy) * 2 + 0], vy1 = vyr[(iy * 4 + qy) * 2 + 1], vy2 = LAP ? d2w[16 + iy * 4 + qy] : 0.0;
     const double *rp = geo + pc * SGEO_NPD, *Lp = rp + NC;
-    double c[NC];
 #pragma unroll
-    for (int k = 0; k < NC; ++k) c[k] = rp[k];
+    for (int k = 0; k < NC; ++k) s.c[k] = rp[k];
     const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1;
-    const double PN = Lp[0] * a_n;
-    double PG[3], QG[3], PL = 0, QL = 0, RL = 0;
+    s.PN = Lp[0] * a_n;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { PG[i] = Lp[10 + i] * a_n + Lp[4 + i] * a_x + Lp[7 + i] * a_y; QG[i] = Lp[1 + i] * a_n; }
+    for (int i = 0; i < 3; ++i) { s.PG[i] = Lp[10 + i] * a_n + Lp[4 + i] * a_x + Lp[7 + i] * a_y; s.QG[i] = Lp[1 + i] * a_n; }
+    s.PL = 0; s.QL = 0; s.RL = 0;
     if constexpr (LAP) {
       const double a_xx = u2 * vy0, a_xy = u1 * vy1, a_yy = u0 * vy2;
-      PL = Lp[22] * a_n + Lp[20] * a_x + Lp[21] * a_y + Lp[16] * a_xx + Lp[17] * a_xy + Lp[18] * a_yy;
-      QL = Lp[19] * a_n + Lp[14] * a_x + Lp[15] * a_y;
-      RL = Lp[13] * a_n;
+      s.PL = Lp[22] * a_n + Lp[20] * a_x + Lp[21] * a_y + Lp[16] * a_xx + Lp[17] * a_xy + Lp[18] * a_yy;
+      s.QL = Lp[19] * a_n + Lp[14] * a_x + Lp[15] * a_y;
+      s.RL = Lp[13] * a_n;
     }
+    s.qw = qw;
+  };
+  Step cur;
+  prep(0, cur);
+#pragma unroll 1
+  for (int j = 0; j < 7; ++j) {
     double A[NF][NB], B[NB][NF];
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
-      double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1], z2 = LAP ? d2w[32 + qw * 4 + t] : 0.0;
+      double z0 = ztg[(cur.qw * 4 + t) * 2 + 0], z1 = ztg[(cur.qw * 4 + t) * 2 + 1], z2 = LAP ? d2w[32 + cur.qw * 4 + t] : 0.0;
       if (RAT) { const double w = wl[t * NB * NB]; z0 *= w; z1 *= w; z2 *= w; }
-      A[0][t] = z0 * PN;
+      A[0][t] = z0 * cur.PN;
 #pragma unroll
-      for (int i = 0; i < 3; ++i) A[1 + i][t] = z0 * PG[i] + z1 * QG[i];
+      for (int i = 0; i < 3; ++i) A[1 + i][t] = z0 * cur.PG[i] + z1 * cur.QG[i];
       double lap = 0.0;
-      if constexpr (LAP) { lap = z0 * PL + z1 * QL + z2 * RL; A[NF - 1][t] = lap; }
+      if constexpr (LAP) { lap = z0 * cur.PL + z1 * cur.QL + z2 * cur.RL; A[NF - 1][t] = lap; }
       const double g[3] = {A[1][t], A[2][t], A[3][t]};
-      Form::pencil_trial(c, A[0][t], g, lap, B[t]);
+      Form::pencil_trial(cur.c, A[0][t], g, lap, B[t]);
     }
+    Step nxt;
+    prep(min(j + 1, 6), nxt);      // (the last one is not used: no branch inside the scheduling region)
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
       for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][ta], B[tb][f], acc[ta][tb], 0, 0, 0);
+    cur = nxt;
+    // the order of the region: the rows of this step, its operands, then the MFMAs with the next step's loads and arithmetic between them
+    if constexpr (RAT) __builtin_amdgcn_sched_group_barrier(0x100, 12, 0); else __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+    sgeo_sched_groups<0, NF * NB * NB>();
   }
 }
 
@@ -1411,7 +1452,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   constexpr int X = (W == 0) ? 1 : 0, Y = (W == 2) ? 1 : 2;   // the two non-walked mesh axes, X the faster one
   static_assert(P == 3 || W == 0, "degrees below 3 are only instantiated for the axis-0 walk");
   constexpr bool STATE = pencil_state_of<Form>::v;             // a Tangent: all tiles, point coefficients from the state (state_pencil)
-  constexpr bool SGEO = STATE && !IDENT;                       // ... on a mapped geometry (p = 2: pencil_sgeo_eval)
+  constexpr bool SGEO = STATE && !IDENT;                       // ... on a mapped geometry (p = 2: pencil_sgeo_sums / pencil_sgeo_point)
   static_assert(!STATE || !SYSTEM, "a Tangent on the walk: matrix only");
   static_assert(!SGEO || P == 2, "a Tangent on a mapped geometry: p = 2");
   constexpr int GZ = SGEO ? SGEO_Z : GEO_Z, GD = SGEO ? SGEO_DOUBLES : GEO_DOUBLES;      // the per-wavefront metric area and the walk-axis rows behind it
@@ -1558,6 +1599,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
     bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
   }
+  double Hsum[SGEO ? 5 : 1][4];      // SGEO: the first-order sums of the next element's points, from its flush-phase half to its MFMA-phase half
   auto geometry = [&](int ei) {   // control points, NURBS weights of the lane's basis functions and the metric of element wh + ei
     if constexpr (GEO) {
       // the element's walk-axis rows, unscaled, where the MFMA phase reads them without a trip to memory (a global load
@@ -1580,7 +1622,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         }
         if constexpr (SGEO) {
           pencil_sgeo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, uc);
-          pencil_sgeo_eval<P, RAT, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
+          pencil_sgeo_sums<P, RAT, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, Hsum);
         } else {
         double xpar[3] = {0, 0, 0};
         const int gqx = lane & 3, gqy = (lane >> 2) & 3;
@@ -1630,7 +1672,11 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       const double wa = rational ? (fs == 0 ? wt[0] : (fs == 1 ? wt[1] : (fs == 2 ? wt[2] : wt[3]))) : 1.0;
       Facc += wa * pencil_f_geo<NB>(geo, lane, uxr, vyr, ztg);
     }
-    if constexpr (SGEO) pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
+    if constexpr (SGEO) {
+      const int gqw = lane >> 4;
+      pencil_sgeo_point<P, RAT, Form>(geo, lane, Hsum, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
+      pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
+    }
     else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
@@ -1701,7 +1747,7 @@ state_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
   gram_pencil_body<false, 0, P, true, false, false, Form, true>(S, out, pa, prm.v);
 }
 
-// ... and on a mapped geometry (p = 2: pencil_sgeo_eval / pencil_mfma_state_geo_p2)
+// ... and on a mapped geometry (p = 2: pencil_sgeo_sums / pencil_sgeo_point / pencil_mfma_state_geo_p2)
 template <int P, bool RAT, class Form>
 __global__ void __launch_bounds__(512, 2)
 state_pencil_geo(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {

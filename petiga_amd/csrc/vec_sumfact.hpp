@@ -16,7 +16,7 @@
 // functions or points (p <= 2: 2 x 27 of the 64 lanes), no matrix cores (there is no
 // dense contraction left: the work per element drops from ~nen * nqp * features to ~(nen + nqp) * (p+1) * components), coloured
 // scatter (conflict-free, fixed order: bitwise repeatable).  dim 3, nen <= 4 and nqp <= 4 per axis; first-order test features on
-// any geometry, second-order test features (Cahn-Hilliard's Laplacian) on the identity geometry; no boundary loads, no boundary
+// any geometry, second-order test features (Cahn-Hilliard's Laplacian) likewise (round 4); no boundary loads, no boundary
 // passes -- everything else stays on the feature kernel.
 #pragma once
 #include "feature_mfma.hpp"
@@ -157,13 +157,13 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   constexpr int EPW = NS == 3 ? 2 : 1, NL = NS * NS * NS;               // elements per wavefront, lanes per element
   constexpr int DOF = Form::DOF;
   constexpr unsigned VMASK = vec_test_mask_of<Form>::v;                  // test features vec() reads (bit f)
-  constexpr bool SECOND_T = shape_order_of<Form>::v >= 2;                // second-order test features (identity geometry only)
+  constexpr bool SECOND_T = shape_order_of<Form>::v >= 2;                // second-order test features
   constexpr bool NEEDHU = (Form::NEED & NEED_HU) != 0, NEEDGU = (Form::NEED & (NEED_GU | NEED_HU)) != 0;
   constexpr int UORD = NEEDHU ? 2 : (NEEDGU ? 1 : 0);                    // derivative order of the state
   constexpr int NFS = SECOND_T ? 13 : 4;
   // derivatives of the test functions that can carry a coefficient: without a geometry feature tf maps to one of them; with one, the
   // inverse Jacobian mixes the three first derivatives and the rational correction reaches the value
-  constexpr unsigned KMASK = GEO ? 0xFu : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
+  constexpr unsigned KMASK = GEO ? (SECOND_T ? 0x3FFu : 0xFu) : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
   constexpr int NBACK = vs_popc(KMASK) + (SECOND_T ? 6 : 3), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
   __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard: 33 KB per workgroup, four workgroups per CU, two elements per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -374,17 +374,40 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
 #pragma unroll
           for (int b = 0; b < 3; ++b) Cq[f][1 + b] += E1[b * 3 + (tf - 1)] * r;
         }
-      } else {                // second-order test feature (a, b): identity geometry (physical = parametric)
-        const int a = (tf - 4) / 3, b = (tf - 4) % 3;
-        Cq[f][k2(a, b)] += r;
+      } else {                // second-order test feature (i, j)
+        const int i = (tf - 4) / 3, j = (tf - 4) % 3;
+        if constexpr (!GEO) Cq[f][k2(i, j)] += r;      // (physical = parametric)
+        else {
+          // d_i d_j R_a = sum_ab E1[a][i] E1[b][j] d_a d_b R_a + sum_a E2[a][i][j] d_a R_a (ShapeFunctions order 2, src/petigamapshf.f90.in:30-58,
+          // transposed: the slot of (a, b) takes both orders)
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) Cq[f][k2(a, b)] += E1[a * 3 + i] * E1[b * 3 + j] * r;
+            Cq[f][1 + a] += E2[a * 9 + i * 3 + j] * r;
+          }
+        }
       }
     }
   }
-  // rational test functions: R_a = w_a N_a / W, d_b R_a = (w_a / W) (d_b N_a - N_a W_b / W): the coefficients of the polynomial basis
+  // rational test functions: R_a = w_a N_a / W, d_b R_a = (w_a / W) (d_b N_a - N_a W_b / W), d_b d_c R_a = (w_a / W) (d_b d_c N_a -
+  // d_b N_a o_c - d_c N_a o_b - N_a (W_bc / W - 2 o_b o_c)) (src/petigarat.f90.in, order 2): the coefficients of the polynomial basis
   if (rat) {
 #pragma unroll
     for (int f = 0; f < DOF; ++f) {
-      const double c0 = Cq[f][0] - (Cq[f][1] * o1[0] + Cq[f][2] * o1[1] + Cq[f][3] * o1[2]);
+      double c0 = Cq[f][0] - (Cq[f][1] * o1[0] + Cq[f][2] * o1[1] + Cq[f][3] * o1[2]);
+      if constexpr (GEO && SECOND_T) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = a; b < 3; ++b) {
+            const double sk = Cq[f][k2(a, b)];      // (the slot holds both orders of (a, b))
+            c0 -= sk * (o2[a * 3 + b] - 2.0 * o1[a] * o1[b]);
+            if (a == b) Cq[f][1 + a] -= 2.0 * sk * o1[a];
+            else { Cq[f][1 + a] -= sk * o1[b]; Cq[f][1 + b] -= sk * o1[a]; }
+            Cq[f][k2(a, b)] = sk * iw;
+          }
+      }
       Cq[f][0] = c0 * iw; Cq[f][1] *= iw; Cq[f][2] *= iw; Cq[f][3] *= iw;
     }
   }
@@ -403,7 +426,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
 
 #ifndef IGX_RTC
 // dim 3, at most 4 basis functions and 4 points per axis; vector-only drivers; no boundary loads (Function / IFunction subtract
-// their lumped flux per element), no boundary-form passes; second-order test features only on the identity geometry
+// their lumped flux per element), no boundary-form passes
 template <class Form>
 static bool vec_sumfact_covers(const Space &s, const OutDev &out) {
   if constexpr (nscalar_of<Form>::v > 0 || has_boundary_of<Form>::v) return false;
@@ -411,7 +434,6 @@ static bool vec_sumfact_covers(const Space &s, const OutDev &out) {
     if (s.env.vec_sumfact == 0) return false;
     if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION) return false;
     if (s.dim != 3 || s.dof != Form::DOF || (s.nsd != 0 && s.nsd != 3)) return false;
-    if (shape_order_of<Form>::v >= 2 && (s.nsd != 0 || s.rational)) return false;
     for (int d = 0; d < 3; ++d) {
       if (s.basis[d].nen > 4 || s.basis[d].nqp > 4) return false;
       for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && s.load[d][sd].count) return false; }
