@@ -877,46 +877,63 @@ __device__ __forceinline__ void pencil_form_eval(double *geo, int lane, const do
 // a polynomial map: Q = (0, a_x, a_y)), the trial operand B_beta(t) = sum_gamma M_beta,gamma g_gamma(t) is the SAME two-term form
 // with PB_beta = M_beta0 P_0 and QB_beta = sum_gamma M_beta,gamma Q_gamma: 20 point-level + 10 per-slot multiply-adds per (qw, qy) instead
 // of 3 + 20 per slot (NURBS: 83 -> 60 per 30 MFMAs; the fp64 VALU work shares the pipe with them).
+// Round 4 (late): pipelined by hand.  Left to the compiler every point's loads and its 46 operand instructions stood in front of its
+// first MFMA (~550 cycles without an MFMA in flight per point: 8.8k of the phase's 43.7k cycles at p = 3).  Now the point-level half
+// of the NEXT point (P, Q, PB, QB: 10 doubles) is prepared in the last third of a point's MFMAs, and each third opens with only
+// its own 8-12 operand instructions; __builtin_amdgcn_sched_barrier(0) keeps the thirds apart.
 template <int NB, bool RAT>
 __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, double u1, const double *vy, const double *ztg,
                                                 const double *geo, int lane, const double (&wt)[4]) {
   const int qx = lane >> 4;
-#pragma unroll 2
-  for (int qw = 0; qw < NB; ++qw) {
+  static_assert(NB % 2 == 0, "two walk-axis points per trip of the rolled loop");
+  struct Pt { double P0, Q0, Q1, Q2, PB[3], QB[3]; };
+  auto prep = [&](int qw, int qy, Pt &s) {
+    const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
+    const int p = (qw * 4 + qy) * 4 + qx;
+    const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
+    const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
+    double P0 = u0 * vy0, Q0 = 0.0, Q1 = u1 * vy0, Q2 = u0 * vy1;
+    if (RAT) {
+      const double rinv = Rp[0];
+      Q0 = -P0 * Rp[1]; Q1 -= P0 * Rp[2]; Q2 -= P0 * Rp[3];
+      P0 *= rinv; Q0 *= rinv; Q1 *= rinv; Q2 *= rinv;
+    }
+    s.P0 = P0; s.Q0 = Q0; s.Q1 = Q1; s.Q2 = Q2;
+    s.PB[0] = m00 * P0; s.PB[1] = m01 * P0; s.PB[2] = m02 * P0;
+    s.QB[0] = m01 * Q1 + m02 * Q2; s.QB[1] = m11 * Q1 + m12 * Q2; s.QB[2] = m12 * Q1 + m22 * Q2;
+    if (RAT) { s.QB[0] += m00 * Q0; s.QB[1] += m01 * Q0; s.QB[2] += m02 * Q0; }
+  };
+  Pt cur;
+  prep(0, 0, cur);
+#pragma unroll 1
+  for (int qw2 = 0; qw2 < NB; qw2 += 2) {
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {
+    const int qw = qw2 + qh;
     double z0[NB], z1[NB];      // the walk-axis row of tile slot t, with the NURBS weight of its control point
 #pragma unroll
     for (int t = 0; t < NB; ++t) { z0[t] = ztg[(qw * 4 + t) * 2 + 0]; z1[t] = ztg[(qw * 4 + t) * 2 + 1]; if (RAT) { z0[t] *= wt[t]; z1[t] *= wt[t]; } }
 #pragma unroll
     for (int qy = 0; qy < NB; ++qy) {
-      const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
-      const int p = (qw * 4 + qy) * 4 + qx;
-      const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
-      const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
-      double P0 = u0 * vy0, Q0 = 0.0, Q1 = u1 * vy0, Q2 = u0 * vy1;
-      if (RAT) {
-        const double rinv = Rp[0];
-        Q0 = -P0 * Rp[1]; Q1 -= P0 * Rp[2]; Q2 -= P0 * Rp[3];
-        P0 *= rinv; Q0 *= rinv; Q1 *= rinv; Q2 *= rinv;
-      }
-      const double PB[3] = {m00 * P0, m01 * P0, m02 * P0};
-      double QB[3] = {m01 * Q1 + m02 * Q2, m11 * Q1 + m12 * Q2, m12 * Q1 + m22 * Q2};
-      if (RAT) { QB[0] += m00 * Q0; QB[1] += m01 * Q0; QB[2] += m02 * Q0; }
-      double g[3][NB];
-#pragma unroll
-      for (int t = 0; t < NB; ++t) {
-        g[0][t] = z1[t] * P0; if (RAT) g[0][t] += z0[t] * Q0;
-        g[1][t] = z0[t] * Q1; g[2][t] = z0[t] * Q2;
-      }
+      Pt nxt;
 #pragma unroll
       for (int be = 0; be < 3; ++be) {
-        double B[NB];
+        double g[NB], B[NB];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) B[t] = z1[t] * PB[be] + z0[t] * QB[be];
+        for (int t = 0; t < NB; ++t) {
+          if (be == 0) { g[t] = z1[t] * cur.P0; if (RAT) g[t] += z0[t] * cur.Q0; }
+          else g[t] = z0[t] * (be == 1 ? cur.Q1 : cur.Q2);
+          B[t] = z1[t] * cur.PB[be] + z0[t] * cur.QB[be];
+        }
+        if (be == 2) prep(qy + 1 < NB ? qw : min(qw + 1, NB - 1), qy + 1 < NB ? qy + 1 : 0, nxt);      // (the last one is not used)
 #pragma unroll
         for (int ta = 0; ta < NB; ++ta)
 #pragma unroll
-          for (int tb = ta; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[be][ta], B[tb], acc[ta][tb], 0, 0, 0);
+          for (int tb = ta; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[ta], B[tb], acc[ta][tb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
+      cur = nxt;
+    }
     }
   }
 }
