@@ -15,9 +15,9 @@ import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC, DST = "gpurun_out/prof", "profiles"
-SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96}
-KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<"}
-FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson"}
+SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96, "cahnhilliard_nurbs": 128}
+KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil"}
+FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson", "cahnhilliard_nurbs": "cahnhilliard"}
 
 
 def pmc(dirs):
@@ -38,7 +38,7 @@ def write_pmc(path, agg):
 
 
 configs = []
-for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhilliard", "nsvms"):
+for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhilliard", "nsvms", "cahnhilliard_nurbs"):
     lf = "%s/line_%s.json" % (SRC, form)
     if not os.path.exists(lf) or not open(lf).read().strip():
         continue
@@ -84,5 +84,13 @@ for src, dst in (("configs.txt", "secondary_configs.txt"), ("rtc.txt", "runtime_
     if os.path.exists(SRC + "/" + src):
         shutil.copy(SRC + "/" + src, "%s/%s_%s" % (DST, tag, dst))
 if configs:
+    # (a run over a subset of the workloads -- TAGS=... scripts/profile_round.sh -- keeps the other entries of the same round)
+    try:
+        old = json.load(open(DST + "/traffic.json"))
+        if old.get("kernel_tag") == tag:
+            have = set(c["tag"] for c in configs)
+            configs = [c for c in old.get("configs", []) if c.get("tag") not in have] + configs
+    except (OSError, ValueError):
+        pass
     json.dump(dict(round=int(tag[1:]), kernel_tag=tag, configs=configs), open(DST + "/traffic.json", "w"), indent=1)
     print(open(DST + "/traffic.json").read())
