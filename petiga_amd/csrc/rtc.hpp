@@ -78,7 +78,7 @@ struct RtcForm {
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
-  std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P
+  std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P (+ 10 + rational on a mapped geometry)
   std::map<int, std::shared_ptr<RtcFeature>> block;     // block_pencil instantiations; key: SYSTEM
   std::map<int, std::shared_ptr<RtcFeature>> band;      // band_points + band_pt instantiations; key: GEO | RAT << 1
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
@@ -509,32 +509,38 @@ static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
 }
 
 // ---- the Tangent of a nonlinear scalar struct on the pencil walk (gram_mfma.hpp: state_pencil<P, UserStruct>): the struct declares
-// PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial like FormCahnHilliard and FormBratu (forms.hpp); dof 1, dim 3, no geometry,
-// uniform degree 2 or 3, Jacobian / IJacobian drivers.  Everything around the kernel is try_gram_mfma, as for form_pencil.
+// PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial like FormCahnHilliard and FormBratu (forms.hpp); dof 1, dim 3, uniform degree
+// 2 or 3 without a geometry, degree 2 on a mapped one (state_pencil_geo<2, RAT, UserStruct>), Jacobian / IJacobian drivers.
+// Everything around the kernel is try_gram_mfma, as for form_pencil.
 static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out, bool &done, bool compile_only = false) {
   done = false;
   const Space &s = g->s;
   const int deg = s.axis[0].p;
   if (s.dim != 3 || (deg != 2 && deg != 3)) return 0;
   // (the struct's constants are read from the loaded module: a compile-only check on a machine without a GPU takes the caller's word)
-  if (!compile_only && (F.meta[11] <= 0 || F.meta[0] != 1 || F.meta[3] > 0 || F.meta[7] || !s.env.state_pencil || s.nsd != 0 || (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN))) return 0;
+  if (!compile_only && (F.meta[11] <= 0 || F.meta[0] != 1 || F.meta[3] > 0 || F.meta[7] || !s.env.state_pencil || (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN))) return 0;
+  const bool geo = s.nsd != 0;
+  if (geo && (s.nsd != 3 || deg != 2)) return 0;
+  const int key = deg + (geo ? 10 + (s.rational ? 1 : 0) : 0);      // (12: p = 2 on a polynomial map, 13: on a NURBS map)
   std::shared_ptr<RtcFeature> K;
-  auto it = F.state.find(deg);
+  auto it = F.state.find(key);
   if (it != F.state.end() && (it->second->module || compile_only)) K = it->second;
   else {
     K.reset(new RtcFeature());
-    const std::string x = std::string("igx::state_pencil<") + std::to_string(deg) + ", " + F.name + ">";
+    const std::string x = geo ? std::string("igx::state_pencil_geo<2, ") + (s.rational ? "true, " : "false, ") + F.name + ">"
+                              : std::string("igx::state_pencil<") + std::to_string(deg) + ", " + F.name + ">";
     const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::OutDev, igx::PencilArgs, igx::ParamsDev);\n";
     if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, true)) return rc;
     if (!compile_only) {
       HIPCK(hipModuleLoadData(&K->module, K->code.data()));
       hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[0].c_str())); K->func.push_back(fn);
     }
-    F.state[deg] = K;
+    F.state[key] = K;
   }
   if (compile_only) { done = true; return 0; }
   PencilModule mod; memset(&mod.prm, 0, sizeof(mod.prm));
-  mod.fn = K->func[0]; mod.name = F.name + ",hiprtc"; mod.state = true; mod.extra_lds = pencil_state_bytes();
+  mod.fn = K->func[0]; mod.name = F.name + ",hiprtc"; mod.state = true; mod.state_geo = geo;
+  mod.extra_lds = pencil_state_bytes() + (geo ? pencil_sgeo_bytes() - pencil_geo_bytes() : 0);
   mod.flop_per_element = 2048.0 * F.meta[11] * (deg == 2 ? 7 * 9 : 16 * 16);
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
@@ -887,7 +893,7 @@ extern "C" int IGXCheckFormSource(IGX g, int with_matrix, int gram) {
   if (gram == 4) {           // state_pencil of a struct with the PENCIL_* hooks, for the current degree: compile only
     bool done = false; OutDev o; memset(&o, 0, sizeof(o)); SpaceDev Sd; memset(&Sd, 0, sizeof(Sd));
     if (int rc = launch_state_rtc(g, *g->rtc, Sd, o, done, true)) return rc;
-    return done ? 0 : fail(IGX_ERR_SUP, "state_pencil needs dim 3, dof 1, degree 2 or 3 and a struct with PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial");
+    return done ? 0 : fail(IGX_ERR_SUP, "state_pencil needs dim 3, dof 1, degree 2 or 3 (2 on a mapped geometry) and a struct with PENCIL_NFEAT / PENCIL_NC / pencil_coef / pencil_trial");
   }
   if (gram == 3) {           // the sum-factorised vector kernel (vec_sumfact) of the struct, with and without a geometry: compile only
     if (s.dim != 3) return fail(IGX_ERR_SUP, "the sum-factorised vector kernel needs dim 3");

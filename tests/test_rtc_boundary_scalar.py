@@ -330,6 +330,40 @@ def test_user_struct_tangent_on_the_pencil_walk(p, N, periodic, driver):
     compare_mats(J, J_o, 1e-12)
 
 
+def test_state_pencil_of_a_user_struct_on_a_mapped_geometry_compiles_without_a_gpu():
+    """IGXCheckFormSource(gram = 4) with a geometry set at p = 2: state_pencil_geo<2, RAT, UserStruct>"""
+    import petiga_amd as P
+    from common import warped_geometry
+    for rational in (False, True):
+        orc, g = make_pair(3, 1, 2, [6, 5, 4])
+        X, W = warped_geometry(orc, 3, seed=2, rational=rational, amp=0.05)
+        g.set_geometry(X, W)
+        g.set_form_source(BRATU3_WALK, "UserBratu3Walk", (3.5,))
+        g.check_form_source(True, 4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rational", [False, True])
+def test_user_struct_tangent_on_the_pencil_walk_on_a_mapped_geometry(rational):
+    from common import warped_geometry
+    orc, eng = make_pair(3, 1, 2, [9, 4, 5])
+    X, W = warped_geometry(orc, 3, seed=9, rational=rational, amp=0.06)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    for g in (orc, eng):
+        for d in range(3):
+            g.set_boundary_value(d, 0, 0, 0.2 * d)
+    lam = C.c_double(3.5)
+    rng = np.random.default_rng(8)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n)
+    eng.set_form_source(BRATU3_WALK, "UserBratu3Walk", (3.5,))
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    eng.compute_ijacobian(4.0, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "state_pencil<UserBratu3Walk,hiprtc>" in eng.kernel_name() and "mapped geometry" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U), 1e-11)
+
+
 ELASTICITY_BANDS = r"""
 // demo/Elasticity3D.c:13-46 as user source (with its :37 quirk); params = {lambda, mu}.  The declarations say what the callback's
 // shape is -- point-independent coefficients on gradient pairs (MAT_PAIR_MASK), which block entries a pair reaches
