@@ -173,6 +173,57 @@ def test_cahn_hilliard_full_size_properties():
     assert (float(val.sum()), float(val.abs().sum())) == chk            # first-touch stores reach every entry; same bits -> same sums
 
 
+def test_cahn_hilliard_on_a_nurbs_patch_properties():
+    """Cahn-Hilliard at 128^3 on the bench's rational map (state_pencil_geo + vec_sumfact at second order; no oracle runs at this
+    size).  NURBS functions are a partition of unity as well, so sum_a R_a = int c_t dx = V . m and the column sums of the tangent
+    are shift * m with m_b = int R_b dx -- taken from an independent kernel: the load vector of the Poisson System driver (f = 1, no
+    Dirichlet faces) on the same geometry (gram_pencil, oracle-checked at small sizes); NaN-poisoned matrix reproduced bit for bit."""
+    import os
+    import sys
+    import petiga_amd as P
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    N, p = 128, 2
+    X, W = bench._bench_geometry(p, N, (False, False, False))
+    def space():
+        g = P.IGX(3, 1)
+        for i in range(3):
+            g.axis_uniform(i, p, N)
+        g.setup()
+        g.set_geometry(X, W)
+        return g
+    gp = space()
+    gp.set_form("poisson")
+    Ap, bp = gp.create_mat(), gp.create_vec()
+    gp.compute_system(Ap, bp); gp.synchronize()
+    assert "mapped geometry" in gp.kernel_name()
+    m = bp.get().copy()
+    del Ap, bp, gp
+    assert abs(m.sum() - 1.0) < 0.2 and m.min() > 0           # (the volume of the warped unit cube)
+    g = space()
+    g.set_form("cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / (3.0 * N * N), 1.0))
+    A, b = g.create_mat(), g.create_vec()
+    n = N + p
+    rng = np.random.default_rng(3)
+    Uh, Vh = 0.63 + 0.05 * (2 * rng.random(n ** 3) - 1), rng.standard_normal(n ** 3)
+    U, V = g.create_vec().set(Uh), g.create_vec().set(Vh)
+    shift = 250.0
+    g.compute_ifunction(shift, V, 0.0, U, b); g.synchronize()
+    assert "vec_sumfact" in g.kernel_name(), g.kernel_name()
+    g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
+    assert "state_pencil<CahnHilliard>" in g.kernel_name() and "mapped geometry" in g.kernel_name(), g.kernel_name()
+    F = b.get()
+    assert abs(F.sum() - Vh @ m) <= 1e-10 * np.abs(F).sum()
+    rp, ci, val = _views(A)
+    scale = float(val.abs().max())
+    cs = _colsums(ci, val, n ** 3).cpu().numpy()
+    assert np.abs(cs - shift * m).max() <= 1e-9 * scale
+    chk = float(val.sum()), float(val.abs().sum())
+    val.fill_(float("nan"))
+    g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
+    assert (float(val.sum()), float(val.abs().sum())) == chk
+
+
 def test_navier_stokes_vms_one_gpu_share_properties():
     """Config 5's share of one GPU (NavierStokesVMS p=3, 96^3 elements of the 192^3 mesh, 4 fields, the bench's rational NURBS
     map, axes 0 and 2 periodic, no-slip walls on axis 1: 3.65 M block rows, 40 GB of values) on the device
