@@ -988,9 +988,9 @@ __device__ __forceinline__ double pencil_f_geo(const double *geo, int lane, cons
   if (fx >= NB || fy >= NB || aw >= NB) return 0.0;
   double s = 0;
 #pragma unroll 1
-  for (int qw = 0; qw < NB; ++qw) {      // (rolled: unrolled, the 64 point values stay live and spill)
+  for (int qw = 0; qw < NB; ++qw) {      // (rolled: unrolled, the 64 point values stay live and spill; one qw slice -- 16 LDS reads in flight -- fits)
     double sy = 0;
-#pragma unroll 1
+#pragma unroll
     for (int qy = 0; qy < NB; ++qy) {
       double sx = 0;
 #pragma unroll
