@@ -938,46 +938,77 @@ __device__ __forceinline__ void pencil_mfma_geo(d4_t (&acc)[4][4], double u0, do
   }
 }
 
-// p = 2 on a mapped geometry: 27 points in 7 k-steps (see pencil_mfma_p2): 126 MFMAs per element instead of 162
+// p = 2 on a mapped geometry: 27 points in 7 k-steps (see pencil_mfma_p2): 126 MFMAs per element instead of 162.  Pipelined by
+// hand like pencil_mfma_geo: the next step's point-level operands and walk-axis rows are prepared under the second third of a step's
+// MFMAs (the compiler's order had a step's ~45 operand instructions and their loads in front of its first MFMA: 16.9k cycles per
+// element for 8.1k of MFMA issue).
 template <bool RAT>
 __device__ __forceinline__ void pencil_mfma_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vy, const double *ztg,
                                                    const double *geo, int lane, const double (&wt)[4]) {
   const int ks = lane >> 4, ix = lane & 3;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
+  struct Pt { double P0, Q0, Q1, Q2, PB[3], QB[3], z0[3], z1[3]; };
+  struct Raw { double u0, u1, vy0, vy1, m[6], r[4], z0[3], z1[3]; };
+  auto loads = [&](int j, Raw &w) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
     const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
-    const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0;
-    const double vy0 = vy[qy * 2 + 0], vy1 = vy[qy * 2 + 1];
+    w.u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0; w.u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0;
+    w.vy0 = vy[qy * 2 + 0]; w.vy1 = vy[qy * 2 + 1];
     const int p = (qw * 4 + qy) * 4 + qx;
     const double *Mp = geo + p * GEO_M, *Rp = geo + 64 * GEO_M + p * 4;
-    const double m00 = Mp[0], m01 = Mp[1], m02 = Mp[2], m11 = Mp[3], m12 = Mp[4], m22 = Mp[5];
-    double P0 = u0 * vy0, Q0 = 0.0, Q1 = u1 * vy0, Q2 = u0 * vy1;      // (see pencil_mfma_geo: the point-level half of both operands)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) w.m[k] = Mp[k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w.r[k] = RAT ? Rp[k] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) { w.z0[t] = ztg[(qw * 4 + t) * 2 + 0]; w.z1[t] = ztg[(qw * 4 + t) * 2 + 1]; }
+  };
+  auto point = [&](const Raw &w, Pt &s) {      // (see pencil_mfma_geo: the point-level half of both operands)
+    double P0 = w.u0 * w.vy0, Q0 = 0.0, Q1 = w.u1 * w.vy0, Q2 = w.u0 * w.vy1;
     if (RAT) {
-      const double rinv = Rp[0];
-      Q0 = -P0 * Rp[1]; Q1 -= P0 * Rp[2]; Q2 -= P0 * Rp[3];
-      P0 *= rinv; Q0 *= rinv; Q1 *= rinv; Q2 *= rinv;
+      Q0 = -P0 * w.r[1]; Q1 -= P0 * w.r[2]; Q2 -= P0 * w.r[3];
+      P0 *= w.r[0]; Q0 *= w.r[0]; Q1 *= w.r[0]; Q2 *= w.r[0];
     }
-    const double PB[3] = {m00 * P0, m01 * P0, m02 * P0};
-    double QB[3] = {m01 * Q1 + m02 * Q2, m11 * Q1 + m12 * Q2, m12 * Q1 + m22 * Q2};
-    if (RAT) { QB[0] += m00 * Q0; QB[1] += m01 * Q0; QB[2] += m02 * Q0; }
-    double g[3][3], B[3][3];
+    s.P0 = P0; s.Q0 = Q0; s.Q1 = Q1; s.Q2 = Q2;
+  };
+  auto trial = [&](const Raw &w, Pt &s) {
+    const double m00 = w.m[0], m01 = w.m[1], m02 = w.m[2], m11 = w.m[3], m12 = w.m[4], m22 = w.m[5];
+    s.PB[0] = m00 * s.P0; s.PB[1] = m01 * s.P0; s.PB[2] = m02 * s.P0;
+    s.QB[0] = m01 * s.Q1 + m02 * s.Q2; s.QB[1] = m11 * s.Q1 + m12 * s.Q2; s.QB[2] = m12 * s.Q1 + m22 * s.Q2;
+    if (RAT) { s.QB[0] += m00 * s.Q0; s.QB[1] += m01 * s.Q0; s.QB[2] += m02 * s.Q0; }
+  };
+  auto rows = [&](const Raw &w, Pt &s) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t) {
-      double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
-      if (RAT) { z0 *= wt[t]; z1 *= wt[t]; }
-      g[0][t] = z1 * P0; if (RAT) g[0][t] += z0 * Q0;
-      g[1][t] = z0 * Q1; g[2][t] = z0 * Q2;
+    for (int t = 0; t < 3; ++t) { s.z0[t] = RAT ? w.z0[t] * wt[t] : w.z0[t]; s.z1[t] = RAT ? w.z1[t] * wt[t] : w.z1[t]; }
+  };
+  Pt cur;
+  { Raw w; loads(0, w); point(w, cur); trial(w, cur); rows(w, cur); }
 #pragma unroll
-      for (int be = 0; be < 3; ++be) B[be][t] = z1 * PB[be] + z0 * QB[be];
+  for (int j = 0; j < 7; ++j) {
+    Pt nxt = cur; Raw w;
+#pragma unroll
+    for (int be = 0; be < 3; ++be) {
+      double g[3], B[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (be == 0) { g[t] = cur.z1[t] * cur.P0; if (RAT) g[t] += cur.z0[t] * cur.Q0; }
+        else g[t] = cur.z0[t] * (be == 1 ? cur.Q1 : cur.Q2);
+        B[t] = cur.z1[t] * cur.PB[be] + cur.z0[t] * cur.QB[be];
+      }
+      // six MFMAs in three pairs, a slice of the next step's preparation behind each of the first pairs
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[0], B[0], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[0], B[1], acc[0][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < 6) { if (be == 0) loads(j + 1, w); else if (be == 1) point(w, nxt); else trial(w, nxt); }
+      acc[0][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[0], B[2], acc[0][2], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[1], B[1], acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j < 6 && be == 2) rows(w, nxt);
+      acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[1], B[2], acc[1][2], 0, 0, 0);
+      acc[2][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[2], B[2], acc[2][2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int be = 0; be < 3; ++be)
-#pragma unroll
-      for (int ta = 0; ta < 3; ++ta)
-#pragma unroll
-        for (int tb = ta; tb < 3; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(g[be][ta], B[be][tb], acc[ta][tb], 0, 0, 0);
+    cur = nxt;
   }
 }
 
