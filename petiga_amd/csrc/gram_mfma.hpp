@@ -1146,34 +1146,65 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
   constexpr int NB = 3, NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4, ix = lane & 3, iy = (lane >> 2) & 3;
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
+  // Round 4 (late): the order is set by hand.  A step's MFMAs go out in threes; the next step's loads follow late (their registers are the dying operands'), its test
+  // operands A the threes of the second-to-last feature, its trial operands B (pencil_trial, one tile slot at a time) those of the last
+  // one -- where this step's other operands are dead.  The compiler's own order left ~25 operand instructions in front of several steps.
+  struct Raw { double u0, u1, u2, v0, v1, v2, c[NC], z0[NB], z1[NB], z2[NB]; };
+  auto loads = [&](int j, Raw &w) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
     const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
-    const double u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0, u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0, u2 = (on && LAP) ? d2w[qx * 4 + ix] : 0.0;
-    const double vy0 = vyr[(iy * 4 + qy) * 2 + 0], vy1 = vyr[(iy * 4 + qy) * 2 + 1], vy2 = LAP ? d2w[16 + iy * 4 + qy] : 0.0;
-    const double *cp = coef + ((qw * 4 + qy) * 4 + qx) * NC;
-    double c[NC];
+    w.u0 = on ? uxr[(qx * 4 + ix) * 2 + 0] : 0.0; w.u1 = on ? uxr[(qx * 4 + ix) * 2 + 1] : 0.0; w.u2 = (on && LAP) ? d2w[qx * 4 + ix] : 0.0;
+    w.v0 = vyr[(iy * 4 + qy) * 2 + 0]; w.v1 = vyr[(iy * 4 + qy) * 2 + 1]; w.v2 = LAP ? d2w[16 + iy * 4 + qy] : 0.0;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) c[k] = cp[k];
-    const double a_n = u0 * vy0, a_x = u1 * vy0, a_y = u0 * vy1, a_l = LAP ? u2 * vy0 + u0 * vy2 : 0.0;
-    double A[NF][NB], B[NB][NF];
+    for (int t = 0; t < NB; ++t) { w.z0[t] = ztg[(qw * 4 + t) * 2 + 0]; w.z1[t] = ztg[(qw * 4 + t) * 2 + 1]; w.z2[t] = LAP ? d2w[32 + qw * 4 + t] : 0.0; }
+  };
+  auto load_coef = [&](int j, Raw &w) {
+    const int pt = 4 * j + ks;
+    const int pc = pt < 27 ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double *cp = coef + ((qw * 4 + qy) * 4 + qx) * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) w.c[k] = cp[k];
+  };
+  auto test_ops = [&](const Raw &w, double (&A)[NF][NB]) {
+    const double a_n = w.u0 * w.v0, a_x = w.u1 * w.v0, a_y = w.u0 * w.v1, a_l = LAP ? w.u2 * w.v0 + w.u0 * w.v2 : 0.0;
 #pragma unroll
     for (int t = 0; t < NB; ++t) {
-      const double z0 = ztg[(qw * 4 + t) * 2 + 0], z1 = ztg[(qw * 4 + t) * 2 + 1];
-      A[0][t] = a_n * z0; A[1][t] = a_n * z1; A[2][t] = a_x * z0; A[3][t] = a_y * z0;
-      double lap = 0.0;
-      if constexpr (LAP) { lap = a_n * d2w[32 + qw * 4 + t] + a_l * z0; A[NF - 1][t] = lap; }
-      const double g[3] = {A[1][t], A[2][t], A[3][t]};
-      Form::pencil_trial(c, A[0][t], g, lap, B[t]);
+      A[0][t] = a_n * w.z0[t]; A[1][t] = a_n * w.z1[t]; A[2][t] = a_x * w.z0[t]; A[3][t] = a_y * w.z0[t];
+      if constexpr (LAP) A[NF - 1][t] = a_n * w.z2[t] + a_l * w.z0[t];
     }
+  };
+  auto trial_ops = [&](const Raw &w, const double (&A)[NF][NB], int t, double (&B)[NB][NF]) {
+    const double g[3] = {A[1][t], A[2][t], A[3][t]};
+    Form::pencil_trial(w.c, A[0][t], g, LAP ? A[NF - 1][t] : 0.0, B[t]);
+  };
+  double A[NF][NB], B[NB][NF];
+  { Raw w; loads(0, w); load_coef(0, w); test_ops(w, A);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) trial_ops(w, A, t, B); }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    double A2[NF][NB], B2[NB][NF]; Raw w;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int ta = 0; ta < NB; ++ta)
+      for (int ta = 0; ta < NB; ++ta) {
 #pragma unroll
         for (int tb = 0; tb < NB; ++tb) acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][ta], B[tb][f], acc[ta][tb], 0, 0, 0);
+        if (j < 6) {
+          if (f == NF - 3 && ta == 1) loads(j + 1, w);
+          if (f == NF - 2 && ta == 0) test_ops(w, A2);
+          if (f == NF - 2 && ta == 1) load_coef(j + 1, w);
+          if (f == NF - 1) trial_ops(w, A2, ta, B2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    if (j < 6) {
+#pragma unroll
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) { A[f][t] = A2[f][t]; B[t][f] = B2[t][f]; }
+    }
   }
 }
 
