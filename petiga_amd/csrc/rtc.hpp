@@ -450,7 +450,6 @@ static bool rtc_vecsf_eligible(const Space &s, const RtcForm &F, const OutDev &o
   if (!s.env.vec_sumfact || s.dim != 3 || F.meta[3] > 0 || F.meta[7]) return false;      // no functionals, no atboundary branch
   if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION) return false;
   if (s.dof != F.meta[0] || (s.nsd != 0 && s.nsd != 3)) return false;
-  if (F.meta[4] >= 2 && (s.nsd != 0 || s.rational)) return false;        // second-order test features: identity geometry only
   for (int d = 0; d < 3; ++d) {
     if (s.basis[d].nen > 4 || s.basis[d].nqp > 4) return false;
     for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && s.load[d][sd].count) return false; }

@@ -364,6 +364,81 @@ def test_user_struct_tangent_on_the_pencil_walk_on_a_mapped_geometry(rational):
     compare_mats(J, orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, 4.0, V, 0.0, U), 1e-11)
 
 
+USER_CH3 = r"""
+// demo/CahnHilliard3D.c:39-179 as user source; params = {theta, alpha, cbar, L0, lambda, tau}.  Second-order test features (the
+// Laplacian of N) and the hooks of the pencil walk.
+struct UserCH3 {
+  static constexpr unsigned MAT_TEST_MASK = 0xFu | (1u << 4) | (1u << 8) | (1u << 12);      // N, grad N, the diagonal of hess N
+  static constexpr unsigned PHI_MASK = MAT_TEST_MASK, VEC_TEST_MASK = MAT_TEST_MASK;
+  static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_U | NEED_UT | NEED_GU | NEED_HU;
+  struct K { double M, dM, d2M, dmu, d2mu, lap, t1; };
+  static __device__ K coef(const PtView &p) {
+    K k; const double c = p.u[0], theta = p.prm[0], L0 = p.prm[3], lambda = p.prm[4];
+    const double scale = L0 * L0 / lambda;
+    k.M = c * (1 - c); k.dM = 1 - 2 * c; k.d2M = -2;
+    k.dmu = (0.5 / theta / (c * (1 - c)) - 2) * scale;
+    k.d2mu = (-0.5 / theta * (1 - 2 * c) / (c * c * (1 - c) * (1 - c))) * scale;
+    k.lap = p.hu[0] + p.hu[4] + p.hu[8];
+    k.t1 = k.M * k.dmu + k.dM * k.lap;
+    return k;
+  }
+  static __device__ double lapN(const double *N) { return N[4] + N[8] + N[12]; }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) {
+    const K k = coef(p);
+    double Ra = Na[0] * p.ut[0];
+    for (int i = 0; i < 3; ++i) Ra += Na[1 + i] * k.t1 * p.gu[i];
+    R[0] = Ra + lapN(Na) * k.M * k.lap;
+  }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const K k = coef(p);
+    const double lapNa = lapN(Na), lapNb = lapN(Nb);
+    double Kab = p.shift * Na[0] * Nb[0];
+    for (int i = 0; i < 3; ++i) Kab += Na[1 + i] * k.t1 * Nb[1 + i];
+    const double t2 = (k.dM * k.dmu + k.M * k.d2mu + k.d2M * k.lap) * Nb[0] + k.dM * lapNb;
+    for (int i = 0; i < 3; ++i) Kab += Na[1 + i] * t2 * p.gu[i];
+    T[0] = Kab + lapNa * (k.dM * k.lap * Nb[0] + k.M * lapNb);
+  }
+  static constexpr int PENCIL_NFEAT = 5, PENCIL_NC = 9;
+  static __device__ void pencil_coef(const PtView &p, double JW, double *c) {
+    const K k = coef(p);
+    c[0] = JW * p.shift; c[1] = JW * k.t1; c[2] = JW * (k.dM * k.dmu + k.M * k.d2mu + k.d2M * k.lap); c[3] = JW * k.dM;
+    c[4] = JW * (k.dM * k.lap); c[5] = JW * k.M;
+    for (int i = 0; i < 3; ++i) c[6 + i] = p.gu[i];
+  }
+  static __device__ void pencil_trial(const double *c, double N, const double *g, double lap, double *B) {
+    const double h = c[2] * N + c[3] * lap;
+    B[0] = c[0] * N;
+    for (int i = 0; i < 3; ++i) B[1 + i] = c[1] * g[i] + c[6 + i] * h;
+    B[4] = c[4] * N + c[5] * lap;
+  }
+};
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geo", [None, "poly", "nurbs"])
+def test_user_cahn_hilliard_struct_on_a_mapped_geometry(geo):
+    """A second-order struct given as source: its IFunction on vec_sumfact and its IJacobian on the state walk, on the identity
+    geometry, a polynomial map and a NURBS map (the physical Laplacian of the test functions needs the map's second derivatives)"""
+    CH = (1.5, 200.0, 0.63, 1.0, 1.0 / 48.0, 1.0)
+    orc, eng = make_pair(3, 1, 2, [9, 4, 5])
+    if geo:
+        X, W = warped_geometry(orc, 3, seed=21, rational=(geo == "nurbs"), amp=0.06)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    ctx = O.CahnHilliardCtx(*CH)
+    rng = np.random.default_rng(5)
+    n = orc.global_size()
+    U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+    eng.set_form_source(USER_CH3, "UserCH3", CH)
+    Uv, Vv, F, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_vec(), eng.create_mat()
+    eng.compute_ifunction(250.0, Vv, 0.0, Uv, F); eng.synchronize()
+    assert "vec_sumfact<UserCH3>(hiprtc" in eng.kernel_name(), eng.kernel_name()
+    assert rel_err(F.get(), orc.compute_ifunction("orc_form_ch_residual", ctx, 250.0, V, 0.0, U)) < 1e-10
+    eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J); eng.synchronize()
+    assert "state_pencil<UserCH3,hiprtc>" in eng.kernel_name() and (("mapped geometry" in eng.kernel_name()) == bool(geo)), eng.kernel_name()
+    compare_mats(J, orc.compute_ijacobian("orc_form_ch_tangent", ctx, 250.0, V, 0.0, U), 1e-10)
+
+
 ELASTICITY_BANDS = r"""
 // demo/Elasticity3D.c:13-46 as user source (with its :37 quirk); params = {lambda, mu}.  The declarations say what the callback's
 // shape is -- point-independent coefficients on gradient pairs (MAT_PAIR_MASK), which block entries a pair reaches
