@@ -35,7 +35,7 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_su
 # the metric configuration's form given as run-time source
 python3 bench.py --source --steps 10 --warmup 2 --no-cpu-baseline > $OUT/line_poisson_source.json 2> $OUT/line_poisson_source.err
 # secondary timings (one assembly each, current kernels)
-BENCH_COMPACT=1 python3 scripts/bench_configs.py c1 c2 full3 full4 full5 c5r c5g c6 c6b c6m c6p c7 > $OUT/configs.txt 2> $OUT/configs.err
+BENCH_COMPACT=1 python3 scripts/bench_configs.py c1 c2 full3 full4 c4g full5 c5r c5g c6 c6b c6m c6p c7 > $OUT/configs.txt 2> $OUT/configs.err
 python3 scripts/bench_rtc.py > $OUT/rtc.txt 2> $OUT/rtc.err
 find $OUT -name "*.csv" | wc -l
 for t in $TAGS; do tail -c 300 $OUT/line_$t.json; echo; done
