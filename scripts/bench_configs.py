@@ -136,3 +136,7 @@ if "n2" in which:
     run("NavierStokesVMS p=2 48^3 tangent", 3, 4, 2, (48,) * 3, "nsvms", (1.472e-4, 3.37204e-3, 0.0, 0.0, 1e-2), periodic=(1, 0, 1), op="ijacobian")
 if "m4" in which:
     run("mass dof=4 p=2 64^3", 3, 4, 2, (64,) * 3, "mass")
+if "c4p3" in which:
+    h2 = 1.0 / (3 * 96 * 96)
+    run("CahnHilliard3D p=3 96^3 tangent", 3, 1, 3, (96,) * 3, "cahnhilliard", (1.5, 200.0, 0.63, 1.0, h2, 1.0), op="ijacobian")
+    run("Bratu p=3 96^3 Jacobian", 3, 1, 3, (96,) * 3, "bratu", (3.5,), op="ijacobian")
