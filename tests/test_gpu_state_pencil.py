@@ -102,6 +102,8 @@ def test_bratu_jacobian_vs_oracle(p, N, periodic, driver):
     ("ch", (12, 3, 4), (False, False, False), True, True, 0, 0.08),      # Dirichlet values on four faces
     ("ch", (17, 4, 3), (False, False, False), True, True, 3, 0.05),      # three segments along the walk
     ("ch", (8, 5, 6), (False, False, False), False, False, 0, 0.0),      # the identity map given as a geometry (Greville net)
+    ("ch", (8, 5, 6), (False, True, True), True, False, 0, 0.05),        # periodic across the walk (the net of a periodic axis is not wrapped: src/petiga.c IGASetGeometry)
+    ("ch", (19, 5, 5), (True, False, True), True, False, 3, 0.05),       # the walk axis periodic and wrapped inside the rank, three segments
     ("bratu", (9, 5, 4), (False, False, False), True, True, 0, 0.06),    # a first-order form: no second derivatives summed
     ("bratu", (11, 4, 6), (False, False, False), False, True, 2, 0.06),
 ])
@@ -116,6 +118,7 @@ def test_tangent_on_a_mapped_geometry_vs_oracle(form, N, periodic, rational, bc,
     X, W = warped_geometry(orc, 3, seed=6, rational=rational, amp=amp)
     orc.set_geometry(X, W); eng.set_geometry(X, W)
     if bc:
+        assert not any(periodic)
         for g in (orc, eng):
             g.set_boundary_value(0, 0, 0, 0.6); g.set_boundary_value(0, 1, 0, 0.66)
             g.set_boundary_value(1, 1, 0, 0.61); g.set_boundary_value(2, 0, 0, 0.65)
