@@ -256,6 +256,7 @@ struct PencilArgs {
   int w_halo_lo;           // lowest element a segment may re-compute as halo (= w_lo unless the walked range is the upper part of the axis: a face pass)
   int open_hi;             // 1: elements beyond w_hi exist and belong to another pass: the last segment owns no rows past its elements
   int free_run;            // 1: no s_barrier ping-pong between the two wave groups: the SIMD's own arbitration interleaves MFMA and flush phases (IGX_FREE_RUN; default: p = 2 on the identity geometry)
+  int wpb;                 // wavefronts (= pencils) per workgroup: 8; 6 for the free-running p = 2 walk on the identity geometry (gram_pencil_w6: three waves per SIMD)
   int debug_noflush;       // experiment switch: 1 = skip the read-modify-write (timing of the MFMA walk alone)
   long long *debug_buf;    // experiment: cycle stamps [block][wave 0 and 4][64 steps][4]
 };
@@ -293,10 +294,10 @@ __device__ __forceinline__ PencilLds pencil_lds_carve(double *sm, int ne_max, bo
   t.cnt = reinterpret_cast<int *>(t.pre + nl); t.rho = t.cnt + nl; t.P = t.rho + nl; t.lay0 = 0;
   return t;
 }
-__host__ __device__ static inline size_t pencil_lds_bytes(int ne_max, bool geo = false) {
+__host__ __device__ static inline size_t pencil_lds_bytes(int ne_max, bool geo = false, int wpb = 8) {
   const int nl = ne_max + 3;
   const size_t tables = (size_t)((geo ? 0 : ne_max * 32) + ne_max * 4 + ((ne_max + 1) & ~1)) * 8 + (size_t)nl * 8 + (size_t)nl * 4 * 10 + 64;
-  return ((tables + 15) & ~(size_t)15) + 2 * 8 * 32 * 8;   // + per-wavefront Y-axis and X-axis basis rows [8 waves][4 a][4 q][2]
+  return ((tables + 15) & ~(size_t)15) + (size_t)2 * wpb * 32 * 8;   // + per-wavefront Y-axis and X-axis basis rows [wpb waves][4 a][4 q][2]
 }
 // mapped geometry: per-wavefront [64 points][7] (JW * F^-1 F^-T: 00,01,02,11,12,22; forcing * JW / W) + [64][4] (1/W, dW/W);
 // the element's control points (homogeneous, [aw][ay][ax][4]) are staged at its start and overwritten by the results
@@ -1539,7 +1540,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int seg = blockIdx.x / pa.blocks_per_seg;
-  const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * 8 + wave;
+  const int pencil = (blockIdx.x - seg * pa.blocks_per_seg) * pa.wpb + wave;
   const int ws = pa.w_lo + seg * pa.seg_len;
   const int we = min(ws + pa.seg_len, pa.w_hi);
   static_assert(ALIAS <= 0 || W == 0, "only the axis-0 walk wraps");
@@ -1554,15 +1555,15 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   PencilLds T = pencil_lds_carve(pencil_sm, pa.ne_max, GEO);
   T.lay0 = alias0 ? AW.off[0] + wh : AW.off[wh];             // (alias0: a virtual layer number; rows and tables are taken modulo the axis)
   {
-    const int tid = threadIdx.x;
-    if (!GEO) for (int i = tid; i < ne * 32; i += 512) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
+    const int tid = threadIdx.x, nthr = pa.wpb * 64;
+    if (!GEO) for (int i = tid; i < ne * 32; i += nthr) {   // i = e*32 + (q*4 + a)*2 + k ; rows scaled by sqrt(w_q * J_e)
       const int e = i >> 5, j = i & 31, q = j >> 3, aa = (j >> 1) & 3, k = j & 1, eg = ew(e);
       T.zt[i] = (q < NB && aa < NB) ? AW.tab[((size_t)eg * NB * NB + q * NB + aa) * NDER + k] * sqrt(AW.w[eg * NB + q] * AW.J[eg]) : 0.0;
     }
     // (GEO: the weight itself, not its root: the metric carries the whole JW)
-    for (int i = tid; i < ne * 4; i += 512) { const int e = i >> 2, q = i & 3, eg = ew(e); const double wj = (q < NB) ? AW.w[eg * NB + q] * AW.J[eg] : 0.0; T.wq[i] = GEO ? wj : sqrt(wj); }
-    for (int i = tid; i < ne; i += 512) T.Jz[i] = AW.J[ew(i)];
-    for (int i = tid; i < nl; i += 512) {
+    for (int i = tid; i < ne * 4; i += nthr) { const int e = i >> 2, q = i & 3, eg = ew(e); const double wj = (q < NB) ? AW.w[eg * NB + q] * AW.J[eg] : 0.0; T.wq[i] = GEO ? wj : sqrt(wj); }
+    for (int i = tid; i < ne; i += nthr) T.Jz[i] = AW.J[ew(i)];
+    for (int i = tid; i < nl; i += nthr) {
       int lay = T.lay0 + i;
       if (alias0) { lay = (lay - AW.off[0]) % nelw; if (lay < 0) lay += nelw; lay += AW.off[0]; }
       if (lay < AW.gwidth) {
@@ -1599,7 +1600,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     L.u0 = 0; L.u1 = 0;
     if (qx < NB && ix < NB) { const double sx = GEO ? 1.0 : sqrt(WX[qx] * AX.J[elx]); L.u0 = TX[(qx * NB + ix) * NDER + 0] * sx; L.u1 = TX[(qx * NB + ix) * NDER + 1] * sx; }
     {   // Y-axis rows of this pencil -> LDS [a][q][2] (zero padded); a lane later reads its own row (a = iy) one q at a time
-      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max, GEO) - 2 * 8 * 32 * 8))) + wave * 32;
+      double *vyw = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + ((pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) - (size_t)2 * pa.wpb * 32 * 8))) + wave * 32;
       if (lane < 32) {
         const int aa = lane >> 3, qq = (lane >> 1) & 3, kk = lane & 1;
         vyw[lane] = (aa < NB && qq < NB) ? TY[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WYq[qq] * AY.J[ely])) : 0.0;
@@ -1607,7 +1608,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       L.vy = vyw + iy * 8;
       if (lane >= 32) {   // X-axis rows [q][a][2]: GEO unscaled, for the geometry evaluation and F; else scaled like u0 / u1 (p = 2: packed k-steps)
         const int l2 = lane - 32, qq = l2 >> 3, aa = (l2 >> 1) & 3, kk = l2 & 1;
-        vyw[8 * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WX[qq] * AX.J[elx])) : 0.0;
+        vyw[pa.wpb * 32 + l2] = (aa < NB && qq < NB) ? TX[(qq * NB + aa) * NDER + kk] * (GEO ? 1.0 : sqrt(WX[qq] * AX.J[elx])) : 0.0;
       }
     }
     if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
@@ -1655,7 +1656,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double *hold = nullptr;
   if (W == 0) {
     constexpr int HS = (P * (P + 1) / 2) * 4 * HOLD_LD;
-    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO)) + wave * HS;
+    hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO, pa.wpb)) + wave * HS;
     for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
   // mapped geometry: this wavefront's metric area, the raw basis rows, the Gauss weights of this lane's point on axes X, Y
@@ -1663,7 +1664,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   constexpr bool rational = GEO && RAT;
   if constexpr (GEO) {
     geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GD;
-    vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + 8 * 32;
+    vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + pa.wpb * 32;
     const int gqx = lane & 3, gqy = (lane >> 2) & 3;
     if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
   }
@@ -1760,7 +1761,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
     else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
-    else if constexpr (P == 2 && W == 0) pencil_mfma_p2(acc, L.vy - ((lane >> 2) & 3) * 8 + 8 * 32, L.vy, zt, lane);
+    else if constexpr (P == 2 && W == 0) pencil_mfma_p2(acc, L.vy - ((lane >> 2) & 3) * 8 + pa.wpb * 32, L.vy, zt, lane);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
     if (SYSTEM && !GEO) {   // F_a += f * J * prod_d sum_q w N : the walk-axis factor is sum_q sqrt(wJ) * (sqrt(wJ) N)
@@ -1809,6 +1810,17 @@ template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FI
 __global__ void __launch_bounds__(512, 2)
 gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
   gram_pencil_body<SYSTEM, W, P, GEO, RAT, FIXT, void, false, ALIAS>(S, out, pa, nullptr);
+}
+
+// Twelve-wave workgroups for the free-running p = 2 walk on the identity geometry (config 2): without the ping-pong nothing ties the
+// waves to pairs, the kernel needs 154-176 VGPRs -- two waves per SIMD with eight-wave workgroups, a third of the register file idle --
+// and a twelve-wave workgroup puts three waves on every SIMD (168 VGPRs each): the MFMA pipe finds a ready wave more often.
+// (Two six-wave workgroups per CU do not do it: a workgroup's waves 4 and 5 land on SIMDs 0 and 1 again, a second workgroup does not fit
+// there and the CU runs six waves: 140 M el/s against 175.)
+template <bool SYSTEM, int P, int ALIAS>
+__global__ void __launch_bounds__(768, 3)
+gram_pencil_w6(SpaceDev S, OutDev out, PencilArgs pa) {
+  gram_pencil_body<SYSTEM, 0, P, false, false, false, void, false, ALIAS>(S, out, pa, nullptr);
 }
 
 // the same walk for a run-time scalar form (rtc.hpp compiles this instantiation with hiprtc; IDENT: no geometry)
@@ -1869,14 +1881,14 @@ inline const char *&pencil_launch_error() { static thread_local const char *e = 
 // elements -- but enough workgroups for the CUs.  One 8-pencil workgroup per CU at a time (LDS; two where the tables are small), so a
 // launch takes ceil(workgroups / slots) rounds of (segment length + halo): the count with the least rounds x length.  Returns the
 // count; *cost = that product (element-steps of the launch's critical path).
-static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bool walk0, size_t extra_lds, bool halo_always, long long *cost_out = nullptr) {
+static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bool walk0, size_t extra_lds, bool halo_always, long long *cost_out = nullptr, int wpb = 8) {
   static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
-  const long long bps = (pencils + 7) / 8;
+  const long long bps = (pencils + wpb - 1) / wpb;
   int nseg = std::max(1, (nw + 159) / 160);
   long long best = -1; int best_n = nseg;
   for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
     const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
-    const size_t lds_n = pencil_lds_bytes(len + 3, geo) + (walk0 ? pencil_hold_bytes(P) : 0) + (geo ? pencil_geo_bytes() : 0) + extra_lds;
+    const size_t lds_n = pencil_lds_bytes(len + 3, geo, wpb) + (walk0 ? pencil_hold_bytes(P) * wpb / 8 : 0) + (geo ? pencil_geo_bytes() : 0) + extra_lds;
     // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
     if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
     const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
@@ -1918,23 +1930,27 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     if (!color_range(s.lay[X], cx, bx.lo[X], bx.hi[X], pa.ex_start, pa.ex_step, pa.ex_count)) continue;
     if (!color_range(s.lay[Y], cy, bx.lo[Y], bx.hi[Y], pa.ey_start, pa.ey_step, pa.ey_count)) continue;
     const long long pencils = (long long)pa.ex_count * pa.ey_count;
-    int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, mod ? mod->extra_lds : 0, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]));
-    if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
-    pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
-    pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
-    pa.blocks_per_seg = (int)((pencils + 7) / 8);
-    pa.ne_max = pa.seg_len + 3;
-    pa.debug_noflush = s.env.debug_noflush;
     // p = 2 on the identity geometry: the flush is the longer phase and the rigid ping-pong makes the MFMA wave wait for it; left to
     // the SIMD's own arbitration the walk gains 5 % (128^3: 166.7 -> 175.3 M el/s).  Everything at p = 3, mapped geometries and
     // Tangents lose 6-8 % without the barriers (256^3: 64.8 -> 59.5).  IGX_FREE_RUN=0/1 overrides.
     pa.free_run = s.env.free_run >= 0 ? s.env.free_run : ((P == 2 && !GEO && !(mod && mod->state)) ? 1 : 0);
+    // ... and free of the pairing, six-wave workgroups put three waves on every SIMD (gram_pencil_w6; IGX_WPB=8: the eight-wave kernel)
+    static const int wpb_env = [] { const char *e = getenv("IGX_WPB"); return e ? atoi(e) : 0; }();
+    const bool w6 = W == 0 && P == 2 && !GEO && !FIXT && !mod && pa.free_run && wpb_env != 8;
+    pa.wpb = w6 ? 12 : 8;
+    int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, mod ? mod->extra_lds : 0, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
+    if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
+    pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
+    pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
+    pa.blocks_per_seg = (int)((pencils + pa.wpb - 1) / pa.wpb);
+    pa.ne_max = pa.seg_len + 3;
+    pa.debug_noflush = s.env.debug_noflush;
     pa.debug_buf = nullptr;
     static int dbg_done = 0;
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO) + (W == 0 ? pencil_hold_bytes(P) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);
+    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? pencil_hold_bytes(P) * pa.wpb / 8 : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
     if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the pencil walk's tables do not fit the 160 KB of LDS for any segment length"; return; }
     if (mod && mod->kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mod->kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1949,8 +1965,9 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     } else {
     void (*kern)(SpaceDev, OutDev, PencilArgs) = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
     if constexpr (W == 0 && !GEO) kern = pa.alias0 ? gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 1> : gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 0>;
+    if constexpr (W == 0 && P == 2 && !GEO && !FIXT) { if (w6) kern = pa.alias0 ? gram_pencil_w6<SYSTEM, P, 1> : gram_pencil_w6<SYSTEM, P, 0>; }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3(512), lds, stream, S, out, pa);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3((unsigned)(pa.wpb * 64)), lds, stream, S, out, pa);
     }
     if (dbg_t) {   // IGX_DEBUG_TIMING=1: cycle stamps of the ping-pong phases of the first launch (diagnostic only)
       dbg_done = 1;
