@@ -152,7 +152,7 @@ __device__ __forceinline__ constexpr unsigned vs_kmask_ident(unsigned vmask) {
 // GEO: a mapped geometry and / or NURBS weights; without them the geometry chain is the identity at compile time (no E1 / E2
 // products, no quotient rule) and the kernel needs half the registers
 template <class Form, bool GEO, int NS = 4>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)      // (two waves per SIMD: the geometry variants of NS-VMS and Cahn-Hilliard need 290-350 VGPRs uncapped, one wave per SIMD)
 vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nelem) {
   constexpr int EPW = NS == 3 ? 2 : 1, NL = NS * NS * NS;               // elements per wavefront, lanes per element
   constexpr int DOF = Form::DOF;
