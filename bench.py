@@ -386,6 +386,8 @@ def main():
         def _expired():
             sys.stderr.write("bench.py: rank %d of %d did not finish within %.0f s (IGX_BENCH_TIMEOUT_S): leaving with exit code 124\n" % (rank, world, limit))
             sys.stderr.flush()
+            import faulthandler
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)      # where every thread of this rank stands
             os._exit(124)
         wd = threading.Timer(limit, _expired)
         wd.daemon = True
@@ -396,7 +398,13 @@ def main():
     from petiga_amd import exchange
     assert not args.source or args.form == "poisson", "--source is the metric configuration's form given as source"
     g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry, args.source)
-    transport = exchange.init_comm(g) if world > 1 else None      # the library's own exchange: RCCL (or the gloo test transport)
+    # the library's own exchange: RCCL (or the gloo test transport).  IGX_BENCH_TRANSPORT=rccl keeps the library on its grouped
+    # ncclSend / ncclRecv path while torch.distributed stays on gloo: with IGX_RCCL_LIB naming tests/fake_rccl's double, N ranks
+    # that share one GPU run the product transport's schedule (tests/test_gpu_bench_ranks.py).
+    want = os.environ.get("IGX_BENCH_TRANSPORT") or None
+    transport = exchange.init_comm(g, transport=want) if world > 1 else None
+    if want and world > 1 and transport != want:
+        sys.exit("bench.py: IGX_BENCH_TRANSPORT=%s asked for, the library bound %r" % (want, transport))
     # what the transport itself reports: ncclCommCount of the library's communicator ("did RCCL see N ranks")
     try:
         comm_kind, comm_ranks = g.comm_ranks() if world > 1 else (None, None)

@@ -591,7 +591,7 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
       const size_t need = (size_t)pencils * pa.nel0 * rec * sizeof(double);
-      if (hipMallocAsync(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
+      if (pool_alloc(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
       const long long nelem = pencils * pa.nel0;
       launch(true, (unsigned)((nelem + 3) / 4), 0, geo, rat, P, pa);
       const size_t lds = (size_t)bpt_carve(rec, pa.seg_len).total * sizeof(double);

@@ -499,7 +499,7 @@ static int launch_boundary_loads_fields(const Space &s, const OutDev &out, hipSt
     }
     double *dt = nullptr;
     const size_t bytes = (sum[0].size() + sum[1].size()) * sizeof(double);
-    if (hipMallocAsync(reinterpret_cast<void **>(&dt), bytes, stream) != hipSuccess) { err = "device allocation of the boundary-load sums failed"; return IGX_ERR_MEM; }
+    if (pool_alloc(reinterpret_cast<void **>(&dt), bytes, stream) != hipSuccess) { err = "device allocation of the boundary-load sums failed"; return IGX_ERR_MEM; }
     (void)hipMemcpyAsync(dt, sum[0].data(), sum[0].size() * sizeof(double), hipMemcpyHostToDevice, stream);
     (void)hipMemcpyAsync(dt + sum[0].size(), sum[1].data(), sum[1].size() * sizeof(double), hipMemcpyHostToDevice, stream);
     (void)hipStreamSynchronize(stream);

@@ -30,12 +30,20 @@ constexpr int kNcclDouble = 8;   // ncclFloat64 (rccl.h)
 
 static int load_rccl(RcclApi &api, const char *path, std::string &err) {
   if (api.handle) return 0;
+  // A library the caller names (argument, then $IGX_RCCL_LIB) is the one that is bound, whatever else the process has loaded
+  // (PyTorch maps its own librccl.so: a test double named here must still win).  Otherwise a copy that is already loaded is
+  // reused, and only then a fresh one.  RTLD_LOCAL: the symbols are taken with dlsym, nobody else should resolve against them.
   const char *env = getenv("IGX_RCCL_LIB");
-  const char *names[] = {path, env, "librccl.so.1", "librccl.so"};
+  for (const char *n : {path, env}) {
+    if (!n || !*n) continue;
+    api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (!api.handle) { err = std::string("cannot load ") + n + ": " + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }
+    break;
+  }
+  const char *names[] = {"librccl.so.1", "librccl.so"};
   for (int pass = 0; pass < 2 && !api.handle; ++pass)     // first a copy that is already loaded, then a fresh one
     for (const char *n : names) {
-      if (!n || !*n) continue;
-      api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+      api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (api.handle) break;
     }
   if (!api.handle) { err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }

@@ -2119,7 +2119,7 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
     if (s.nsd) {      // mapped geometry: face areas per element on the device, then the per-node sums
       FaceAreaArgs A; A.d = d; A.t = t; A.u = u; A.side = sd; A.nt = s.elem_width[t]; A.nu = s.elem_width[u];
       const int ne = A.nt * A.nu, nn = F.nt * F.nu;
-      if (hipMallocAsync(reinterpret_cast<void **>(&A.area), (size_t)ne * sizeof(double), stream) != hipSuccess) { err = "device allocation of the face areas failed"; return IGX_ERR_MEM; }
+      if (pool_alloc(reinterpret_cast<void **>(&A.area), (size_t)ne * sizeof(double), stream) != hipSuccess) { err = "device allocation of the face areas failed"; return IGX_ERR_MEM; }
       F.value = load; F.st = F.su = nullptr;
       hipLaunchKernelGGL(k_face_areas, dim3((unsigned)((ne + 63) / 64)), dim3(64), 0, stream, S, A);
       hipLaunchKernelGGL(k_boundary_loads_mapped, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, stream, S, F, A, s.lay[0].nrow, s.lay[1].nrow, out.vec);
@@ -2129,7 +2129,7 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
     // the two short tables live for this launch only: stream-ordered allocation, copy, kernel, free
     double *dt = nullptr;
     const size_t bytes = (sum[0].size() + sum[1].size()) * sizeof(double);
-    if (hipMallocAsync(reinterpret_cast<void **>(&dt), bytes, stream) != hipSuccess) { err = "device allocation of the boundary-load sums failed"; return IGX_ERR_MEM; }
+    if (pool_alloc(reinterpret_cast<void **>(&dt), bytes, stream) != hipSuccess) { err = "device allocation of the boundary-load sums failed"; return IGX_ERR_MEM; }
     (void)hipMemcpyAsync(dt, sum[0].data(), sum[0].size() * sizeof(double), hipMemcpyHostToDevice, stream);
     (void)hipMemcpyAsync(dt + sum[0].size(), sum[1].data(), sum[1].size() * sizeof(double), hipMemcpyHostToDevice, stream);
     (void)hipStreamSynchronize(stream);      // (pageable host memory: the vectors go out of scope below; a face with loads is rare and small)

@@ -52,6 +52,30 @@ struct Box { int lo[3], hi[3]; };   // local element box [lo,hi)
 // face's messages half (a quarter, an eighth) of the assembly to travel.  A multiple of p+1, at least p+1 from both ends.
 static inline int face_cut(int n, int p) { const int c = (n / 2) / (p + 1) * (p + 1); return std::max(p + 1, std::min(c, n - (p + 1))); }
 
+// Launch-scoped device arrays (the point records of band_pt, the boundary-load sums of the pencil kernels) live in a
+// stream-ordered pool of the library's own: what one launch frees is what the next one takes, and nothing goes back to the
+// driver at a synchronisation point.  (The device's default pool has a release threshold of 0: after every host synchronisation
+// the next assembly paid a fresh device allocation for each of its launches, on the host, in the middle of its launch sequence.)
+// One pool per process (inline: the translation units of the library share it).
+inline hipMemPool_t igx_pool() {
+  static hipMemPool_t pool = [] {
+    hipMemPool_t p = nullptr; int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return p;
+    hipMemPoolProps props; memset(&props, 0, sizeof(props));
+    props.allocType = hipMemAllocationTypePinned; props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice; props.location.id = dev;
+    if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return (hipMemPool_t) nullptr; }
+    uint64_t keep = ~0ull;
+    (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
+    return p;
+  }();
+  return pool;
+}
+inline hipError_t pool_alloc(void **ptr, size_t bytes, hipStream_t stream) {
+  if (hipMemPool_t p = igx_pool()) return hipMallocFromPoolAsync(ptr, bytes, p, stream);
+  return hipMallocAsync(ptr, bytes, stream);
+}
+
 // colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element
 static bool color_range(const AxisLayout &L, int c, int lo, int hi, int &start, int &step, int &count) {
   start = -1; count = 0; step = L.p + 1;

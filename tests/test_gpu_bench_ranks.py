@@ -17,7 +17,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GRID = {2: [1, 1, 2], 4: [1, 2, 2], 8: [2, 2, 2]}
 
 
-def _check_line(r, form, size, ranks=2):
+FAKE_RCCL = os.path.join(ROOT, "tests", "fake_rccl", "libfake_rccl.so")
+
+
+def _env(transport):
+    """gloo for torch.distributed (ranks share the one GPU); the library's exchange on the host-callback transport, or on its
+    product transport (grouped ncclSend / ncclRecv) bound to tests/fake_rccl's double of librccl.so"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(IGX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "rccl":
+        env.update(IGX_BENCH_TRANSPORT="rccl", IGX_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_TIMEOUT_S="240")
+    return env
+
+
+def _check_line(r, form, size, ranks=2, transport="host"):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -27,7 +40,8 @@ def _check_line(r, form, size, ranks=2):
     chk = line["config"]["checksum_check"]
     assert chk is not None and chk["size"] == size and max(chk["rel_diff"]) < 1e-9, chk
     assert line["config"]["partition"] == GRID[ranks]
-    assert line["config"]["transport"] == "host" and line["config"]["transport_ranks"] == ranks and line["config"]["rccl_ranks"] is None
+    assert line["config"]["transport"] == transport and line["config"]["transport_ranks"] == ranks
+    assert line["config"]["rccl_ranks"] == (ranks if transport == "rccl" else None)      # ncclCommCount of the library's communicator
     per_rank = line["roofline_per_rank"]
     assert [r_["rank"] for r_ in per_rank] == list(range(ranks)) and sum(r_["local_elements"] for r_ in per_rank) == size ** 3
     assert all(r_["frac"] is not None and r_["avg_launch_ms"] > 0 for r_ in per_rank)
@@ -35,26 +49,23 @@ def _check_line(r, form, size, ranks=2):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("form,size", [("poisson", 64), ("elasticity", 48), ("cahnhilliard", 64), ("nsvms", 32)])
-def test_bench_two_ranks_checksums(form, size):
+@pytest.mark.parametrize("form,size,transport", [("poisson", 64, "rccl"), ("elasticity", 48, "host"), ("cahnhilliard", 64, "host"), ("nsvms", 32, "rccl")])
+def test_bench_two_ranks_checksums(form, size, transport):
     """The way the driver starts it: `python bench.py --gpus 2 ...`, no launcher, WORLD_SIZE unset."""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(IGX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--form", form, "--size", str(size), "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    _check_line(r, form, size)
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(transport), capture_output=True, text=True, timeout=900)
+    _check_line(r, form, size, 2, transport)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("ranks,form,size", [(8, "cahnhilliard", 48), (4, "nsvms", 32), (8, "poisson", 64)])
 def test_bench_four_and_eight_ranks(ranks, form, size):
     """[1,2,2] and [2,2,2] as processes sharing the one GPU: the ghost refresh of a nonlinear form (its lists differ in length from the
-    reduction's: the exchange buffers of round 3 did not survive that) and the whole N-rank flow of the driver's SCALE run"""
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    env.update(IGX_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    reduction's: the exchange buffers of round 3 did not survive that) and the whole N-rank flow of the driver's SCALE run --
+    through the library's RCCL branch (comm.hpp kind == 1) on the test double: rccl_ranks == N in the line"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--form", form, "--size", str(size), "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    _check_line(r, form, size, ranks)
+    r = subprocess.run(cmd, cwd=ROOT, env=_env("rccl"), capture_output=True, text=True, timeout=900)
+    _check_line(r, form, size, ranks, "rccl")
 
 
 @pytest.mark.gpu

@@ -2,10 +2,13 @@
 IGXReduceGhostRows, IGXRefreshGhosts): replaces MatAssemblyBegin/End + VecAssemblyBegin/End (src/petigaksp.c:197-200) and the
 DMGlobalToLocal of IGAGetLocalVecArray (src/petigavec.c:256-269).
 
-A gpurun box has one GPU, so the N-rank flow runs as N processes sharing it, with the host-callback transport over gloo
-(pack kernels -> exchange stream -> callback -> unpack kernels -> event back to the engine stream: everything but the wire);
-the RCCL binding itself (dlopen, communicator, grouped ncclSend / ncclRecv on the exchange stream, events) is exercised on one
-rank through IGXCommLoopbackTest.  Results are compared with the single-rank ORACLE."""
+A gpurun box has one GPU, so the N-rank flow runs as N processes sharing it.  Every case goes through the PRODUCT transport
+(comm.hpp kind == 1: grouped ncclSend / ncclRecv on the exchange stream, three stream-ordered phases, receives posted ahead of the
+assembly) bound to tests/fake_rccl's double of librccl.so ($IGX_RCCL_LIB), which keeps RCCL's ordering semantics -- stream-enqueued
+operations, concurrent progress inside a group, ordered groups, rendezvous -- between processes on one device; a few cases also
+run on the host-callback transport over gloo (kind == 2: the hook an MPI caller uses).  The real librccl.so is exercised on one
+rank through IGXCommLoopbackTest.  Results are compared with the single-rank ORACLE.  A deliberately broken schedule (every
+group finishes its receives before it starts its sends) must hang and be reported: the double can see what it is there to see."""
 import os
 import sys
 
@@ -48,8 +51,14 @@ def _poisson_loads(g):
     g.set_boundary_load(2, 0, 0, 0.4)
 
 
-def _rank_main(rank, world, port, case, outdir, name=""):
+FAKE_RCCL = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
+
+
+def _rank_main(rank, world, port, case, outdir, name="", transport="rccl", fake_env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "rccl":
+        os.environ.update(IGX_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_TIMEOUT_S="90")
+        os.environ.update(fake_env or {})
     if "pencil" in name:
         os.environ["IGX_OVERLAP"] = "1"       # the face-first passes whatever their cost (unset, the walk weighs it against the size of the faces: tiny here)
     if "combine" in name:
@@ -90,7 +99,8 @@ def _rank_main(rank, world, port, case, outdir, name=""):
             g.set_boundary_load(1, 1, 2, 0.5)
             g.set_boundary_load(2, 0, 1, -0.25)
     g.set_form(form, params)
-    assert exchange.init_comm(g) == "host"
+    assert exchange.init_comm(g, transport=transport) == transport
+    assert g.comm_ranks() == (transport, world)      # kind 1: ncclCommCount of the communicator the library created
     A, b = g.create_mat(), g.create_vec()
     n_global = int(np.prod(g.sizes()["node_sizes"])) * dof
     rng = np.random.default_rng(5)
@@ -188,18 +198,40 @@ CASES = {
     "elasticity-p2-2ranks-split": (2, (3, 3, 2, (5, 6, 13), (0, 0, 0), "elasticity", (1.5, 0.8))),
     "cahnhilliard-p2-2ranks-split": (2, (3, 1, 2, (6, 6, 12), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
     "cahnhilliard-p2-2ranks": (2, (3, 1, 2, (6, 6, 8), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
+    # ranks of two elements at p = 3 ([1,1,3]): rank 0's ghost layer belongs to ranks 1 AND 2 -- two messages up, one of them skipping a rank
+    "poisson-p3-3ranks-thin": (3, (3, 1, 3, (4, 4, 6), (0, 0, 0), "poisson", ())),
 }
+# the host-callback transport (kind == 2) keeps a few cases: both list shapes, the refresh, the face passes
+HOST_CASES = ["poisson-p3-2ranks", "poisson-p2-8ranks-pencil-faces", "cahnhilliard-p2-2ranks", "elasticity-p3-2ranks-split-block-loads"]
 
 
-@pytest.mark.parametrize("name", sorted(CASES))
-def test_library_exchange_matches_single_rank_oracle(name, tmp_path):
+def test_broken_schedule_hangs_and_is_reported(tmp_path):
+    """The double must be able to fail.  With FAKE_RCCL_BREAK=recv_first every group completes its receives before it starts its
+    sends -- what comm.hpp would get if it split a phase into a receive group followed by a send group on the exchange stream.
+    On a periodic axis split over two ranks each rank both sends to and receives from the other in one phase: both wait for the
+    other's send for ever.  The double reports the deadlock after FAKE_RCCL_TIMEOUT_S and the ranks leave with an error; the SAME
+    case passes in the parametrised test below with the switch unset."""
+    import torch.multiprocessing as mp
+    name = "poisson-p3-2ranks-pencil-periodic"
+    world, case = CASES[name]
+    port = 29600 + (os.getpid() + hash(name) + 7) % 300
+    with pytest.raises(Exception) as e:
+        mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name, "rccl", dict(FAKE_RCCL_BREAK="recv_first", FAKE_RCCL_TIMEOUT_S="6")), nprocs=world, join=True)
+    assert "exit code 86" in str(e.value) or "terminated" in str(e.value), str(e.value)[-600:]
+    assert not os.path.exists(os.path.join(str(tmp_path), "rank0.npz")) and not os.path.exists(os.path.join(str(tmp_path), "rank1.npz"))
+    for f in [f for f in os.listdir("/dev/shm") if f.startswith("fake_rccl_")]:      # what the aborted ranks left staged
+        os.unlink(os.path.join("/dev/shm", f))
+
+
+@pytest.mark.parametrize("name,transport", [(n, "rccl") for n in sorted(CASES)] + [(n, "host") for n in HOST_CASES])
+def test_library_exchange_matches_single_rank_oracle(name, transport, tmp_path):
     import torch.multiprocessing as mp
     import oracle_api as O
     from common import make_pair
     world, case = CASES[name]
     dim, dof, p, N, periodic, form, params = case
     port = 29600 + (os.getpid() + hash(name)) % 300
-    mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name), nprocs=world, join=True)
+    mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name, transport), nprocs=world, join=True)
     orc, _ = make_pair(dim, dof, p, list(N), periodic=[bool(x) for x in periodic], engine=False)
     if "nurbs" in name:
         from common import warped_geometry
