@@ -111,6 +111,7 @@ def live_traffic(child_args, dom_name, timeout=300):
     (2 x FETCH_SIZE + WRITE_SIZE: gfx950 tallies a 128-byte read request as 64 bytes)."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     import tempfile
@@ -127,7 +128,8 @@ def live_traffic(child_args, dom_name, timeout=300):
             per = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and ("igx::" + key + "<") in r["Kernel_Name"]:
+                    # the symbol may carry a variant suffix the engine's kernel name does not (gram_pencil_w6<...>, state_pencil_geo<...>)
+                    if r["Counter_Name"] == counter and re.search(r"igx::" + re.escape(key) + r"(_\w+)?<", r["Kernel_Name"]):
                         per.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
             if not per:
                 return None, "no %s samples of %s" % (counter, key)

@@ -52,9 +52,10 @@ def lib(build_if_needed=False):
     if _LIB is not None:
         return _LIB
     so = os.path.join(_HERE, "libpetiga_amd_debug.so" if os.environ.get("IGX_USE_DEBUG_LIB") else "libpetiga_amd.so")   # the -DIGX_DEBUG experiment build
-    if os.environ.get("IGX_LIB"):      # another build of this same library (A/B measurements, scripts/headline_ab.py)
+    named = bool(os.environ.get("IGX_LIB"))
+    if named:      # another build of this same library (A/B measurements, scripts/headline_ab.py): it is the one that is loaded, never rebuilt
         so = os.path.abspath(os.environ["IGX_LIB"])
-    if build_if_needed:
+    elif build_if_needed:
         so = _build.build()
     if not os.path.exists(so):
         raise ImportError("libpetiga_amd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
@@ -104,12 +105,17 @@ def lib(build_if_needed=False):
         "IGXCommLoopbackTest": [V, C.c_int64, _dp], "IGXCommGetRanks": [V, C.POINTER(C.c_int), C.POINTER(C.c_int)], "IGXCommGetEarlyPhases": [V, C.POINTER(C.c_int)],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
+    missing = []
     for name, args in sig.items():
-        if os.environ.get("IGX_LIB") and not hasattr(L, name):      # an older build of the library under A/B: it lacks newer entry points
+        if named and not hasattr(L, name):      # an older build of the library under A/B: it lacks newer entry points
+            missing.append(name)
             continue
         f = getattr(L, name)
         f.argtypes = args
         f.restype = C.c_int
+    if named:      # say which library this is and what it cannot do, here, not as an AttributeError far from the cause
+        import sys
+        print("petiga_amd: loaded IGX_LIB=%s%s" % (so, (" -- it lacks %d entry point(s) of include/petiga_amd.h: %s" % (len(missing), ", ".join(missing))) if missing else ""), file=sys.stderr)
     _LIB = L
     return L
 

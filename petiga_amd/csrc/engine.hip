@@ -1128,7 +1128,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       if (!g->slab_ev && hipEventCreateWithFlags(&g->slab_ev, hipEventDisableTiming) != hipSuccess) return;
       if (hipEventRecord(g->slab_ev, g->stream) == hipSuccess) { g->slab_valid |= 1; g->slab_A = A; g->slab_b = b; }
     };
-    if (g->comm && s.env.overlap) g->face_done = [&](int axis) {      // (run-time forms on the pencil walk: rtc.hpp)
+    if (g->comm && s.env.overlap && s.env.overlap != 2) g->face_done = [&](int axis) {      // (run-time forms on the pencil walk: rtc.hpp; IGX_OVERLAP=2: the mark of axis 2 alone, as for the built-in forms)
       if (axis < 0 || axis > 1) return;
       if (!g->face_ev[axis] && hipEventCreateWithFlags(&g->face_ev[axis], hipEventDisableTiming) != hipSuccess) return;
       if (hipEventRecord(g->face_ev[axis], g->stream) == hipSuccess) { g->slab_valid |= (axis == 1 ? 2 : 4); g->slab_A = A; g->slab_b = b; }

@@ -355,7 +355,9 @@ struct FormNSVMS {
   // the advective feature negated: 52 instead of 64 multiply-adds per k-step.
   static constexpr int BAND_NACC = 17, BAND_NCOEF = 3;
   static constexpr bool BAND_NEG_FEAT5 = true;
-  static bool band_params_ok(const double *prm) { return prm[0] > 0.0; }      // (the scaling by 1 / nu; an inviscid flow stays on the feature kernel)
+  // (the scaling by 1 / nu; an inviscid flow stays on the feature kernel.  Host AND device: the launcher of a built-in struct calls
+  //  it directly, a run-time struct's is evaluated by a one-lane kernel of its module -- rtc.hpp)
+  __host__ __device__ static bool band_params_ok(const double *prm) { return prm[0] > 0.0; }
   static __device__ __forceinline__ void band_coef(const PtView &p, double *c) { double tM, tC; tau(p, tM, tC); c[0] = tM; c[1] = tC / p.prm[0]; c[2] = 1.0 + c[1]; }
   static constexpr unsigned band_acc_mask(int n) {
     if (n == 16) return 0xFu;

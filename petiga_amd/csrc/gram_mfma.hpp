@@ -1899,14 +1899,20 @@ static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bo
   return best_n;
 }
 // the same summed over the colour launches of a box of elements (axis-0 walk): what a pass of an assembly costs
-static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always) {
+// waves per workgroup of the axis-0 walk: twelve for the free-running p = 2 kernel on the identity geometry (gram_pencil_w6), else eight
+static inline int pencil_wpb(const Space &s, int P, bool geo, bool fixt, bool has_mod) {
+  static const int wpb_env = [] { const char *e = getenv("IGX_WPB"); return e ? atoi(e) : 0; }();
+  const int free_run = s.env.free_run >= 0 ? s.env.free_run : ((P == 2 && !geo && !has_mod) ? 1 : 0);
+  return (P == 2 && !geo && !fixt && !has_mod && free_run && wpb_env != 8) ? 12 : 8;
+}
+static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always, int wpb = 8) {
   long long total = 0;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return 0;
   for (int cy = 0; cy < s.lay[2].ncolors; ++cy) for (int cx = 0; cx < s.lay[1].ncolors; ++cx) {
     int st, sp, nx, ny;
     if (!color_range(s.lay[1], cx, bx.lo[1], bx.hi[1], st, sp, nx) || !color_range(s.lay[2], cy, bx.lo[2], bx.hi[2], st, sp, ny)) continue;
     long long c = 0;
-    (void)pencil_segments((long long)nx * ny, bx.hi[0] - bx.lo[0], P, geo, true, extra_lds, halo_always || s.lay[0].alias, &c);
+    (void)pencil_segments((long long)nx * ny, bx.hi[0] - bx.lo[0], P, geo, true, extra_lds, halo_always || s.lay[0].alias, &c, wpb);
     total += c;
   }
   return total;
@@ -1935,8 +1941,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     // Tangents lose 6-8 % without the barriers (256^3: 64.8 -> 59.5).  IGX_FREE_RUN=0/1 overrides.
     pa.free_run = s.env.free_run >= 0 ? s.env.free_run : ((P == 2 && !GEO && !(mod && mod->state)) ? 1 : 0);
     // ... and free of the pairing, six-wave workgroups put three waves on every SIMD (gram_pencil_w6; IGX_WPB=8: the eight-wave kernel)
-    static const int wpb_env = [] { const char *e = getenv("IGX_WPB"); return e ? atoi(e) : 0; }();
-    const bool w6 = W == 0 && P == 2 && !GEO && !FIXT && !mod && pa.free_run && wpb_env != 8;
+    const bool w6 = W == 0 && pencil_wpb(s, P, GEO, FIXT, mod != nullptr) == 12;
     pa.wpb = w6 ? 12 : 8;
     int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, mod ? mod->extra_lds : 0, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
@@ -2259,12 +2264,13 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       // is 141 MB = 2.4 ms: one pass; at 2 ranks (256 x 256 x 128) the pass costs 2.3 ms and the face is 552 MB = 9 ms: faces first
       // (scripts/time_rank_box.py, profiles/r04_face_passes.txt).
       const size_t xl = mod ? mod->extra_lds : 0;
+      const int wpb = pencil_wpb(s, deg, geo, fixt, mod != nullptr);      // (the workgroup count the launches will really have)
       Box R = P; long long multi = 0;
-      if (can2) { Box A = R; A.lo[2] = c2; R.hi[2] = c2; multi += pencil_box_cost(s, deg, geo || mod, xl, A, false); }
-      if (can1) { Box B = R; B.lo[1] = c1; R.hi[1] = c1; multi += pencil_box_cost(s, deg, geo || mod, xl, B, false); }
-      if (can0) { Box C = R; C.lo[0] = c0; R.hi[0] = c0; multi += pencil_box_cost(s, deg, geo || mod, xl, C, true); }
-      multi += pencil_box_cost(s, deg, geo || mod, xl, R, false);
-      const long long single = pencil_box_cost(s, deg, geo || mod, xl, P, false);
+      if (can2) { Box A = R; A.lo[2] = c2; R.hi[2] = c2; multi += pencil_box_cost(s, deg, geo || mod, xl, A, false, wpb); }
+      if (can1) { Box B = R; B.lo[1] = c1; R.hi[1] = c1; multi += pencil_box_cost(s, deg, geo || mod, xl, B, false, wpb); }
+      if (can0) { Box C = R; C.lo[0] = c0; R.hi[0] = c0; multi += pencil_box_cost(s, deg, geo || mod, xl, C, true, wpb); }
+      multi += pencil_box_cost(s, deg, geo || mod, xl, R, false, wpb);
+      const long long single = pencil_box_cost(s, deg, geo || mod, xl, P, false, wpb);
       const double t_step = (deg == 3 ? 30e-6 : 9e-6) * ((geo || mod) ? 1.4 : 1.0);      // s per element-step of a launch (256^3: 16 ms / (4 rounds x 131))
       const double cost_s = (double)(multi - single) * t_step;
       const char *lr = getenv("IGX_LINK_GBS"); const double rate = (lr && atof(lr) > 0 ? atof(lr) : 60.0) * 1e9;

@@ -58,6 +58,7 @@ static int load_hiprtc(std::string &err) {
 
 // feature_assemble<UserForm, dim, TA, NW, I0, DOFI, HASM> for one wave layout: one function per group of row fields
 struct RtcFeature {
+  bool guard_known = false, guard_ok = true; std::vector<double> guard_prm;     // band_pt: the struct's band_params_ok at the parameters it was last asked about
   std::vector<char> code;
   std::vector<std::string> lowered;
   hipModule_t module = nullptr; std::vector<hipFunction_t> func;
@@ -80,7 +81,7 @@ struct RtcForm {
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
   std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P (+ 10 + rational on a mapped geometry)
   std::map<int, std::shared_ptr<RtcFeature>> block;     // block_pencil instantiations; key: SYSTEM
-  std::map<int, std::shared_ptr<RtcFeature>> band;      // band_points + band_pt instantiations; key: GEO | RAT << 1
+  std::map<int, std::shared_ptr<RtcFeature>> band;      // band_points + band_pt instantiations; key: GEO | RAT << 1 | degree << 2
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -623,7 +624,11 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
     const std::string xp = std::string("igx::band_points<") + F.name + ", " + std::to_string(deg) + ">";
     const std::string xb = std::string("igx::band_pt<") + F.name + ", " + (geo ? "true" : "false") + ", " + (rat ? "true" : "false") + ", " + std::to_string(deg) + ">";
     const std::string tail = "static_assert(igx::bpt_form_ok<" + F.name + ">(), \"band_pt: four fields, first order, NCOEF / point_coef / mat_c, no atboundary branch\");\n"
-                             "__device__ int igx_band_meta[4] = {igx::bpt_rec<" + F.name + ">(), igx::bpt_products<" + F.name + ">(), 0, 0};\n"
+                             "__device__ int igx_band_meta[4] = {igx::bpt_rec<" + F.name + ">(), igx::bpt_products<" + F.name + ">(), igx::band_nacc_of<" + F.name + ">::own ? 1 : 0, 0};\n"
+                             // the struct's own guard on the parameters (a struct with BAND_NACC hooks declares band_params_ok __host__ __device__)
+                             "__device__ double igx_band_prm[igx::MAXPARAM]; __device__ int igx_band_ok;\n"
+                             "template <class F> __device__ int igx_band_guard_of(const double *prm) { if constexpr (igx::band_nacc_of<F>::own) return F::band_params_ok(prm) ? 1 : 0; else return 1; }\n"
+                             "extern \"C\" __global__ void igx_band_guard() { igx_band_ok = igx_band_guard_of<" + F.name + ">(igx_band_prm); }\n"
                              "template __global__ void " + xp + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n"
                              "template __global__ void " + xb + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n";
     if (int rc = rtc_build(F.source, true, tail, {xp, xb}, K->code, K->lowered, false, false, false, true)) return rc;
@@ -641,6 +646,25 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
   ParamsDev prm; memset(&prm, 0, sizeof(prm));
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
   hipStream_t stream = g->stream;
+  // The struct's guard on its parameters, as the built-in path has it (band_pt.hpp: Form::band_params_ok): band_coef / band_finish
+  // may divide by a parameter (FormNSVMS: 1 / nu), and a struct that says no stays on the feature kernel.  Evaluated by the
+  // module's one-lane kernel whenever the parameters differ from the ones it was last asked about.
+  if (K->meta[2]) {
+    const std::vector<double> now(prm.v, prm.v + MAXPARAM);
+    if (!K->guard_known || now != K->guard_prm) {
+      hipFunction_t gf = nullptr; hipDeviceptr_t pp = nullptr, po = nullptr; size_t n = 0; int ok = 0;
+      HIPCK(hipModuleGetFunction(&gf, K->module, "igx_band_guard"));
+      HIPCK(hipModuleGetGlobal(&pp, &n, K->module, "igx_band_prm"));
+      if (n != sizeof(prm.v)) return fail(IGX_ERR_LIB, "unexpected igx_band_prm size");
+      HIPCK(hipModuleGetGlobal(&po, &n, K->module, "igx_band_ok"));
+      HIPCK(hipMemcpyAsync(pp, prm.v, sizeof(prm.v), hipMemcpyHostToDevice, stream));
+      HIPCK(hipModuleLaunchKernel(gf, 1, 1, 1, 1, 1, 1, 0, stream, nullptr, nullptr));
+      HIPCK(hipMemcpyAsync(&ok, po, sizeof(int), hipMemcpyDeviceToHost, stream));
+      HIPCK(hipStreamSynchronize(stream));
+      K->guard_known = true; K->guard_ok = ok != 0; K->guard_prm = now;
+    }
+    if (!K->guard_ok) return 0;       // done stays false: the caller goes on to the feature kernel
+  }
   int lrc = 0;
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
   const int rc = band_pt_run(s, S, out, stream, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, K->meta[0], K->meta[1],

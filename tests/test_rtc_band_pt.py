@@ -128,6 +128,37 @@ def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo, p):
 
 
 @pytest.mark.gpu
+def test_inviscid_parameters_keep_both_forms_of_the_struct_off_band_pt():
+    """FormNSVMS's band_coef scales by 1 / nu: its band_params_ok says no at nu = 0 (forms.hpp), and the built-in launcher
+    (band_pt.hpp) then leaves the work to the feature kernel.  The SAME struct given as run-time source must take the same
+    decision -- its guard is evaluated by a one-lane kernel of its module (rtc.hpp) -- and give the same finite numbers as the
+    oracle's demo/NavierStokesVMS.c:166-244 Tangent; with nu > 0 again the band kernel is back."""
+    N, periodic = (8, 4, 5), (True, False, True)
+    orc, eng_b = _problem(N, periodic, "nurbs", 3)
+    _, eng_s = _problem(N, periodic, "nurbs", 3)
+    X, W = warped_geometry(orc, 3, seed=sum(N), rational=True, amp=0.08)
+    for e in (eng_b, eng_s):
+        e.set_geometry(X, W)
+    rng = np.random.default_rng(32)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n) * 0.1
+    shift = 2.0 / DT
+    src, name = builtin_text_as_source()
+    for nu, kernel in ((0.0, "feature_assemble"), (NU, "band_pt")):
+        params = (nu, FX, 0.0, 0.0, DT)
+        J_o = orc.compute_ijacobian("orc_form_ns_tangent", O.NSVMSCtx(*params), shift, V, 0.0, U)
+        assert np.isfinite(J_o.val).all()
+        eng_b.set_form("nsvms", params)
+        eng_s.set_form_source(src, name, params)
+        for e in (eng_b, eng_s):
+            Uv, Vv, J = e.create_vec().set(U), e.create_vec().set(V), e.create_mat()
+            e.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+            e.synchronize()
+            assert kernel in e.kernel_name(), (nu, e.kernel_name())
+            compare_mats(J, J_o, 1e-11)
+
+
+@pytest.mark.gpu
 def test_the_builtin_struct_given_as_source_runs_at_the_builtin_rate():
     """demo/NavierStokesVMS.c's Tangent as source at 48^3 on a NURBS map: within 5 % of the built-in form (min of 4 assemblies each)"""
     import petiga_amd as P
