@@ -361,6 +361,90 @@ __device__ __forceinline__ void pencil_mfma_p2(d4_t (&acc)[4][4], const double *
   }
 }
 
+// ---- p = 2 on the identity geometry, PACKED (gram_pencil_w6).  The layout above puts a 3 x 3 block of (a_x, a_y) into the 4 x 4 row
+// slots of a tile and one tile per pair of node layers: 9 x 9 of 16 x 16 entries of every MFMA are real, 2.2 x the algorithmic
+// flops.  Here the element's 27 basis functions are numbered a = 9 a_w + 3 a_y + a_x and packed into TWO tiles of 16 rows (27 of 32
+// rows real), K_e is 2 x 2 tiles of which the 3 with Ta <= Tb are computed: 3 MFMAs per k-step instead of 6, 63 per element
+// instead of 126.  The price: a tile no longer IS a pair of node layers, so the sum over the elements of the pencil (the combine
+// before the write) cannot stay in the accumulators; it moves into a per-wavefront LDS window of band rows,
+//   win[3 node layers (ring)][9 (a_y, a_x)][5 column layers][9 (b_y, b_x)],
+// to which every lane adds its 16 entries with ds_add_f64 (both (a, b) and (b, a) for the off-diagonal tile), and from which the
+// leaving layer's band row -- all five column layers: no transposed half to park -- is read by the flush (pencil0_leave<LDSWIN>).
+constexpr int WIN_ROW = 45, WIN_LAYER = 9 * WIN_ROW, WIN_DOUBLES = 3 * WIN_LAYER + 1;      // 1216 doubles per wavefront
+__host__ __device__ static inline size_t pencil_win_bytes(int wpb) { return (size_t)wpb * WIN_DOUBLES * 8; }
+
+struct P2kLane {
+  int ua[2], va[2], za[2];     // this lane's operand row of tile T = function 16 T + (lane & 15): offsets (doubles) into the X rows [q][a][2], Y rows [a][q][2], walk rows [q][a][2]
+  int rs[2][4], cs[2][4], aw[2][4];   // the lane's result rows a = 16 T + 4 i + (lane >> 4): window row part 45 xy - 9 aw, column part 9 aw + xy + 18, layer slot (-1: padding)
+  int rsc[2], csc[2], awc[2];  // ... and its result column b = 16 T + (lane & 15)
+};
+__device__ __forceinline__ P2kLane pencil_p2k_lane(int lane) {
+  P2kLane K;
+  auto split = [](int f, int &aw, int &ay, int &ax) { aw = f / 9; const int r = f - 9 * aw; ay = r / 3; ax = r - 3 * ay; };
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+    const int f = 16 * T + (lane & 15);
+    int aw, ay, ax; split(f < 27 ? f : 0, aw, ay, ax);
+    if (f >= 27) ax = 3;                       // the zero-padded slot of the X rows: a padding row contributes nothing
+    K.ua[T] = ax * 2; K.va[T] = ay * 8; K.za[T] = aw * 2;
+    K.awc[T] = f < 27 ? aw : -1; K.rsc[T] = (3 * ay + ax) * WIN_ROW - 9 * aw; K.csc[T] = 9 * aw + 3 * ay + ax + 18;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int g = 16 * T + 4 * i + (lane >> 4);
+      int bw, by, bx; split(g < 27 ? g : 0, bw, by, bx);
+      K.aw[T][i] = g < 27 ? bw : -1; K.rs[T][i] = (3 * by + bx) * WIN_ROW - 9 * bw; K.cs[T][i] = 9 * bw + 3 * by + bx + 18;
+    }
+  }
+  return K;
+}
+
+__device__ __forceinline__ void pencil_mfma_p2k(d4_t (&pk)[3], const double *uxs /*LDS [q][a][2], pre-scaled, zero padded*/, const double *vys /*LDS [a][q][2]*/,
+                                                const double *zt /*LDS [q][a][2]*/, const P2kLane &K, int lane) {
+  const int ks = lane >> 4;
+  pk[0] = pk[1] = pk[2] = (d4_t){0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = on ? rem - 3 * qy : 3;      // (q_x = 3: the zero-padded point of the X rows)
+    double op[2][3];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const d2u_t u = *reinterpret_cast<const d2u_t *>(uxs + qx * 8 + K.ua[T]);
+      const d2u_t v = *reinterpret_cast<const d2u_t *>(vys + K.va[T] + qy * 2);
+      const d2u_t z = *reinterpret_cast<const d2u_t *>(zt + qw * 8 + K.za[T]);
+      const double cw = u[0] * v[0], cx = u[1] * v[0], cy = u[0] * v[1];
+      op[T][0] = cw * z[1]; op[T][1] = cx * z[0]; op[T][2] = cy * z[0];
+    }
+#pragma unroll
+    for (int al = 0; al < 3; ++al) {
+      pk[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[0][al], op[0][al], pk[0], 0, 0, 0);
+      pk[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[0][al], op[1][al], pk[1], 0, 0, 0);
+      pk[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(op[1][al], op[1][al], pk[2], 0, 0, 0);
+    }
+  }
+}
+
+// the element's entries into the window: lane holds K[16 Ta + 4 i + (lane >> 4)][16 Tb + (lane & 15)] in pk[tile][i]; li = the element's
+// first node layer (segment-local): the row of layer li + aw lives in ring slot (li + aw) % 3
+__device__ __forceinline__ void pencil_win_add(double *win, const d4_t (&pk)[3], const P2kLane &K, int li) {
+  const int e3 = li % 3;
+  const int ro0 = e3 * WIN_LAYER, ro1 = (e3 == 2 ? 0 : e3 + 1) * WIN_LAYER, ro2 = (e3 == 0 ? 2 : e3 - 1) * WIN_LAYER;
+  auto ring = [&](int aw) { return aw == 0 ? ro0 : (aw == 1 ? ro1 : ro2); };
+  auto add = [&](int idx, double v) { (void)__hip_atomic_fetch_add(win + idx, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); };
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int Ta = t == 2 ? 1 : 0, Tb = t == 0 ? 0 : 1;
+    if (K.awc[Tb] < 0) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (K.aw[Ta][i] < 0) continue;
+      add(ring(K.aw[Ta][i]) + K.rs[Ta][i] + K.csc[Tb], pk[t][i]);
+      if (t == 1) add(ring(K.awc[Tb]) + K.rsc[Tb] + K.cs[Ta][i], pk[t][i]);      // the mirror entry of the off-diagonal tile
+    }
+  }
+}
+
 // the 7 tiles that leave with layer `lay`: k = 0..3 -> (row lay, col lay+k), k = 4..6 -> (row lay+k-3, col lay);
 // position of entry (row layer rl, this lane's (a,r) ; col layer cl, this lane's (b1,b2)):
 //   pos = L.A[r] + L.C[r]*prefix0[rl] + L.B[r]*cnt0[rl] + P0[rl][cl-rl+3]
@@ -487,7 +571,9 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
 // BCMAT: the Dirichlet fix-up of the band row without a right-hand side (IGAElementFixJacobian, src/petigaelem.c:1425-1447).
 // RB: rows (accumulator registers r) per read-add-write batch of an interior band row: all P+1 at once (one memory round trip), or 2
 // where the registers of the old values are what the kernel spills (System driver on a mapped geometry at p = 3)
-template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM, int RB = P + 1>
+// LDSWIN (p = 2 packed, see pencil_mfma_p2k): `hold` is the wavefront's window of band rows; the leaving layer's row is read from it
+// (and its slots zeroed for the layer that takes the ring slot next), nothing is parked and the accumulators are not a window.
+template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM, int RB = P + 1, bool LDSWIN = false>
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem,
@@ -509,6 +595,17 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   // lower half: distance dd was parked by layer lay-dd; read before this step re-uses the slots
   const int ls = lane ^ (lane >> 4);   // swizzled lane slot: keeps the transposed writes below off a single bank
   double v[NB][BW];
+  if constexpr (LDSWIN) {
+    static_assert(!LDSWIN || (P == 2 && !NONSYM), "the LDS window: p = 2 Gram");
+    const int wb = (((li % 3) + 3) % 3) * WIN_LAYER + a * WIN_ROW + b2 * 3 + b1;      // + (3 r) * WIN_ROW + 9 d
+#pragma unroll
+    for (int r = 0; r < NB; ++r)
+#pragma unroll
+      for (int d = 0; d < BW; ++d) {
+        v[r][d] = lane_ok ? hold[wb + 3 * r * WIN_ROW + 9 * d] : 0.0;
+        if (lane_ok) hold[wb + 3 * r * WIN_ROW + 9 * d] = 0.0;
+      }
+  } else {
 #pragma unroll
   for (int dd = 1; dd <= P; ++dd) {
     const int slot = dd * (dd - 1) / 2 + (((lay - dd) % dd) + dd) % dd;
@@ -519,6 +616,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   for (int r = 0; r < NB; ++r)
 #pragma unroll
     for (int k = 0; k <= P; ++k) v[r][P + k] = acc[0][k][r];
+  }
   if (owned) {
     double Fold = 0; long long frow = 0; const bool fdo = SYSTEM && L.fslot == 0 && (lane & 3) < NB && ((lane >> 2) & 3) < NB;
     if (fdo) { frow = L.frowxy + T.rho[li]; Fold = out.vec[frow]; }
@@ -600,6 +698,11 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   }
   // park the transposes of tiles (0,1..P): entry (row lay ; a, r') x (col lay+dd ; b1, b2) of this lane is entry
   // (row lay+dd ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
+  if constexpr (LDSWIN) {      // (only F slides: slot t takes over slot t + 1's partial sum)
+    const double up = __shfl_down(Facc, 16);
+    Facc = (L.fslot >= NB - 1) ? 0.0 : up;
+    return;
+  } else
   if constexpr (NONSYM) {
 #pragma unroll
     for (int dd = 1; dd <= P; ++dd) {
@@ -1522,9 +1625,10 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
 
 // ALIAS: the wrapped walk axis (PencilArgs::alias0) known at compile time -- 0: not wrapped, 1: wrapped, -1: read from the arguments.
 // The identity-geometry Gram instantiations come in both fixed flavours, so the headline kernel carries none of the modulo logic.
-template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1>
+template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1, bool PACK = false>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
+  static_assert(!PACK || (P == 2 && W == 0 && !GEO && !FIXT && is_builtin_gram<Form>::v), "packed tiles: p = 2 Gram on the identity geometry (pencil_mfma_p2k)");
   static_assert(is_builtin_gram<Form>::v || (GEO && !FIXT), "a run-time form takes the metric path");
   static_assert(!IDENT || (GEO && !RAT && !is_builtin_gram<Form>::v), "IDENT: a run-time form without a geometry");
   static_assert(!FIXT || (SYSTEM && W == 0), "fix tables: System driver, axis-0 walk");
@@ -1655,10 +1759,12 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double Facc = 0;
   double *hold = nullptr;
   if (W == 0) {
-    constexpr int HS = (P * (P + 1) / 2) * 4 * HOLD_LD;
+    constexpr int HS = PACK ? WIN_DOUBLES : (P * (P + 1) / 2) * 4 * HOLD_LD;      // (PACK: the window of band rows takes the place of the hold area)
     hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO, pa.wpb)) + wave * HS;
     for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
+  P2kLane K2;
+  if constexpr (PACK) K2 = pencil_p2k_lane(lane);
   // mapped geometry: this wavefront's metric area, the raw basis rows, the Gauss weights of this lane's point on axes X, Y
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
   constexpr bool rational = GEO && RAT;
@@ -1761,6 +1867,12 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
     else if constexpr (GEO) pencil_mfma_geo<NB, RAT>(acc, L.u0, L.u1, L.vy, ztg, geo, lane, wt);
+    else if constexpr (PACK) {
+      d4_t pk[3];
+      const double *vys = L.vy - ((lane >> 2) & 3) * 8;
+      pencil_mfma_p2k(pk, vys + pa.wpb * 32, vys, zt, K2, lane);
+      pencil_win_add(hold, pk, K2, ei);
+    }
     else if constexpr (P == 2 && W == 0) pencil_mfma_p2(acc, L.vy - ((lane >> 2) & 3) * 8 + pa.wpb * 32, L.vy, zt, lane);
     else pencil_mfma<W, W == 0, NB>(acc, L, zt);
     if (kDebug && pa.debug_buf) tq1 = __builtin_readcyclecounter();
@@ -1778,7 +1890,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, PACK>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -1798,7 +1910,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (seg == pa.nseg - 1 && !alias0 && !pa.open_hi)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
-        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, PACK>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
         held[NB - 1] = 0;
@@ -1817,10 +1929,12 @@ gram_pencil(SpaceDev S, OutDev out, PencilArgs pa) {
 // and a twelve-wave workgroup puts three waves on every SIMD (168 VGPRs each): the MFMA pipe finds a ready wave more often.
 // (Two six-wave workgroups per CU do not do it: a workgroup's waves 4 and 5 land on SIMDs 0 and 1 again, a second workgroup does not fit
 // there and the CU runs six waves: 140 M el/s against 175.)
-template <bool SYSTEM, int P, int ALIAS>
+// PACK: the element's 27 basis functions in two tiles of 16 rows, 63 MFMAs per element instead of 126, the band rows combined in an LDS
+// window (pencil_mfma_p2k); IGX_P2_PACK=0 selects the layer-pair tiles above.
+template <bool SYSTEM, int P, int ALIAS, bool PACK = false>
 __global__ void __launch_bounds__(768, 3)
 gram_pencil_w6(SpaceDev S, OutDev out, PencilArgs pa) {
-  gram_pencil_body<SYSTEM, 0, P, false, false, false, void, false, ALIAS>(S, out, pa, nullptr);
+  gram_pencil_body<SYSTEM, 0, P, false, false, false, void, false, ALIAS, PACK>(S, out, pa, nullptr);
 }
 
 // the same walk for a run-time scalar form (rtc.hpp compiles this instantiation with hiprtc; IDENT: no geometry)
@@ -1905,6 +2019,11 @@ static inline int pencil_wpb(const Space &s, int P, bool geo, bool fixt, bool ha
   const int free_run = s.env.free_run >= 0 ? s.env.free_run : ((P == 2 && !geo && !has_mod) ? 1 : 0);
   return (P == 2 && !geo && !fixt && !has_mod && free_run && wpb_env != 8) ? 12 : 8;
 }
+// ... and whether that kernel packs the element's 27 functions into two tiles (pencil_mfma_p2k; IGX_P2_PACK=0: the layer-pair tiles)
+static inline bool pencil_p2_pack(const Space &s, int P, bool geo, bool fixt, bool has_mod) {
+  static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
+  return pack_env && pencil_wpb(s, P, geo, fixt, has_mod) == 12;
+}
 static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always, int wpb = 8) {
   long long total = 0;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return 0;
@@ -1943,7 +2062,9 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     // ... and free of the pairing, six-wave workgroups put three waves on every SIMD (gram_pencil_w6; IGX_WPB=8: the eight-wave kernel)
     const bool w6 = W == 0 && pencil_wpb(s, P, GEO, FIXT, mod != nullptr) == 12;
     pa.wpb = w6 ? 12 : 8;
-    int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, mod ? mod->extra_lds : 0, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
+    const bool pack = W == 0 && pencil_p2_pack(s, P, GEO, FIXT, mod != nullptr);      // (p = 2 on the identity geometry: packed tiles, the band rows combined in an LDS window instead of the hold areas)
+    const size_t win_extra = pack ? pencil_win_bytes(pa.wpb) - pencil_hold_bytes(P) * pa.wpb / 8 : 0;
+    int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, (mod ? mod->extra_lds : 0) + win_extra, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
@@ -1955,7 +2076,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? pencil_hold_bytes(P) * pa.wpb / 8 : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
+    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? (pack ? pencil_win_bytes(pa.wpb) : pencil_hold_bytes(P) * pa.wpb / 8) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
     if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the pencil walk's tables do not fit the 160 KB of LDS for any segment length"; return; }
     if (mod && mod->kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mod->kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1970,7 +2091,10 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     } else {
     void (*kern)(SpaceDev, OutDev, PencilArgs) = gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT>;
     if constexpr (W == 0 && !GEO) kern = pa.alias0 ? gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 1> : gram_pencil<SYSTEM, W, P, GEO, RAT, FIXT, 0>;
-    if constexpr (W == 0 && P == 2 && !GEO && !FIXT) { if (w6) kern = pa.alias0 ? gram_pencil_w6<SYSTEM, P, 1> : gram_pencil_w6<SYSTEM, P, 0>; }
+    if constexpr (W == 0 && P == 2 && !GEO && !FIXT) {
+      if (pack) kern = pa.alias0 ? gram_pencil_w6<SYSTEM, P, 1, true> : gram_pencil_w6<SYSTEM, P, 0, true>;
+      else if (w6) kern = pa.alias0 ? gram_pencil_w6<SYSTEM, P, 1> : gram_pencil_w6<SYSTEM, P, 0>;
+    }
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, dim3((unsigned)(pa.blocks_per_seg * pa.nseg)), dim3((unsigned)(pa.wpb * 64)), lds, stream, S, out, pa);
     }
@@ -2297,7 +2421,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     dom.name = std::string(state ? "state_pencil<walk=" : mod ? "form_pencil<hiprtc,walk=" : "gram_pencil<walk=") + char('0' + walk_axis) + ",p=" + char('0' + deg) + (geo ? ",geometry" : "") + ">"; dom.launches = launches - l0;
     dom.elements = (long long)std::max(0, P.hi[0] - P.lo[0]) * std::max(0, P.hi[1] - P.lo[1]) * std::max(0, P.hi[2] - P.lo[2]);
     // executed MFMA flops per element: 2*16*16*4 per v_mfma_f64_16x16x4, 48 k-steps, 10 (symmetric, walk 0) or 16 tiles
-    dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 21 * 6);
+    // (p = 2: 21 k-steps x 6 layer-pair tiles, or x 3 packed tiles)
+    dom.flop_per_element = 2048.0 * (deg == 3 ? 48 * (walk_axis == 0 ? 10 : 16) : 21 * ((walk_axis == 0 && pencil_p2_pack(s, deg, geo, fixt, mod != nullptr)) ? 3 : 6));
     if (state) dom.flop_per_element = mod->flop_per_element;
     // E as disjoint slabs: axis 0 faces (full), axis 1 faces (inside P along 0), axis 2 faces (inside P along 0,1)
     for (int d = 0; d < 3; ++d) for (int side = 0; side < 2; ++side) {
@@ -2307,7 +2432,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + ((deg == 2 && walk_axis == 0 && pencil_p2_pack(s, deg, geo, fixt, mod != nullptr)) ? ",packed tiles" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }

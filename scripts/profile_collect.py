@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Turn the output of scripts/profile_round.sh (gpurun_out/prof) into the committed evidence under profiles/.
-usage: python scripts/profile_collect.py <round-tag, e.g. r03>
+usage: python scripts/profile_collect.py <round-tag, e.g. r03> [workload tags ...]
+(with workload tags only those are collected -- gpurun_out/prof merges over what earlier calls left there, so a subset run must
+name its subset or stale files of other workloads would be re-labelled with this round's tag)
 
 Per workload: <tag>_<form>_line.json (the bench line; its roofline.traffic filled in from the PMC passes of the same gpurun
 call), <tag>_<form>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), <tag>_<form>_pmc_summary.csv (mean per dispatch of every
@@ -13,7 +15,8 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+ONLY = set(sys.argv[2:])
 SRC, DST = "gpurun_out/prof", "profiles"
 SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96, "cahnhilliard_nurbs": 128}
 KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil"}
@@ -40,6 +43,8 @@ def write_pmc(path, agg):
 configs = []
 for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhilliard", "nsvms", "cahnhilliard_nurbs"):
     lf = "%s/line_%s.json" % (SRC, form)
+    if ONLY and form not in ONLY:
+        continue
     if not os.path.exists(lf) or not open(lf).read().strip():
         continue
     line = json.loads(open(lf).read().strip().splitlines()[-1])
@@ -78,18 +83,17 @@ for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhil
             if r.get("avg_launch_ms"):
                 line["roofline"]["hbm_frac"] = ent["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 8e12
     json.dump(line, open("%s/%s_%s_line.json" % (DST, tag, form), "w"), indent=1)
-if os.path.exists(SRC + "/line_poisson_source.json") and open(SRC + "/line_poisson_source.json").read().strip():
+if not ONLY and os.path.exists(SRC + "/line_poisson_source.json") and open(SRC + "/line_poisson_source.json").read().strip():
     shutil.copy(SRC + "/line_poisson_source.json", "%s/%s_poisson_source_line.json" % (DST, tag))
 for src, dst in (("configs.txt", "secondary_configs.txt"), ("rtc.txt", "runtime_forms.txt")):
-    if os.path.exists(SRC + "/" + src):
+    if not ONLY and os.path.exists(SRC + "/" + src):
         shutil.copy(SRC + "/" + src, "%s/%s_%s" % (DST, tag, dst))
 if configs:
     # (a run over a subset of the workloads -- TAGS=... scripts/profile_round.sh -- keeps the other entries of the same round)
     try:
         old = json.load(open(DST + "/traffic.json"))
-        if old.get("kernel_tag") == tag:
-            have = set(c["tag"] for c in configs)
-            configs = [c for c in old.get("configs", []) if c.get("tag") not in have] + configs
+        have = set(c["tag"] for c in configs)      # (entries carry their own kernel_tag: an older round's figure stays until its workload is re-measured)
+        configs = [c for c in old.get("configs", []) if c.get("tag") not in have] + configs
     except (OSError, ValueError):
         pass
     json.dump(dict(round=int(tag[1:]), kernel_tag=tag, configs=configs), open(DST + "/traffic.json", "w"), indent=1)

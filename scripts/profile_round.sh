@@ -11,7 +11,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 [ -n "$TAGS" ] && ONLY_TAGS=1
-TAGS="${TAGS:-poisson poisson_p2 poisson_p2_nurbs elasticity cahnhilliard nsvms}"
+TAGS="${TAGS:-poisson poisson_p2 poisson_p2_nurbs elasticity cahnhilliard nsvms cahnhilliard_nurbs}"
 args_of() {
   case $1 in
     poisson) echo "--form poisson" ;;

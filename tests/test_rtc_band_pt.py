@@ -133,7 +133,7 @@ def test_inviscid_parameters_keep_both_forms_of_the_struct_off_band_pt():
     (band_pt.hpp) then leaves the work to the feature kernel.  The SAME struct given as run-time source must take the same
     decision -- its guard is evaluated by a one-lane kernel of its module (rtc.hpp) -- and give the same finite numbers as the
     oracle's demo/NavierStokesVMS.c:166-244 Tangent; with nu > 0 again the band kernel is back."""
-    N, periodic = (8, 4, 5), (True, False, True)
+    N, periodic = (9, 3, 8), (True, False, True)
     orc, eng_b = _problem(N, periodic, "nurbs", 3)
     _, eng_s = _problem(N, periodic, "nurbs", 3)
     X, W = warped_geometry(orc, 3, seed=sum(N), rational=True, amp=0.08)
