@@ -1115,6 +1115,13 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         st.kfn = deg == 2 ? state_pencil<2, FormBratu<3>> : state_pencil<3, FormBratu<3>>; st.name = "Bratu";
         st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * (deg == 2 ? 7 * 9 : 16 * 16);
       }
+      // p = 2: packed tiles (state_pencil_k: 4 MFMAs per feature and k-step instead of 9; IGX_P2_PACK=0: the layer-pair tiles)
+      static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
+      if (st.kfn && deg == 2 && pack_env) {
+        st.pack = true;
+        if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
+        else { st.kfn = state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
+      }
       if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes(); for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
     }
     rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done, st.kfn ? &st : nullptr, face_done);

@@ -445,6 +445,24 @@ __device__ __forceinline__ void pencil_win_add(double *win, const d4_t (&pk)[3],
   }
 }
 
+// ... of a Tangent (not symmetric: all four tiles pk[2 Ta + Tb], no mirror entries)
+__device__ __forceinline__ void pencil_win_add_ns(double *win, const d4_t (&pk)[4], const P2kLane &K, int li) {
+  const int e3 = li % 3;
+  const int ro0 = e3 * WIN_LAYER, ro1 = (e3 == 2 ? 0 : e3 + 1) * WIN_LAYER, ro2 = (e3 == 0 ? 2 : e3 - 1) * WIN_LAYER;
+  auto ring = [&](int aw) { return aw == 0 ? ro0 : (aw == 1 ? ro1 : ro2); };
+#pragma unroll
+  for (int Ta = 0; Ta < 2; ++Ta)
+#pragma unroll
+    for (int Tb = 0; Tb < 2; ++Tb) {
+      if (K.awc[Tb] < 0) continue;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (K.aw[Ta][i] < 0) continue;
+        (void)__hip_atomic_fetch_add(win + ring(K.aw[Ta][i]) + K.rs[Ta][i] + K.csc[Tb], pk[Ta * 2 + Tb][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+}
+
 // the 7 tiles that leave with layer `lay`: k = 0..3 -> (row lay, col lay+k), k = 4..6 -> (row lay+k-3, col lay);
 // position of entry (row layer rl, this lane's (a,r) ; col layer cl, this lane's (b1,b2)):
 //   pos = L.A[r] + L.C[r]*prefix0[rl] + L.B[r]*cnt0[rl] + P0[rl][cl-rl+3]
@@ -596,7 +614,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   const int ls = lane ^ (lane >> 4);   // swizzled lane slot: keeps the transposed writes below off a single bank
   double v[NB][BW];
   if constexpr (LDSWIN) {
-    static_assert(!LDSWIN || (P == 2 && !NONSYM), "the LDS window: p = 2 Gram");
+    static_assert(!LDSWIN || P == 2, "the LDS window: p = 2");
     const int wb = (((li % 3) + 3) % 3) * WIN_LAYER + a * WIN_ROW + b2 * 3 + b1;      // + (3 r) * WIN_ROW + 9 d
 #pragma unroll
     for (int r = 0; r < NB; ++r)
@@ -1312,6 +1330,49 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
   }
 }
 
+// p = 2 PACKED (see pencil_mfma_p2k): the 27 functions in two tiles of 16 rows, all four tiles of the (non-symmetric) Tangent: 4 MFMAs
+// per feature and k-step instead of 9 -- CahnHilliard 140 per element instead of 315 -- and two operand columns per lane instead of
+// three.  The sum over the pencil's elements moves into the LDS window (pencil_win_add_ns).
+template <class Form>
+__device__ __forceinline__ void pencil_mfma_state_p2k(d4_t (&pk)[4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
+                                                      const double *coef, const P2kLane &K, int lane) {
+  constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+  constexpr bool LAP = NF > 4;
+  const int ks = lane >> 4;
+  pk[0] = pk[1] = pk[2] = pk[3] = (d4_t){0, 0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qp = rem - 3 * qy, qx = on ? qp : 3;      // (q_x = 3: the zero-padded point of the X rows)
+    const double *cp = coef + ((qw * 4 + qy) * 4 + qp) * NC;
+    double c[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = cp[k];
+    double A[NF][2], B[2][NF];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const d2u_t u = *reinterpret_cast<const d2u_t *>(uxr + qx * 8 + K.ua[T]);
+      const d2u_t v = *reinterpret_cast<const d2u_t *>(vyr + K.va[T] + qy * 2);
+      const d2u_t z = *reinterpret_cast<const d2u_t *>(ztg + qw * 8 + K.za[T]);
+      const double a_n = u[0] * v[0], a_x = u[1] * v[0], a_y = u[0] * v[1];
+      A[0][T] = a_n * z[0]; A[1][T] = a_n * z[1]; A[2][T] = a_x * z[0]; A[3][T] = a_y * z[0];
+      if constexpr (LAP) {
+        const double u2 = d2w[qx * 4 + (K.ua[T] >> 1)], v2 = d2w[16 + (K.va[T] >> 1) + qy], z2 = d2w[32 + qw * 4 + (K.za[T] >> 1)];
+        A[NF - 1][T] = a_n * z2 + (u2 * v[0] + u[0] * v2) * z[0];
+      }
+      const double g[3] = {A[1][T], A[2][T], A[3][T]};
+      Form::pencil_trial(c, A[0][T], g, LAP ? A[NF - 1][T] : 0.0, B[T]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int Ta = 0; Ta < 2; ++Ta)
+#pragma unroll
+        for (int Tb = 0; Tb < 2; ++Tb) pk[Ta * 2 + Tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][Ta], B[Tb][f], pk[Ta * 2 + Tb], 0, 0, 0);
+  }
+}
+
 // ---- Tangents on a mapped geometry (p = 2; state_pencil_geo below).  The physical features of a basis function R_a = w_a N_a / W at
 // a Gauss point are LINEAR in the parametric derivatives of the polynomial N_a up to the form's order:
 //   R = n / W,   d_i R = sum_b E_bi (n_b - n o_b) / W                    (E = du/dx, o = dW / W: K3 Rationalize + K5 InverseMap)
@@ -1628,7 +1689,8 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
 template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1, bool PACK = false>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
-  static_assert(!PACK || (P == 2 && W == 0 && !GEO && !FIXT && is_builtin_gram<Form>::v), "packed tiles: p = 2 Gram on the identity geometry (pencil_mfma_p2k)");
+  static_assert(!PACK || (P == 2 && W == 0 && !FIXT && ((!GEO && is_builtin_gram<Form>::v) || (IDENT && pencil_state_of<Form>::v))),
+                "packed tiles: p = 2 on the identity geometry, the Gram matrix (pencil_mfma_p2k) or a Tangent (pencil_mfma_state_p2k)");
   static_assert(is_builtin_gram<Form>::v || (GEO && !FIXT), "a run-time form takes the metric path");
   static_assert(!IDENT || (GEO && !RAT && !is_builtin_gram<Form>::v), "IDENT: a run-time form without a geometry");
   static_assert(!FIXT || (SYSTEM && W == 0), "fix tables: System driver, axis-0 walk");
@@ -1716,7 +1778,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       }
     }
     if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
-      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P) + (size_t)8 * GD * 8) + wave * STATE_D2;
+      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (PACK ? pencil_win_bytes(8) : pencil_hold_bytes(P)) + (size_t)8 * GD * 8) + wave * STATE_D2;
       if (lane < 16) { const int qq = lane >> 2, aa = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TX[(qq * NB + aa) * NDER + 2] : 0.0; }
       else if (lane < 32) { const int aa = (lane - 16) >> 2, qq = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TY[(qq * NB + aa) * NDER + 2] : 0.0; }
       if (qx < NB && ix < NB) u2 = TX[(qx * NB + ix) * NDER + 2];
@@ -1769,7 +1831,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
   constexpr bool rational = GEO && RAT;
   if constexpr (GEO) {
-    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + pencil_hold_bytes(P)) + wave * GD;
+    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (PACK ? pencil_win_bytes(8) : pencil_hold_bytes(P))) + wave * GD;
     vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + pa.wpb * 32;
     const int gqx = lane & 3, gqy = (lane >> 2) & 3;
     if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
@@ -1863,6 +1925,11 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       pencil_sgeo_point<P, RAT, Form>(geo, lane, Hsum, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
       pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     }
+    else if constexpr (STATE && PACK) {
+      d4_t pk[4];
+      pencil_mfma_state_p2k<Form>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
+      pencil_win_add_ns(hold, pk, K2, ei);
+    }
     else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
     else if constexpr (GEO && P == 2) pencil_mfma_geo_p2<RAT>(acc, uxr, L.vy, ztg, geo, lane, wt);
@@ -1952,6 +2019,14 @@ state_pencil(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
   gram_pencil_body<false, 0, P, true, false, false, Form, true>(S, out, pa, prm.v);
 }
 
+// ... at p = 2 with packed tiles and the LDS window of band rows (pencil_mfma_state_p2k; IGX_P2_PACK=0: state_pencil<2, Form>)
+template <class Form>
+__global__ void __launch_bounds__(512, 2)
+state_pencil_k(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  static_assert(pencil_state_of<Form>::v, "state_pencil_k: the form declares PENCIL_NFEAT, PENCIL_NC, pencil_coef and pencil_trial");
+  gram_pencil_body<false, 0, 2, true, false, false, Form, true, -1, true>(S, out, pa, prm.v);
+}
+
 // ... and on a mapped geometry (p = 2: pencil_sgeo_sums / pencil_sgeo_point / pencil_mfma_state_geo_p2)
 template <int P, bool RAT, class Form>
 __global__ void __launch_bounds__(512, 2)
@@ -1984,7 +2059,8 @@ typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
 // the first-touch rule of axis X (like fty for axis Y), and, when the pass is a part of the walk axis, how its ends join the others
 struct PencilPass { int ftx[3] = {0, 0x7fffffff, 0x7fffffff}; int halo_lo = -1; bool open_hi = false; };
 struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0;
-                      bool state_geo = false; };      // state_geo: the instantiation is state_pencil_geo (evaluates the geometry itself)
+                      bool state_geo = false;         // state_geo: the instantiation is state_pencil_geo (evaluates the geometry itself)
+                      bool pack = false; };           // pack: packed tiles, the window of band rows in the place of the hold areas (state_pencil_k)
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 // a launch that could not be made (the LDS of the chosen segments beyond the device's, a module launch refused): try_gram_mfma
@@ -2062,7 +2138,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     // ... and free of the pairing, six-wave workgroups put three waves on every SIMD (gram_pencil_w6; IGX_WPB=8: the eight-wave kernel)
     const bool w6 = W == 0 && pencil_wpb(s, P, GEO, FIXT, mod != nullptr) == 12;
     pa.wpb = w6 ? 12 : 8;
-    const bool pack = W == 0 && pencil_p2_pack(s, P, GEO, FIXT, mod != nullptr);      // (p = 2 on the identity geometry: packed tiles, the band rows combined in an LDS window instead of the hold areas)
+    const bool pack = W == 0 && (pencil_p2_pack(s, P, GEO, FIXT, mod != nullptr) || (mod && mod->pack));      // (p = 2 on the identity geometry: packed tiles, the band rows combined in an LDS window instead of the hold areas)
     const size_t win_extra = pack ? pencil_win_bytes(pa.wpb) - pencil_hold_bytes(P) * pa.wpb / 8 : 0;
     int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, (mod ? mod->extra_lds : 0) + win_extra, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
@@ -2432,7 +2508,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       else { b.lo[d] = std::max(P.hi[d], P.lo[d]); b.hi[d] = all.hi[d]; }
       if (sys) launch_elements<true>(s, S, out, stream, b, ga, launches); else launch_elements<false>(s, S, out, stream, b, ga, launches);
     }
-    kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + ((deg == 2 && walk_axis == 0 && pencil_p2_pack(s, deg, geo, fixt, mod != nullptr)) ? ",packed tiles" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
+    kname = (state ? std::string("state_pencil<") + mod->name + ">(mfma_f64_16x16x4,p=" : mod ? std::string("form_pencil<") + mod->name + ">(hiprtc,mfma_f64_16x16x4,p=" : std::string("gram_pencil(mfma_f64_16x16x4,p=")) + char('0' + deg) + ",walk=" + char('0' + walk_axis) + (geo ? ",mapped geometry" : "") + ((deg == 2 && walk_axis == 0 && (pencil_p2_pack(s, deg, geo, fixt, mod != nullptr) || (mod && mod->pack))) ? ",packed tiles" : "") + (walk_axis == 0 ? ")" : ")+gram_p3_element(faces)");
   }
   if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
   if (hipGetLastError() != hipSuccess) { err = "gram MFMA kernel launch failed"; return IGX_ERR_LIB; }
