@@ -1100,6 +1100,12 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         st.kfn = s.rational ? state_pencil_geo<2, true, FormBratu<3>> : state_pencil_geo<2, false, FormBratu<3>>; st.name = "Bratu";
         st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 9;
       }
+      static const bool pack_geo_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
+      if (st.kfn && pack_geo_env) {      // packed tiles (state_pencil_geo_k): 4 MFMAs per feature and k-step instead of 9
+        st.pack = 2;
+        if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = s.rational ? state_pencil_geo_k<true, FormCahnHilliard<3>> : state_pencil_geo_k<false, FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
+        else { st.kfn = s.rational ? state_pencil_geo_k<true, FormBratu<3>> : state_pencil_geo_k<false, FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
+      }
       if (st.kfn) {
         st.state = true; st.state_geo = true; st.extra_lds = pencil_state_bytes() + pencil_sgeo_bytes() - pencil_geo_bytes();
         for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i];
@@ -1118,7 +1124,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       // p = 2: packed tiles (state_pencil_k: 4 MFMAs per feature and k-step instead of 9; IGX_P2_PACK=0: the layer-pair tiles)
       static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
       if (st.kfn && deg == 2 && pack_env) {
-        st.pack = true;
+        st.pack = 1;
         if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
         else { st.kfn = state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
       }

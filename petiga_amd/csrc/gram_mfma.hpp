@@ -463,6 +463,34 @@ __device__ __forceinline__ void pencil_win_add_ns(double *win, const d4_t (&pk)[
     }
 }
 
+// The COMPACT window (12 blocks of 9 x 9 instead of 15), for kernels whose LDS is short (state_pencil_geo_k).  Between the leave of layer
+// e - 1 and the leave of layer e the live (row layer, column layer) pairs are: row e with d = 0..4, row e + 1 with d = 0..3, row e + 2
+// with d = 0..2 (d = column layer - row layer + 2).  So d <= 2 gets a private block per ring slot of the row, the two live d = 3 blocks
+// (rows e, e + 1) alternate between two blocks by the parity of the row layer, and the one live d = 4 block has its own:
+//   block(row layer r, d) = d <= 2 ? 3 (r % 3) + d : (d == 3 ? 9 + (r & 1) : 11),   offset = 81 block + 9 xy_row + xy_col.
+constexpr int WINC_DOUBLES = 12 * 81 + 4;      // 976 doubles per wavefront
+__host__ __device__ static inline size_t pencil_winc_bytes(int wpb) { return (size_t)wpb * WINC_DOUBLES * 8; }
+__device__ __forceinline__ int pencil_winc_block(int r, int d) { return d <= 2 ? 3 * (r % 3) + d : (d == 3 ? 9 + (r & 1) : 11); }
+// a Tangent's four tiles into the compact window: li = the element's first node layer (segment-local)
+__device__ __forceinline__ void pencil_winc_add_ns(double *win, const d4_t (&pk)[4], const P2kLane &K, int li) {
+  // (aw, xy) of a function from its window parts: rs = 45 xy - 9 aw, cs = 9 aw + xy + 18
+#pragma unroll
+  for (int Ta = 0; Ta < 2; ++Ta)
+#pragma unroll
+    for (int Tb = 0; Tb < 2; ++Tb) {
+      if (K.awc[Tb] < 0) continue;
+      const int xyb = K.csc[Tb] - 18 - 9 * K.awc[Tb];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int awa = K.aw[Ta][i];
+        if (awa < 0) continue;
+        const int xya = K.cs[Ta][i] - 18 - 9 * awa;
+        const int off = 81 * pencil_winc_block(li + awa, K.awc[Tb] - awa + 2) + 9 * xya + xyb;
+        (void)__hip_atomic_fetch_add(win + off, pk[Ta * 2 + Tb][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      }
+    }
+}
+
 // the 7 tiles that leave with layer `lay`: k = 0..3 -> (row lay, col lay+k), k = 4..6 -> (row lay+k-3, col lay);
 // position of entry (row layer rl, this lane's (a,r) ; col layer cl, this lane's (b1,b2)):
 //   pos = L.A[r] + L.C[r]*prefix0[rl] + L.B[r]*cnt0[rl] + P0[rl][cl-rl+3]
@@ -591,7 +619,7 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
 // where the registers of the old values are what the kernel spills (System driver on a mapped geometry at p = 3)
 // LDSWIN (p = 2 packed, see pencil_mfma_p2k): `hold` is the wavefront's window of band rows; the leaving layer's row is read from it
 // (and its slots zeroed for the layer that takes the ring slot next), nothing is parked and the accumulators are not a window.
-template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM, int RB = P + 1, bool LDSWIN = false>
+template <bool SYSTEM, int P, bool FIXT = false, bool NONSYM = false, bool BCMAT = SYSTEM, int RB = P + 1, int LDSWIN = 0>      // LDSWIN: 0 none, 1 the window, 2 the compact window
 __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, double *hold, int lane,
                                               const PencilLane &L, const PencilLds &T, int nl, const OutDev &out,
                                               int lay, int own_lo, int own_hi, long long T0, long long T10, const PencilBC &bc, int nelem,
@@ -613,8 +641,20 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   // lower half: distance dd was parked by layer lay-dd; read before this step re-uses the slots
   const int ls = lane ^ (lane >> 4);   // swizzled lane slot: keeps the transposed writes below off a single bank
   double v[NB][BW];
-  if constexpr (LDSWIN) {
-    static_assert(!LDSWIN || P == 2, "the LDS window: p = 2");
+  if constexpr (LDSWIN == 2) {
+    static_assert(LDSWIN != 2 || P == 2, "the LDS window: p = 2");
+    const int lp = li < 0 ? 0 : li;      // (the walk leaves layers li >= 0 only)
+#pragma unroll
+    for (int d = 0; d < BW; ++d) {
+      const int wb = 81 * pencil_winc_block(lp, d) + 9 * a + b2 * 3 + b1;      // + 27 r
+#pragma unroll
+      for (int r = 0; r < NB; ++r) {
+        v[r][d] = lane_ok ? hold[wb + 27 * r] : 0.0;
+        if (lane_ok) hold[wb + 27 * r] = 0.0;
+      }
+    }
+  } else if constexpr (LDSWIN == 1) {
+    static_assert(LDSWIN != 1 || P == 2, "the LDS window: p = 2");
     const int wb = (((li % 3) + 3) % 3) * WIN_LAYER + a * WIN_ROW + b2 * 3 + b1;      // + (3 r) * WIN_ROW + 9 d
 #pragma unroll
     for (int r = 0; r < NB; ++r)
@@ -716,7 +756,7 @@ __device__ __forceinline__ void pencil0_leave(d4_t (&acc)[4][4], double &Facc, d
   }
   // park the transposes of tiles (0,1..P): entry (row lay ; a, r') x (col lay+dd ; b1, b2) of this lane is entry
   // (row lay+dd ; b1, b2) x (col lay ; a, r') of the consumer lane (a_c = b1, b1_c = a, b2_c = r') register r_c = b2
-  if constexpr (LDSWIN) {      // (only F slides: slot t takes over slot t + 1's partial sum)
+  if constexpr (LDSWIN != 0) {      // (only F slides: slot t takes over slot t + 1's partial sum)
     const double up = __shfl_down(Facc, 16);
     Facc = (L.fslot >= NB - 1) ? 0.0 : up;
     return;
@@ -1621,6 +1661,63 @@ __device__ __forceinline__ void sgeo_sched_groups() {      // one MFMA, then its
     sgeo_sched_groups<M + 1, N>();
   }
 }
+// ... PACKED (see pencil_mfma_state_p2k): two operand columns per lane (its functions 16 T + (lane & 15)), each with its own fold of the
+// point's map, four tiles: 4 MFMAs per feature and k-step instead of 9.  The NURBS weight of function f sits at ztg[32 + f].
+template <bool RAT, class Form>
+__device__ __forceinline__ void pencil_mfma_state_geo_p2k(d4_t (&pk)[4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
+                                                          const double *geo, const P2kLane &K, int lane) {
+  constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+  constexpr bool LAP = NF > 4;
+  const int ks = lane >> 4;
+  double wf[2] = {1.0, 1.0};
+  if constexpr (RAT) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) { const int f = 16 * T + (lane & 15); wf[T] = ztg[32 + (f < 27 ? f : 26)]; }
+  }
+  pk[0] = pk[1] = pk[2] = pk[3] = (d4_t){0, 0, 0, 0};
+#pragma unroll 1
+  for (int j = 0; j < 7; ++j) {
+    const int pt = 4 * j + ks;
+    const bool on = pt < 27;
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qp = rem - 3 * qy, qx = on ? qp : 3;      // (q_x = 3: the zero-padded point of the X rows)
+    const double *rp = geo + pc * SGEO_NPD, *Lp = rp + NC;
+    double c[NC], Lm[23];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) c[k] = rp[k];
+#pragma unroll
+    for (int k = 0; k < 23; ++k) Lm[k] = (LAP || k < 13) ? Lp[k] : 0.0;
+    double A[NF][2], B[2][NF];
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const d2u_t u = *reinterpret_cast<const d2u_t *>(uxr + qx * 8 + K.ua[T]);
+      const d2u_t v = *reinterpret_cast<const d2u_t *>(vyr + K.va[T] + qy * 2);
+      const d2u_t z = *reinterpret_cast<const d2u_t *>(ztg + qw * 8 + K.za[T]);
+      const double z0 = z[0] * wf[T], z1 = z[1] * wf[T];
+      const double a_n = u[0] * v[0], a_x = u[1] * v[0], a_y = u[0] * v[1];
+      A[0][T] = z0 * (Lm[0] * a_n);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) A[1 + i][T] = z0 * (Lm[10 + i] * a_n + Lm[4 + i] * a_x + Lm[7 + i] * a_y) + z1 * (Lm[1 + i] * a_n);
+      double lap = 0.0;
+      if constexpr (LAP) {
+        const double u2 = d2w[qx * 4 + (K.ua[T] >> 1)], v2 = d2w[16 + (K.va[T] >> 1) + qy], z2 = d2w[32 + qw * 4 + (K.za[T] >> 1)] * wf[T];
+        const double a_xx = u2 * v[0], a_xy = u[1] * v[1], a_yy = u[0] * v2;
+        const double PL = Lm[22] * a_n + Lm[20] * a_x + Lm[21] * a_y + Lm[16] * a_xx + Lm[17] * a_xy + Lm[18] * a_yy;
+        const double QL = Lm[19] * a_n + Lm[14] * a_x + Lm[15] * a_y, RL = Lm[13] * a_n;
+        lap = z0 * PL + z1 * QL + z2 * RL;
+        A[NF - 1][T] = lap;
+      }
+      const double g[3] = {A[1][T], A[2][T], A[3][T]};
+      Form::pencil_trial(c, A[0][T], g, lap, B[T]);
+    }
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+      for (int Ta = 0; Ta < 2; ++Ta)
+#pragma unroll
+        for (int Tb = 0; Tb < 2; ++Tb) pk[Ta * 2 + Tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][Ta], B[Tb][f], pk[Ta * 2 + Tb], 0, 0, 0);
+  }
+}
+
 template <bool RAT, class Form>
 __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
                                                          const double *geo, int lane) {
@@ -1689,8 +1786,9 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
 template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1, bool PACK = false>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
-  static_assert(!PACK || (P == 2 && W == 0 && !FIXT && ((!GEO && is_builtin_gram<Form>::v) || (IDENT && pencil_state_of<Form>::v))),
-                "packed tiles: p = 2 on the identity geometry, the Gram matrix (pencil_mfma_p2k) or a Tangent (pencil_mfma_state_p2k)");
+  static_assert(!PACK || (P == 2 && W == 0 && !FIXT && ((!GEO && is_builtin_gram<Form>::v) || pencil_state_of<Form>::v)),
+                "packed tiles: p = 2, the Gram matrix on the identity geometry (pencil_mfma_p2k) or a Tangent (pencil_mfma_state_p2k / pencil_mfma_state_geo_p2k)");
+  constexpr int WINMODE = !PACK ? 0 : ((pencil_state_of<Form>::v && !IDENT) ? 2 : 1);      // the window of band rows: none / 15 blocks / compact (12 blocks: a Tangent on a mapped geometry is short of LDS)
   static_assert(is_builtin_gram<Form>::v || (GEO && !FIXT), "a run-time form takes the metric path");
   static_assert(!IDENT || (GEO && !RAT && !is_builtin_gram<Form>::v), "IDENT: a run-time form without a geometry");
   static_assert(!FIXT || (SYSTEM && W == 0), "fix tables: System driver, axis-0 walk");
@@ -1778,7 +1876,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       }
     }
     if constexpr (STATE) {   // second derivatives of the X rows [q][a] and of the Y rows [a][q]
-      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (PACK ? pencil_win_bytes(8) : pencil_hold_bytes(P)) + (size_t)8 * GD * 8) + wave * STATE_D2;
+      d2w = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (WINMODE == 2 ? pencil_winc_bytes(8) : (WINMODE == 1 ? pencil_win_bytes(8) : pencil_hold_bytes(P))) + (size_t)8 * GD * 8) + wave * STATE_D2;
       if (lane < 16) { const int qq = lane >> 2, aa = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TX[(qq * NB + aa) * NDER + 2] : 0.0; }
       else if (lane < 32) { const int aa = (lane - 16) >> 2, qq = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TY[(qq * NB + aa) * NDER + 2] : 0.0; }
       if (qx < NB && ix < NB) u2 = TX[(qx * NB + ix) * NDER + 2];
@@ -1821,7 +1919,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double Facc = 0;
   double *hold = nullptr;
   if (W == 0) {
-    constexpr int HS = PACK ? WIN_DOUBLES : (P * (P + 1) / 2) * 4 * HOLD_LD;      // (PACK: the window of band rows takes the place of the hold area)
+    constexpr int HS = WINMODE == 2 ? WINC_DOUBLES : (WINMODE == 1 ? WIN_DOUBLES : (P * (P + 1) / 2) * 4 * HOLD_LD);      // (PACK: the window of band rows takes the place of the hold area)
     hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO, pa.wpb)) + wave * HS;
     for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
@@ -1831,7 +1929,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
   constexpr bool rational = GEO && RAT;
   if constexpr (GEO) {
-    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (PACK ? pencil_win_bytes(8) : pencil_hold_bytes(P))) + wave * GD;
+    geo = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, true) + (WINMODE == 2 ? pencil_winc_bytes(8) : (WINMODE == 1 ? pencil_win_bytes(8) : pencil_hold_bytes(P)))) + wave * GD;
     vyr = L.vy - ((lane >> 2) & 3) * 8; uxr = vyr + pa.wpb * 32;
     const int gqx = lane & 3, gqy = (lane >> 2) & 3;
     if (gqx < NB && gqy < NB) wjxy = (AX.w[elx * NB + gqx] * AX.J[elx]) * (AY.w[ely * NB + gqy] * AY.J[ely]);
@@ -1923,6 +2021,11 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if constexpr (SGEO) {
       const int gqw = lane >> 4;
       pencil_sgeo_point<P, RAT, Form>(geo, lane, Hsum, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
+      if constexpr (PACK) {
+        d4_t pk[4];
+        pencil_mfma_state_geo_p2k<RAT, Form>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
+        pencil_winc_add_ns(hold, pk, K2, ei);
+      } else
       pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     }
     else if constexpr (STATE && PACK) {
@@ -1957,7 +2060,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
-    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, PACK>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+    if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, WINMODE>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -1977,7 +2080,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (seg == pa.nseg - 1 && !alias0 && !pa.open_hi)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
-        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, PACK>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
+        pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, WINMODE>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
         held[NB - 1] = 0;
@@ -2028,6 +2131,12 @@ state_pencil_k(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
 }
 
 // ... and on a mapped geometry (p = 2: pencil_sgeo_sums / pencil_sgeo_point / pencil_mfma_state_geo_p2)
+template <bool RAT, class Form>
+__global__ void __launch_bounds__(512, 2)
+state_pencil_geo_k(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {      // packed tiles, the compact window of band rows
+  static_assert(pencil_state_of<Form>::v, "state_pencil_geo_k: the form declares PENCIL_NFEAT, PENCIL_NC, pencil_coef and pencil_trial");
+  gram_pencil_body<false, 0, 2, true, RAT, false, Form, false, -1, true>(S, out, pa, prm.v);
+}
 template <int P, bool RAT, class Form>
 __global__ void __launch_bounds__(512, 2)
 state_pencil_geo(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
@@ -2060,7 +2169,7 @@ typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
 struct PencilPass { int ftx[3] = {0, 0x7fffffff, 0x7fffffff}; int halo_lo = -1; bool open_hi = false; };
 struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0;
                       bool state_geo = false;         // state_geo: the instantiation is state_pencil_geo (evaluates the geometry itself)
-                      bool pack = false; };           // pack: packed tiles, the window of band rows in the place of the hold areas (state_pencil_k)
+                      int pack = 0; };                // pack: packed tiles, the window of band rows in the place of the hold areas (1: state_pencil_k; 2: the compact window, state_pencil_geo_k)
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 // a launch that could not be made (the LDS of the chosen segments beyond the device's, a module launch refused): try_gram_mfma
@@ -2139,7 +2248,8 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool w6 = W == 0 && pencil_wpb(s, P, GEO, FIXT, mod != nullptr) == 12;
     pa.wpb = w6 ? 12 : 8;
     const bool pack = W == 0 && (pencil_p2_pack(s, P, GEO, FIXT, mod != nullptr) || (mod && mod->pack));      // (p = 2 on the identity geometry: packed tiles, the band rows combined in an LDS window instead of the hold areas)
-    const size_t win_extra = pack ? pencil_win_bytes(pa.wpb) - pencil_hold_bytes(P) * pa.wpb / 8 : 0;
+    const size_t win_bytes = (mod && mod->pack == 2) ? pencil_winc_bytes(pa.wpb) : pencil_win_bytes(pa.wpb);
+    const size_t win_extra = pack ? win_bytes - pencil_hold_bytes(P) * pa.wpb / 8 : 0;
     int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, (mod ? mod->extra_lds : 0) + win_extra, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
@@ -2152,7 +2262,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
     const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
-    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? (pack ? pencil_win_bytes(pa.wpb) : pencil_hold_bytes(P) * pa.wpb / 8) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
+    const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? (pack ? win_bytes : pencil_hold_bytes(P) * pa.wpb / 8) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
     if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the pencil walk's tables do not fit the 160 KB of LDS for any segment length"; return; }
     if (mod && mod->kfn) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mod->kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -33,7 +33,7 @@ def _bc(objs, kind):
 
 @pytest.mark.parametrize("rational", [False, True])
 @pytest.mark.parametrize("p,N,bc,form", [(3, (9, 4, 5), "all", "poisson"), (3, (8, 3, 3), "none", "poisson"), (3, (12, 5, 4), "some", "poisson_f"),
-                                         (2, (10, 5, 6), "all", "poisson"), (2, (8, 4, 3), "some", "poisson"), (3, (70, 4, 4), "all", "poisson")])
+                                         (2, (10, 5, 6), "all", "poisson"), (2, (8, 4, 3), "some", "poisson"), (3, (70, 3, 3), "all", "poisson")])
 def test_pencil_kernel_on_mapped_geometry(p, N, bc, form, rational):
     orc, eng = make_pair(3, 1, p, list(N))
     X, W = warped_geometry(orc, 3, seed=p * 7 + N[0], rational=rational, amp=0.12)

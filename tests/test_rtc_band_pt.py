@@ -100,9 +100,10 @@ def test_a_struct_without_point_coefficients_does_not_compile_for_band_pt():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which", ["plain", "full"])
-@pytest.mark.parametrize("N,periodic,geo,p", [((8, 4, 4), (False, False, False), None, 3), ((9, 3, 8), (True, False, True), "nurbs", 3), ((10, 4, 5), (False, False, False), "poly", 3),
-                                              ((9, 4, 6), (True, False, True), "nurbs", 2)])
+# (every geometry class with the built-in struct's text; the plain struct -- mat_unit's generic path -- without a geometry and on the NURBS net)
+@pytest.mark.parametrize("which,N,periodic,geo,p", [("full", (8, 4, 4), (False, False, False), None, 3), ("full", (9, 3, 8), (True, False, True), "nurbs", 3),
+                                                    ("full", (10, 4, 5), (False, False, False), "poly", 3), ("full", (9, 4, 6), (True, False, True), "nurbs", 2),
+                                                    ("plain", (8, 4, 4), (False, False, False), None, 3), ("plain", (9, 3, 8), (True, False, True), "nurbs", 3)])
 def test_user_vms_tangent_on_band_pt_vs_oracle(which, N, periodic, geo, p):
     orc, eng = _problem(N, periodic, geo, p)
     ctx, params = O.NSVMSCtx(NU, FX, 0.0, 0.0, DT), (NU, FX, 0.0, 0.0, DT)
