@@ -79,6 +79,9 @@ struct BpPencil {
 struct BpBC {
   bool any; int wlo, whi; bool on[6]; unsigned m[6];
   const double *v;      // LDS [6][4]
+  // IGASetFixTable (src/petigaform.c:273-298): the value of a fixed dof comes from a row-indexed table [rows][dof] instead of the face's
+  // constant; row of node (ix, iy, lay) = rowmap0[lay] + s1 rmx[ix] + s2 rmy[iy] (the pencil's row maps: LDS)
+  const double *table; const int *rowmap0; int gw0, dof; long long s1, s2; const int *rmx, *rmy;
 };
 template <int P>
 __device__ __forceinline__ bool bp_fixed(const BpBC &b, int ix, int iy, int lay, int i, double &val) {
@@ -89,6 +92,8 @@ __device__ __forceinline__ bool bp_fixed(const BpBC &b, int ix, int iy, int lay,
   if (b.on[3] && ix == P && ((b.m[3] >> i) & 1u)) { f = true; val = b.v[3 * 4 + i]; }
   if (b.on[4] && iy == 0 && ((b.m[4] >> i) & 1u)) { f = true; val = b.v[4 * 4 + i]; }
   if (b.on[5] && iy == P && ((b.m[5] >> i) & 1u)) { f = true; val = b.v[5 * 4 + i]; }
+  // (a layer this rank does not hold has no node here: its entries are zero, any finite value does)
+  if (f && b.table) val = (lay >= 0 && lay < b.gw0 && ix <= P && iy <= P) ? b.table[((long long)b.rowmap0[lay] + b.s1 * b.rmx[ix] + b.s2 * b.rmy[iy]) * b.dof + i] : 0.0;
   return f;
 }
 
@@ -252,6 +257,8 @@ block_pencil(SpaceDev S, ParamsDev prm, OutDev out, BlockPencilArgs pa) {
   for (int k = 0; k < 6; ++k) { bc.m[k] = SYSTEM ? (unsigned)__builtin_amdgcn_readfirstlane((int)bcm[k]) : 0u; bc.on[k] = bc.m[k] != 0u; bc.any = bc.any || bc.on[k]; }
   bc.wlo = bc.on[0] ? lay_first : -1000;
   bc.whi = bc.on[1] ? lay_first + NL - 1 : -1000;
+  bc.table = SYSTEM ? S.fixtable : nullptr; bc.rowmap0 = AW.rowmap; bc.gw0 = AW.gwidth; bc.dof = DOF;
+  bc.s1 = (long long)S.ax[0].nrow; bc.s2 = (long long)S.ax[0].nrow * S.ax[1].nrow; bc.rmx = pen->rmx; bc.rmy = pen->rmy;
 
   // ---- per-lane operand factors of axes 1, 2: k slot qx = lane >> 4, tile slot (ix, iy) = (lane & 3, (lane >> 2) & 3)
   double uv[4][3];
@@ -534,7 +541,7 @@ template <class Form> constexpr bool bp_form_ok() {
 static bool block_pencil_covers_space(const Space &s, const SpaceDev &S, const OutDev &out, int dof) {
   if (s.env.block_pencil == 0) return false;
   if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return false;
-  if (s.dim != 3 || s.dof != dof || s.nsd != 0 || S.fixtable) return false;
+  if (s.dim != 3 || s.dof != dof || s.nsd != 0) return false;      // (a fix table is read in the fix-up: bp_fixed)
   for (int d = 0; d < 3; ++d) {
     if (s.axis[d].p != 3 || s.basis[d].nqp != 4 || s.basis[d].nen != 4 || s.lay[d].alias) return false;
     for (int sd = 0; sd < 2; ++sd) if (s.visit[d][sd]) return false;

@@ -1111,6 +1111,9 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i];
       }
     }
+    // (asked for by name, a Tangent on a mapped geometry at another degree is refused with the reason; the automatic choice goes on to the feature kernel)
+    if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 3 && s.axis[0].p != 2 && g->kernel_choice == 2 && (s.form == IGX_FORM_CAHNHILLIARD || s.form == IGX_FORM_BRATU))
+      return fail(IGX_ERR_SUP, "a Tangent on a mapped geometry takes the walk at p = 2 only (state_pencil_geo); the feature kernel covers the other degrees");
     if ((op == OP_JACOBIAN || op == OP_IJACOBIAN) && s.dim == 3 && s.nsd == 0 && s.env.state_pencil && (g->kernel_choice == 0 || g->kernel_choice == 2)) {
       const int deg = s.axis[0].p;
       if (s.form == IGX_FORM_CAHNHILLIARD && (deg == 2 || deg == 3)) {

@@ -78,6 +78,38 @@ def test_elasticity_vs_oracle(N, bc, nseg, monkeypatch):
     compare_mats(A, A_o2, 1e-12)
 
 
+@pytest.mark.parametrize("N,bc,nseg", [((8, 4, 4), "demo", 0), ((9, 5, 6), "all", 0), ((11, 4, 5), "override", 3)])
+def test_elasticity_with_a_fix_table(N, bc, nseg, monkeypatch):
+    """IGASetFixTable (src/petigaform.c:273-298): the Dirichlet values of the fixed dofs come from a vector, per node and field.  The
+    band-row kernel reads them in its fix-up (lifting of F through the fixed columns, value x multiplicity in the fixed rows) instead
+    of leaving the case to the feature kernel."""
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 3, 3, list(N))
+    _bc((orc, eng), bc, 3)
+    table = np.random.default_rng(17).standard_normal(orc.global_size())
+    orc.set_fixtable(table)
+    eng.set_fixtable(eng.create_vec().set(table))
+    octx, prm = O.ElasticityCtx(2.5, 0.7), (2.5, 0.7)
+    A_o, b_o = orc.compute_system("orc_form_elasticity", octx)
+    eng.set_form("elasticity", prm)
+    eng.set_kernel(4)               # the band-row kernel or an error
+    A, b = eng.create_mat(), eng.create_vec()
+    _poison(A)
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "block_pencil" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(A, A_o, 1e-12)
+    _close(b.get(), b_o, 1e-12)
+    orc.set_fixtable(None)          # the table is what fixes the values: with the faces' constants F differs
+    _, b_const = orc.compute_system("orc_form_elasticity", octx)
+    assert np.abs(b_const - b_o).max() > 1e-3
+    eng.set_kernel(0)               # ... and it is the automatic choice
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "block_pencil" in eng.kernel_name(), eng.kernel_name()
+
+
 def test_nonuniform_knots_and_zeroed_matrix(monkeypatch):
     """Stretched knot vectors on every axis (per-element Jacobians differ); IGX_NO_FIRST_TOUCH: MatZeroEntries + read-add-write."""
     monkeypatch.setenv("IGX_NO_FIRST_TOUCH", "1")

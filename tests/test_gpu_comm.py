@@ -199,6 +199,8 @@ CASES = {
     "cahnhilliard-p2-2ranks": (2, (3, 1, 2, (6, 6, 8), (1, 1, 1), "cahnhilliard", (1.5, 200.0, 0.63, 1.0, 1.0 / 108.0, 1.0))),
     # ranks of two elements at p = 3 ([1,1,3]): rank 0's ghost layer belongs to ranks 1 AND 2 -- two messages up, one of them skipping a rank
     "poisson-p3-3ranks-thin": (3, (3, 1, 3, (4, 4, 6), (0, 0, 0), "poisson", ())),
+    # one element per rank on a periodic axis of 2p + 1 functions ([1,1,5]): every ghost layer reaches two ranks, those of ranks 3 and 4 across the seam
+    "poisson-p2-5ranks-periodic-wrap": (5, (3, 1, 2, (3, 3, 5), (0, 0, 1), "poisson", ())),
 }
 # the host-callback transport (kind == 2) keeps a few cases: both list shapes, the refresh, the face passes
 HOST_CASES = ["poisson-p3-2ranks", "poisson-p2-8ranks-pencil-faces", "cahnhilliard-p2-2ranks"]

@@ -169,3 +169,9 @@ def test_switch_and_fallbacks(monkeypatch):
         eng.synchronize()
         assert "state_pencil" not in eng.kernel_name(), (tag, eng.kernel_name())
         compare_mats(J, orc.compute_ijacobian("orc_form_ch_tangent", ctx, 10.0, V, 0.0, U), 1e-11)
+        if tag == "mapped":      # asked for by name (IGXSetKernel(2)) the walk says why it cannot: PETSC_ERR_SUP, not another kernel's numbers
+            import petiga_amd as P
+            eng.set_kernel(2)
+            with pytest.raises(P.IGXError) as e:
+                eng.compute_ijacobian(10.0, Vv, 0.0, Uv, J)
+            assert e.value.code == 56 and "p = 2 only" in str(e.value), str(e.value)

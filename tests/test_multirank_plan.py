@@ -137,16 +137,38 @@ def test_ghost_rows_reach_their_owner_however_thin_the_ranks(p, N, size):
         assert any(q - r >= 2 for r in range(size) for q, _, _ in sends[r])
 
 
-def test_exchange_refuses_a_ghost_layer_that_wraps_onto_its_own_rank():
-    """A periodic axis split so that a rank's ghost layer would reach around to the rank itself cannot be served"""
+def test_a_periodic_ghost_layer_never_wraps_onto_its_own_rank():
+    """The reference's ghost indices wrap unconditionally (src/petigagrid.c:160-163), and so do the exchange's: on a split periodic
+    axis ranks are taken unwrapped (exchange.hpp), a ghost layer may cross the seam and reach several thin ranks.  The one thing the
+    exchange cannot serve -- a layer that reaches around to its own rank, IGX_ERR_SUP 56 in exchange_supported() -- needs the OTHER
+    ranks of the axis to own fewer than p nodes together.  IGA_Distribute balances the elements (src/petigapart.c:170-202), so the
+    others own at least floor(N / 2) >= p nodes once the axis has the 2p + 1 functions a split periodic axis needs to hold its own
+    stencil (refused at IGXSetUp otherwise).  Swept here: every degree, element count and rank count -- never refused; every ghost
+    node is sent exactly once and the send / receive lists of all ranks agree.  (The wrapped thin-rank case runs against the oracle
+    on the GPU: tests/test_gpu_comm.py, poisson-p2-5ranks-periodic-wrap.)"""
     import petiga_amd as P
+    for p in (1, 2, 3, 4):
+        for N in range(2 * p + 1, 2 * p + 8):
+            for size in range(2, N + 1):
+                gs = []
+                for rank in range(size):
+                    g = P.IGX(1, 1)
+                    g.set_comm(size, rank)
+                    g.axis_uniform(0, p, N, periodic=True)
+                    g.setup()
+                    gs.append(g)
+                sends = [g.neighbors(True) for g in gs]          # (raises IGXError 56 if a layer wrapped onto its own rank)
+                recvs = [g.neighbors(False) for g in gs]
+                for r in range(size):
+                    sz = gs[r].sizes()
+                    assert sum(v for _, _, v in sends[r]) == sz["node_gwidth"][0] - sz["node_lwidth"][0]
+                    assert all(q != r for q, _, _ in sends[r])
+                    for q, m, v in sends[r]:
+                        assert [(m2, v2) for r2, m2, v2 in recvs[q] if r2 == r] == [(m, v)], (p, N, size, r, q)
+    # fewer than 2p + 1 functions on a split periodic axis: refused at set-up, with a message, before any exchange entry point
     g = P.IGX(1, 1)
     g.set_comm(2, 0)
     g.axis_uniform(0, 3, 4, periodic=True)
-    try:
-        g.setup()
-    except P.IGXError:
-        return          # (refused earlier: fewer than 2p+1 functions on a split periodic axis)
     with pytest.raises(P.IGXError) as e:
-        g.neighbors(True)
-    assert e.value.code == 56
+        g.setup()
+    assert "2p+1" in str(e.value)
