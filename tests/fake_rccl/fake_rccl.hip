@@ -97,10 +97,21 @@ struct PendingOp { Comm *c; hipStream_t stream; bool send; void *buf; size_t byt
 thread_local int t_group_depth = 0;
 thread_local std::vector<PendingOp> t_pending;
 
+// every shared-memory name this process created or opened and has not yet unlinked: a rank that leaves through die() takes them
+// along (several test processes may use the double at once: nobody may clean /dev/shm by prefix)
+static std::mutex g_names_mu;
+static std::vector<std::string> g_names;
+static void remember(const std::string &n) { std::lock_guard<std::mutex> lk(g_names_mu); g_names.push_back(n); }
+static void forget(const std::string &n) {
+  std::lock_guard<std::mutex> lk(g_names_mu);
+  for (size_t i = 0; i < g_names.size(); ++i) if (g_names[i] == n) { g_names.erase(g_names.begin() + (long)i); break; }
+}
+
 static void die(const char *fmt, ...) {
   va_list ap; va_start(ap, fmt);
   fprintf(stderr, "fake_rccl: "); vfprintf(stderr, fmt, ap); fprintf(stderr, "\n"); fflush(stderr);
   va_end(ap);
+  for (const std::string &n : g_names) shm_unlink(n.c_str());      // (no lock: this thread is the last thing the process does)
   _exit(86);
 }
 
@@ -189,6 +200,7 @@ static int open_segment(Comm *c, const std::string &nm, size_t bytes, Seg &out) 
   if (p == MAP_FAILED) return kSystemError;
   if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { munmap(p, bytes); return kUnhandledCudaError; }
   out.host = p; out.bytes = bytes; out.name = nm;
+  remember(nm);
   return kSuccess;
 }
 
@@ -196,6 +208,7 @@ static void release(GroupRec &g) {
   for (Seg &s : g.segs) {
     if (s.host) { (void)hipHostUnregister(s.host); munmap(s.host, s.bytes); }
     if (s.unlink_after) shm_unlink(s.name.c_str());
+    forget(s.name);
   }
   g.segs.clear();
   if (g.dev) { (void)hipHostFree(g.dev); g.dev = nullptr; }
@@ -372,6 +385,7 @@ int ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank) {
   close(fd);
   if (p == MAP_FAILED) return kSystemError;
   c->ctl = static_cast<Control *>(p);       // (a fresh segment is zero-filled: every counter starts at 0)
+  remember(c->name);
   if (creator) { c->ctl->nranks = nranks; __atomic_store_n(&c->ctl->magic, kMagic, __ATOMIC_RELEASE); }
   while (__atomic_load_n(&c->ctl->magic, __ATOMIC_ACQUIRE) != kMagic) { if (late()) return kSystemError; std::this_thread::sleep_for(std::chrono::milliseconds(1)); }
   if (c->ctl->nranks != nranks) { fprintf(stderr, "fake_rccl: rank %d says %d ranks, the communicator has %d\n", rank, nranks, c->ctl->nranks); return kInvalidUsage; }
@@ -413,6 +427,7 @@ int ncclCommDestroy(ncclComm_t c) {
     (void)hipHostUnregister(c->ctl);
     munmap(c->ctl, c->ctl_bytes);
     if (last) shm_unlink(c->name.c_str());
+    forget(c->name);
   }
   delete c;
   return kSuccess;

@@ -127,10 +127,8 @@ def test_receive_group_before_send_group_deadlocks_and_is_reported(tmp_path):
     rcs, outs = _run("split", tmp_path, 5)
     assert all(rc == 86 for rc in rcs), (rcs, outs)
     assert any("DEADLOCK" in o for o in outs) and all("ok" not in o for o in outs), outs
-    # nothing is left behind in /dev/shm (message segments are unlinked by the receiver; staged ones die with the test's names)
-    left = [f for f in os.listdir("/dev/shm") if f.startswith("fake_rccl_")]
-    for f in left:
-        os.unlink(os.path.join("/dev/shm", f))
+    # (a rank that leaves through the watchdog unlinks the shared-memory names it created or opened: nothing to clean here, and
+    #  nobody may clean /dev/shm by prefix -- another test process may be using the double at the same time)
 
 
 @pytest.mark.gpu
@@ -138,5 +136,3 @@ def test_count_mismatch_is_an_error(tmp_path):
     rcs, outs = _run("mismatch", tmp_path, 20)
     # the side that issues second sees the other's size at ncclGroupEnd (ncclInvalidUsage); the side that waits is told and leaves
     assert all(rc != 0 for rc in rcs) and 86 in rcs and any("count mismatch" in o for o in outs), (rcs, outs)
-    for f in [f for f in os.listdir("/dev/shm") if f.startswith("fake_rccl_")]:
-        os.unlink(os.path.join("/dev/shm", f))
