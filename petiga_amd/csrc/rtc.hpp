@@ -79,7 +79,7 @@ struct RtcForm {
   std::map<int, std::shared_ptr<RtcFeature>> feature;   // key: TA | NW << 4 | DOFI << 8 | HASM << 12
   std::map<int, std::shared_ptr<RtcFeature>> pencil;    // form_pencil instantiations; key: SYSTEM | P << 1 | IDENT << 4 | RAT << 5
   std::map<int, std::shared_ptr<RtcFeature>> vecsf;     // vec_sumfact instantiations; key: GEO
-  std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P (+ 10 + rational on a mapped geometry)
+  std::map<int, std::shared_ptr<RtcFeature>> state;     // state_pencil instantiations; key: P (+ 10 + rational on a mapped geometry, + 100 packed tiles)
   std::map<int, std::shared_ptr<RtcFeature>> block;     // block_pencil instantiations; key: SYSTEM
   std::map<int, std::shared_ptr<RtcFeature>> band;      // band_points + band_pt instantiations; key: GEO | RAT << 1 | degree << 2
   ~RtcForm() { if (module) (void)hipModuleUnload(module); }
@@ -521,13 +521,18 @@ static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   if (!compile_only && (F.meta[11] <= 0 || F.meta[0] != 1 || F.meta[3] > 0 || F.meta[7] || !s.env.state_pencil || (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN))) return 0;
   const bool geo = s.nsd != 0;
   if (geo && (s.nsd != 3 || deg != 2)) return 0;
-  const int key = deg + (geo ? 10 + (s.rational ? 1 : 0) : 0);      // (12: p = 2 on a polynomial map, 13: on a NURBS map)
+  static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
+  const bool pack = deg == 2 && pack_env;
+  const int key = deg + (geo ? 10 + (s.rational ? 1 : 0) : 0) + (pack ? 100 : 0);      // (12: p = 2 on a polynomial map, 13: on a NURBS map; + 100: packed tiles)
   std::shared_ptr<RtcFeature> K;
   auto it = F.state.find(key);
   if (it != F.state.end() && (it->second->module || compile_only)) K = it->second;
   else {
     K.reset(new RtcFeature());
-    const std::string x = geo ? std::string("igx::state_pencil_geo<2, ") + (s.rational ? "true, " : "false, ") + F.name + ">"
+    // p = 2: the packed-tile kernels, as for the built-in forms (IGX_P2_PACK=0: the layer-pair tiles; the key below tells them apart)
+    const std::string x = (deg == 2 && pack) ? (geo ? std::string("igx::state_pencil_geo_k<") + (s.rational ? "true, " : "false, ") + F.name + ">"
+                                                    : std::string("igx::state_pencil_k<") + F.name + ">")
+                        : geo ? std::string("igx::state_pencil_geo<2, ") + (s.rational ? "true, " : "false, ") + F.name + ">"
                               : std::string("igx::state_pencil<") + std::to_string(deg) + ", " + F.name + ">";
     const std::string tail = "template __global__ void " + x + "(igx::SpaceDev, igx::OutDev, igx::PencilArgs, igx::ParamsDev);\n";
     if (int rc = rtc_build(F.source, true, tail, {x}, K->code, K->lowered, true)) return rc;
@@ -541,7 +546,8 @@ static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   PencilModule mod; memset(&mod.prm, 0, sizeof(mod.prm));
   mod.fn = K->func[0]; mod.name = F.name + ",hiprtc"; mod.state = true; mod.state_geo = geo;
   mod.extra_lds = pencil_state_bytes() + (geo ? pencil_sgeo_bytes() - pencil_geo_bytes() : 0);
-  mod.flop_per_element = 2048.0 * F.meta[11] * (deg == 2 ? 7 * 9 : 16 * 16);
+  mod.pack = pack ? (geo ? 2 : 1) : 0;
+  mod.flop_per_element = 2048.0 * F.meta[11] * (deg == 2 ? 7 * (pack ? 4 : 9) : 16 * 16);
   for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) mod.prm.v[i] = s.params[i];
   std::function<void()> zero = g->zero_matrix ? g->zero_matrix : std::function<void()>([] {});
   return try_gram_mfma(s, S, out, g->stream, false, g->last_kernel, g->last_launches, g_err, done, g->dom, zero, g->slab_done, &mod, g->face_done);
