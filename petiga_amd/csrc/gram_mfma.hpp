@@ -17,6 +17,7 @@
 #include <functional>
 #include "first_touch.hpp"
 #include <hip/hip_runtime.h>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -1380,36 +1381,67 @@ __device__ __forceinline__ void pencil_mfma_state_p2k(d4_t (&pk)[4], const doubl
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4;
   pk[0] = pk[1] = pk[2] = pk[3] = (d4_t){0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < 7; ++j) {
+  // The order is set by hand, as in pencil_mfma_state_p2: a step's MFMAs go out in pairs (one operand column against both trial
+  // columns); the next step's rows are read behind the pairs of the third-to-last feature, its test operands built behind the first
+  // pair of the second-to-last one, its coefficients read behind the second, its trial operands (pencil_trial, one column at a time)
+  // behind the pairs of the last feature -- where this step's other operands are dead.
+  struct Raw { d2u_t u[2], v[2], z[2]; double u2[2], v2[2], z2[2], c[NC]; };
+  auto loads = [&](int j, Raw &w) {
     const int pt = 4 * j + ks;
     const bool on = pt < 27;
-    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qp = rem - 3 * qy, qx = on ? qp : 3;      // (q_x = 3: the zero-padded point of the X rows)
-    const double *cp = coef + ((qw * 4 + qy) * 4 + qp) * NC;
-    double c[NC];
-#pragma unroll
-    for (int k = 0; k < NC; ++k) c[k] = cp[k];
-    double A[NF][2], B[2][NF];
+    const int pc = on ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = on ? rem - 3 * qy : 3;      // (q_x = 3: the zero-padded point of the X rows)
 #pragma unroll
     for (int T = 0; T < 2; ++T) {
-      const d2u_t u = *reinterpret_cast<const d2u_t *>(uxr + qx * 8 + K.ua[T]);
-      const d2u_t v = *reinterpret_cast<const d2u_t *>(vyr + K.va[T] + qy * 2);
-      const d2u_t z = *reinterpret_cast<const d2u_t *>(ztg + qw * 8 + K.za[T]);
-      const double a_n = u[0] * v[0], a_x = u[1] * v[0], a_y = u[0] * v[1];
-      A[0][T] = a_n * z[0]; A[1][T] = a_n * z[1]; A[2][T] = a_x * z[0]; A[3][T] = a_y * z[0];
-      if constexpr (LAP) {
-        const double u2 = d2w[qx * 4 + (K.ua[T] >> 1)], v2 = d2w[16 + (K.va[T] >> 1) + qy], z2 = d2w[32 + qw * 4 + (K.za[T] >> 1)];
-        A[NF - 1][T] = a_n * z2 + (u2 * v[0] + u[0] * v2) * z[0];
-      }
-      const double g[3] = {A[1][T], A[2][T], A[3][T]};
-      Form::pencil_trial(c, A[0][T], g, LAP ? A[NF - 1][T] : 0.0, B[T]);
+      w.u[T] = *reinterpret_cast<const d2u_t *>(uxr + qx * 8 + K.ua[T]);
+      w.v[T] = *reinterpret_cast<const d2u_t *>(vyr + K.va[T] + qy * 2);
+      w.z[T] = *reinterpret_cast<const d2u_t *>(ztg + qw * 8 + K.za[T]);
+      w.u2[T] = LAP ? d2w[qx * 4 + (K.ua[T] >> 1)] : 0.0; w.v2[T] = LAP ? d2w[16 + (K.va[T] >> 1) + qy] : 0.0; w.z2[T] = LAP ? d2w[32 + qw * 4 + (K.za[T] >> 1)] : 0.0;
     }
+  };
+  auto load_coef = [&](int j, Raw &w) {
+    const int pt = 4 * j + ks;
+    const int pc = pt < 27 ? pt : 0, qw = pc / 9, rem = pc - 9 * qw, qy = rem / 3, qx = rem - 3 * qy;
+    const double *cp = coef + ((qw * 4 + qy) * 4 + qx) * NC;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) w.c[k] = cp[k];
+  };
+  auto test_ops = [&](const Raw &w, double (&A)[NF][2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      const double a_n = w.u[T][0] * w.v[T][0], a_x = w.u[T][1] * w.v[T][0], a_y = w.u[T][0] * w.v[T][1];
+      A[0][T] = a_n * w.z[T][0]; A[1][T] = a_n * w.z[T][1]; A[2][T] = a_x * w.z[T][0]; A[3][T] = a_y * w.z[T][0];
+      if constexpr (LAP) A[NF - 1][T] = a_n * w.z2[T] + (w.u2[T] * w.v[T][0] + w.u[T][0] * w.v2[T]) * w.z[T][0];
+    }
+  };
+  auto trial_ops = [&](const Raw &w, const double (&A)[NF][2], int T, double (&B)[2][NF]) {
+    const double g[3] = {A[1][T], A[2][T], A[3][T]};
+    Form::pencil_trial(w.c, A[0][T], g, LAP ? A[NF - 1][T] : 0.0, B[T]);
+  };
+  double A[NF][2], B[2][NF];
+  { Raw w; loads(0, w); load_coef(0, w); test_ops(w, A); trial_ops(w, A, 0, B); trial_ops(w, A, 1, B); }
+#pragma unroll
+  for (int j = 0; j < 7; ++j) {
+    double A2[NF][2], B2[2][NF]; Raw w;
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-      for (int Ta = 0; Ta < 2; ++Ta)
+      for (int Ta = 0; Ta < 2; ++Ta) {
+        pk[Ta * 2 + 0] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][Ta], B[0][f], pk[Ta * 2 + 0], 0, 0, 0);
+        pk[Ta * 2 + 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][Ta], B[1][f], pk[Ta * 2 + 1], 0, 0, 0);
+        if (j < 6) {
+          if (f == NF - 3) { if (Ta == 0) loads(j + 1, w); }
+          if (f == NF - 2 && Ta == 0) test_ops(w, A2);
+          if (f == NF - 2 && Ta == 1) load_coef(j + 1, w);
+          if (f == NF - 1) trial_ops(w, A2, Ta, B2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    if (j < 6) {
 #pragma unroll
-        for (int Tb = 0; Tb < 2; ++Tb) pk[Ta * 2 + Tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[f][Ta], B[Tb][f], pk[Ta * 2 + Tb], 0, 0, 0);
+      for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int T = 0; T < 2; ++T) { A[f][T] = A2[f][T]; B[T][f] = B2[T][f]; }
+    }
   }
 }
 
@@ -1801,6 +1833,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   static_assert(!SGEO || P == 2, "a Tangent on a mapped geometry: p = 2");
   constexpr int GZ = SGEO ? SGEO_Z : GEO_Z, GD = SGEO ? SGEO_DOUBLES : GEO_DOUBLES;      // the per-wavefront metric area and the walk-axis rows behind it
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
+  long long tw_entry = 0, tw_staged = 0, tw_loop = 0, tw_loopend = 0;      // -DIGX_DEBUG: the life of a workgroup (entry | tables staged | first element | last element | end)
+  if (kDebug && pa.debug_buf) tw_entry = __builtin_readcyclecounter();
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int seg = blockIdx.x / pa.blocks_per_seg;
@@ -1838,6 +1872,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     }
   }
   __syncthreads();
+  if (kDebug && pa.debug_buf) tw_staged = __builtin_readcyclecounter();
   // an idle wavefront (grid padding) keeps running the barrier schedule below on pencil 0 with writes disabled
   const bool valid = pencil < pa.ex_count * pa.ey_count;
 
@@ -2004,6 +2039,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   const bool pingpong = pa.free_run == 0;
   if (grp == 1 && pingpong) __builtin_amdgcn_s_barrier();
   int lay = T.lay0;
+  if (kDebug && pa.debug_buf) tw_loop = __builtin_readcyclecounter();
   for (int ei = 0; ei < ne; ++ei) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
@@ -2031,7 +2067,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     else if constexpr (STATE && PACK) {
       d4_t pk[4];
       pencil_mfma_state_p2k<Form>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
-      pencil_win_add_ns(hold, pk, K2, ei);
+      pencil_win_add_ns(hold, pk, K2, ei);      // (measured: in the flush phase instead, behind the barrier, 130.4 -> 125.8 M el/s at 128^3)
     }
     else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
@@ -2070,6 +2106,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     if (pingpong) __builtin_amdgcn_s_barrier();
   }
+  if (kDebug && pa.debug_buf) tw_loopend = __builtin_readcyclecounter();
   if (out.clk && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && wave == 0 && lane == 0) {
     // IGX_CLOCK_PROBE: s_memtime against the 100 MHz s_memrealtime over the walk, first and last workgroup of every launch
     atomicAdd(reinterpret_cast<unsigned long long *>(out.clk), (unsigned long long)(__builtin_readcyclecounter() - tk0));
@@ -2086,6 +2123,10 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         held[NB - 1] = 0;
       } else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, rs[W]);
     }
+  if (kDebug && pa.debug_buf && wave == 0 && lane == 0) {      // (slots 62, 63 of the workgroup's stamp area: segments are shorter than 62 elements where this is read)
+    long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2) * 64 + 62) * 4;
+    d[0] = tw_entry; d[1] = tw_staged; d[2] = tw_loop; d[3] = tw_loopend; d[4] = __builtin_readcyclecounter(); d[5] = ne;
+  }
 }
 
 template <bool SYSTEM, int W, int P, bool GEO = false, bool RAT = false, bool FIXT = false, int ALIAS = -1>
@@ -2300,6 +2341,28 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
               pa.blocks_per_seg * pa.nseg, pa.seg_len, cnt, sm / cnt, sw / cnt, sf / cnt, sp / cnt);
       for (int i = 0; i < 16; ++i) fprintf(stderr, " %lld", hist[i]);
       fprintf(stderr, "\n");
+      {   // the life of a workgroup (wave 0): entry -> tables staged -> first element -> last element -> end
+        double a = 0, b2 = 0, c = 0, d2 = 0, nel = 0; long long nb = 0;
+        for (size_t b = 0; b < dbg_n / 4 / 64 / 2; ++b) {
+          const long long *d = &h[((b * 2) * 64 + 62) * 4];
+          if (!d[0] || !d[4]) continue;
+          a += (double)(d[1] - d[0]); b2 += (double)(d[2] - d[1]); c += (double)(d[3] - d[2]); d2 += (double)(d[4] - d[3]); nel += (double)d[5]; nb++;
+        }
+        if (nb) fprintf(stderr, "[igx pencil timing] workgroup life (wave 0, mean of %lld): staging %.0f | lane set-up %.0f | walk %.0f (%.1f elements) | trailing leaves %.0f cycles\n", nb, a / nb, b2 / nb, c / nb, nel / nb, d2 / nb);
+        // ... its spread, per segment of the pencils, and the span of the launch (first entry to last end) on the same counter
+        long long t_first = LLONG_MAX, t_last = 0;
+        for (int sg = 0; sg < pa.nseg; ++sg) {
+          double mn = 1e30, mx = 0, sm2 = 0; long long n2 = 0;
+          for (int bb = 0; bb < pa.blocks_per_seg; ++bb) {
+            const long long *d = &h[(((size_t)sg * pa.blocks_per_seg + bb) * 2 * 64 + 62) * 4];
+            if (!d[0] || !d[4]) continue;
+            const double life = (double)(d[4] - d[0]); mn = std::min(mn, life); mx = std::max(mx, life); sm2 += life; n2++;
+            t_first = std::min(t_first, d[0]); t_last = std::max(t_last, d[4]);
+          }
+          if (n2) fprintf(stderr, "[igx pencil timing]   segment %d: %lld workgroups, life min %.0f mean %.0f max %.0f\n", sg, n2, mn, sm2 / n2, mx);
+        }
+        if (t_last > t_first) fprintf(stderr, "[igx pencil timing]   launch span %.0f cycles (s_memtime is per XCC: spans compare within one)\n", (double)(t_last - t_first));
+      }
       (void)hipFree(pa.debug_buf);
     }
     launches++;
