@@ -1,5 +1,6 @@
-"""Size-independent properties at the BASELINE sizes (no oracle can run there): 3-D p=3 Poisson on 256^3 elements
-(5.84e9 non-zeros) and p=2 on 128^3, checked on the device through torch views of the library's arrays."""
+"""The BASELINE sizes (no oracle can run there): size-independent properties -- 3-D p=3 Poisson on 256^3 elements (5.84e9
+non-zeros) and p=2 on 128^3, checked on the device through torch views of the library's arrays -- and, for the identity-geometry
+configs, VALUES: every distinct kind of row against the CPU oracle's matrix of a small mesh scaled by the element size."""
 import numpy as np
 import pytest
 
@@ -34,6 +35,98 @@ def _int1d(p, N):
     """integral of every basis function of the uniform open knot vector over [0,1] = (U[i+p+1]-U[i])/(p+1)"""
     U = np.concatenate([np.zeros(p + 1), np.arange(1, N) / N, np.ones(p + 1)])
     return (U[p + 1:] - U[:-p - 1]) / (p + 1)
+
+
+# ---- VALUES at full size.  On the identity geometry with uniform open knot vectors the entry K[(i), (i + d)] of a node depends only on
+# where the node sits relative to the two ends of each axis (the first / last 2p nodes see the repeated end knots, every other node is
+# "interior") and on the element size h: K scales with h^(dim - 2) per field pair, F with h^dim.  So a SMALL oracle mesh (3p + 3
+# elements per axis) holds, up to that scale, every distinct row of the 256^3 matrix: rows of the big matrix are sampled over all
+# combinations of per-axis position classes -- 0 .. 2p-1 from either end and a middle node -- and every one of their entries (343
+# per row at p = 3) is compared with the oracle's entry at the corresponding small-mesh node pair.  A coefficient that is wrong but
+# conservative (row sums still zero, pattern intact) does not survive this.
+def _axis_classes(p, n_big, n_small):
+    """(sampled big-mesh indices, the small-mesh index of each)"""
+    m = 2 * p
+    big = list(range(m)) + [n_big // 2] + list(range(n_big - m, n_big))
+    small = list(range(m)) + [n_small // 2] + list(range(n_small - m, n_small))
+    return np.array(big), np.array(small)
+
+
+def _sampled_rows_vs_scaled_oracle(A, p, N, dof, A_small, Ns, scale, tol=1e-11):
+    import torch
+    n, ns, W = N + p, Ns + p, 2 * p + 1
+    rp, ci, val = A.device_ptrs()
+    bs2 = dof * dof
+    rpt = torch.as_tensor(_DevArray(rp, A.nbrows + 1, "<i8"), device="cuda")
+    cit = torch.as_tensor(_DevArray(ci, A.nblocks, "<i4"), device="cuda")
+    vt = torch.as_tensor(_DevArray(val, A.nblocks * bs2, "<f8"), device="cuda").view(-1, bs2)
+    big, small = _axis_classes(p, n, ns)
+    B0, B1, B2 = np.meshgrid(big, big, big, indexing="ij")
+    S0, S1, S2 = np.meshgrid(small, small, small, indexing="ij")
+    rows = (B0 + n * (B1 + n * B2)).reshape(-1)                      # axis 0 fastest
+    srow = np.stack([S0.reshape(-1), S1.reshape(-1), S2.reshape(-1)], axis=1)
+    rows_t = torch.as_tensor(rows, device="cuda")
+    lo, hi = rpt[rows_t].cpu().numpy(), rpt[rows_t + 1].cpu().numpy()
+    ref = A_small.tocsr()
+    worst, vmax, nent = 0.0, 0.0, 0
+    for k, r in enumerate(rows):
+        cols = cit[lo[k]:hi[k]].cpu().numpy().astype(np.int64)
+        vals = vt[lo[k]:hi[k]].cpu().numpy()
+        c0, c1, c2 = cols % n, (cols // n) % n, cols // (n * n)
+        r0, r1, r2 = r % n, (r // n) % n, r // (n * n)
+        sc = (srow[k, 0] + (c0 - r0)) + ns * ((srow[k, 1] + (c1 - r1)) + ns * (srow[k, 2] + (c2 - r2)))     # the same offsets from the small-mesh node
+        sr = srow[k, 0] + ns * (srow[k, 1] + ns * srow[k, 2])
+        for i in range(dof):
+            dense_row = ref[sr * dof + i].toarray().ravel()          # (one row of the small matrix, dense: (Ns + p)^3 dof numbers)
+            for j in range(dof):
+                want = dense_row[sc * dof + j] * scale
+                got = vals[:, i * dof + j]
+                worst = max(worst, float(np.abs(got - want).max()))
+                vmax = max(vmax, float(np.abs(want).max()))
+        nent += cols.size * bs2
+    assert worst <= tol * vmax, (worst, vmax)
+    return rows, srow, nent
+
+
+@pytest.mark.parametrize("p,N", [(3, 256), (2, 128)])
+def test_poisson_full_size_values_vs_scaled_oracle(p, N):
+    """Every distinct kind of row of the full-size Poisson System -- with and without the Dirichlet data of demo/Poisson3D.c:37-43 --
+    against the CPU oracle's matrix of a (3p + 3)^3 mesh scaled by the ratio of the element sizes; F likewise (h^3)."""
+    import petiga_amd as P
+    import oracle_api as O
+    Ns = 3 * p + 3
+    g, orc = P.IGX(3, 1), O.OracleIGA(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, p, N)
+        orc.axis_uniform(i, p, Ns)
+    g.setup(); orc.setup()
+    g.set_form("poisson")
+    A, b = g.create_mat(), g.create_vec()
+    s = Ns / N                                   # h_big / h_small
+    for bc in (False, True):
+        if bc:
+            for x in (g, orc):
+                for d in range(3):
+                    for sd in range(2):
+                        x.set_boundary_value(d, sd, 0, 1.0)
+        g.compute_system(A, b); g.synchronize()
+        assert "pencil" in g.kernel_name()
+        A_o, b_o = orc.compute_system("orc_form_poisson")
+        M = A_o.scipy()
+        if bc:      # a fixed row holds the element multiplicity on its diagonal (no length in it): undo the scale there
+            n_s = Ns + p
+            idx = np.arange(n_s ** 3)
+            i0, i1, i2 = idx % n_s, (idx // n_s) % n_s, idx // (n_s * n_s)
+            onb = (i0 == 0) | (i0 == n_s - 1) | (i1 == 0) | (i1 == n_s - 1) | (i2 == 0) | (i2 == n_s - 1)
+            import scipy.sparse as sp
+            D = sp.diags(np.where(onb, 1.0 / s, 1.0))
+            M = (D @ M).tocsr()
+        rows, srow, nent = _sampled_rows_vs_scaled_oracle(A, p, N, 1, M, Ns, s)
+        assert len(rows) == (4 * p + 1) ** 3 and nent >= len(rows) * (p + 1) ** 3      # (a corner row has (p + 1)^3 entries, an interior one (2p + 1)^3)
+        if not bc:
+            n_s = Ns + p
+            sr = srow[:, 0] + n_s * (srow[:, 1] + n_s * srow[:, 2])
+            assert np.abs(b.get()[rows] - b_o[sr] * s ** 3).max() <= 1e-12 * np.abs(b_o).max() * s ** 3
 
 
 @pytest.mark.parametrize("p,N", [(3, 256), (2, 128)])
@@ -83,6 +176,41 @@ def test_poisson_full_size_properties(p, N):
     # lifting: b_i = F_i - sum_k K_ik over the fixed columns, and the full row sums to zero => b_i = F_i + (row sum after fix-up)
     free_near = ~onb & ~deep
     assert np.abs(bk[free_near] - (F[free_near] + rowsum[free_near])).max() <= 1e-11 * max(scale, 1.0)
+
+
+def test_elasticity_full_size_values_vs_scaled_oracle():
+    """Config 3 at 128^3: the 3 x 3 blocks of every distinct kind of row against the oracle's demo/Elasticity3D.c:13-46 on a 12^3 mesh,
+    scaled by the ratio of the element sizes (the blocks are sums of grad N . grad N terms: h^1 in 3-D), with the demo's boundary
+    data (demo/Elasticity3D.c:67-70: the face x = 0 clamped, u_x = 1 on the face x = 1)."""
+    import petiga_amd as P
+    import oracle_api as O
+    p, N, Ns = 3, 128, 12
+    g, orc = P.IGX(3, 3), O.OracleIGA(3, 3)
+    for i in range(3):
+        g.axis_uniform(i, p, N)
+        orc.axis_uniform(i, p, Ns)
+    g.setup(); orc.setup()
+    for x in (g, orc):
+        for f in range(3):
+            x.set_boundary_value(0, 0, f, 0.0)
+        x.set_boundary_value(0, 1, 0, 1.0)
+    g.set_form("elasticity", (1.3, 0.7))
+    A, b = g.create_mat(), g.create_vec()
+    g.compute_system(A, b); g.synchronize()
+    assert "block_pencil(mfma" in g.kernel_name()
+    A_o, _ = orc.compute_system("orc_form_elasticity", O.ElasticityCtx(1.3, 0.7))
+    s = Ns / N
+    M = A_o.scipy()
+    n_s = Ns + p
+    idx = np.arange(n_s ** 3)
+    i0 = idx % n_s
+    fixed = np.zeros((n_s ** 3, 3), dtype=bool)
+    fixed[i0 == 0, :] = True
+    fixed[i0 == n_s - 1, 0] = True
+    import scipy.sparse as sp
+    M = (sp.diags(np.where(fixed.reshape(-1), 1.0 / s, 1.0)) @ M).tocsr()      # fixed rows: the multiplicity on the diagonal carries no length
+    rows, _, nent = _sampled_rows_vs_scaled_oracle(A, p, N, 3, M, Ns, s)
+    assert len(rows) == 13 ** 3 and nent >= 9 * 64 * len(rows)
 
 
 def test_elasticity_full_size_properties():
@@ -171,6 +299,36 @@ def test_cahn_hilliard_full_size_properties():
     val.fill_(float("nan"))
     g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
     assert (float(val.sum()), float(val.abs().sum())) == chk            # first-touch stores reach every entry; same bits -> same sums
+
+
+def test_cahn_hilliard_full_size_values_vs_scaled_oracle():
+    """Config 4's Tangent at 256^3 by VALUE.  At a uniform state c the Tangent of demo/CahnHilliard3D.c:111-179 is
+    shift N_a N_b + M mu'(c) grad N_a . grad N_b + M lap N_a lap N_b with mu' proportional to L0^2 / lambda: three terms that scale
+    with h^3, h, 1/h.  Give the small oracle mesh shift s^4 and lambda / s^2 (s = h_big / h_small) and the big matrix is the small one
+    times 1/s, row class by row class (see _sampled_rows_vs_scaled_oracle).  The state-dependent terms (grad c, lap c) are zero here:
+    they are compared with the oracle at oracle sizes, on random states (tests/test_gpu_state_pencil.py)."""
+    import petiga_amd as P
+    import oracle_api as O
+    N, p, Ns = 256, 2, 9
+    theta, alpha, cbar, L0, lam, tau = 1.5, 200.0, 0.63, 1.0, 1.0 / (3.0 * N * N), 1.0
+    g, orc = P.IGX(3, 1), O.OracleIGA(3, 1)
+    for i in range(3):
+        g.axis_uniform(i, p, N)
+        orc.axis_uniform(i, p, Ns)
+    g.setup(); orc.setup()
+    g.set_form("cahnhilliard", (theta, alpha, cbar, L0, lam, tau))
+    A = g.create_mat()
+    n = N + p
+    U, V = g.create_vec().set(np.full(n ** 3, cbar)), g.create_vec().set(np.zeros(n ** 3))
+    shift = 250.0
+    g.compute_ijacobian(shift, V, 0.0, U, A); g.synchronize()
+    assert "state_pencil" in g.kernel_name() and "packed" in g.kernel_name(), g.kernel_name()
+    s = Ns / N
+    ns = Ns + p
+    J_o = orc.compute_ijacobian("orc_form_ch_tangent", O.CahnHilliardCtx(theta, alpha, cbar, L0, lam / (s * s), tau), shift * s ** 4,
+                                np.zeros(ns ** 3), 0.0, np.full(ns ** 3, cbar))
+    rows, _, nent = _sampled_rows_vs_scaled_oracle(A, p, N, 1, J_o.scipy(), Ns, 1.0 / s, tol=1e-10)
+    assert len(rows) == 9 ** 3 and nent >= 27 * len(rows)
 
 
 def test_cahn_hilliard_on_a_nurbs_patch_properties():
