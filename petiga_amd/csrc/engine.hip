@@ -1100,8 +1100,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         st.kfn = s.rational ? state_pencil_geo<2, true, FormBratu<3>> : state_pencil_geo<2, false, FormBratu<3>>; st.name = "Bratu";
         st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 9;
       }
-      static const bool pack_geo_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
-      if (st.kfn && pack_geo_env) {      // packed tiles (state_pencil_geo_k): 4 MFMAs per feature and k-step instead of 9
+      if (st.kfn && s.env.p2_pack != 0) {      // packed tiles (state_pencil_geo_k): 4 MFMAs per feature and k-step instead of 9
         st.pack = 2;
         if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = s.rational ? state_pencil_geo_k<true, FormCahnHilliard<3>> : state_pencil_geo_k<false, FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
         else { st.kfn = s.rational ? state_pencil_geo_k<true, FormBratu<3>> : state_pencil_geo_k<false, FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
@@ -1125,8 +1124,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * (deg == 2 ? 7 * 9 : 16 * 16);
       }
       // p = 2: packed tiles (state_pencil_k: 4 MFMAs per feature and k-step instead of 9; IGX_P2_PACK=0: the layer-pair tiles)
-      static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
-      if (st.kfn && deg == 2 && pack_env) {
+      if (st.kfn && deg == 2 && s.env.p2_pack != 0) {
         st.pack = 1;
         if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
         else { st.kfn = state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }

@@ -2247,8 +2247,7 @@ static inline int pencil_wpb(const Space &s, int P, bool geo, bool fixt, bool ha
 }
 // ... and whether that kernel packs the element's 27 functions into two tiles (pencil_mfma_p2k; IGX_P2_PACK=0: the layer-pair tiles)
 static inline bool pencil_p2_pack(const Space &s, int P, bool geo, bool fixt, bool has_mod) {
-  static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
-  return pack_env && pencil_wpb(s, P, geo, fixt, has_mod) == 12;
+  return s.env.p2_pack != 0 && pencil_wpb(s, P, geo, fixt, has_mod) == 12;
 }
 static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always, int wpb = 8) {
   long long total = 0;

@@ -41,6 +41,7 @@ struct EnvSwitches {
   int state_pencil = 1;      // IGX_STATE_PENCIL=0: Tangents of scalar forms stay on the feature kernel (gram_mfma.hpp: state_pencil)
   int vec_sumfact = 1;       // IGX_VEC_SUMFACT=0: the vector-only drivers stay on the feature kernel (vec_sumfact.hpp)
   int free_run = -1;         // IGX_FREE_RUN=0/1: the pencil walk with / without its s_barrier ping-pong (-1: the launcher's choice)
+  int p2_pack = 1;           // IGX_P2_PACK=0: the p = 2 walks keep one tile per pair of node layers (round 4) instead of the packed tiles
   int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)
   int debug_feature = 0, debug_noflush = 0, debug_timing = 0;   // only honoured by -DIGX_DEBUG builds
 };

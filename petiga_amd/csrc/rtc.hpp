@@ -521,8 +521,7 @@ static int launch_state_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
   if (!compile_only && (F.meta[11] <= 0 || F.meta[0] != 1 || F.meta[3] > 0 || F.meta[7] || !s.env.state_pencil || (out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN))) return 0;
   const bool geo = s.nsd != 0;
   if (geo && (s.nsd != 3 || deg != 2)) return 0;
-  static const bool pack_env = [] { const char *e = getenv("IGX_P2_PACK"); return !e || atoi(e) != 0; }();
-  const bool pack = deg == 2 && pack_env;
+  const bool pack = deg == 2 && s.env.p2_pack != 0;
   const int key = deg + (geo ? 10 + (s.rational ? 1 : 0) : 0) + (pack ? 100 : 0);      // (12: p = 2 on a polynomial map, 13: on a NURBS map; + 100: packed tiles)
   std::shared_ptr<RtcFeature> K;
   auto it = F.state.find(key);

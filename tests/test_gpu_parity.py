@@ -525,10 +525,13 @@ def test_create_from_tables_matches_oracle(dim, dof, p, N, geo, form):
     assert np.abs(b.get() - b_o).max() <= (1e-11 if geo else TOL) * max(np.abs(b_o).max(), 1.0)
 
 
+@pytest.mark.parametrize("pack", [1, 0])
 @pytest.mark.parametrize("N,bc", [((10, 5, 6), "all1"), ((70, 4, 5), "mixed"), ((9, 9, 9), "none"), ((8, 1, 1), "all1"), ((33, 7, 3), "axis0")])
-def test_mfma_pencil_degree2(N, bc):
-    """BASELINE config 2 family (demo/Poisson3D.c at p=2 C1): the pencil kernel with the 3x3x3 basis zero-padded
-    into the 4x4 tile slots, band width 5."""
+def test_mfma_pencil_degree2(N, bc, pack, monkeypatch):
+    """BASELINE config 2 family (demo/Poisson3D.c at p=2 C1), band width 5: the packed tiles of round 5 (27 functions in two MFMA
+    tiles, band rows combined in an LDS window) and, with IGX_P2_PACK=0, the kernel they replaced (the 3x3x3 basis zero-padded into
+    4x4 tile slots, one tile per pair of node layers) -- still the code of p = 2 on mapped geometries, so it stays tested."""
+    monkeypatch.setenv("IGX_P2_PACK", str(pack))      # (read when an IGX is created)
     orc, eng = make_pair(3, 1, 2, list(N))
     for g in (orc, eng):
         if bc == "all1":
@@ -544,7 +547,7 @@ def test_mfma_pencil_degree2(N, bc):
             g.set_boundary_value(0, 1, 0, -1.0)
     eng.set_kernel(2)
     A, b, A_o, b_o = system_pair(orc, eng, "orc_form_poisson", "poisson")
-    assert "p=2" in eng.kernel_name() and "pencil" in eng.kernel_name()
+    assert "p=2" in eng.kernel_name() and "pencil" in eng.kernel_name() and (("packed tiles" in eng.kernel_name()) == bool(pack)), eng.kernel_name()
     compare_mats(A, A_o, TOL)
     assert np.abs(b.get() - b_o).max() <= TOL * max(np.abs(b_o).max(), 1e-300)
     eng.set_form("poisson")

@@ -145,6 +145,37 @@ def test_tangent_on_a_mapped_geometry_vs_oracle(form, N, periodic, rational, bc,
     assert np.array_equal(J.to_coo_global()[2], vals)
 
 
+@pytest.mark.parametrize("geo", [None, "nurbs"])
+def test_layer_pair_tiles_stay_alive(geo, monkeypatch):
+    """IGX_P2_PACK=0: the p = 2 Tangents with one tile per pair of node layers (state_pencil<2> / state_pencil_geo<2>: what ran before
+    the packed tiles of round 5 and still is the code of p = 3 and of run-time structs under that switch) against the oracle, and the
+    same matrix from the packed kernel to rounding."""
+    from common import warped_geometry
+    ctx = O.CahnHilliardCtx(*CH)
+    vals = {}
+    for pack in ("0", "1"):
+        monkeypatch.setenv("IGX_P2_PACK", pack)
+        orc, eng = make_pair(3, 1, 2, [12, 4, 5])
+        if geo:
+            X, W = warped_geometry(orc, 3, seed=8, rational=True, amp=0.06)
+            orc.set_geometry(X, W); eng.set_geometry(X, W)
+        for g in (orc, eng):
+            g.set_boundary_value(0, 0, 0, 0.6); g.set_boundary_value(2, 1, 0, 0.64)
+        rng = np.random.default_rng(21)
+        n = orc.global_size()
+        U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+        eng.set_form("cahnhilliard", CH)
+        Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+        _poison(J)
+        eng.compute_ijacobian(250.0, Vv, 0.0, Uv, J)
+        eng.synchronize()
+        assert "state_pencil<CahnHilliard>" in eng.kernel_name() and (("packed tiles" in eng.kernel_name()) == (pack == "1")), eng.kernel_name()
+        J_o = orc.compute_ijacobian("orc_form_ch_tangent", ctx, 250.0, V, 0.0, U)
+        compare_mats(J, J_o, 1e-10 if geo else 1e-11)
+        vals[pack] = J.to_coo_global()[2]
+    assert np.abs(vals["0"] - vals["1"]).max() <= 1e-10 * np.abs(vals["0"]).max()
+
+
 def test_switch_and_fallbacks(monkeypatch):
     """IGX_STATE_PENCIL=0, a short walk axis and a mapped geometry at p = 3 keep the feature kernel"""
     from common import warped_geometry
