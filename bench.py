@@ -30,7 +30,7 @@ ALG = {"elasticity": (4718592, 25400), "cahnhilliard": (790000, 1009), "nsvms": 
 NOMINAL_MHZ = 2400.0
 FP64_PEAK_TFLOPS = 78.6                        # MI355X fp64 vector = matrix peak (256 CU * 4 SIMD * 32 flop/clk * 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
-KERNEL_TAG = "r04"                             # profiles/traffic.json must describe this round's kernel to be quoted
+KERNEL_TAG = "r05"                             # profiles/traffic.json must describe this round's kernel to be quoted
 
 
 def physical_cores():
@@ -572,7 +572,8 @@ def main():
         try:
             tj = json.load(open(tf))
             for ent in tj.get("configs", [tj]):
-                if ent.get("form", "poisson") == args.form and ent.get("size") == size and ent.get("degree", p) == p and ent.get("n_gpus") == world and ent.get("kernel_tag") == KERNEL_TAG and bool(ent.get("geometry", args.form == "nsvms")) == bool(geometry):
+                if ent.get("form", "poisson") == args.form and ent.get("size") == size and ent.get("degree", p) == p and ent.get("n_gpus") == world and ent.get("kernel_tag") == KERNEL_TAG and bool(ent.get("geometry", args.form == "nsvms")) == bool(geometry) \
+                        and dom_name.split("<")[0].split("(")[0] in ent.get("kernel", ""):      # (the entry must describe the kernel that ran: gram_pencil ~ gram_pencil_w6<...>)
                     # PMC passes run one step: bytes per launch of the dominant kernel of THIS step shape
                     traffic = ent.get("bytes_per_launch")
                     traffic_source = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, round %s; replayed, not measured in this run)" % ent.get("round", tj.get("round"))
