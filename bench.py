@@ -153,8 +153,7 @@ def live_traffic(child_args, dom_name, timeout=300):
 def _bench_geometry(p, size, periodic):
     """The smooth rational map of `--geometry` (config 5's premise): the same control net for the engine and the oracle."""
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from common import greville
+    from petiga_amd.geometry import greville       # no tests/ (and with it no oracle module) on the GPU leg
     gv = []
     for i in range(3):
         U = (np.arange(-p, size + p + 1) / size) if periodic[i] else np.concatenate([[0.0] * (p + 1), np.arange(1, size) / size, [1.0] * (p + 1)])

@@ -85,6 +85,15 @@ int IGXSetDim(IGX iga,int dim);                            /* IGASetDim         
 int IGXSetDof(IGX iga,int dof);                            /* IGASetDof          src/petiga.c:334  */
 int IGXSetOrder(IGX iga,int order);                        /* IGASetOrder        src/petiga.c:463  (clipped to [1,4]) */
 int IGXSetQuadrature(IGX iga,int i,int q);                 /* IGASetQuadrature   src/petiga.c:530  */
+/* Quadrature rule of an axis (IGARuleType, include/petiga.h:82-87).  LEGENDRE (q = 1..10) and LOBATTO (q = 2..10) carry the
+ * doubles of the reference's tables (src/petigarule.c:182-319, :321-459); USER takes any rule on [-1,1]; REDUCED (a point
+ * count that varies along the axis, src/petigabasis.c:144-171) is refused with PETSC_ERR_SUP at IGXSetUp. */
+typedef enum { IGX_RULE_LEGENDRE = 0, IGX_RULE_LOBATTO = 1, IGX_RULE_REDUCED = 2, IGX_RULE_USER = 3 } IGXRuleType;
+int IGXSetRuleType(IGX iga,int i,IGXRuleType type);        /* IGASetRuleType     src/petiga.c:500  */
+int IGXSetRuleSize(IGX iga,int i,int nqp);                 /* IGASetRuleSize     src/petiga.c:515  */
+int IGXSetRule(IGX iga,int i,int q,const double x[],const double w[]); /* IGAGetRule + IGARuleSetRule  src/petigarule.c:145 */
+int IGXGetRule(IGX iga,int i,int *q,double x[],double w[]); /* IGAGetRule + IGARuleGetRule  src/petigarule.c:160: the rule IGXSetUp
+                                                              will use (x, w may be NULL; room for *q entries: ask for q first) */
 int IGXSetProcessors(IGX iga,int i,int processors);        /* IGASetProcessors   src/petiga.c:547  */
 int IGXSetComm(IGX iga,int size,int rank);                 /* the (size,rank) of the MPI_Comm given to IGACreate */
 int IGXAxisSetDegree(IGX iga,int i,int p);                 /* IGAAxisSetDegree   src/petigaaxis.c:168 */
@@ -153,6 +162,17 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  *       static __device__ void pencil_coef(const PtView &p,double JW,double *c);        // from u, grad u, diag hess u, shift, prm
  *       static __device__ void pencil_trial(const double *c,double N,const double *g,double lap,double *B);   // B[0..PENCIL_NFEAT)
  * (FormCahnHilliard / FormBratu in petiga_amd/csrc/forms.hpp are written this way; 3-D, p = 2 or 3, no geometry, dof 1.)
+ * A four-field first-order struct that separates its point coefficients from the basis functions -- demo/NavierStokesVMS.c's
+ * Tangent -- takes the band-row kernel with point records (band_points + band_pt<MyForm>, 3-D, p = 3; p = 2 with IGXSetKernel(4)):
+ *       static constexpr int NCOEF = <coefficients per Gauss point>;
+ *       static __device__ void point_coef(const PtView &p,double *c);                   // from the state and prm at the point
+ *       static __device__ void mat_c(const double *c,const double *Na,const double *Nb,double *T);
+ * and optionally mat_unit / BAND_NFEAT / BAND_NACC with band_coef / band_finish (FormNSVMS in petiga_amd/csrc/forms.hpp is the
+ * model).  A struct with the BAND_NACC hooks also declares a guard on its parameters, evaluated on the DEVICE by a one-lane
+ * kernel whenever the parameters change, so it must be callable there:
+ *       __host__ __device__ static bool band_params_ok(const double *prm);      // false: stay on the feature kernel (e.g. nu = 0)
+ * A guard that does not compile for the device (a plain host function) does not fail the assembly: the automatic choice falls
+ * through to the feature kernel and IGXGetKernelName says why; IGXSetKernel(4) and IGXCheckFormSource(…, 6) report the compiler's log.
  *       static constexpr int SHAPE_ORDER = 1;                  // ORDER = 2 only for hess u: second derivatives of N are not kept
  *       static constexpr bool VEC_ZERO = true;                 // vec() returns zeros: the vector phase runs for the Dirichlet lifting only
  * Boundary-form passes (IGXSetBoundaryForm; `if (p->atboundary)` in the reference's callback, e.g. demo/NitscheMethod.c:69-110): a
@@ -174,6 +194,10 @@ int IGXReadVec (IGX iga,IGXVec vec,const char filename[]); /* IGAReadVec  src/pe
 int IGXGetSizes(IGX iga,int elem_sizes[3],int elem_start[3],int elem_width[3],
                 int node_sizes[3],int node_lstart[3],int node_lwidth[3],int node_gstart[3],int node_gwidth[3]);
 int IGXGetProcessors(IGX iga,int proc_sizes[3],int proc_ranks[3]);
+/* IGAGetBasis + struct _n_IGABasis (include/petiga.h:122-141): the 1-D tables IGXSetUp built for axis i, as the element loop
+ * reads them (src/petigabasis.c:83-219): offset[nel], detJac[nel], weight[nel][nqp], point[nel][nqp], value[nel][nqp][nen][5].
+ * Any array may be NULL; ask for the three sizes first. */
+int IGXGetBasis(IGX iga,int i,int *nel,int *nqp,int *nen,int offset[],double detJac[],double weight[],double point[],double value[]);
 int64_t IGXGetElementCount(IGX iga);   /* local elements */
 
 /* ------------------------------------------------------------------------------------------

@@ -23,35 +23,89 @@ static void *xcalloc(size_t n,size_t sz) { void *p = calloc(n?n:1,sz); if(!p){pe
 static int ipow(int b,int e) { int r=1; while (e-- > 0) r*=b; return r; }
 
 /* ------------------------------------------------------------------ */
-/* Quadrature rule: src/petigarule.c:182-319 tabulates Gauss-Legendre */
-/* nodes/weights for q=1..10 as 36-digit constants, ascending nodes,  */
-/* exactly symmetric (X[q-1-i] = -X[i]).  Here the same numbers are   */
-/* computed (Newton on P_q in long double) instead of tabulated.      */
+/* Quadrature rules.  src/petigarule.c:182-319 tabulates Gauss-Legendre */
+/* nodes/weights for q=1..10 and :321-459 Gauss-Lobatto for q=2..10 as  */
+/* 36-digit constants, ascending nodes, exactly symmetric               */
+/* (X[q-1-i] = -X[i]).  The constants are not copied: the same numbers  */
+/* are computed (Newton in long double, two more steps in __float128 so */
+/* that the cast to double rounds correctly) and held, bit for bit, to  */
+/* the doubles of the reference's table kept in                         */
+/* tests/golden/gauss_rules.json (tests/test_golden.py).                */
 /* ------------------------------------------------------------------ */
+typedef __float128 orcq;
+
+/* P_n(x) and P_{n-1}(x) by the three-term recurrence */
+static void orc_legendre_pair(int n,orcq x,orcq *Pn,orcq *Pm)
+{
+  orcq p0 = 1, p1 = x; int k;
+  if (n == 0) { *Pn = 1; *Pm = 0; return; }
+  for (k=2; k<=n; k++) { orcq p2 = ((2*k-1)*x*p1 - (k-1)*p0)/k; p0=p1; p1=p2; }
+  *Pn = p1; *Pm = p0;
+}
+
 int orc_gauss_legendre(int q,double *X,double *W)
 {
-  int i,k,it;
+  int i,it;
   if (q < 1 || q > 10) return 1;   /* the reference implements 1..10 only */
   for (i=0; i<(q+1)/2; i++) {
-    long double x = cosl(3.14159265358979323846264338327950288L*(i+0.75L)/(q+0.5L));
-    long double p0,p1,pp=0,dx;
-    for (it=0; it<100; it++) {
-      p0 = 1; p1 = x;
-      for (k=2; k<=q; k++) { long double p2 = ((2*k-1)*x*p1 - (k-1)*p0)/k; p0=p1; p1=p2; }
-      if (q == 0) p1 = 1;
-      pp = q*(x*p1 - p0)/(x*x-1);
-      dx = p1/pp; x -= dx;
+    long double xl = cosl(3.14159265358979323846264338327950288L*(i+0.75L)/(q+0.5L));
+    orcq x,p,pm,dp,w;
+    for (it=0; it<100; it++) {                 /* long double Newton */
+      long double dx;
+      orc_legendre_pair(q,(orcq)xl,&p,&pm);
+      dp = q*((orcq)xl*p - pm)/((orcq)xl*xl-1);
+      dx = (long double)(p/dp); xl -= dx;
       if (fabsl(dx) < 1e-19L) break;
     }
-    p0 = 1; p1 = x;
-    for (k=2; k<=q; k++) { long double p2 = ((2*k-1)*x*p1 - (k-1)*p0)/k; p0=p1; p1=p2; }
-    pp = q*(x*p1 - p0)/(x*x-1);
-    {
-      long double w = 2/((1-x*x)*pp*pp);
-      /* x is the i-th largest root; store ascending and mirrored */
-      X[q-1-i] = (double)x;  W[q-1-i] = (double)w;
-      X[i]     = -(double)x; W[i]     = (double)w;
+    x = xl;
+    for (it=0; it<2; it++) {                   /* quadruple-precision polish */
+      orc_legendre_pair(q,x,&p,&pm);
+      dp = q*(x*p - pm)/(x*x-1);
+      x -= p/dp;
     }
+    orc_legendre_pair(q,x,&p,&pm);
+    dp = q*(x*p - pm)/(x*x-1);
+    w = 2/((1-x*x)*dp*dp);
+    /* x is the i-th largest root; store ascending and mirrored */
+    X[q-1-i] = (double)x;  W[q-1-i] = (double)w;
+    X[i]     = -(double)x; W[i]     = (double)w;
+  }
+  if (q % 2) X[q/2] = 0.0;
+  return 0;
+}
+
+/* Gauss-Lobatto (src/petigarule.c:321-459 tabulates q=2..10): x = +-1 and the roots of P'_{q-1};
+   w = 2/(q(q-1) P_{q-1}(x)^2).  With n = q-1: (1-x^2) P_n' = n (P_{n-1} - x P_n) and
+   (1-x^2) P_n'' = 2x P_n' - n(n+1) P_n. */
+int orc_gauss_lobatto(int q,double *X,double *W)
+{
+  int i,it,n=q-1;
+  if (q < 2 || q > 10) return 1;
+  for (i=0; i<(q+1)/2; i++) {
+    orcq x = 1,p,pm,w,d1,d2;
+    if (i > 0) {
+      long double xl = cosl(3.14159265358979323846264338327950288L*i/n);
+      for (it=0; it<100; it++) {               /* long double Newton on P_n' */
+        long double dx;
+        x = xl;
+        orc_legendre_pair(n,x,&p,&pm);
+        d1 = n*(pm - x*p)/(1-x*x);
+        d2 = (2*x*d1 - n*(n+1)*p)/(1-x*x);
+        dx = (long double)(d1/d2); xl -= dx;
+        if (fabsl(dx) < 1e-19L) break;
+      }
+      x = xl;
+      for (it=0; it<2; it++) {                 /* quadruple-precision polish */
+        orc_legendre_pair(n,x,&p,&pm);
+        d1 = n*(pm - x*p)/(1-x*x);
+        d2 = (2*x*d1 - n*(n+1)*p)/(1-x*x);
+        x -= d1/d2;
+      }
+    }
+    orc_legendre_pair(n,x,&p,&pm);
+    w = 2/((orcq)(q*n)*p*p);
+    X[q-1-i] = (double)x;  W[q-1-i] = (double)w;
+    X[i]     = -(double)x; W[i]     = (double)w;
   }
   if (q % 2) X[q/2] = 0.0;
   return 0;
@@ -208,13 +262,18 @@ static void basis_free(OrcBasis *b)
   memset(b,0,sizeof(*b));
 }
 
-/* src/petigabasis.c:83-219 (IGABasisInitQuadrature), Gauss-Legendre rule only */
-static int basis_init_quadrature(OrcBasis *bs,const OrcAxis *ax,int nqp)
+/* src/petigabasis.c:83-219 (IGABasisInitQuadrature) with the rule of IGARuleSetUp (src/petigarule.c:116-143):
+   type 0 Gauss-Legendre, 1 Gauss-Lobatto, 3 user-defined (ux, uw); the reduced rule (type 2, :144-171) is not restated */
+static int basis_init_quadrature(OrcBasis *bs,const OrcAxis *ax,int nqp,int type,const double *ux,const double *uw)
 {
   int p=ax->p, m=ax->m, n=m-p-1, nel=ax->nel, nen=p+1, d=(p<4)?p:4, e,q;
-  double X[10],W[10];
+  double X[64],W[64];
   const double *U = ax->U;
-  if (orc_gauss_legendre(nqp,X,W)) ORC_ERR("rule size not implemented");
+  if (nqp > 64) ORC_ERR("rule size not implemented");
+  if (type == 0)      { if (orc_gauss_legendre(nqp,X,W)) ORC_ERR("rule size not implemented"); }
+  else if (type == 1) { if (orc_gauss_lobatto(nqp,X,W))  ORC_ERR("rule size not implemented"); }
+  else if (type == 3) { if (!ux || !uw) ORC_ERR("user rule not set"); for (q=0; q<nqp; q++) { X[q]=ux[q]; W[q]=uw[q]; } }
+  else ORC_ERR("reduced rules are not restated");
   basis_free(bs);
   bs->nel=nel; bs->nqp=nqp; bs->nen=nen;
   bs->offset = (int*)   xcalloc((size_t)nel,sizeof(int));
@@ -357,11 +416,23 @@ void orc_destroy(OrcIGA *iga)
   int i;
   if (!iga) return;
   for (i=0; i<3; i++) { axis_free(&iga->axis[i]); basis_free(&iga->basis[i]); }
+  for (i=0; i<3; i++) { free(iga->rule_x[i]); free(iga->rule_w[i]); }
   free(iga->geometryX); free(iga->rationalW); free(iga->fixtableU);
   free(iga);
 }
 
 int orc_set_quadrature(OrcIGA *iga,int i,int q) { if (q < 1) ORC_ERR("nqp must be positive"); iga->rule_nqp[i] = q; iga->setup = 0; return 0; }
+/* src/petiga.c:500-513 (IGASetRuleType) -> src/petigarule.c:89-98 */
+int orc_set_rule_type(OrcIGA *iga,int i,int type) { if (type < 0 || type > 2) ORC_ERR("rule type"); iga->rule_type[i] = type; iga->setup = 0; return 0; }
+/* src/petigarule.c:145-158 (IGARuleSetRule): a user-defined rule on [-1,1] */
+int orc_set_rule(OrcIGA *iga,int i,int q,const double *x,const double *w)
+{
+  if (q < 1) ORC_ERR("nqp must be positive");
+  free(iga->rule_x[i]); free(iga->rule_w[i]);
+  iga->rule_x[i] = (double*)xcalloc((size_t)q,sizeof(double)); iga->rule_w[i] = (double*)xcalloc((size_t)q,sizeof(double));
+  memcpy(iga->rule_x[i],x,(size_t)q*sizeof(double)); memcpy(iga->rule_w[i],w,(size_t)q*sizeof(double));
+  iga->rule_type[i] = 3; iga->rule_user_n[i] = q; iga->rule_nqp[i] = q; iga->setup = 0; return 0;
+}
 /* src/petiga.c:463-472 (IGASetOrder): clipped to [1,4] */
 int orc_set_order(OrcIGA *iga,int order) { if (order < 0) ORC_ERR("order must be >= 0"); iga->order = order<1?1:(order>4?4:order); return 0; }
 
@@ -405,7 +476,8 @@ int orc_setup(OrcIGA *iga)
   if (iga->order < 0) { int o = 0; for (i=0; i<dim; i++) if (iga->axis[i].p > o) o = iga->axis[i].p; orc_set_order(iga,o); }
   for (i=0; i<dim; i++) {
     int q = iga->rule_nqp[i] > 0 ? iga->rule_nqp[i] : iga->axis[i].p + 1;   /* src/petigabasis.c:103 */
-    if (basis_init_quadrature(&iga->basis[i],&iga->axis[i],q)) return 1;
+    if (iga->rule_type[i] == 3) q = iga->rule_user_n[i];
+    if (basis_init_quadrature(&iga->basis[i],&iga->axis[i],q,iga->rule_type[i],iga->rule_x[i],iga->rule_w[i])) return 1;
   }
   for (i=dim; i<3; i++) {   /* unused axes: one "element", one point, N=1 (what IGAAxisReset+rule reset give) */
     OrcBasis *b = &iga->basis[i];

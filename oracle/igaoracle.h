@@ -96,6 +96,9 @@ struct OrcIGA {
   int   visit[3][2];
   int   fixtable; double *fixtableU;  /* ghosted local [..][dof] */
   int   setup;
+  int   rule_type[3];      /* IGARuleType: 0 Legendre, 1 Lobatto, 3 user (include/petiga.h:82-87) */
+  int   rule_user_n[3];
+  double *rule_x[3], *rule_w[3];   /* user-defined rule on [-1,1] */
 };
 
 /* global (natural-order) CSR: rows = node*dof + c, i0 fastest */
@@ -114,6 +117,8 @@ int     orc_axis_set_periodic(OrcIGA*,int i,int flag);
 int     orc_axis_init_uniform(OrcIGA*,int i,int N,double Ui,double Uf,int C);
 int     orc_axis_set_knots(OrcIGA*,int i,int m,const double *U);
 int     orc_set_quadrature(OrcIGA*,int i,int q);
+int     orc_set_rule_type(OrcIGA*,int i,int type);
+int     orc_set_rule(OrcIGA*,int i,int q,const double *x,const double *w);
 int     orc_set_order(OrcIGA*,int order);
 int     orc_set_partition(OrcIGA*,int size,int rank);
 int     orc_setup(OrcIGA*);
@@ -126,6 +131,7 @@ int     orc_set_fixtable(OrcIGA*,const double *Uglobal);
 
 /* ---- building blocks exposed for known-answer tests ---- */
 int     orc_gauss_legendre(int q,double *X,double *W);
+int     orc_gauss_lobatto(int q,double *X,double *W);
 void    orc_bspline_ders(int k,double u,int p,int d,const double *U,double *B /*[p+1][5]*/);
 int     orc_partition(int size,int rank,int dim,const int N[],int n[],int i[]);
 void    orc_distribute(int dim,const int size[],const int rank[],const int N[],int n[],int s[]);

@@ -41,7 +41,8 @@ class OrcIGAStruct(C.Structure):
                 ("node_gstart", C.c_int * 3), ("node_gwidth", C.c_int * 3),
                 ("geometryX", c_dp), ("rationalW", c_dp),
                 ("value", (OrcBC * 2) * 3), ("load", (OrcBC * 2) * 3), ("visit", (C.c_int * 2) * 3),
-                ("fixtable", C.c_int), ("fixtableU", c_dp), ("setup", C.c_int)]
+                ("fixtable", C.c_int), ("fixtableU", c_dp), ("setup", C.c_int),
+                ("rule_type", C.c_int * 3), ("rule_user_n", C.c_int * 3), ("rule_x", c_dp * 3), ("rule_w", c_dp * 3)]
 
 
 class OrcMat(C.Structure):
@@ -98,6 +99,9 @@ def lib():
         L.orc_clear_boundary.argtypes = [P]
         L.orc_set_fixtable.argtypes = [P, c_dp]
         L.orc_gauss_legendre.argtypes = [C.c_int, c_dp, c_dp]
+        L.orc_gauss_lobatto.argtypes = [C.c_int, c_dp, c_dp]
+        L.orc_set_rule_type.argtypes = [P, C.c_int, C.c_int]
+        L.orc_set_rule.argtypes = [P, C.c_int, C.c_int, c_dp, c_dp]
         L.orc_bspline_ders.restype = None
         L.orc_bspline_ders.argtypes = [C.c_int, C.c_double, C.c_int, C.c_int, c_dp, c_dp]
         L.orc_partition.argtypes = [C.c_int, C.c_int, C.c_int, c_ip, c_ip, c_ip]
@@ -136,6 +140,14 @@ def gauss_legendre(q):
     W = np.zeros(q)
     rc = lib().orc_gauss_legendre(q, _dp(X), _dp(W))
     if rc:
+        raise ValueError("rule size %d not implemented" % q)
+    return X, W
+
+
+def gauss_lobatto(q):
+    X = np.zeros(q)
+    W = np.zeros(q)
+    if lib().orc_gauss_lobatto(q, _dp(X), _dp(W)):
         raise ValueError("rule size %d not implemented" % q)
     return X, W
 
@@ -225,6 +237,13 @@ class OracleIGA:
 
     def set_quadrature(self, i, q):
         self._ck(self.L.orc_set_quadrature(self.p, i, q))
+
+    def set_rule_type(self, i, kind):
+        self._ck(self.L.orc_set_rule_type(self.p, i, dict(legendre=0, lobatto=1)[kind] if isinstance(kind, str) else kind))
+
+    def set_rule(self, i, x, w):
+        x, w = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(w, dtype=np.float64)
+        self._ck(self.L.orc_set_rule(self.p, i, len(x), _dp(x), _dp(w)))
 
     def set_order(self, o):
         self._ck(self.L.orc_set_order(self.p, o))

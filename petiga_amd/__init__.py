@@ -16,6 +16,7 @@ _LIB = None
 
 SCALARS = dict(volume=1, x2err=2, errnorm=3)
 FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10, bratu=11)
+RULE_TYPES = dict(legendre=0, lobatto=1, reduced=2, user=3)      # IGARuleType, include/petiga.h:82-87
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
@@ -70,7 +71,9 @@ def lib(build_if_needed=False):
     L.IGXGetElementCount.argtypes = [V]
     sig = {
         "IGXCreate": [C.POINTER(V)], "IGXDestroy": [C.POINTER(V)], "IGXSetDim": [V, C.c_int], "IGXSetDof": [V, C.c_int],
-        "IGXSetOrder": [V, C.c_int], "IGXSetQuadrature": [V, C.c_int, C.c_int], "IGXSetProcessors": [V, C.c_int, C.c_int],
+        "IGXSetOrder": [V, C.c_int], "IGXSetQuadrature": [V, C.c_int, C.c_int], "IGXSetRuleType": [V, C.c_int, C.c_int], "IGXSetRuleSize": [V, C.c_int, C.c_int],
+        "IGXSetRule": [V, C.c_int, C.c_int, _dp, _dp], "IGXGetRule": [V, C.c_int, _ip, _dp, _dp],
+        "IGXGetBasis": [V, C.c_int, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp], "IGXSetProcessors": [V, C.c_int, C.c_int],
         "IGXSetComm": [V, C.c_int, C.c_int], "IGXAxisSetDegree": [V, C.c_int, C.c_int], "IGXAxisSetPeriodic": [V, C.c_int, C.c_int],
         "IGXAxisInitUniform": [V, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], "IGXAxisSetKnots": [V, C.c_int, C.c_int, _dp],
         "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp],
@@ -294,6 +297,20 @@ class IGX:
     def set_dof(self, dof): _ck(lib().IGXSetDof(self.h, dof)); self.dof = dof
     def set_order(self, o): _ck(lib().IGXSetOrder(self.h, o))
     def set_quadrature(self, i, q): _ck(lib().IGXSetQuadrature(self.h, i, q))
+    def set_rule_type(self, i, kind): _ck(lib().IGXSetRuleType(self.h, i, RULE_TYPES[kind] if isinstance(kind, str) else kind))
+    def set_rule_size(self, i, q): _ck(lib().IGXSetRuleSize(self.h, i, q))
+
+    def set_rule(self, i, x, w):
+        x, w = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(w, dtype=np.float64)
+        assert x.shape == w.shape and x.ndim == 1
+        _ck(lib().IGXSetRule(self.h, i, len(x), x.ctypes.data_as(_dp), w.ctypes.data_as(_dp)))
+
+    def rule(self, i):
+        q = C.c_int(0)
+        _ck(lib().IGXGetRule(self.h, i, C.byref(q), None, None))
+        x, w = np.zeros(q.value), np.zeros(q.value)
+        _ck(lib().IGXGetRule(self.h, i, C.byref(q), x.ctypes.data_as(_dp), w.ctypes.data_as(_dp)))
+        return x, w
     def set_comm(self, size, rank):
         _ck(lib().IGXSetComm(self.h, size, rank))
         self._comm = (size, rank)
@@ -348,6 +365,16 @@ class IGX:
         out["proc_sizes"], out["proc_ranks"] = list(ps), list(pr)
         return out
 
+    def basis(self, i):
+        """The 1-D tables of axis i (IGAGetBasis): offset, detJac, weight, point, value[nel][nqp][nen][5]."""
+        n = [C.c_int(0) for _ in range(3)]
+        _ck(lib().IGXGetBasis(self.h, i, C.byref(n[0]), C.byref(n[1]), C.byref(n[2]), None, None, None, None, None))
+        nel, nqp, nen = (v.value for v in n)
+        off = np.zeros(nel, dtype=np.int32)
+        J, w, pt, val = np.zeros(nel), np.zeros((nel, nqp)), np.zeros((nel, nqp)), np.zeros((nel, nqp, nen, 5))
+        _ck(lib().IGXGetBasis(self.h, i, None, None, None, off.ctypes.data_as(_ip), J.ctypes.data_as(_dp), w.ctypes.data_as(_dp), pt.ctypes.data_as(_dp), val.ctypes.data_as(_dp)))
+        return dict(nel=nel, nqp=nqp, nen=nen, offset=off, detJac=J, weight=w, point=pt, value=val)
+
     def compute_scalar(self, kind, U=None, params=()):
         """IGAComputeScalar for one of the built-in functionals; returns the rank-local sums."""
         k = SCALARS[kind] if isinstance(kind, str) else kind
@@ -383,8 +410,8 @@ class IGX:
     def set_timing(self, flag=True): _ck(lib().IGXSetTiming(self.h, int(flag)))
 
     def kernel_name(self):
-        buf = C.create_string_buffer(256)
-        _ck(lib().IGXGetKernelName(self.h, buf, 256))
+        buf = C.create_string_buffer(1024)
+        _ck(lib().IGXGetKernelName(self.h, buf, 1024))
         return buf.value.decode()
 
     def last_timing(self):

@@ -37,7 +37,11 @@ static int load_rccl(RcclApi &api, const char *path, std::string &err) {
   for (const char *n : {path, env}) {
     if (!n || !*n) continue;
     api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (!api.handle) { err = std::string("cannot load ") + n + ": " + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }
+    if (!api.handle) {     // dlerror() hands its message out once and clears it: read it into a local
+      const char *why = dlerror();
+      err = std::string("cannot load ") + n + ": " + (why ? why : "not found");
+      return IGX_ERR_LIB;
+    }
     break;
   }
   const char *names[] = {"librccl.so.1", "librccl.so"};
@@ -46,7 +50,11 @@ static int load_rccl(RcclApi &api, const char *path, std::string &err) {
       api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
       if (api.handle) break;
     }
-  if (!api.handle) { err = std::string("cannot load librccl.so: ") + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }
+  if (!api.handle) {
+    const char *why = dlerror();
+    err = std::string("cannot load librccl.so: ") + (why ? why : "not found");
+    return IGX_ERR_LIB;
+  }
   auto sym = [&](const char *n) { return dlsym(api.handle, n); };
   api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(sym("ncclGetUniqueId"));
   api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(sym("ncclCommInitRank"));

@@ -78,6 +78,7 @@ struct _p_IGX {
   int kernel_choice = 0;
   _p_IGX() { s.env = read_env_switches(); kernel_choice = s.env.kernel; }   // environment switches are read here, once per IGX
   std::string last_kernel = "none";
+  std::string rtc_note;           // why a run-time form was kept off a kernel it asked for (appended to the kernel name)
   bool timing = false;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // step begin, kernels begin/end, step end, dominant kernel begin/end
   double last_total_ms = 0, last_kernel_ms = 0; int last_launches = 0;
@@ -110,14 +111,16 @@ extern "C" const char *IGXGetLastError(void) { return g_err.c_str(); }
 
 #ifndef IGX_TU_DISPATCH
 // ------------------------------------------------------------------ set-up mirror
-extern "C" int IGXCreate(IGX *iga) { if (!iga) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *iga = new _p_IGX(); return 0; }
+extern "C" int IGXCreate(IGX *iga) { if (!iga) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *iga = new _p_IGX(); igx_pool_acquire(); return 0; }
 extern "C" int IGXDestroy(IGX *iga) {
   if (!iga || !*iga) return 0;
   (*iga)->comm.reset();       // (synchronises its exchange stream first)
   for (auto &e : (*iga)->ev) if (e) (void)hipEventDestroy(e);
   if ((*iga)->slab_ev) (void)hipEventDestroy((*iga)->slab_ev);
   for (int k = 0; k < 2; ++k) if ((*iga)->face_ev[k]) (void)hipEventDestroy((*iga)->face_ev[k]);
-  delete *iga; *iga = nullptr; return 0;
+  delete *iga; *iga = nullptr;
+  igx_pool_release();          // the last one out hands the launch-scoped pool back to the driver
+  return 0;
 }
 #define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
 #define AXISCK(g, i) do { NEEDIGA(g); if ((i) < 0 || (i) >= 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,2]"); } while (0)
@@ -128,6 +131,36 @@ extern "C" int IGXSetDim(IGX g, int dim) { NEEDIGA(g); if (dim < 1 || dim > 3) r
 extern "C" int IGXSetDof(IGX g, int dof) { NEEDIGA(g); if (dof < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of DOFs per node must be greater than one"); if (dof > MAXBC) return fail(IGX_ERR_SUP, "device path supports dof <= 8"); g->s.dof = dof; touch(g); return 0; }
 extern "C" int IGXSetOrder(IGX g, int order) { NEEDIGA(g); if (order < 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Order must be nonnegative"); g->s.order = order < 1 ? 1 : (order > 4 ? 4 : order); return 0; }
 extern "C" int IGXSetQuadrature(IGX g, int i, int q) { AXISCK(g, i); if (q == IGX_DECIDE && g->s.axis[i].p > 0) q = g->s.axis[i].p + 1; if (q <= 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of quadrature points must be positive"); g->s.rule_nqp[i] = q; touch(g); return 0; }
+extern "C" int IGXSetRuleType(IGX g, int i, IGXRuleType type) {
+  AXISCK(g, i);
+  if ((int)type < 0 || (int)type > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "unknown rule type");
+  if (g->s.rule[i].type == (int)type) return 0;
+  if (type == IGX_RULE_USER) return fail(IGX_ERR_ARG_WRONGSTATE, "a user-defined rule is set with IGXSetRule");
+  g->s.rule[i].type = (int)type; g->s.rule[i].x.clear(); g->s.rule[i].w.clear(); touch(g); return 0;
+}
+extern "C" int IGXSetRuleSize(IGX g, int i, int nqp) {
+  AXISCK(g, i);
+  if (nqp < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of quadrature points must be greater than zero");
+  if (g->s.rule[i].type == IGX_RULE_USER && (int)g->s.rule[i].x.size() != nqp) return fail(IGX_ERR_ARG_WRONGSTATE, "the size of a user-defined rule is set with IGXSetRule");
+  g->s.rule_nqp[i] = nqp; touch(g); return 0;
+}
+extern "C" int IGXSetRule(IGX g, int i, int q, const double x[], const double w[]) {
+  AXISCK(g, i);
+  if (q < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of quadrature points must be greater than zero");
+  if (!x || !w) return fail(IGX_ERR_ARG_WRONG, "null rule");
+  g->s.rule[i].type = IGX_RULE_USER; g->s.rule[i].x.assign(x, x + q); g->s.rule[i].w.assign(w, w + q); g->s.rule_nqp[i] = q; touch(g); return 0;
+}
+extern "C" int IGXGetRule(IGX g, int i, int *q, double x[], double w[]) {
+  AXISCK(g, i);
+  const int n = g->s.rule_nqp[i] > 0 ? g->s.rule_nqp[i] : g->s.axis[i].p + 1;      // src/petigabasis.c:103
+  if (q) *q = n;
+  if (!x && !w) return 0;
+  std::vector<double> X(std::max(n, 10)), W(std::max(n, 10));
+  std::string e;
+  if (int rc = rule_setup(g->s.rule[i], n, X.data(), W.data(), e)) return fail(rc, e);
+  for (int k = 0; k < n; ++k) { if (x) x[k] = X[k]; if (w) w[k] = W[k]; }
+  return 0;
+}
 extern "C" int IGXSetProcessors(IGX g, int i, int n) { AXISCK(g, i); g->s.proc_req[i] = n; touch(g); return 0; }
 extern "C" int IGXSetComm(IGX g, int size, int rank) { NEEDIGA(g); if (size < 1 || rank < 0 || rank >= size) return fail(IGX_ERR_ARG_OUTOFRANGE, "bad communicator size/rank"); g->s.comm_size = size; g->s.comm_rank = rank; touch(g); return 0; }
 extern "C" int IGXAxisSetDegree(IGX g, int i, int p) { AXISCK(g, i); if (p < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Polynomial degree must be greater than zero"); if (p > 7) return fail(IGX_ERR_SUP, "degree > 7 not supported"); g->s.axis[i].p = p; touch(g); drop_net(g); return 0; }
@@ -215,6 +248,18 @@ extern "C" int IGXGetSizes(IGX g, int es[3], int est[3], int ew[3], int ns[3], i
   }
   return 0;
 }
+extern "C" int IGXGetBasis(IGX g, int i, int *nel, int *nqp, int *nen, int offset[], double detJac[], double weight[], double point[], double value[]) {
+  AXISCK(g, i); const Space &s = g->s;
+  if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  const Basis1D &b = s.basis[i];
+  if (nel) *nel = b.nel; if (nqp) *nqp = b.nqp; if (nen) *nen = b.nen;
+  if (offset) std::copy(b.offset.begin(), b.offset.end(), offset);
+  if (detJac) std::copy(b.detJac.begin(), b.detJac.end(), detJac);
+  if (weight) std::copy(b.weight.begin(), b.weight.end(), weight);
+  if (point) std::copy(b.point.begin(), b.point.end(), point);
+  if (value) std::copy(b.value.begin(), b.value.end(), value);
+  return 0;
+}
 extern "C" int IGXGetProcessors(IGX g, int ps[3], int pr[3]) { NEEDIGA(g); for (int i = 0; i < 3; ++i) { if (ps) ps[i] = g->s.proc_sizes[i]; if (pr) pr[i] = g->s.proc_ranks[i]; } return 0; }
 extern "C" int64_t IGXGetElementCount(IGX g) { if (!g || !g->s.setup) return 0; return (int64_t)g->s.elem_width[0] * g->s.elem_width[1] * g->s.elem_width[2]; }
 extern "C" int IGXGetColoring(IGX g, int nc[3]) { NEEDIGA(g); if (!g->s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first"); for (int i = 0; i < 3; ++i) nc[i] = g->s.lay[i].ncolors; return 0; }
@@ -264,7 +309,7 @@ extern "C" int IGXCreateFromTables(const IGXTables *t, IGX *out) {
     s.geomX.assign(t->geometryX, t->geometryX + n * t->nsd); s.nsd = t->nsd;
     if (t->rational) { if (!t->rationalW) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set"); s.geomW.assign(t->rationalW, t->rationalW + n); s.rational = 1; }
   }
-  *out = g.release();
+  *out = g.release(); igx_pool_acquire();
   return 0;
 }
 
@@ -455,7 +500,7 @@ extern "C" int IGXSynchronize(IGX g) {
   return 0;
 }
 extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 4) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1, 2, 3 or 4"); g->kernel_choice = which; return 0; }
-extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s", g->last_kernel.c_str()); return 0; }
+extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s%s%s%s", g->last_kernel.c_str(), g->rtc_note.empty() ? "" : " [", g->rtc_note.c_str(), g->rtc_note.empty() ? "" : "]"); return 0; }
 extern "C" int IGXSetTiming(IGX g, int flag) {
   NEEDIGA(g); g->timing = flag != 0;
   if (g->timing) for (auto &e : g->ev) if (!e) HIPCK(hipEventCreate(&e));

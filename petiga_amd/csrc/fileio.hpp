@@ -36,7 +36,7 @@ static int igx_read_into(Space &s, FILE *f, const Space &keep) {
   if (!rd_int(f, info) || !rd_int(f, dim) || dim < 1 || dim > 3) return fail(66 /*PETSC_ERR_FILE_READ*/, "bad IGA header");
   // IGAReset (src/petiga.c:225) drops the discretisation, not the options the caller set
   s.dof = keep.dof; s.order = keep.order; s.comm_size = keep.comm_size; s.comm_rank = keep.comm_rank; s.env = keep.env;
-  for (int i = 0; i < 3; ++i) { s.proc_req[i] = keep.proc_req[i]; s.rule_nqp[i] = keep.rule_nqp[i]; s.axis[i].periodic = 0; }
+  for (int i = 0; i < 3; ++i) { s.proc_req[i] = keep.proc_req[i]; s.rule_nqp[i] = keep.rule_nqp[i]; s.rule[i] = keep.rule[i]; s.axis[i].periodic = 0; }
   s.form = keep.form; s.params = keep.params; s.dim = dim;
   for (int i = 0; i < dim; ++i) {
     int p = 0, nk = 0;

@@ -2249,6 +2249,16 @@ static inline int pencil_wpb(const Space &s, int P, bool geo, bool fixt, bool ha
 static inline bool pencil_p2_pack(const Space &s, int P, bool geo, bool fixt, bool has_mod) {
   return s.env.p2_pack != 0 && pencil_wpb(s, P, geo, fixt, has_mod) == 12;
 }
+// LDS the packed p = 2 walks take on top of what pencil_segments counts itself: the window of band rows in the place of the hold
+// areas (about + 28 KB at eight waves, + 43 KB at twelve).  One function for the launcher and for the pass-cost model, so that the
+// model's resident-workgroup count and LDS-limited segment lengths are those of the launch.
+static size_t pencil_win_extra(const Space &s, int P, bool geo, bool fixt, const PencilModule *mod, int wpb) {
+  const bool pack = pencil_p2_pack(s, P, geo, fixt, mod != nullptr) || (mod && mod->pack);
+  if (!pack) return 0;
+  const size_t win_bytes = (mod && mod->pack == 2) ? pencil_winc_bytes(wpb) : pencil_win_bytes(wpb);
+  return win_bytes - pencil_hold_bytes(P) * wpb / 8;
+}
+
 static long long pencil_box_cost(const Space &s, int P, bool geo, size_t extra_lds, const Box &bx, bool halo_always, int wpb = 8) {
   long long total = 0;
   for (int d = 0; d < 3; ++d) if (bx.hi[d] <= bx.lo[d]) return 0;
@@ -2289,7 +2299,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.wpb = w6 ? 12 : 8;
     const bool pack = W == 0 && (pencil_p2_pack(s, P, GEO, FIXT, mod != nullptr) || (mod && mod->pack));      // (p = 2 on the identity geometry: packed tiles, the band rows combined in an LDS window instead of the hold areas)
     const size_t win_bytes = (mod && mod->pack == 2) ? pencil_winc_bytes(pa.wpb) : pencil_win_bytes(pa.wpb);
-    const size_t win_extra = pack ? win_bytes - pencil_hold_bytes(P) * pa.wpb / 8 : 0;
+    const size_t win_extra = W == 0 ? pencil_win_extra(s, P, GEO, FIXT, mod, pa.wpb) : 0;
     int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, (mod ? mod->extra_lds : 0) + win_extra, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
     if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
@@ -2635,8 +2645,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       // direction).  At 8 ranks of the metric configuration (128^3 per rank) three passes cost 6 ms of a 33 ms assembly and a face
       // is 141 MB = 2.4 ms: one pass; at 2 ranks (256 x 256 x 128) the pass costs 2.3 ms and the face is 552 MB = 9 ms: faces first
       // (scripts/time_rank_box.py, profiles/r04_face_passes.txt).
-      const size_t xl = mod ? mod->extra_lds : 0;
       const int wpb = pencil_wpb(s, deg, geo, fixt, mod != nullptr);      // (the workgroup count the launches will really have)
+      const size_t xl = (mod ? mod->extra_lds : 0) + pencil_win_extra(s, deg, geo, fixt, mod, wpb);      // (and their LDS: the window of the packed walks)
       Box R = P; long long multi = 0;
       if (can2) { Box A = R; A.lo[2] = c2; R.hi[2] = c2; multi += pencil_box_cost(s, deg, geo || mod, xl, A, false, wpb); }
       if (can1) { Box B = R; B.lo[1] = c1; R.hi[1] = c1; multi += pencil_box_cost(s, deg, geo || mod, xl, B, false, wpb); }

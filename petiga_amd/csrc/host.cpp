@@ -33,34 +33,78 @@ EnvSwitches read_env_switches() {
   return e;
 }
 
-// ------------------------------------------------------------------ Gauss-Legendre
-// The reference tabulates q = 1..10 (src/petigarule.c:182-319).  Nodes are the roots of P_q, found by
-// Newton's method in extended precision from the Chebyshev-like initial guess; weights 2/((1-x^2) P_q'(x)^2).
-static void legendre(int q, long double x, long double &P, long double &dP) {
-  long double a = 1.0L, b = x;
-  if (q == 0) { P = 1; dP = 0; return; }
-  for (int k = 2; k <= q; ++k) { long double c = ((2 * k - 1) * x * b - (k - 1) * a) / k; a = b; b = c; }
-  P = b;
-  dP = q * (x * b - a) / (x * x - 1);
+// ------------------------------------------------------------------ quadrature rules
+// The reference tabulates Gauss-Legendre q = 1..10 (src/petigarule.c:182-319) and Gauss-Lobatto q = 2..10 (:321-459) as
+// 36-digit constants.  Here the nodes are computed: Newton's method on P_q (Legendre) or P'_{q-1} (Lobatto) in long double
+// from a cosine guess, polished in quadruple precision so that the value cast to double is the correctly rounded one -- the
+// double the reference's literal denotes (tests/test_golden.py holds both rules to tests/golden/gauss_rules.json, bit for bit).
+namespace {
+using quad = __float128;
+struct Leg { quad P, dP, ddP; };        // P_n(x), P_n'(x), P_n''(x)
+Leg legendre(int n, quad x) {
+  quad a = 1, b = x;
+  if (n == 0) return {1, 0, 0};
+  for (int k = 2; k <= n; ++k) { quad c = ((2 * k - 1) * x * b - (k - 1) * a) / k; a = b; b = c; }
+  const quad dP = n * (x * b - a) / (x * x - 1);
+  return {b, dP, (2 * x * dP - n * (n + 1) * b) / (1 - x * x)};      // Legendre's equation gives the second derivative
 }
+template <bool LOBATTO> quad rule_root(int n, long double guess) {
+  long double x = guess;
+  for (int it = 0; it < 64; ++it) {
+    const Leg l = legendre(n, (quad)x);
+    const long double dx = LOBATTO ? (long double)(l.dP / l.ddP) : (long double)(l.P / l.dP);
+    x -= dx;
+    if (fabsl(dx) < 1e-19L) break;
+  }
+  quad xq = x;
+  for (int it = 0; it < 3; ++it) { const Leg l = legendre(n, xq); xq -= LOBATTO ? l.dP / l.ddP : l.P / l.dP; }
+  return xq;
+}
+const long double kPi = 3.14159265358979323846264338327950288L;
+}  // namespace
 
 int gauss_legendre(int q, double *X, double *W) {
   if (q < 1 || q > 10) return IGX_ERR_ARG_OUTOFRANGE;
-  const long double pi = 3.14159265358979323846264338327950288L;
   for (int i = 0; i < (q + 1) / 2; ++i) {
-    long double x = cosl(pi * (i + 0.75L) / (q + 0.5L)), P, dP;
-    for (int it = 0; it < 64; ++it) {
-      legendre(q, x, P, dP);
-      long double dx = P / dP;
-      x -= dx;
-      if (fabsl(dx) < 1e-19L) break;
-    }
-    legendre(q, x, P, dP);
-    long double w = 2 / ((1 - x * x) * dP * dP);
+    const quad x = rule_root<false>(q, cosl(kPi * (i + 0.75L) / (q + 0.5L)));
+    const Leg l = legendre(q, x);
+    const quad w = 2 / ((1 - x * x) * l.dP * l.dP);
     X[i] = -(double)x; X[q - 1 - i] = (double)x;
     W[i] = (double)w;  W[q - 1 - i] = (double)w;
   }
   if (q & 1) X[q / 2] = 0.0;
+  return 0;
+}
+
+// Gauss-Lobatto: the end points and the roots of P'_{q-1}; weights 2 / (q (q-1) P_{q-1}(x)^2).
+int gauss_lobatto(int q, double *X, double *W) {
+  if (q < 2 || q > 10) return IGX_ERR_ARG_OUTOFRANGE;
+  const int n = q - 1;
+  for (int i = 0; i < (q + 1) / 2; ++i) {
+    const quad x = i == 0 ? (quad)1 : rule_root<true>(n, cosl(kPi * i / n));
+    const Leg l = legendre(n, x);
+    const quad w = 2 / ((quad)(q * n) * l.P * l.P);
+    X[i] = -(double)x; X[q - 1 - i] = (double)x;
+    W[i] = (double)w;  W[q - 1 - i] = (double)w;
+  }
+  if (q & 1) X[q / 2] = 0.0;
+  return 0;
+}
+
+// IGARuleSetUp (src/petigarule.c:116-143): the rule of an axis by type.
+int rule_setup(const Rule1D &r, int nqp, double *X, double *W, std::string &err) {
+  int rc = 0;
+  switch (r.type) {
+    case IGX_RULE_LEGENDRE: rc = gauss_legendre(nqp, X, W); break;
+    case IGX_RULE_LOBATTO:  rc = gauss_lobatto(nqp, X, W); break;
+    case IGX_RULE_USER:
+      if ((int)r.x.size() != nqp) { err = "user-defined rule has a different number of points"; return IGX_ERR_ARG_WRONGSTATE; }
+      for (int q = 0; q < nqp; ++q) { X[q] = r.x[q]; W[q] = r.w[q]; }
+      break;
+    default:   // IGA_RULE_REDUCED changes the number of points from element to element (src/petigabasis.c:144-171, petigaelem.c:764-776)
+      err = "reduced Gauss-Legendre rules (a point count that varies along the axis) are not supported"; return IGX_ERR_SUP;
+  }
+  if (rc) { err = "Number of quadrature points not implemented"; return IGX_ERR_ARG_OUTOFRANGE; }
   return 0;
 }
 
@@ -177,9 +221,10 @@ int axis_set_knots(Axis &ax, int m, const double *U, std::string &err) {   // sr
 }
 
 // ------------------------------------------------------------------ 1-D tables (src/petigabasis.c:83-219)
-int basis_init(Basis1D &b, const Axis &ax, int nqp, std::string &err) {
-  double X[10], W[10];
-  if (gauss_legendre(nqp, X, W)) { err = "Number of quadrature points not implemented"; return IGX_ERR_ARG_OUTOFRANGE; }
+int basis_init(Basis1D &b, const Axis &ax, const Rule1D &rule, int nqp, std::string &err) {
+  std::vector<double> Xv(std::max(nqp, 10)), Wv(std::max(nqp, 10));
+  double *X = Xv.data(), *W = Wv.data();
+  if (int rc = rule_setup(rule, nqp, X, W, err)) return rc;
   if (ax.p > 7) { err = "degree > 7 not supported"; return IGX_ERR_SUP; }
   const int p = ax.p, nel = ax.nel, nen = p + 1, d = std::min(p, 4);
   b.nel = nel; b.nqp = nqp; b.nen = nen;
@@ -385,7 +430,7 @@ int space_setup(Space &s, std::string &err) {
   if (s.order < 0) { int o = 0; for (int i = 0; i < dim; ++i) o = std::max(o, s.axis[i].p); s.order = std::min(std::max(o, 1), 4); }
   for (int i = 0; i < dim; ++i) {
     const int q = s.rule_nqp[i] > 0 ? s.rule_nqp[i] : s.axis[i].p + 1;   // src/petigabasis.c:103
-    if (int rc = basis_init(s.basis[i], s.axis[i], q, err)) return rc;
+    if (int rc = basis_init(s.basis[i], s.axis[i], s.rule[i], q, err)) return rc;
   }
   for (int i = dim; i < 3; ++i) {   // a collapsed axis: one element, one point, the constant 1
     Basis1D &b = s.basis[i];

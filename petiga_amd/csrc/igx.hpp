@@ -68,12 +68,19 @@ struct BC {                   // struct _IGAFormBC, include/petiga.h:220-225
   double value[64];
 };
 
+struct Rule1D {               // struct _n_IGARule, include/petiga.h:91-99 (the size lives in Space::rule_nqp)
+  int type = 0;               // IGXRuleType
+  std::vector<double> x, w;   // IGX_RULE_USER: the rule on [-1, 1]
+};
+
 int  gauss_legendre(int q, double *X, double *W);
+int  gauss_lobatto(int q, double *X, double *W);
+int  rule_setup(const Rule1D &r, int nqp, double *X, double *W, std::string &err);
 void bspline_ders(int span, double u, int p, int nders, const double *U, double *out /*[p+1][5]*/);
 int  axis_init_uniform(Axis &ax, int N, double Ui, double Uf, int C, std::string &err);
 int  axis_set_knots(Axis &ax, int m, const double *U, std::string &err);
 void axis_finish(Axis &ax);   // spans + nnp from U
-int  basis_init(Basis1D &b, const Axis &ax, int nqp, std::string &err);
+int  basis_init(Basis1D &b, const Axis &ax, const Rule1D &rule, int nqp, std::string &err);
 int  partition(int size, int rank, int dim, const int N[3], int n[3], int coords[3]);
 void distribute(int dim, const int size[3], const int rank[3], const int N[3], int n[3], int s[3]);
 void stencil(const Axis &ax, int i, int *first, int *last);   // src/petigamat.c:197-233
@@ -99,6 +106,7 @@ struct Space {
   int dim = 0, dof = 0, order = -1;
   Axis axis[3];
   int rule_nqp[3] = {-1, -1, -1};
+  Rule1D rule[3];
   Basis1D basis[3];
   int comm_size = 1, comm_rank = 0;
   int proc_req[3] = {-1, -1, -1};

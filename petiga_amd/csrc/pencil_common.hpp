@@ -5,6 +5,7 @@
 #pragma once
 #ifndef IGX_RTC
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "first_touch.hpp"
 #endif
 #include "igx.hpp"
@@ -56,24 +57,52 @@ static inline int face_cut(int n, int p) { const int c = (n / 2) / (p + 1) * (p 
 // stream-ordered pool of the library's own: what one launch frees is what the next one takes, and nothing goes back to the
 // driver at a synchronisation point.  (The device's default pool has a release threshold of 0: after every host synchronisation
 // the next assembly paid a fresh device allocation for each of its launches, on the host, in the middle of its launch sequence.)
-// One pool per process (inline: the translation units of the library share it).
+// One pool per device (inline: the translation units of the library share the table); the pool of the device that is current at
+// the call is the one used, so an IGX created after the application switched devices allocates where its stream lives.  The pool
+// keeps what it was given while any IGX is alive (release threshold: everything) and hands it back to the driver when the last
+// one is destroyed (igx_pool_release) or when an allocation fails (trim, then one more try) -- torch / PETSc share the device.
+constexpr int IGX_MAX_DEVICES = 64;
+struct IgxPools { std::mutex mu; hipMemPool_t pool[IGX_MAX_DEVICES] = {}; bool tried[IGX_MAX_DEVICES] = {}; int live = 0; };
+inline IgxPools &igx_pools() { static IgxPools p; return p; }
 inline hipMemPool_t igx_pool() {
-  static hipMemPool_t pool = [] {
-    hipMemPool_t p = nullptr; int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return p;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= IGX_MAX_DEVICES) return nullptr;
+  IgxPools &t = igx_pools();
+  std::lock_guard<std::mutex> lock(t.mu);
+  if (!t.tried[dev]) {
+    t.tried[dev] = true;
+    hipMemPool_t p = nullptr;
     hipMemPoolProps props; memset(&props, 0, sizeof(props));
     props.allocType = hipMemAllocationTypePinned; props.handleTypes = hipMemHandleTypeNone;
     props.location.type = hipMemLocationTypeDevice; props.location.id = dev;
-    if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); return (hipMemPool_t) nullptr; }
-    uint64_t keep = ~0ull;
-    (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep);
-    return p;
-  }();
-  return pool;
+    if (hipMemPoolCreate(&p, &props) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+    if (p) { uint64_t keep = ~0ull; (void)hipMemPoolSetAttribute(p, hipMemPoolAttrReleaseThreshold, &keep); }
+    t.pool[dev] = p;
+  }
+  return t.pool[dev];
+}
+inline void igx_pool_trim() {            // every device's pool: give unused memory back to the driver
+  IgxPools &t = igx_pools();
+  std::lock_guard<std::mutex> lock(t.mu);
+  for (hipMemPool_t p : t.pool) if (p) (void)hipMemPoolTrimTo(p, 0);
+}
+inline void igx_pool_acquire() { IgxPools &t = igx_pools(); std::lock_guard<std::mutex> lock(t.mu); ++t.live; }
+inline void igx_pool_release() {
+  bool last;
+  { IgxPools &t = igx_pools(); std::lock_guard<std::mutex> lock(t.mu); last = --t.live <= 0; if (last) t.live = 0; }
+  if (last) igx_pool_trim();
 }
 inline hipError_t pool_alloc(void **ptr, size_t bytes, hipStream_t stream) {
-  if (hipMemPool_t p = igx_pool()) return hipMallocFromPoolAsync(ptr, bytes, p, stream);
-  return hipMallocAsync(ptr, bytes, stream);
+  hipMemPool_t p = igx_pool();
+  if (!p) return hipMallocAsync(ptr, bytes, stream);
+  hipError_t rc = hipMallocFromPoolAsync(ptr, bytes, p, stream);
+  if (rc != hipSuccess) {                // the pool may sit on memory that other launches freed in other sizes
+    (void)hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    igx_pool_trim();
+    rc = hipMallocFromPoolAsync(ptr, bytes, p, stream);
+  }
+  return rc;
 }
 
 // colour c of axis d restricted to [lo,hi): arithmetic sequence (regular colours) or a single element

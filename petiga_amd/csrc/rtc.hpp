@@ -38,7 +38,11 @@ static int load_hiprtc(std::string &err) {
   const char *names[] = {env, "libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
   for (int pass = 0; pass < 2 && !a.h; ++pass)
     for (const char *n : names) { if (!n || !*n) continue; a.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0)); if (a.h) break; }
-  if (!a.h) { err = std::string("cannot load libhiprtc.so: ") + (dlerror() ? dlerror() : "not found"); return IGX_ERR_LIB; }
+  if (!a.h) {
+    const char *why = dlerror();     // one call: the second would return NULL
+    err = std::string("cannot load libhiprtc.so: ") + (why ? why : "not found");
+    return IGX_ERR_LIB;
+  }
   auto sym = [&](const char *n) { return dlsym(a.h, n); };
   a.Create = reinterpret_cast<decltype(a.Create)>(sym("hiprtcCreateProgram"));
   a.AddName = reinterpret_cast<decltype(a.AddName)>(sym("hiprtcAddNameExpression"));
@@ -63,6 +67,7 @@ struct RtcFeature {
   std::vector<std::string> lowered;
   hipModule_t module = nullptr; std::vector<hipFunction_t> func;
   int meta[4] = {0, 0, 0, 0};          // workgroups per CU the kernel is compiled for, features kept in LDS, executed MFMAs per k-step, 0
+  bool failed = false; std::string why;     // band_pt under the automatic choice: the instantiation did not compile; the form stays on the feature kernel
   ~RtcFeature() { if (module) (void)hipModuleUnload(module); }
 };
 
@@ -623,6 +628,7 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
   const int key = (geo ? 1 : 0) | (rat ? 2 : 0) | (deg << 2);
   std::shared_ptr<RtcFeature> K;
   auto it = F.band.find(key);
+  if (it != F.band.end() && it->second->failed && !compile_only && g->kernel_choice == 0) { g->rtc_note = it->second->why; return 0; }
   if (it != F.band.end() && (it->second->module || compile_only)) K = it->second;
   else {
     K.reset(new RtcFeature());
@@ -636,7 +642,16 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
                              "extern \"C\" __global__ void igx_band_guard() { igx_band_ok = igx_band_guard_of<" + F.name + ">(igx_band_prm); }\n"
                              "template __global__ void " + xp + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n"
                              "template __global__ void " + xb + "(igx::SpaceDev, igx::ParamsDev, igx::OutDev, igx::BandArgs);\n";
-    if (int rc = rtc_build(F.source, true, tail, {xp, xb}, K->code, K->lowered, false, false, false, true)) return rc;
+    if (int rc = rtc_build(F.source, true, tail, {xp, xb}, K->code, K->lowered, false, false, false, true)) {
+      // Under the automatic choice a struct whose band-row instantiation does not compile (the usual reason: a band_params_ok
+      // that is not __host__ __device__, include/petiga_amd.h) is a struct the band-row kernel does not cover: the feature kernel
+      // takes the assembly and the kernel name carries the reason.  Asked for by name (IGXSetKernel(4), IGXCheckFormSource) it fails.
+      if (compile_only || g->kernel_choice != 0) return rc;
+      K->failed = true;
+      K->why = "band_pt<" + F.name + "> did not compile (is band_params_ok declared __host__ __device__?): " + g_err.substr(0, 400);
+      F.band[key] = K; g->rtc_note = K->why;
+      return 0;
+    }
     if (!compile_only) {
       HIPCK(hipModuleLoadData(&K->module, K->code.data()));
       for (int k = 0; k < 2; ++k) { hipFunction_t fn = nullptr; HIPCK(hipModuleGetFunction(&fn, K->module, K->lowered[k].c_str())); K->func.push_back(fn); }
@@ -687,6 +702,7 @@ static int launch_band_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &o
 
 static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
+  g->rtc_note.clear();
   if (!g->rtc || g->rtc->dim != s.dim) {
     std::shared_ptr<RtcForm> f;
     if (int rc = rtc_compile(g, g->rtc_source, g->rtc_name, s.dim, f)) return rc;

@@ -9,6 +9,13 @@ import numpy as np
 IGA_FILE_CLASSID, VEC_FILE_CLASSID = 1211299, 1211214      # include/petiga.h:394, PETSc's VEC_FILE_CLASSID
 
 
+def greville(U, p):
+    """Greville abscissae of a knot vector: the mean of p consecutive knots (IGA_Greville, src/petigaaxis.c)."""
+    U = np.asarray(U, dtype=np.float64)
+    n = len(U) - p - 1
+    return np.array([U[i + 1:i + p + 1].mean() for i in range(n)])
+
+
 def find_span(p, U, u):
     """Index k with U[k] <= u < U[k+1] (last non-empty span for u == U[-1]); IGA_FindSpan, src/petigabsp.F90."""
     n = len(U) - p - 2

@@ -20,8 +20,7 @@ def run(name, dim, dof, p, N, form, params=(), periodic=None, op="system", bc=No
         bc(g)
     g.set_form(form, params)
     if geo:
-        sys.path.insert(0, "tests"); sys.path.insert(0, "oracle")
-        from common import greville
+        from petiga_amd.geometry import greville
         import numpy as _np
         gv = [greville(_np.concatenate([[0.0] * (p + 1), _np.arange(1, N[i]) / N[i], [1.0] * (p + 1)]), p) for i in range(dim)]
         mesh = _np.meshgrid(*gv[::-1], indexing="ij")[::-1]

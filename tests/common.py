@@ -2,6 +2,7 @@
 import numpy as np
 
 import oracle_api as O
+from petiga_amd.geometry import greville      # noqa: F401  (the tests take it from here)
 
 
 def make_pair(dim, dof, p, N, C=None, periodic=None, nqp=None, order=None, knots=None, engine=True):
@@ -31,9 +32,6 @@ def make_pair(dim, dof, p, N, C=None, periodic=None, nqp=None, order=None, knots
     return orc, eng
 
 
-def greville(U, p):
-    n = len(U) - p - 1
-    return np.array([U[i + 1:i + p + 1].mean() for i in range(n)])
 
 
 def warped_geometry(orc, dim, seed=0, rational=True, amp=0.15):

@@ -24,10 +24,11 @@ def _has_gpu():
 # tests/test_gpu_parity.py runs every case under both kernel families (its autouse fixture sets IGX_KERNEL).  A test that pins the
 # kernel itself (set_kernel(...) / its own IGX_KERNEL) and never looks at the fixture's value ran the SAME case twice: the second
 # copy is dropped at collection (the GPU suite has a time limit to keep).  The multi-rank reduction keeps the generic kernel on its
-# first cases of each kind.
+# first cases of each kind.  test_multirank_nonlinear_assembly_with_ghost_refresh does NOT pin its kernel (its IGX objects read the
+# fixture's IGX_KERNEL at creation): both families run it.
 _PINNED = {"test_mfma_poisson_p3", "test_mfma_matrix_driver_and_default_selection", "test_mfma_pencil_segments_and_walk_axes",
            "test_mfma_falls_back_when_axis0_not_walkable", "test_mfma_pencil_degree2", "test_feature_mfma_kernel_is_selected_and_matches",
-           "test_pencil_first_touch_needs_no_zeroing", "test_multirank_nonlinear_assembly_with_ghost_refresh"}
+           "test_pencil_first_touch_needs_no_zeroing"}
 
 
 def _redundant(item):

@@ -7,6 +7,7 @@ import scipy.sparse.linalg as sla
 import oracle_api as O
 
 SQ2 = np.sqrt(2.0)
+TIGHT = 1e-12        # the closed forms of the reference tests are asserted at the parity tolerance, not at the reference's 1e-6
 
 
 # ---------------------------------------------------------------- structural known answers
@@ -66,7 +67,7 @@ def test_bspline_partition_of_unity_and_uniform_axis():
     b = g.basis(0)
     assert np.allclose(b["value"][..., 0].sum(-1), 1, atol=1e-14)
     for k in (1, 2, 3):
-        assert np.abs(b["value"][..., k].sum(-1)).max() < 1e-6 * 256 ** k
+        assert np.abs(b["value"][..., k].sum(-1)).max() < TIGHT * 256 ** k
     assert np.all(b["value"][..., 4] == 0)
     assert np.allclose(b["detJac"], 1 / 512)
 
@@ -97,8 +98,9 @@ def quarter_annulus(dim):
 
 
 def check_geometry_map(e, dim):
-    """TestGeometryMap, test/IGAGeometryMap.c:34-258, tolerance 1e-6 as in the reference."""
-    tol = 1e-6
+    """TestGeometryMap, test/IGAGeometryMap.c:34-258.  The reference asserts 1e-6; the chain reproduces the closed forms to a few
+    ulps (3e-15), and parity is claimed at 1e-12, so that is what is asserted here."""
+    tol = TIGHT
     for q in range(e["nqp"]):
         u, v = e["point"][q][0], e["point"][q][1]
         w = e["point"][q][2] if dim == 3 else 0.0
@@ -154,18 +156,18 @@ def test_geometry_map_quarter_annulus(dim):
             n, X = f["normal"][q], f["mapX0"][q]
             if axis == 0:
                 r = np.hypot(X[0], X[1])
-                assert abs(r - (2.0 if side else 1.0)) < 1e-6
+                assert abs(r - (2.0 if side else 1.0)) < TIGHT
                 sgn = 1.0 if side else -1.0
-                assert abs(n[0] - sgn * X[0] / r) < 1e-6 and abs(n[1] - sgn * X[1] / r) < 1e-6
+                assert abs(n[0] - sgn * X[0] / r) < TIGHT and abs(n[1] - sgn * X[1] / r) < TIGHT
             elif axis == 1:
-                assert abs(f["detS"][q] - (1.0 if dim == 2 else 2.0)) < 1e-6
+                assert abs(f["detS"][q] - (1.0 if dim == 2 else 2.0)) < TIGHT
                 expect = [-1.0, 0.0] if side else [0.0, -1.0]
-                assert np.allclose(n[:2], expect, atol=1e-6)
+                assert np.allclose(n[:2], expect, atol=TIGHT)
             else:
-                assert abs(f["detS"][q] - f["detX"][q] / (dim - 1)) < 1e-6
-                assert np.allclose(n, [0, 0, 1.0 if side else -1.0], atol=1e-6)
+                assert abs(f["detS"][q] - f["detX"][q] / (dim - 1)) < TIGHT
+                assert np.allclose(n, [0, 0, 1.0 if side else -1.0], atol=TIGHT)
             if dim == 3 and axis < 2:
-                assert abs(n[2]) < 1e-6
+                assert abs(n[2]) < TIGHT
     # volume and surface area (:545-568)
     for a in range(dim):
         for s in range(2):
@@ -175,7 +177,7 @@ def test_geometry_map_quarter_annulus(dim):
     P = 2 * (2 - 1) + np.pi * (2 + 1) / 2
     V = A if dim == 2 else 2 * A
     Sf = P if dim == 2 else 2 * A + 2 * P
-    assert abs(S[0] - V) < 1e-6 and abs(S[1] - Sf) < 1e-6
+    assert abs(S[0] - V) < TIGHT and abs(S[1] - Sf) < TIGHT
 
 
 # ---------------------------------------------------------------- test/IGAErrNorm.c
@@ -193,7 +195,7 @@ def test_errnorm_radicals_and_projection(dim):
     L2 = {1: [1, 1 / s(3), 1 / s(5), 1 / s(3)], 2: [1, s(7) / s(6), s(28) / s(45), 1 / s(9)], 3: [1, s(5) / s(2), s(19) / s(15), 1 / s(27)]}
     H1 = {1: [0, 1, 2 / s(3), 1], 2: [0, s(2), s(8) / s(3), s(2) / s(3)], 3: [0, s(3), 2, 1 / s(3)]}
     H2 = {1: [0, 0, 2, 0], 2: [0, 0, s(8), s(2)], 3: [0, 0, s(12), s(2)]}
-    tol = np.sqrt(np.finfo(float).eps)
+    tol = TIGHT        # the reference: sqrt(eps)
     zero = np.zeros(g.global_size())
     for order, expect in ((0, L2), (1, H1), (2, H2)):
         o = C.c_int(order)
@@ -204,7 +206,7 @@ def test_errnorm_radicals_and_projection(dim):
     for order in (0, 1, 2):
         o = C.c_int(order)
         S = np.sqrt(g.compute_scalar("orc_scalar_errnorm", 4, U=x, ctx=o))
-        assert np.all(S < tol), (order, S)
+        assert np.all(S < tol * (2 * n) ** order), (order, S)      # a seminorm of order k amplifies the rounding of the solve by h^-k
 
 
 # ---------------------------------------------------------------- test/IGAFixTable.c
@@ -227,7 +229,7 @@ def test_fixtable_poisson(dim, nel):
     x = sla.spsolve(M.tocsc(), b)
     g.set_fixtable(None)
     err = np.sqrt(g.compute_scalar("orc_scalar_x2err", 1, U=x)[0])
-    assert err < 1e-6
+    assert err < TIGHT
 
 
 def test_dirichlet_diagonal_is_element_multiplicity():

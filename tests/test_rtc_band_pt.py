@@ -198,3 +198,48 @@ def test_the_builtin_struct_given_as_source_runs_at_the_builtin_rate():
     # (10 %: the suite runs two test processes side by side, the other one's kernels share the GPU with these timings; what this line
     #  guards against is the element mode's 4 x, not a percent)
     assert times["source"] <= 1.10 * times["builtin"], times
+
+
+def _host_only_guard_source():
+    """the built-in struct's text with band_params_ok written to the contract of before round 5: a plain host function"""
+    src, name = builtin_text_as_source("UserNSVMSHostGuard")
+    assert "__host__ __device__ static bool band_params_ok" in src
+    return src.replace("__host__ __device__ static bool band_params_ok", "static bool band_params_ok"), name
+
+
+def test_a_host_only_guard_is_reported_by_the_compile_check():
+    import petiga_amd as P
+    src, name = _host_only_guard_source()
+    g = P.IGX(3, 4)
+    for i in range(3):
+        g.axis_uniform(i, 3, 8)
+    g.set_form_source(src, name, (NU, FX, 0.0, 0.0, DT))
+    with pytest.raises(P.IGXError) as e:         # asked for by name: the compiler's log, band_params_ok in it
+        g.check_form_source(True, 6)
+    assert "band_params_ok" in str(e.value)
+
+
+@pytest.mark.gpu
+def test_a_host_only_guard_falls_through_to_the_feature_kernel():
+    """A struct whose band_params_ok cannot run on the device does not fail the assembly: the automatic choice keeps the form on
+    the feature kernel (same numbers as the oracle), the kernel name says why, and IGXSetKernel(4) reports the compile error."""
+    import petiga_amd as P
+    N, periodic = (8, 4, 4), (False, False, False)
+    orc, eng = _problem(N, periodic, None, 3)
+    src, name = _host_only_guard_source()
+    params = (NU, FX, 0.0, 0.0, DT)
+    rng = np.random.default_rng(5)
+    n = orc.global_size()
+    U, V = rng.standard_normal(n) * 0.3, rng.standard_normal(n) * 0.1
+    shift = 2.0 / DT
+    J_o = orc.compute_ijacobian("orc_form_ns_tangent", O.NSVMSCtx(*params), shift, V, 0.0, U)
+    eng.set_form_source(src, name, params)
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    for _ in range(2):                            # the second assembly takes the remembered decision, not a second compile
+        eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+        eng.synchronize()
+        assert "feature_assemble" in eng.kernel_name() and "band_params_ok" in eng.kernel_name(), eng.kernel_name()
+        compare_mats(J, J_o, 1e-11)
+    eng.set_kernel(4)
+    with pytest.raises(P.IGXError):
+        eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
