@@ -306,8 +306,12 @@ def launch_ranks(n):
     with socket.socket() as sk:               # a free rendezvous port on the loop-back interface
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool supports only dmabuf IPC; with the legacy mode (the runtime's
+    # default) hipIpcGetMemHandle fails with "invalid argument", and with it RCCL's intra-node transport between processes and any
+    # sharing of device memory across ranks (the RCCL double of tests/fake_rccl included).  The image exports it already; it is set
+    # here only when the caller's environment lacks it, and never overrides a value the caller chose.
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     procs = []
     for r in range(n):
@@ -484,6 +488,10 @@ def main():
         early_phases = g.comm_early_phases() if world > 1 else None
     except Exception:
         early_phases = None
+    # what the face-first decision of the pencil walks rested on, on this rank: the link rate the communicator measured at its
+    # creation (or $IGX_LINK_GBS, or the constant when nothing could be probed) and the passes the last assembly made
+    link = g.comm_link_rate() if world > 1 else None
+    face_passes = g.face_passes() if world > 1 else None
 
     def assemble(gg, AA, bb, UU, VV):
         if tangent:
@@ -625,7 +633,10 @@ def main():
                                    (" -- the form given as run-time source (IGXSetFormSource)" if args.source else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
                        "transport": transport, "rccl_ranks": comm_ranks if comm_kind == "rccl" else None, "transport_ranks": comm_ranks,
-                       "exchange_started_before_assembly_end_ms": overlap_ms, "exchange_early_phases": early_phases, "checksum": [float(x) for x in cs], "checksum_check": check},
+                       "exchange_started_before_assembly_end_ms": overlap_ms, "exchange_early_phases": early_phases,
+                       "exchange_link_gbs": round(link[0], 2) if link else None, "exchange_link_source": link[1] if link else None,
+                       "exchange_link_probe": ("%.3f ms for %d face message(s) of %s MB per direction" % (link[2], link[3], os.environ.get("IGX_LINK_PROBE_MB", "64"))) if link and link[1] == "measured" else None,
+                       "face_passes": face_passes, "checksum": [float(x) for x in cs], "checksum_check": check},
             "roofline": roof,
             "device": P.device_info(),
         }

@@ -355,6 +355,15 @@ int IGXCommDestroy(IGX iga);
 int IGXReduceGhostRows(IGX iga,IGXMat A,IGXVec b);        /* A or b may be NULL */
 int IGXRefreshGhosts(IGX iga,IGXVec v);
 int IGXCommGetLastBytes(IGX iga,int64_t *bytes_sent);      /* of the last exchange */
+/* The rate (GB/s per direction) a face message of the ghost-row reduction travels at, as the face-first decision of the pencil
+ * walks uses it: IGXCommInitRCCL times one grouped ncclSend / ncclRecv of IGX_LINK_PROBE_MB (default 64) MB with
+ * every face neighbour, all faces at once, after an untimed one that pays the connection set-up; $IGX_LINK_GBS overrides it.
+ * source: 0 the constant 60 (no probe: one rank, no face neighbour, a host transport), 1 measured, 2 $IGX_LINK_GBS;
+ * probe_ms / faces: the timed group and the face messages per direction it held.  Any pointer may be NULL. */
+int IGXCommGetLinkRate(IGX iga,double *gbs,int *source,double *probe_ms,int *faces);
+/* Passes of the last pencil-walk assembly over the rank's box: 1, or 1 + the upper faces (axes 2, 1, 0) that were assembled first
+ * so that their messages travel under the rest (the decision: extra passes' cost against largest face / link rate). */
+int IGXGetFacePasses(IGX iga,int *passes);
 /* one rank sends n doubles to itself through the RCCL path (binding, communicator, streams and events on a single GPU) */
 int IGXCommLoopbackTest(IGX iga,int64_t n,double *maxdiff);
 /* What the bound transport itself reports: kind 1 = RCCL, 2 = host callback (0: none bound); ranks = ncclCommCount of the RCCL

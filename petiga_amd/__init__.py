@@ -106,6 +106,7 @@ def lib(build_if_needed=False):
         "IGXCommGetUniqueId": [C.c_void_p, C.c_char_p], "IGXCommInitRCCL": [V, C.c_void_p, C.c_char_p], "IGXCommInitTransport": [V, TRANSPORT_FN, C.c_void_p],
         "IGXCommDestroy": [V], "IGXReduceGhostRows": [V, V, V], "IGXRefreshGhosts": [V, V], "IGXCommGetLastBytes": [V, C.POINTER(C.c_int64)],
         "IGXCommLoopbackTest": [V, C.c_int64, _dp], "IGXCommGetRanks": [V, C.POINTER(C.c_int), C.POINTER(C.c_int)], "IGXCommGetEarlyPhases": [V, C.POINTER(C.c_int)],
+        "IGXCommGetLinkRate": [V, _dp, _ip, _dp, _ip], "IGXGetFacePasses": [V, _ip],
         "IGXGetDeviceInfo": [C.c_char_p, C.c_int], "IGXCreateFromTables": [V, C.POINTER(V)],
     }
     missing = []
@@ -502,6 +503,17 @@ class IGX:
         ms = C.c_double(0)
         _ck(lib().IGXCommGetOverlap(self.h, C.byref(ms)))
         return ms.value
+
+    def comm_link_rate(self):
+        """(GB/s per direction, source, probe ms, faces): what the face-first decision uses (IGXCommGetLinkRate)."""
+        gbs, src, ms, faces = C.c_double(0), C.c_int(0), C.c_double(0), C.c_int(0)
+        _ck(lib().IGXCommGetLinkRate(self.h, C.byref(gbs), C.byref(src), C.byref(ms), C.byref(faces)))
+        return gbs.value, ("constant", "measured", "env")[src.value], ms.value, faces.value
+
+    def face_passes(self):
+        n = C.c_int(0)
+        _ck(lib().IGXGetFacePasses(self.h, C.byref(n)))
+        return n.value
 
     def comm_early_phases(self):
         """phases (upper faces of axes 2, 1, 0) of the last reduce_ghost_rows that were packed behind a face mark of the assembly"""

@@ -85,6 +85,8 @@ struct IgxComm {
   std::vector<DevBuf> sbuf, rbuf;     // one per neighbour of the larger of the two lists
   int64_t last_bytes = 0;
   int early_phases = 0;               // phases of the last reduction that started on a face mark of the assembly (IGXCommGetEarlyPhases)
+  double link_gbs = 0; int link_source = 0;      // IGXCommGetLinkRate: GB/s per direction of a face message; 0 assumed constant, 1 measured at init, 2 $IGX_LINK_GBS
+  double link_probe_ms = 0; int link_faces = 0;
   ~IgxComm() {
     if (xs) (void)hipStreamSynchronize(xs);      // nothing of this communicator is in flight when it goes
     if (nccl && rccl_api().CommDestroy) (void)rccl_api().CommDestroy(nccl);
@@ -106,6 +108,63 @@ static int comm_common_init(IGX g, std::unique_ptr<IgxComm> &c) {
   return 0;
 }
 
+// The rate a face message travels at, measured once per communicator: the face-first decision of the pencil walks weighs the cost
+// of its extra passes against (largest face) / (this rate) (gram_mfma.hpp), and a constant (60 GB/s per direction was the guess
+// of rounds 3-5) would make the first run on real links a matter of luck.  Every rank exchanges IGX_LINK_PROBE_MB (default 64) MB
+// with each FACE neighbour of its ghost-row reduction -- the same grouped ncclSend / ncclRecv, the same stream, the same
+// direction as the real exchange, all faces at once as they travel in the real exchange -- twice: the first group also pays
+// RCCL's connection set-up, the second one is timed with events.  $IGX_LINK_GBS, when set, is taken instead (no probe).
+// Collective over the communicator (every rank calls IGXCommInitRCCL); a rank without a face neighbour keeps the default.
+static int comm_probe_links(IGX g) {
+  IgxComm &c = *g->comm;
+  const char *lr = getenv("IGX_LINK_GBS");
+  if (lr && atof(lr) > 0) { c.link_gbs = atof(lr); c.link_source = 2; g->s.link_gbs = c.link_gbs; return 0; }
+  c.link_gbs = 60.0; c.link_source = 0; g->s.link_gbs = 0;
+  const char *pm = getenv("IGX_LINK_PROBE_MB");
+  const double mb = pm ? atof(pm) : 64.0;
+  if (g->s.comm_size < 2 || mb <= 0) return 0;
+  auto face = [](const NbrPlan &p) { return (p.off[0] != 0) + (p.off[1] != 0) + (p.off[2] != 0) == 1; };
+  std::vector<int> to, from;
+  for (const NbrPlan &p : neighbour_plans(g->s, true)) if (face(p)) to.push_back(p.rank);
+  for (const NbrPlan &p : neighbour_plans(g->s, false)) if (face(p)) from.push_back(p.rank);
+  if (to.empty() && from.empty()) return 0;
+  const size_t n = (size_t)(mb * 1e6 / 8);
+  std::vector<DevBuf> sb(to.size()), rb(from.size());
+  for (DevBuf &b : sb) { if (b.alloc(n * 8)) return fail(IGX_ERR_MEM, "link probe: buffer allocation failed"); HIPCK(hipMemsetAsync(b.p, 0, n * 8, c.xs)); }
+  for (DevBuf &b : rb) if (b.alloc(n * 8)) return fail(IGX_ERR_MEM, "link probe: buffer allocation failed");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  HIPCK(hipEventCreate(&e0)); HIPCK(hipEventCreate(&e1));
+  int rc = 0;
+  for (int rep = 0; rep < 2 && !rc; ++rep) {
+    if (hipEventRecord(e0, c.xs) != hipSuccess) { rc = IGX_ERR_LIB; break; }
+    int r1 = rccl_api().GroupStart(), r2 = 0;
+    for (size_t k = 0; k < from.size() && !r1 && !r2; ++k) r2 = rccl_api().Recv(rb[k].p, n, kNcclDouble, from[k], c.nccl, c.xs);
+    for (size_t k = 0; k < to.size() && !r1 && !r2; ++k) r2 = rccl_api().Send(sb[k].p, n, kNcclDouble, to[k], c.nccl, c.xs);
+    const int r3 = r1 ? 0 : rccl_api().GroupEnd();
+    if (r1 || r2 || r3) { rc = IGX_ERR_LIB; g_err = std::string("link probe: ") + (rccl_api().GetErrorString ? rccl_api().GetErrorString(r1 ? r1 : (r2 ? r2 : r3)) : "RCCL error"); break; }
+    if (hipEventRecord(e1, c.xs) != hipSuccess) { rc = IGX_ERR_LIB; break; }
+  }
+  if (!rc && hipStreamSynchronize(c.xs) != hipSuccess) { rc = IGX_ERR_LIB; g_err = "link probe: the exchange stream failed"; }
+  float ms = 0;
+  if (!rc && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms > 0) {
+    c.link_probe_ms = ms; c.link_faces = (int)std::max(to.size(), from.size());
+    c.link_gbs = (double)n * 8 / (ms * 1e-3) / 1e9; c.link_source = 1; g->s.link_gbs = c.link_gbs;
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return rc;
+}
+
+// gbs: the rate the face-first decision uses; source: 0 the constant (no probe: one rank, no face neighbour, IGX_LINK_PROBE_MB=0),
+// 1 measured at IGXCommInitRCCL, 2 $IGX_LINK_GBS; probe_ms / faces: the timed group and the face messages per direction it held
+extern "C" int IGXCommGetLinkRate(IGX g, double *gbs, int *source, double *probe_ms, int *faces) {
+  NEEDIGA(g); if (!g->comm) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGXCommInitRCCL() / IGXCommInitTransport() first");
+  if (gbs) *gbs = g->comm->link_gbs > 0 ? g->comm->link_gbs : 60.0;
+  if (source) *source = g->comm->link_source;
+  if (probe_ms) *probe_ms = g->comm->link_probe_ms;
+  if (faces) *faces = g->comm->link_faces;
+  return 0;
+}
+
 extern "C" int IGXCommGetUniqueId(IGXUniqueId *id, const char *librccl_path) {
   if (!id) return fail(IGX_ERR_ARG_WRONG, "null id");
   std::string e; if (int rc = load_rccl(rccl_api(), librccl_path, e)) return fail(rc, e);
@@ -120,17 +179,20 @@ extern "C" int IGXCommInitRCCL(IGX g, const IGXUniqueId *id, const char *librccl
   std::unique_ptr<IgxComm> c(new IgxComm());
   c->kind = 1;
   NCCLCK(rccl_api().CommInitRank(&c->nccl, g->s.comm_size, *id, g->s.comm_rank));
-  return comm_common_init(g, c);
+  if (int rc = comm_common_init(g, c)) return rc;
+  return comm_probe_links(g);
 }
 
 extern "C" int IGXCommInitTransport(IGX g, IGXTransportFn fn, void *ctx) {
   NEEDIGA(g); if (!fn) return fail(IGX_ERR_ARG_WRONG, "null transport");
   std::unique_ptr<IgxComm> c(new IgxComm());
   c->kind = 2; c->fn = fn; c->fnctx = ctx;
+  const char *lr = getenv("IGX_LINK_GBS");
+  if (lr && atof(lr) > 0) { c->link_gbs = atof(lr); c->link_source = 2; g->s.link_gbs = c->link_gbs; } else { c->link_gbs = 60.0; g->s.link_gbs = 0; }
   return comm_common_init(g, c);
 }
 
-extern "C" int IGXCommDestroy(IGX g) { NEEDIGA(g); if (g->comm) { (void)hipStreamSynchronize(g->comm->xs); g->comm.reset(); } return 0; }
+extern "C" int IGXCommDestroy(IGX g) { NEEDIGA(g); if (g->comm) { (void)hipStreamSynchronize(g->comm->xs); g->comm.reset(); } g->s.link_gbs = 0; return 0; }
 
 // One exchange: pack `npack` messages (list `pack_send_list`), move them, unpack the `nunp` received ones.  reduce = true:
 // ghost rows to their owners (added); false: owner values to the ghosts (assigned; vectors only).

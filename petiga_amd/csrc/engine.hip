@@ -501,6 +501,7 @@ extern "C" int IGXSynchronize(IGX g) {
 }
 extern "C" int IGXSetKernel(IGX g, int which) { NEEDIGA(g); if (which < 0 || which > 4) return fail(IGX_ERR_ARG_OUTOFRANGE, "kernel choice must be 0, 1, 2, 3 or 4"); g->kernel_choice = which; return 0; }
 extern "C" int IGXGetKernelName(IGX g, char *buf, int len) { NEEDIGA(g); if (!buf || len < 1) return fail(IGX_ERR_ARG_WRONG, "bad buffer"); snprintf(buf, (size_t)len, "%s%s%s%s", g->last_kernel.c_str(), g->rtc_note.empty() ? "" : " [", g->rtc_note.c_str(), g->rtc_note.empty() ? "" : "]"); return 0; }
+extern "C" int IGXGetFacePasses(IGX g, int *passes) { NEEDIGA(g); if (passes) *passes = g->dom.passes; return 0; }
 extern "C" int IGXSetTiming(IGX g, int flag) {
   NEEDIGA(g); g->timing = flag != 0;
   if (g->timing) for (auto &e : g->ev) if (!e) HIPCK(hipEventCreate(&e));

@@ -11,6 +11,7 @@ namespace igx {
 // the dominant kernel of the last assembly, for bench.py's roofline block (filled by the pencil launcher)
 struct DomInfo {
   std::string name = "none"; int launches = 0; long long elements = 0; double flop_per_element = 0;
+  int passes = 1;      // face-first passes of the last pencil-walk assembly (1: one pass over the rank's box)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // recorded around those launches when timing is on
 };
 

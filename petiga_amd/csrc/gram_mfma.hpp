@@ -2655,7 +2655,8 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       const long long single = pencil_box_cost(s, deg, geo || mod, xl, P, false, wpb);
       const double t_step = (deg == 3 ? 30e-6 : 9e-6) * ((geo || mod) ? 1.4 : 1.0);      // s per element-step of a launch (256^3: 16 ms / (4 rounds x 131))
       const double cost_s = (double)(multi - single) * t_step;
-      const char *lr = getenv("IGX_LINK_GBS"); const double rate = (lr && atof(lr) > 0 ? atof(lr) : 60.0) * 1e9;
+      // (the communicator's figure: $IGX_LINK_GBS, else what IGXCommInitRCCL measured on this rank's own links, else 60)
+      const char *lr = getenv("IGX_LINK_GBS"); const double rate = (lr && atof(lr) > 0 ? atof(lr) : (s.link_gbs > 0 ? s.link_gbs : 60.0)) * 1e9;
       double face = 0; const double rowb = 8.0 * (2 * deg + 1) * (2 * deg + 1) * (2 * deg + 1);
       const double nr[3] = {(double)s.lay[0].nrow, (double)s.lay[1].nrow, (double)s.lay[2].nrow};
       if (can2) face = std::max(face, deg * nr[0] * nr[1] * rowb);
@@ -2663,6 +2664,7 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
       if (can0) face = std::max(face, deg * nr[1] * nr[2] * rowb);
       faces_first = face / rate > cost_s;
     }
+    dom.passes = faces_first ? 1 + (can2 ? 1 : 0) + (can1 ? 1 : 0) + (can0 ? 1 : 0) : 1;
     if (faces_first) {
       Box R = P;
       auto pass_of = [&](const Box &b, bool face0, bool rest0, int *fty, PencilPass &pp) {

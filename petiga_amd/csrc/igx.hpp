@@ -123,6 +123,7 @@ struct Space {
   IGXFormKind form = IGX_FORM_NONE;
   std::vector<double> params;
   bool setup = false;
+  double link_gbs = 0;        // GB/s per direction of a face message as the communicator measured it (comm.hpp); 0: not measured
   AxisLayout lay[3];
   EnvSwitches env;
 };

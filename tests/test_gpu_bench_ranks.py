@@ -42,6 +42,14 @@ def _check_line(r, form, size, ranks=2, transport="host"):
     assert line["config"]["partition"] == GRID[ranks]
     assert line["config"]["transport"] == transport and line["config"]["transport_ranks"] == ranks
     assert line["config"]["rccl_ranks"] == (ranks if transport == "rccl" else None)      # ncclCommCount of the library's communicator
+    # what the face-first decision rested on: measured over the transport at the communicator's creation (RCCL branch), the
+    # constant for the host transport; and the passes the last assembly made because of it
+    cfg = line["config"]
+    if transport == "rccl":
+        assert cfg["exchange_link_source"] == "measured" and cfg["exchange_link_gbs"] > 0 and "face message" in cfg["exchange_link_probe"], cfg
+    else:
+        assert cfg["exchange_link_source"] == "constant" and cfg["exchange_link_gbs"] == 60.0, cfg
+    assert cfg["face_passes"] in (1, 2, 3, 4), cfg
     per_rank = line["roofline_per_rank"]
     assert [r_["rank"] for r_ in per_rank] == list(range(ranks)) and sum(r_["local_elements"] for r_ in per_rank) == size ** 3
     assert all(r_["frac"] is not None and r_["avg_launch_ms"] > 0 for r_ in per_rank)

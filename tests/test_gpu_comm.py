@@ -65,7 +65,7 @@ FAKE_RCCL = os.path.join(HERE, "fake_rccl", "libfake_rccl.so")
 def _rank_main(rank, world, port, case, outdir, name="", transport="rccl", fake_env=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     if transport == "rccl":
-        os.environ.update(IGX_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_TIMEOUT_S="90")
+        os.environ.update(IGX_RCCL_LIB=FAKE_RCCL, FAKE_RCCL_TIMEOUT_S="90", IGX_LINK_PROBE_MB="8")
         os.environ.update(fake_env or {})
     if "pencil" in name:
         os.environ["IGX_OVERLAP"] = "1"       # the face-first passes whatever their cost (unset, the walk weighs it against the size of the faces: tiny here)
@@ -108,6 +108,13 @@ def _rank_main(rank, world, port, case, outdir, name="", transport="rccl", fake_
             g.set_boundary_load(2, 0, 1, -0.25)
     g.set_form(form, params)
     assert exchange.init_comm(g, transport=transport) == transport
+    # the link rate of the face-first decision: measured over the transport when the communicator was created (a grouped
+    # ncclSend / ncclRecv with every face neighbour; 8 MB here), the constant for a host transport
+    gbs, source, probe_ms, faces = g.comm_link_rate()
+    if transport == "rccl" and os.environ.get("IGX_LINK_PROBE_MB") != "0":      # ("0": no probe -- the broken-schedule case must hang in the exchange proper)
+        assert source == "measured" and gbs > 0 and probe_ms > 0 and faces >= 1, (gbs, source, probe_ms, faces)
+    else:
+        assert (gbs, source) == (60.0, "constant")
     assert g.comm_ranks() == (transport, world)      # kind 1: ncclCommCount of the communicator the library created
     A, b = g.create_mat(), g.create_vec()
     n_global = int(np.prod(g.sizes()["node_sizes"])) * dof
@@ -225,7 +232,7 @@ def test_broken_schedule_hangs_and_is_reported(tmp_path):
     world, case = CASES[name]
     port = _free_port()
     with pytest.raises(Exception) as e:
-        mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name, "rccl", dict(FAKE_RCCL_BREAK="recv_first", FAKE_RCCL_TIMEOUT_S="6")), nprocs=world, join=True)
+        mp.spawn(_rank_main, args=(world, port, case, str(tmp_path), name, "rccl", dict(FAKE_RCCL_BREAK="recv_first", FAKE_RCCL_TIMEOUT_S="6", IGX_LINK_PROBE_MB="0")), nprocs=world, join=True)
     assert "exit code 86" in str(e.value) or "terminated" in str(e.value), str(e.value)[-600:]
     assert not os.path.exists(os.path.join(str(tmp_path), "rank0.npz")) and not os.path.exists(os.path.join(str(tmp_path), "rank1.npz"))
 
