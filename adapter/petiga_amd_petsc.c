@@ -66,7 +66,10 @@ static PetscErrorCode IGAAmdCtxDestroy(void *p)
 
 #define IGXCHK(comm,call) do { int rc_ = (call); if (PetscUnlikely(rc_)) SETERRQ(comm,(PetscErrorCode)rc_,"%s",IGXGetLastError()); } while (0)
 /* a driver's IGXCompute* call: PETSC_ERR_SUP from the engine means "no device kernel covers this case" -> PetIGA's own loop */
-#define IGXTRY(comm,call,fallback) do { int rc_ = (call); if (rc_ == IGX_ERR_SUP) PetscFunctionReturn(fallback); if (PetscUnlikely(rc_)) SETERRQ(comm,(PetscErrorCode)rc_,"%s",IGXGetLastError()); } while (0)
+/* (the hand-over is not silent: -info prints which driver left the GPU and the engine's reason) */
+#define IGXTRY(comm,call,fallback) do { int rc_ = (call); \
+    if (rc_ == IGX_ERR_SUP) { PetscCall(PetscInfo(NULL,"petiga_amd: %s is not covered by a device kernel (%s); assembling with PetIGA's CPU loop\n",#call,IGXGetLastError())); PetscFunctionReturn(fallback); } \
+    if (PetscUnlikely(rc_)) SETERRQ(comm,(PetscErrorCode)rc_,"%s",IGXGetLastError()); } while (0)
 
 static PetscErrorCode IGAAmdCtxGet(IGA iga,IGAAmdCtx **out)
 {

@@ -17,8 +17,10 @@
 #include <functional>
 #include "first_touch.hpp"
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <map>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -1834,7 +1836,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   constexpr int GZ = SGEO ? SGEO_Z : GEO_Z, GD = SGEO ? SGEO_DOUBLES : GEO_DOUBLES;      // the per-wavefront metric area and the walk-axis rows behind it
   extern __shared__ __attribute__((aligned(16))) double pencil_sm[];
   long long tw_entry = 0, tw_staged = 0, tw_loop = 0, tw_loopend = 0;      // -DIGX_DEBUG: the life of a workgroup (entry | tables staged | first element | last element | end)
-  if (kDebug && pa.debug_buf) tw_entry = __builtin_readcyclecounter();
+  long long tw_wall = 0;                                                   // ... and its entry on the 100 MHz clock all XCCs share
+  if (kDebug && pa.debug_buf) { tw_entry = __builtin_readcyclecounter(); tw_wall = wall_clock64(); }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int seg = blockIdx.x / pa.blocks_per_seg;
@@ -2103,7 +2106,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     held[NB - 1] = 0;
     if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
     __builtin_amdgcn_s_setprio(0);
-    if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && lane == 0 && ei < 64) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
+    if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && wave < 8 && lane == 0 && ei < 62) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     if (pingpong) __builtin_amdgcn_s_barrier();
   }
   if (kDebug && pa.debug_buf) tw_loopend = __builtin_readcyclecounter();
@@ -2126,6 +2129,9 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (kDebug && pa.debug_buf && wave == 0 && lane == 0) {      // (slots 62, 63 of the workgroup's stamp area: segments are shorter than 62 elements where this is read)
     long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2) * 64 + 62) * 4;
     d[0] = tw_entry; d[1] = tw_staged; d[2] = tw_loop; d[3] = tw_loopend; d[4] = __builtin_readcyclecounter(); d[5] = ne;
+    // the workgroup's record behind the stamps: entry / exit on the shared 100 MHz clock, HW_ID (wave, SIMD, CU, SH, SE), XCC_ID
+    long long *w = pa.debug_buf + (size_t)gridDim.x * 2 * 64 * 4 + (size_t)blockIdx.x * 4;
+    w[0] = tw_wall; w[1] = wall_clock64(); w[2] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4); w[3] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20);
   }
 }
 
@@ -2308,9 +2314,11 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.ne_max = pa.seg_len + 3;
     pa.debug_noflush = s.env.debug_noflush;
     pa.debug_buf = nullptr;
-    static int dbg_done = 0;
-    const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done;
-    const size_t dbg_n = (size_t)pa.blocks_per_seg * pa.nseg * 2 * 64 * 4;
+    static int dbg_done = 0, dbg_seen = 0;
+    // IGX_DEBUG_TIMING=n: the n-th pencil launch of the process is the one that is stamped (1: the first)
+    const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done && ++dbg_seen >= std::max(1, atoi(getenv("IGX_DEBUG_TIMING") ? getenv("IGX_DEBUG_TIMING") : "1"));
+    const size_t dbg_blocks = (size_t)pa.blocks_per_seg * pa.nseg;
+    const size_t dbg_n = dbg_blocks * 2 * 64 * 4 + dbg_blocks * 4;
     if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     const size_t lds = pencil_lds_bytes(pa.ne_max, GEO, pa.wpb) + (W == 0 ? (pack ? win_bytes : pencil_hold_bytes(P) * pa.wpb / 8) : 0) + (GEO ? pencil_geo_bytes() : 0) + (mod ? mod->extra_lds : 0);      // (the hold areas are per wavefront and come last when there is no metric area)
     if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the pencil walk's tables do not fit the 160 KB of LDS for any segment length"; return; }
@@ -2340,7 +2348,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       std::vector<long long> h(dbg_n);
       (void)hipMemcpy(h.data(), pa.debug_buf, dbg_n * 8, hipMemcpyDeviceToHost);
       double sm = 0, sw = 0, sf = 0, sp = 0; long long cnt = 0; long long hist[16] = {0};
-      for (size_t b = 0; b < dbg_n / 4 / 64; ++b) for (int e = 4; e < 60; ++e) {
+      for (size_t b = 0; b < dbg_blocks * 2; ++b) for (int e = 4; e < 60; ++e) {
         const long long *d = &h[(b * 64 + e) * 4], *dn = &h[(b * 64 + e + 1) * 4];
         if (!d[3] || !dn[0]) continue;
         sm += (double)(d[1] - d[0]); sw += (double)(d[2] - d[1]); sf += (double)(d[3] - d[2]); sp += (double)(dn[0] - d[0]); cnt++;
@@ -2352,25 +2360,56 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
       fprintf(stderr, "\n");
       {   // the life of a workgroup (wave 0): entry -> tables staged -> first element -> last element -> end
         double a = 0, b2 = 0, c = 0, d2 = 0, nel = 0; long long nb = 0;
-        for (size_t b = 0; b < dbg_n / 4 / 64 / 2; ++b) {
+        for (size_t b = 0; b < dbg_blocks; ++b) {
           const long long *d = &h[((b * 2) * 64 + 62) * 4];
           if (!d[0] || !d[4]) continue;
           a += (double)(d[1] - d[0]); b2 += (double)(d[2] - d[1]); c += (double)(d[3] - d[2]); d2 += (double)(d[4] - d[3]); nel += (double)d[5]; nb++;
         }
         if (nb) fprintf(stderr, "[igx pencil timing] workgroup life (wave 0, mean of %lld): staging %.0f | lane set-up %.0f | walk %.0f (%.1f elements) | trailing leaves %.0f cycles\n", nb, a / nb, b2 / nb, c / nb, nel / nb, d2 / nb);
         // ... its spread, per segment of the pencils, and the span of the launch (first entry to last end) on the same counter
-        long long t_first = LLONG_MAX, t_last = 0;
         for (int sg = 0; sg < pa.nseg; ++sg) {
           double mn = 1e30, mx = 0, sm2 = 0; long long n2 = 0;
           for (int bb = 0; bb < pa.blocks_per_seg; ++bb) {
             const long long *d = &h[(((size_t)sg * pa.blocks_per_seg + bb) * 2 * 64 + 62) * 4];
             if (!d[0] || !d[4]) continue;
             const double life = (double)(d[4] - d[0]); mn = std::min(mn, life); mx = std::max(mx, life); sm2 += life; n2++;
-            t_first = std::min(t_first, d[0]); t_last = std::max(t_last, d[4]);
           }
           if (n2) fprintf(stderr, "[igx pencil timing]   segment %d: %lld workgroups, life min %.0f mean %.0f max %.0f\n", sg, n2, mn, sm2 / n2, mx);
         }
-        if (t_last > t_first) fprintf(stderr, "[igx pencil timing]   launch span %.0f cycles (s_memtime is per XCC: spans compare within one)\n", (double)(t_last - t_first));
+      }
+      {   // The launch as a timeline on the 100 MHz clock the XCCs share: where the time between the first entry and the last exit
+          // goes.  Per CU (XCC, SE, SH, CU of HW_ID) the workgroups in the order they ran: how late the first one starts (dispatch
+          // ramp), the gap between one workgroup's exit and the next one's entry, the tail after its last exit.
+        const long long *wr = &h[dbg_blocks * 2 * 64 * 4];
+        long long t0 = LLONG_MAX, t1 = 0;
+        std::map<long long, std::vector<std::pair<long long, long long>>> cu;
+        for (size_t b = 0; b < dbg_blocks; ++b) {
+          const long long *w = wr + b * 4;
+          if (!w[0] || !w[1]) continue;
+          t0 = std::min(t0, w[0]); t1 = std::max(t1, w[1]);
+          const long long hw = w[2], key = ((w[3] & 15) << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+          cu[key].push_back({w[0], w[1]});
+        }
+        if (t1 > t0 && !cu.empty()) {
+          const double span = (double)(t1 - t0);
+          double busy = 0, ramp = 0, gap = 0, tail = 0, life1 = 0, life2 = 0, ramp_max = 0; long long n1 = 0, n2 = 0, ngap = 0; int rounds_max = 0;
+          for (auto &kv : cu) {
+            auto &v = kv.second; std::sort(v.begin(), v.end());
+            ramp += (double)(v.front().first - t0); ramp_max = std::max(ramp_max, (double)(v.front().first - t0));
+            tail += (double)(t1 - v.back().second);
+            rounds_max = std::max(rounds_max, (int)v.size());
+            for (size_t i = 0; i < v.size(); ++i) {
+              busy += (double)(v[i].second - v[i].first);
+              if (i == 0) { life1 += (double)(v[i].second - v[i].first); n1++; } else { life2 += (double)(v[i].second - v[i].first); n2++; gap += (double)(v[i].first - v[i - 1].second); ngap++; }
+            }
+          }
+          const double ncu = (double)cu.size();
+          fprintf(stderr, "[igx pencil timing]   timeline (100 MHz ticks = 10 ns): span %.0f = %.1f us over %d CUs that ran a workgroup, at most %d workgroups on one CU\n", span, span * 0.01, (int)cu.size(), rounds_max);
+          fprintf(stderr, "[igx pencil timing]   per CU, mean ticks: first entry after the launch's first %.0f (max %.0f) | busy %.0f | between workgroups %.1f (x %.2f per CU) | idle after its last exit %.0f\n",
+                  ramp / ncu, ramp_max, busy / ncu, ngap ? gap / ngap : 0.0, (double)ngap / ncu, tail / ncu);
+          fprintf(stderr, "[igx pencil timing]   workgroup life, ticks: first on its CU %.0f (%lld) | later ones %.0f (%lld); CU-time in a workgroup's life %.3f of span x CUs (x %.3f of 256 CUs)\n",
+                  n1 ? life1 / n1 : 0.0, n1, n2 ? life2 / n2 : 0.0, n2, busy / (span * ncu), busy / (span * 256.0));
+        }
       }
       (void)hipFree(pa.debug_buf);
     }

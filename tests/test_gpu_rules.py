@@ -28,8 +28,8 @@ def _pair(dim, dof, p, N, rule, nq=None):
 
 
 @pytest.mark.parametrize("kernel", [0, 1])
-@pytest.mark.parametrize("dim,p,N,rule,nq,geo", [(2, 2, [7, 6], "lobatto", None, "none"), (2, 2, [6, 5], "lobatto", 5, "nurbs"), (3, 3, [5, 4, 4], "lobatto", None, "none"),
-                                                 (3, 2, [6, 5, 4], "lobatto", None, "nurbs"), (3, 3, [4, 4, 5], "user", 4, "poly"), (3, 2, [5, 5, 4], "user", 3, "none"),
+@pytest.mark.parametrize("dim,p,N,rule,nq,geo", [(2, 2, [7, 6], "lobatto", None, "none"), (2, 2, [6, 5], "lobatto", 5, "nurbs"), (3, 3, [9, 4, 4], "lobatto", None, "none"),
+                                                 (3, 2, [9, 5, 4], "lobatto", None, "nurbs"), (3, 3, [8, 4, 5], "user", 4, "poly"), (3, 2, [10, 5, 4], "user", 3, "none"),
                                                  (1, 3, [9], "lobatto", 6, "none")])
 def test_poisson_system_with_other_rules(dim, p, N, rule, nq, geo, kernel):
     orc, eng = _pair(dim, 1, p, N, rule, nq)
@@ -57,7 +57,7 @@ def test_poisson_system_with_other_rules(dim, p, N, rule, nq, geo, kernel):
 @pytest.mark.parametrize("form,dof", [("elasticity", 3), ("cahnhilliard", 1)])
 def test_multi_field_and_nonlinear_forms_with_lobatto(form, dof):
     p = 3 if form == "elasticity" else 2
-    orc, eng = _pair(3, dof, p, [5, 4, 4], "lobatto")
+    orc, eng = _pair(3, dof, p, [9, 4, 4], "lobatto")
     if form == "elasticity":
         import ctypes as C
         import oracle_api as O
