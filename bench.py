@@ -346,6 +346,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 MFMA pencil, 3 feature")
     ap.add_argument("--geometry", action="store_true", help="mapped rational geometry (default for nsvms)")
     ap.add_argument("--source", action="store_true", help="poisson only: the form is given as run-time source (IGXSetFormSource), not as the built-in struct")
+    ap.add_argument("--two-calls", action="store_true", help="tangent workloads: IFunction and IJacobian as two calls (two passes of the element loop) instead of IGXComputeIFunctionIJacobian")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not spawn the rocprofv3 --pmc passes that measure roofline.traffic (N = 1); replay profiles/traffic.json instead")
@@ -423,8 +424,11 @@ def main():
             if world > 1:          # DMGlobalToLocal of the state (IGAGetLocalVecArray): owner values to the ghosts
                 g.refresh_ghosts(U)
                 g.refresh_ghosts(V)
-            g.compute_ifunction(shift, V, 0.0, U, b)
-            g.compute_ijacobian(shift, V, 0.0, U, A)
+            if args.two_calls:
+                g.compute_ifunction(shift, V, 0.0, U, b)
+                g.compute_ijacobian(shift, V, 0.0, U, A)
+            else:                  # the pair of a Newton step at one state in one call: one pass of the walk where a fused kernel exists
+                g.compute_ifunction_ijacobian(shift, V, 0.0, U, b, A)      # (F and J are those of the two drivers: tests/test_gpu_state_pencil.py)
         else:
             g.compute_system(A, b)
         if world > 1:              # MatAssemblyBegin/End + VecAssemblyBegin/End: ghost rows to their owners
@@ -632,6 +636,7 @@ def main():
                                    (" (one GPU's share of the 192^3 configuration)" if (args.form == "nsvms" and size == 96 and not args.size) else "") +
                                    (" -- the form given as run-time source (IGXSetFormSource)" if args.source else ""),
                        "kernels": kernel_name, "partition": proc_sizes,
+                       "pair_call": (None if not tangent else ("IGXComputeIFunction + IGXComputeIJacobian (two passes)" if args.two_calls else "IGXComputeIFunctionIJacobian (F and J of one state in one call)")),
                        "transport": transport, "rccl_ranks": comm_ranks if comm_kind == "rccl" else None, "transport_ranks": comm_ranks,
                        "exchange_started_before_assembly_end_ms": overlap_ms, "exchange_early_phases": early_phases,
                        "exchange_link_gbs": round(link[0], 2) if link else None, "exchange_link_source": link[1] if link else None,

@@ -269,6 +269,14 @@ int IGXComputeFunction (IGX iga,IGXVec U,IGXVec F);                             
 int IGXComputeJacobian (IGX iga,IGXVec U,IGXMat J);                               /* src/petigasnes.c:82 */
 int IGXComputeIFunction(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXVec F);    /* src/petigats.c:23   */
 int IGXComputeIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXMat J);    /* src/petigats.c:92   */
+/* The pair a Newton step asks for at one state -- SNESComputeFunction then SNESComputeJacobian on the same U (TS: the same a, V, t)
+ * -- in ONE pass of the element loop (R_e and K_e share the tabulation and the state's point values).  F and J are
+ * those of IGXComputeIFunction + IGXComputeIJacobian (IGXComputeFunction + IGXComputeJacobian).  With IGX_FUSE_RESID=1 in the
+ * environment and where a fused kernel exists (state_pencil_kr: Cahn-Hilliard / Bratu, 3-D, p = 2, no geometry, no boundary
+ * loads: config 4) the Residual rides on the Tangent's MFMAs as one more operand column; otherwise -- the default: the fused walk
+ * measured 3 % slower than the two passes, DESIGN.md 3.1 -- the two drivers run one after the other.  IGXGetKernelName tells. */
+int IGXComputeIFunctionIJacobian(IGX iga,double a,IGXVec V,double t,IGXVec U,IGXVec F,IGXMat J);
+int IGXComputeFunctionJacobian(IGX iga,IGXVec U,IGXVec F,IGXMat J);
 
 /* Functionals of a discrete field: S[k] = sum over this rank's elements and points of JW * scalar_k(point)
  * (IGAComputeScalar, src/petigacomp.c:35-98, before its MPI_Allreduce: with several ranks the caller sums S over the

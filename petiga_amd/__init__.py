@@ -92,6 +92,7 @@ def lib(build_if_needed=False):
         "IGXComputeSystem": [V, V, V], "IGXComputeMatrix": [V, V], "IGXComputeVector": [V, V],
         "IGXComputeFunction": [V, V, V], "IGXComputeJacobian": [V, V, V],
         "IGXComputeIFunction": [V, C.c_double, V, C.c_double, V, V], "IGXComputeIJacobian": [V, C.c_double, V, C.c_double, V, V],
+        "IGXComputeIFunctionIJacobian": [V, C.c_double, V, C.c_double, V, V, V], "IGXComputeFunctionJacobian": [V, V, V, V],
         "IGXSetStream": [V, V], "IGXSynchronize": [V], "IGXSetKernel": [V, C.c_int], "IGXGetKernelName": [V, C.c_char_p, C.c_int],
         "IGXSetTiming": [V, C.c_int], "IGXGetLastTiming": [V, _dp, _dp, _ip],
         "IGXGetDominantKernelTiming": [V, C.c_char_p, C.c_int, _dp, _ip, C.POINTER(C.c_int64), _dp],
@@ -404,6 +405,12 @@ class IGX:
     def compute_jacobian(self, U, J): _ck(lib().IGXComputeJacobian(self.h, U.h, J.h))
     def compute_ifunction(self, a, V, t, U, F): _ck(lib().IGXComputeIFunction(self.h, a, V.h, t, U.h, F.h))
     def compute_ijacobian(self, a, V, t, U, J): _ck(lib().IGXComputeIJacobian(self.h, a, V.h, t, U.h, J.h))
+
+    def compute_ifunction_ijacobian(self, a, V, t, U, F, J):
+        """F and J of one Newton step in one pass of the walk where a fused kernel exists (IGXComputeIFunctionIJacobian)."""
+        _ck(lib().IGXComputeIFunctionIJacobian(self.h, a, V.h, t, U.h, F.h, J.h))
+
+    def compute_function_jacobian(self, U, F, J): _ck(lib().IGXComputeFunctionJacobian(self.h, U.h, F.h, J.h))
 
     def set_stream(self, stream): _ck(lib().IGXSetStream(self.h, stream))
     def synchronize(self): _ck(lib().IGXSynchronize(self.h))

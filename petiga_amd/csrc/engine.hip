@@ -1088,13 +1088,24 @@ static int dispatch_by_dim(IGX g, const SpaceDev &S, const OutDev &out) {
 }
 
 // ------------------------------------------------------------------ the drivers
-static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double shift, double t) {
+// fused (IGXComputeFunctionJacobian / IGXComputeIFunctionIJacobian): op is the Jacobian's, b the Function's vector; one pass of the
+// walk forms both (state_pencil_kr).  *fused_done = false and nothing written when no fused kernel covers the case: the caller
+// then runs the two drivers one after the other.
+static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double shift, double t, bool *fused_done = nullptr) {
   NEEDIGA(g);
   if (int rc = ensure_device(g)) return rc;
   const Space &s = g->s;
   if (s.form == IGX_FORM_NONE) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetForm...() first");
+  const bool fused = fused_done != nullptr;
+  if (fused) {
+    *fused_done = false;
+    bool ok = s.dim == 3 && s.nsd == 0 && s.axis[0].p == 2 && s.env.state_pencil && s.env.p2_pack != 0 && s.env.fuse_resid != 0 && (g->kernel_choice == 0 || g->kernel_choice == 2) &&
+              (s.form == IGX_FORM_CAHNHILLIARD || s.form == IGX_FORM_BRATU);
+    for (int d = 0; d < 3 && ok; ++d) for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count || s.visit[d][sd]) ok = false;      // (loads: F_e[k] -= flux, src/petigaelem.c:1449-1454 -- the element kernels' business)
+    if (!ok) return 0;
+  }
   const bool hasM = (op == OP_SYSTEM || op == OP_MATRIX || op == OP_JACOBIAN || op == OP_IJACOBIAN);
-  const bool hasV = (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
+  const bool hasV = fused || (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
   if (hasM && (!A || A->iga != g)) return fail(IGX_ERR_ARG_WRONG, "matrix missing or created by another IGX");
   if (hasV && (!b || b->iga != g)) return fail(IGX_ERR_ARG_WRONG, "vector missing or created by another IGX");
   if (U && U->iga != g) return fail(IGX_ERR_ARG_WRONG, "state vector created by another IGX");
@@ -1172,14 +1183,20 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
       // p = 2: packed tiles (state_pencil_k: 4 MFMAs per feature and k-step instead of 9; IGX_P2_PACK=0: the layer-pair tiles)
       if (st.kfn && deg == 2 && s.env.p2_pack != 0) {
         st.pack = 1;
-        if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
-        else { st.kfn = state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
+        if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = fused ? state_pencil_kr<FormCahnHilliard<3>> : state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
+        else { st.kfn = fused ? state_pencil_kr<FormBratu<3>> : state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
+        if (fused) st.name += "+Residual";
       }
-      if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes(); for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
+      if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes() + (fused ? (size_t)8 * (RWIN_DOUBLES + 128) * 8 : 0) /* fused: the Residual's ring and the scratch of its u_t sums, per wavefront */; for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
     }
     rc = try_gram_mfma(g->s, S, out, g->stream, g->kernel_choice == 2, g->last_kernel, g->last_launches, g_err, done, g->dom, zero_matrix, slab_done, st.kfn ? &st : nullptr, face_done);
     g->face_done = nullptr;
     if (rc) return rc;
+  }
+  if (fused) {      // (no walk took it -- a non-walkable axis 0, a reduced continuity: the caller falls back to the two drivers)
+    *fused_done = done;
+    if (g->timing) { HIPCK(hipEventRecord(g->ev[2], g->stream)); HIPCK(hipEventRecord(g->ev[3], g->stream)); }
+    return 0;
   }
   if (!done) {
     g->zero_matrix = zero_matrix;      // the feature kernel stores first touches and skips it; everything else zeroes first
@@ -1212,6 +1229,30 @@ extern "C" int IGXComputeFunction(IGX g, IGXVec U, IGXVec F) { if (!U) return fa
 extern "C" int IGXComputeJacobian(IGX g, IGXVec U, IGXMat J) { if (!U) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_JACOBIAN, J, nullptr, U, nullptr, 0, 0); }
 extern "C" int IGXComputeIFunction(IGX g, double a, IGXVec V, double t, IGXVec U, IGXVec F) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IFUNCTION, nullptr, F, U, V, a, t); }
 extern "C" int IGXComputeIJacobian(IGX g, double a, IGXVec V, double t, IGXVec U, IGXMat J) { if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector"); return compute(g, OP_IJACOBIAN, J, nullptr, U, V, a, t); }
+// One pass for the pair a Newton step asks for at the same state (SNESComputeFunction + SNESComputeJacobian; src/petigats.c:23-159,
+// src/petigasnes.c:23-139): the results are those of the two drivers, in one walk where a fused kernel exists, else in two calls.
+extern "C" int IGXComputeIFunctionIJacobian(IGX g, double a, IGXVec V, double t, IGXVec U, IGXVec F, IGXMat J) {
+  if (!U || !V) return fail(IGX_ERR_ARG_WRONG, "null state vector");
+  bool done = false;
+  if (int rc = compute(g, OP_IJACOBIAN, J, F, U, V, a, t, &done)) return rc;
+  if (done) return 0;
+  if (int rc = compute(g, OP_IFUNCTION, nullptr, F, U, V, a, t)) return rc;
+  const std::string kf = g->last_kernel;
+  if (int rc = compute(g, OP_IJACOBIAN, J, nullptr, U, V, a, t)) return rc;
+  g->last_kernel = kf + " | " + g->last_kernel;
+  return 0;
+}
+extern "C" int IGXComputeFunctionJacobian(IGX g, IGXVec U, IGXVec F, IGXMat J) {
+  if (!U) return fail(IGX_ERR_ARG_WRONG, "null state vector");
+  bool done = false;
+  if (int rc = compute(g, OP_JACOBIAN, J, F, U, nullptr, 0, 0, &done)) return rc;
+  if (done) return 0;
+  if (int rc = compute(g, OP_FUNCTION, nullptr, F, U, nullptr, 0, 0)) return rc;
+  const std::string kf = g->last_kernel;
+  if (int rc = compute(g, OP_JACOBIAN, J, nullptr, U, nullptr, 0, 0)) return rc;
+  g->last_kernel = kf + " | " + g->last_kernel;
+  return 0;
+}
 
 // ------------------------------------------------------------------ IGAComputeScalar (src/petigacomp.c:35-98)
 extern "C" int IGXComputeScalar(IGX g, IGXVec U, int kind, const double params[], int nparams, int n, double S[]) {

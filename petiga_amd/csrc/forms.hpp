@@ -31,6 +31,15 @@ struct PtView {
 template <class Form, class = void> struct pencil_state_of { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
 template <class Form> struct pencil_state_of<Form, decltype((void)Form::PENCIL_NFEAT)> { static constexpr bool v = true; static constexpr int nfeat = Form::PENCIL_NFEAT, nc = Form::PENCIL_NC; };
 template <> struct pencil_state_of<void, void> { static constexpr bool v = false; static constexpr int nfeat = 0, nc = 0; };
+// ... and its Residual can ride on the same walk (a fused IFunction + IJacobian pass: state_pencil_kr) when it is the same test
+// features against point numbers, R_a = sum_q sum_f A_f(a, q) r_f(q): PENCIL_NCR more numbers per point and pencil_resid(c, r)
+// for the PENCIL_NFEAT numbers r_f.  pencil_coef_r fills all PENCIL_NC + PENCIL_NCR from the state's point values WITHOUT u_t
+// (p.ut is null there) and leaves JW in c[PENCIL_NC]; the engine evaluates u_t from V later -- at the head of the wave's own MFMA
+// phase, where fp64 arithmetic does not wait for the partner's MFMAs -- and multiplies that slot by it: pencil_resid reads
+// c[PENCIL_NC] = JW u_t.
+template <class Form, class = void> struct pencil_resid_of { static constexpr bool v = false; static constexpr int ncr = 0; };
+template <class Form> struct pencil_resid_of<Form, decltype((void)Form::PENCIL_NCR)> { static constexpr bool v = true; static constexpr int ncr = Form::PENCIL_NCR; };
+template <> struct pencil_resid_of<void, void> { static constexpr bool v = false; static constexpr int ncr = 0; };
 
 // demo/Poisson{1,2,3}D.c System (demo/Poisson3D.c:3-23)
 template <int DIM> struct FormPoisson {
@@ -190,6 +199,19 @@ template <int DIM> struct FormCahnHilliard {
     for (int i = 0; i < DIM; ++i) B[1 + i] = c[1] * g[i] + c[6 + i] * h;
     B[1 + DIM] = c[4] * N + c[5] * lap;
   }
+  // The Residual (demo/CahnHilliard3D.c:55-109) on the same test features: R_a = JW (N_a c_t + t1 grad N_a . grad c + lap N_a M lap c)
+  static constexpr int PENCIL_NCR = 2;
+  static __device__ __forceinline__ void pencil_coef_r(const PtView &p, double JW, double *c) {
+    pencil_coef(p, JW, c);
+    const Coef k = coef(p);
+    c[PENCIL_NC] = JW; c[PENCIL_NC + 1] = JW * (k.M * k.lap);      // (c[PENCIL_NC] becomes JW c_t)
+  }
+  static __device__ __forceinline__ void pencil_resid(const double *c, double *r) {
+    r[0] = c[PENCIL_NC];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) r[1 + i] = c[1] * c[6 + i];
+    r[1 + DIM] = c[PENCIL_NC + 1];
+  }
 };
 
 // demo/Bratu.c + demo/BratuFJ.F90:23-176 (Function / Jacobian and IFunction / IJacobian, Galerkin branches); params {lambda}.
@@ -216,6 +238,19 @@ template <int DIM> struct FormBratu {
     B[0] = c[0] * N;
 #pragma unroll
     for (int i = 0; i < DIM; ++i) B[1 + i] = c[1] * g[i];
+  }
+  // the Function (demo/BratuFJ.F90:23-118) on the same test features: R_a = JW (N_a (u_t - lambda e^u) + grad N_a . grad u)
+  static constexpr int PENCIL_NCR = 2 + DIM;
+  static __device__ __forceinline__ void pencil_coef_r(const PtView &p, double JW, double *c) {
+    pencil_coef(p, JW, c);
+    c[PENCIL_NC] = JW; c[PENCIL_NC + 1] = -JW * (p.prm[0] * exp(p.u[0]));      // (c[PENCIL_NC] becomes JW u_t)
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) c[PENCIL_NC + 2 + i] = JW * p.gu[i];
+  }
+  static __device__ __forceinline__ void pencil_resid(const double *c, double *r) {
+    r[0] = c[PENCIL_NC] + c[PENCIL_NC + 1];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) r[1 + i] = c[PENCIL_NC + 2 + i];
   }
 };
 

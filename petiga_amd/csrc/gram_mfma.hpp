@@ -376,33 +376,68 @@ __device__ __forceinline__ void pencil_mfma_p2(d4_t (&acc)[4][4], const double *
 constexpr int WIN_ROW = 45, WIN_LAYER = 9 * WIN_ROW, WIN_DOUBLES = 3 * WIN_LAYER + 1;      // 1216 doubles per wavefront
 __host__ __device__ static inline size_t pencil_win_bytes(int wpb) { return (size_t)wpb * WIN_DOUBLES * 8; }
 
-struct P2kLane {
+// PK = false: the indices as 30 ints (config 2 and the Tangent on the identity geometry: registers to spare, and the decode's integer
+// work in the MFMA phase cost them 8-9 %); PK = true: packed into 10 (the fused pass and the Tangents on mapped geometries, which
+// spilled them: xy | aw << 4, negative for a function of the padding) and decoded at the adds.
+template <bool PK> struct P2kLaneT;
+template <> struct P2kLaneT<false> {
   int ua[2], va[2], za[2];     // this lane's operand row of tile T = function 16 T + (lane & 15): offsets (doubles) into the X rows [q][a][2], Y rows [a][q][2], walk rows [q][a][2]
-  int rs[2][4], cs[2][4], aw[2][4];   // the lane's result rows a = 16 T + 4 i + (lane >> 4): window row part 45 xy - 9 aw, column part 9 aw + xy + 18, layer slot (-1: padding)
-  int rsc[2], csc[2], awc[2];  // ... and its result column b = 16 T + (lane & 15)
+  int rs_[2][4], cs_[2][4], aw_[2][4];   // the lane's result rows a = 16 T + 4 i + (lane >> 4): window row part 45 xy - 9 aw, column part 9 aw + xy + 18, layer slot (-1: padding)
+  int rsc_[2], csc_[2], awc_[2];  // ... and its result column b = 16 T + (lane & 15)
+  int o;
+  __device__ __forceinline__ void set(int T, int i, int xy, int aw, bool ok) { aw_[T][i] = ok ? aw : -1; rs_[T][i] = xy * 45 - 9 * aw; cs_[T][i] = 9 * aw + xy + 18; }
+  __device__ __forceinline__ void setc(int T, int xy, int aw, bool ok) { awc_[T] = ok ? aw : -1; rsc_[T] = xy * 45 - 9 * aw; csc_[T] = 9 * aw + xy + 18; }
+  __device__ __forceinline__ int aw(int T, int i) const { return aw_[T][i]; }
+  __device__ __forceinline__ int rs(int T, int i) const { return rs_[T][i]; }
+  __device__ __forceinline__ int cs(int T, int i) const { return cs_[T][i]; }
+  __device__ __forceinline__ int xy(int T, int i) const { return cs_[T][i] - 18 - 9 * (aw_[T][i] < 0 ? 0 : aw_[T][i]); }
+  __device__ __forceinline__ int awc(int T) const { return awc_[T]; }
+  __device__ __forceinline__ int rsc(int T) const { return rsc_[T]; }
+  __device__ __forceinline__ int csc(int T) const { return csc_[T]; }
 };
-__device__ __forceinline__ P2kLane pencil_p2k_lane(int lane) {
-  P2kLane K;
+template <> struct P2kLaneT<true> {
+  int ua[2], va[2], za[2];
+  // one int per result row: (rs + 18) | xy << 9 | aw << 13 (aw = 7: padding), decoded with one or two bit-field instructions where it
+  // is used; the result columns keep plain ints (four registers)
+  int code[2][4], csc_[2], awc_[2];
+  // `o`: a zero the compiler cannot see through, made once per element of the walk: the decode then stays inside the walk loop --
+  // hoisted out of it, it IS the registers it saves -- while its instructions remain free to be scheduled.
+  int o;
+  __device__ __forceinline__ void set(int T, int i, int xy, int aw, bool ok) { code[T][i] = (xy * 45 - 9 * aw + 18) | (xy << 9) | ((ok ? aw : 7) << 13); }
+  __device__ __forceinline__ void setc(int T, int xy, int aw, bool ok) { awc_[T] = ok ? aw : -1; csc_[T] = 9 * aw + xy + 18; }
+  __device__ __forceinline__ int aw(int T, int i) const { const int a = (code[T][i] | o) >> 13; return a == 7 ? -1 : a; }
+  __device__ __forceinline__ int rs(int T, int i) const { return ((code[T][i] | o) & 511) - 18; }
+  __device__ __forceinline__ int xy(int T, int i) const { return ((code[T][i] | o) >> 9) & 15; }
+  __device__ __forceinline__ int cs(int T, int i) const { const int c = code[T][i] | o, a = c >> 13; return 9 * (a == 7 ? 0 : a) + ((c >> 9) & 15) + 18; }
+  __device__ __forceinline__ int awc(int T) const { return awc_[T]; }
+  __device__ __forceinline__ int rsc(int T) const { return (csc_[T] - 18 - 9 * (awc_[T] < 0 ? 0 : awc_[T])) * 45 - 9 * (awc_[T] < 0 ? 0 : awc_[T]); }
+  __device__ __forceinline__ int csc(int T) const { return csc_[T]; }
+};
+template <bool PK>
+__device__ __forceinline__ P2kLaneT<PK> pencil_p2k_lane(int lane) {
+  static_assert(WIN_ROW == 45, "the window's row stride is part of the packed indices");
+  P2kLaneT<PK> K; K.o = 0;
   auto split = [](int f, int &aw, int &ay, int &ax) { aw = f / 9; const int r = f - 9 * aw; ay = r / 3; ax = r - 3 * ay; };
 #pragma unroll
   for (int T = 0; T < 2; ++T) {
     const int f = 16 * T + (lane & 15);
     int aw, ay, ax; split(f < 27 ? f : 0, aw, ay, ax);
+    K.setc(T, 3 * ay + ax, aw, f < 27);
     if (f >= 27) ax = 3;                       // the zero-padded slot of the X rows: a padding row contributes nothing
     K.ua[T] = ax * 2; K.va[T] = ay * 8; K.za[T] = aw * 2;
-    K.awc[T] = f < 27 ? aw : -1; K.rsc[T] = (3 * ay + ax) * WIN_ROW - 9 * aw; K.csc[T] = 9 * aw + 3 * ay + ax + 18;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int g = 16 * T + 4 * i + (lane >> 4);
       int bw, by, bx; split(g < 27 ? g : 0, bw, by, bx);
-      K.aw[T][i] = g < 27 ? bw : -1; K.rs[T][i] = (3 * by + bx) * WIN_ROW - 9 * bw; K.cs[T][i] = 9 * bw + 3 * by + bx + 18;
+      K.set(T, i, 3 * by + bx, bw, g < 27);
     }
   }
   return K;
 }
 
+template <class KL>
 __device__ __forceinline__ void pencil_mfma_p2k(d4_t (&pk)[3], const double *uxs /*LDS [q][a][2], pre-scaled, zero padded*/, const double *vys /*LDS [a][q][2]*/,
-                                                const double *zt /*LDS [q][a][2]*/, const P2kLane &K, int lane) {
+                                                const double *zt /*LDS [q][a][2]*/, const KL &K, int lane) {
   const int ks = lane >> 4;
   pk[0] = pk[1] = pk[2] = (d4_t){0, 0, 0, 0};
 #pragma unroll
@@ -430,7 +465,8 @@ __device__ __forceinline__ void pencil_mfma_p2k(d4_t (&pk)[3], const double *uxs
 
 // the element's entries into the window: lane holds K[16 Ta + 4 i + (lane >> 4)][16 Tb + (lane & 15)] in pk[tile][i]; li = the element's
 // first node layer (segment-local): the row of layer li + aw lives in ring slot (li + aw) % 3
-__device__ __forceinline__ void pencil_win_add(double *win, const d4_t (&pk)[3], const P2kLane &K, int li) {
+template <class KL>
+__device__ __forceinline__ void pencil_win_add(double *win, const d4_t (&pk)[3], const KL &K, int li) {
   const int e3 = li % 3;
   const int ro0 = e3 * WIN_LAYER, ro1 = (e3 == 2 ? 0 : e3 + 1) * WIN_LAYER, ro2 = (e3 == 0 ? 2 : e3 - 1) * WIN_LAYER;
   auto ring = [&](int aw) { return aw == 0 ? ro0 : (aw == 1 ? ro1 : ro2); };
@@ -438,18 +474,19 @@ __device__ __forceinline__ void pencil_win_add(double *win, const d4_t (&pk)[3],
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int Ta = t == 2 ? 1 : 0, Tb = t == 0 ? 0 : 1;
-    if (K.awc[Tb] < 0) continue;
+    if (K.awc(Tb) < 0) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (K.aw[Ta][i] < 0) continue;
-      add(ring(K.aw[Ta][i]) + K.rs[Ta][i] + K.csc[Tb], pk[t][i]);
-      if (t == 1) add(ring(K.awc[Tb]) + K.rsc[Tb] + K.cs[Ta][i], pk[t][i]);      // the mirror entry of the off-diagonal tile
+      if (K.aw(Ta, i) < 0) continue;
+      add(ring(K.aw(Ta, i)) + K.rs(Ta, i) + K.csc(Tb), pk[t][i]);
+      if (t == 1) add(ring(K.awc(Tb)) + K.rsc(Tb) + K.cs(Ta, i), pk[t][i]);      // the mirror entry of the off-diagonal tile
     }
   }
 }
 
 // ... of a Tangent (not symmetric: all four tiles pk[2 Ta + Tb], no mirror entries)
-__device__ __forceinline__ void pencil_win_add_ns(double *win, const d4_t (&pk)[4], const P2kLane &K, int li) {
+template <class KL>
+__device__ __forceinline__ void pencil_win_add_ns(double *win, const d4_t (&pk)[4], const KL &K, int li) {
   const int e3 = li % 3;
   const int ro0 = e3 * WIN_LAYER, ro1 = (e3 == 2 ? 0 : e3 + 1) * WIN_LAYER, ro2 = (e3 == 0 ? 2 : e3 - 1) * WIN_LAYER;
   auto ring = [&](int aw) { return aw == 0 ? ro0 : (aw == 1 ? ro1 : ro2); };
@@ -457,15 +494,34 @@ __device__ __forceinline__ void pencil_win_add_ns(double *win, const d4_t (&pk)[
   for (int Ta = 0; Ta < 2; ++Ta)
 #pragma unroll
     for (int Tb = 0; Tb < 2; ++Tb) {
-      if (K.awc[Tb] < 0) continue;
+      if (K.awc(Tb) < 0) continue;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if (K.aw[Ta][i] < 0) continue;
-        (void)__hip_atomic_fetch_add(win + ring(K.aw[Ta][i]) + K.rs[Ta][i] + K.csc[Tb], pk[Ta * 2 + Tb][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (K.aw(Ta, i) < 0) continue;
+        (void)__hip_atomic_fetch_add(win + ring(K.aw(Ta, i)) + K.rs(Ta, i) + K.csc(Tb), pk[Ta * 2 + Tb][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
     }
 }
 
+// The Residual of a fused pass (state_pencil_kr): column 27 of tiles (0, 1) and (1, 1) is R_a of the element (pencil_mfma_state_p2k<RESID>),
+// held by the lanes with (lane & 15) == 11: row a = 16 Ta + 4 i + (lane >> 4).  It is summed over the pencil's elements in a ring of
+// its own, rwin[3 node layers][9 (a_y, a_x)] (+ padding: 32 doubles per wavefront), like the band rows in theirs.
+template <class KL>
+__device__ __forceinline__ void pencil_rwin_add(double *rwin, const d4_t (&pk)[4], const KL &K, int li, int lane) {
+  if ((lane & 15) != 11) return;
+  const int e3 = li % 3;
+  const int ro0 = e3 * 9, ro1 = (e3 == 2 ? 0 : e3 + 1) * 9, ro2 = (e3 == 0 ? 2 : e3 - 1) * 9;
+#pragma unroll
+  for (int Ta = 0; Ta < 2; ++Ta)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (Ta == 1 && i == 3) continue;               // rows 28..31: padding in every lane
+      const int aw = K.aw(Ta, i);                     // (-1 only at Ta = 1, i = 2, lane >> 4 == 3: row 27; it adds 0 to the pad slot 27)
+      const int xy = K.xy(Ta, i);
+      const int idx = aw < 0 ? 27 : (aw == 0 ? ro0 : (aw == 1 ? ro1 : ro2)) + xy;
+      (void)__hip_atomic_fetch_add(rwin + idx, aw < 0 ? 0.0 : pk[Ta * 2 + 1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+}
 // The COMPACT window (12 blocks of 9 x 9 instead of 15), for kernels whose LDS is short (state_pencil_geo_k).  Between the leave of layer
 // e - 1 and the leave of layer e the live (row layer, column layer) pairs are: row e with d = 0..4, row e + 1 with d = 0..3, row e + 2
 // with d = 0..2 (d = column layer - row layer + 2).  So d <= 2 gets a private block per ring slot of the row, the two live d = 3 blocks
@@ -475,20 +531,21 @@ constexpr int WINC_DOUBLES = 12 * 81 + 4;      // 976 doubles per wavefront
 __host__ __device__ static inline size_t pencil_winc_bytes(int wpb) { return (size_t)wpb * WINC_DOUBLES * 8; }
 __device__ __forceinline__ int pencil_winc_block(int r, int d) { return d <= 2 ? 3 * (r % 3) + d : (d == 3 ? 9 + (r & 1) : 11); }
 // a Tangent's four tiles into the compact window: li = the element's first node layer (segment-local)
-__device__ __forceinline__ void pencil_winc_add_ns(double *win, const d4_t (&pk)[4], const P2kLane &K, int li) {
+template <class KL>
+__device__ __forceinline__ void pencil_winc_add_ns(double *win, const d4_t (&pk)[4], const KL &K, int li) {
   // (aw, xy) of a function from its window parts: rs = 45 xy - 9 aw, cs = 9 aw + xy + 18
 #pragma unroll
   for (int Ta = 0; Ta < 2; ++Ta)
 #pragma unroll
     for (int Tb = 0; Tb < 2; ++Tb) {
-      if (K.awc[Tb] < 0) continue;
-      const int xyb = K.csc[Tb] - 18 - 9 * K.awc[Tb];
+      if (K.awc(Tb) < 0) continue;
+      const int xyb = K.csc(Tb) - 18 - 9 * K.awc(Tb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int awa = K.aw[Ta][i];
+        const int awa = K.aw(Ta, i);
         if (awa < 0) continue;
-        const int xya = K.cs[Ta][i] - 18 - 9 * awa;
-        const int off = 81 * pencil_winc_block(li + awa, K.awc[Tb] - awa + 2) + 9 * xya + xyb;
+        const int xya = K.cs(Ta, i) - 18 - 9 * awa;
+        const int off = 81 * pencil_winc_block(li + awa, K.awc(Tb) - awa + 2) + 9 * xya + xyb;
         (void)__hip_atomic_fetch_add(win + off, pk[Ta * 2 + Tb][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
       }
     }
@@ -605,6 +662,31 @@ __device__ __forceinline__ bool pencil_fixed(const PencilBC &b, int ix, int iy, 
     }
   }
   return f;
+}
+
+// The Residual of a fused pass (pencil_rwin_add) leaves with its node layer: lanes 0..8 = (a_y, a_x) add the layer's nine sums to F.  A
+// Dirichlet row holds nelem (u - v) instead -- IGAElementFixFunction sets F_e[k] = u - v in each of the nelem elements of the pencil
+// that hold the node (src/petigaelem.c:1441-1462) -- with u the vector's own entry, not the value the state was evaluated with.
+// The add is a memory-side atomic without a return: a colour's pencils share no row, so every row takes ONE add per launch and the
+// result does not depend on an order -- and nothing waits for it (a load / add / store chain of its own in every flush cost 35 % of a
+// launch; split around the band row's leave it held six registers across the walk's tightest spot).  rwin: [27 sums][5 pad][9 rows],
+// the rows being this pencil's F rows without the walk-axis part (64-bit, written once per pencil).
+constexpr int RWIN_DOUBLES = 48;
+template <int P>
+__device__ __forceinline__ void pencil_rwin_leave(double *rwin, int lane, const PencilLds &T, int nl, const OutDev &out, const double *fixtable, int lay, int own_lo, int own_hi,
+                                                  const PencilBC &bc, int nelem, long long rsw) {
+  const int li = lay - T.lay0;
+  const bool exists = li >= 0 && li < nl && T.cnt[li] > 0;
+  const bool owned = exists && lay >= own_lo && lay < own_hi;
+  if (lane >= 9) return;
+  const int slot = (((li % 3) + 3) % 3) * 9 + lane;
+  double r = rwin[slot];
+  rwin[slot] = 0.0;
+  if (!owned) return;
+  const long long row = (long long)T.rho[li] * rsw + reinterpret_cast<const long long *>(rwin + 32)[lane];
+  double fv = 0;
+  if (bc.any && pencil_fixed<P, false>(bc, lane % 3, lane / 3, lay, fv)) r = (double)nelem * (out.U[row] - (fixtable ? fixtable[row] : fv));
+  (void)__hip_atomic_fetch_add(out.vec + row, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Walk along axis 0: leaving layer `lay`, band-row variant (degree P, NB = P+1 basis functions per axis,
@@ -1211,11 +1293,13 @@ __host__ __device__ static inline size_t pencil_state_bytes() { return (size_t)8
 
 // lane = (aw, ay, ax) holds ucoef, the coefficient of U at its node (the Dirichlet value there: IGAElementFixValues,
 // src/petigaelem.c:1334-1358); on return geo[point * NC + k] holds the point coefficients (zeros on the padding)
-template <int P, class Form>
+// RESID (the fused IFunction + IJacobian pass): pencil_coef_r leaves the Residual's point numbers behind the Tangent's, u_t apart
+// (pencil_resid_ut below).
+template <int P, class Form, bool RESID = false>
 __device__ __forceinline__ void pencil_state_eval(double *geo, const double *d2w, int lane, const double *uxr, const double *vyr, const double *ztg,
                                                   double wj, double ucoef, const double *prm, double shift, double tt, const double (&xpar)[3]) {
-  constexpr int NB = P + 1, NC = Form::PENCIL_NC;
-  static_assert(NC * 64 <= 64 + 192 + 320, "point coefficients fit the scratch they replace");
+  constexpr int NB = P + 1, NC = Form::PENCIL_NC + (RESID ? pencil_resid_of<Form>::ncr : 0);
+  static_assert(NC * 64 <= (RESID ? GEO_Z : 64 + 192 + 320), "point coefficients fit the scratch they replace");
   double *C0 = geo, *T1 = geo + 64, *T2 = geo + 256;
   const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the previous element's readers are done
@@ -1255,12 +1339,40 @@ __device__ __forceinline__ void pencil_state_eval(double *geo, const double *d2w
     if (i0 < NB && i1 < NB && i2 < NB) {
       PtView p; p.x = xpar; p.u = &u; p.ut = nullptr; p.gu = gu; p.hu = hu; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = tt;
       p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
-      Form::pencil_coef(p, wj, c);
+      if constexpr (RESID) Form::pencil_coef_r(p, wj, c); else Form::pencil_coef(p, wj, c);
     }
   }
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // every lane has read the partial sums
 #pragma unroll
   for (int k = 0; k < NC; ++k) geo[lane * NC + k] = c[k];
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// The Residual's u_t (fused pass): V's value at the element's points by the same three stages, at the HEAD of the wave's own MFMA phase
+// -- in the flush phase every fp64 instruction waits for a gap in the partner's MFMA stream (about one MFMA each: the 30 of this
+// evaluation cost 3k cycles there).  scr: 128 doubles of the wavefront's own, the first 64 holding the lanes' coefficients of V at
+// their nodes (aw, ay, ax), gathered in the flush phase before (0 at a Dirichlet node: IGAElementDelValues,
+// src/petigaelem.c:1327-1341); the slot PENCIL_NC of the point's numbers (JW from pencil_coef_r) becomes JW u_t.
+template <int P, class Form>
+__device__ __forceinline__ void pencil_resid_ut(double *geo, double *scr, int lane, const double *uxr, const double *vyr, const double *ztg) {
+  constexpr int NB = P + 1, NC0 = Form::PENCIL_NC, NC = NC0 + pencil_resid_of<Form>::ncr;
+  double *C1 = scr, *T1v = scr + 64, *T2v = scr;      // (C1: the lanes' coefficients of V, left there by the flush phase before; T2v takes its place once stage X has read it)
+  const int i0 = lane & 3, i1 = (lane >> 2) & 3, i2 = lane >> 4;
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double sv = 0;
+#pragma unroll
+  for (int ax = 0; ax < NB; ++ax) sv += C1[(i2 * 4 + i1) * 4 + ax] * uxr[(i0 * 4 + ax) * 2 + 0];
+  T1v[(i1 * 4 + i2) * 4 + i0] = sv;
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double mv = 0;
+#pragma unroll
+  for (int ay = 0; ay < NB; ++ay) mv += T1v[(ay * 4 + i2) * 4 + i0] * vyr[(ay * 4 + i1) * 2 + 0];
+  T2v[(i2 * 4 + i1) * 4 + i0] = mv;
+  __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  double ut = 0;
+#pragma unroll
+  for (int aw = 0; aw < NB; ++aw) ut += T2v[(aw * 4 + i1) * 4 + i0] * ztg[(i2 * 4 + aw) * 2 + 0];
+  geo[lane * NC + NC0] *= ut;      // (padding lanes hold zeros)
   __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -1376,10 +1488,14 @@ __device__ __forceinline__ void pencil_mfma_state_p2(d4_t (&acc)[4][4], const do
 // p = 2 PACKED (see pencil_mfma_p2k): the 27 functions in two tiles of 16 rows, all four tiles of the (non-symmetric) Tangent: 4 MFMAs
 // per feature and k-step instead of 9 -- CahnHilliard 140 per element instead of 315 -- and two operand columns per lane instead of
 // three.  The sum over the pencil's elements moves into the LDS window (pencil_win_add_ns).
-template <class Form>
+// RESID: the Residual on the same MFMAs.  Tile 1 has five padding columns (functions 27..31); column 27 -- the operand of the lanes
+// with (lane & 15) == 11 -- carries the Residual's point numbers r_f(q) in the place of a trial function's B_f(b, q), so that
+// K[a][27] = sum_q sum_f A_f(a, q) r_f(q) = R_a comes out of tiles (0, 1) and (1, 1) with the Tangent, for nothing on the pipe.
+template <class Form, bool RESID = false, class KL = void>
 __device__ __forceinline__ void pencil_mfma_state_p2k(d4_t (&pk)[4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
-                                                      const double *coef, const P2kLane &K, int lane) {
-  constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
+                                                      const double *coef, const KL &K, int lane) {
+  constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC + (RESID ? pencil_resid_of<Form>::ncr : 0);
+  const bool rcol = RESID && (lane & 15) == 11;
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4;
   pk[0] = pk[1] = pk[2] = pk[3] = (d4_t){0, 0, 0, 0};
@@ -1418,6 +1534,13 @@ __device__ __forceinline__ void pencil_mfma_state_p2k(d4_t (&pk)[4], const doubl
   auto trial_ops = [&](const Raw &w, const double (&A)[NF][2], int T, double (&B)[2][NF]) {
     const double g[3] = {A[1][T], A[2][T], A[3][T]};
     Form::pencil_trial(w.c, A[0][T], g, LAP ? A[NF - 1][T] : 0.0, B[T]);
+    if constexpr (RESID) {
+      if (T == 1) {      // (the 28th point of the last step is padding: its TEST operands are zero, whatever r holds)
+        double r[NF]; Form::pencil_resid(w.c, r);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) B[1][f] = rcol ? r[f] : B[1][f];
+      }
+    }
   };
   double A[NF][2], B[2][NF];
   { Raw w; loads(0, w); load_coef(0, w); test_ops(w, A); trial_ops(w, A, 0, B); trial_ops(w, A, 1, B); }
@@ -1697,9 +1820,9 @@ __device__ __forceinline__ void sgeo_sched_groups() {      // one MFMA, then its
 }
 // ... PACKED (see pencil_mfma_state_p2k): two operand columns per lane (its functions 16 T + (lane & 15)), each with its own fold of the
 // point's map, four tiles: 4 MFMAs per feature and k-step instead of 9.  The NURBS weight of function f sits at ztg[32 + f].
-template <bool RAT, class Form>
+template <bool RAT, class Form, class KL = void>
 __device__ __forceinline__ void pencil_mfma_state_geo_p2k(d4_t (&pk)[4], const double *uxr, const double *vyr, const double *ztg, const double *d2w,
-                                                          const double *geo, const P2kLane &K, int lane) {
+                                                          const double *geo, const KL &K, int lane) {
   constexpr int NF = Form::PENCIL_NFEAT, NC = Form::PENCIL_NC;
   constexpr bool LAP = NF > 4;
   const int ks = lane >> 4;
@@ -1817,8 +1940,9 @@ __device__ __forceinline__ void pencil_mfma_state_geo_p2(d4_t (&acc)[4][4], cons
 
 // ALIAS: the wrapped walk axis (PencilArgs::alias0) known at compile time -- 0: not wrapped, 1: wrapped, -1: read from the arguments.
 // The identity-geometry Gram instantiations come in both fixed flavours, so the headline kernel carries none of the modulo logic.
-template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1, bool PACK = false>
+template <bool SYSTEM, int W, int P, bool GEO, bool RAT, bool FIXT, class Form, bool IDENT, int ALIAS = -1, bool PACK = false, bool RESID = false>
 __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev &out, const PencilArgs &pa, const double *prm) {
+  static_assert(!RESID || (PACK && IDENT && pencil_state_of<Form>::v && pencil_resid_of<Form>::v), "the fused Residual: a packed Tangent on the identity geometry of a form with the PENCIL_NCR hooks");
   static_assert(!GEO || W == 0, "the mapped-geometry variant walks axis 0");
   static_assert(!PACK || (P == 2 && W == 0 && !FIXT && ((!GEO && is_builtin_gram<Form>::v) || pencil_state_of<Form>::v)),
                 "packed tiles: p = 2, the Gram matrix on the identity geometry (pencil_mfma_p2k) or a Tangent (pencil_mfma_state_p2k / pencil_mfma_state_geo_p2k)");
@@ -1893,6 +2017,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
 
   PencilLane L;
   double *d2w = nullptr; double u2 = 0;      // STATE: second derivatives of the 1-D rows (LDS, per wavefront); this lane's X-row entry
+  double *rwin = nullptr, *vscr = nullptr;   // RESID: the Residual's ring of node layers and the scratch of its u_t sums (LDS, per wavefront)
   {
     const double *__restrict__ TX = AX.tab + (size_t)elx * (NB * NB * NDER);
     const double *__restrict__ TY = AY.tab + (size_t)ely * (NB * NB * NDER);
@@ -1918,6 +2043,11 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       if (lane < 16) { const int qq = lane >> 2, aa = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TX[(qq * NB + aa) * NDER + 2] : 0.0; }
       else if (lane < 32) { const int aa = (lane - 16) >> 2, qq = lane & 3; d2w[lane] = (qq < NB && aa < NB) ? TY[(qq * NB + aa) * NDER + 2] : 0.0; }
       if (qx < NB && ix < NB) u2 = TX[(qx * NB + ix) * NDER + 2];
+      if constexpr (RESID) {      // the Residual's ring behind the eight waves' second-derivative rows (PencilModule::extra_lds has its 2 KB)
+        rwin = d2w - wave * STATE_D2 + 8 * STATE_D2 + wave * RWIN_DOUBLES;
+        if (lane < 32) rwin[lane] = 0.0;
+        vscr = d2w - wave * STATE_D2 + 8 * STATE_D2 + 8 * RWIN_DOUBLES + wave * 128;
+      }
     }
     // scatter constants: this lane's result rows are (X: a = lane>>4, Y: r), columns (X: b1 = lane&3, Y: b2 = (lane>>2)&3)
     const int a = lane >> 4, b1 = lane & 3, b2 = (lane >> 2) & 3;
@@ -1961,8 +2091,9 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     hold = reinterpret_cast<double *>(reinterpret_cast<char *>(pencil_sm) + pencil_lds_bytes(pa.ne_max, GEO, pa.wpb)) + wave * HS;
     for (int i = lane; i < HS; i += 64) hold[i] = 0.0;
   }
-  P2kLane K2;
-  if constexpr (PACK) K2 = pencil_p2k_lane(lane);
+  constexpr bool PKIDX = PACK && (RESID || SGEO);      // the window indices packed into 10 registers where 30 are what spills (P2kLaneT)
+  P2kLaneT<PKIDX> K2; K2.o = 0;
+  if constexpr (PACK) K2 = pencil_p2k_lane<PKIDX>(lane);
   // mapped geometry: this wavefront's metric area, the raw basis rows, the Gauss weights of this lane's point on axes X, Y
   double *geo = nullptr; const double *uxr = nullptr, *vyr = nullptr; double wjxy = 0, wt[4] = {1, 1, 1, 1};
   constexpr bool rational = GEO && RAT;
@@ -1983,6 +2114,9 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     if (!AW.periodic && S.bcv[W][1].count > 0 && AW.estart + AW.nel == AW.esizes) { bc.whi = AW.off[AW.nel - 1] + P; bc.vwhi = S.bcv[W][1].value[0]; }
     bc.any = bc.xlo || bc.xhi || bc.ylo || bc.yhi || bc.wlo > -1000 || bc.whi > -1000;
   }
+  if constexpr (RESID) {             // the F rows of (a_y, a_x) = (lane / 3, lane % 3) without the walk-axis part, behind the ring (lanes 0..8)
+    if (lane < 9) reinterpret_cast<long long *>(rwin + 32)[lane] = rs[X] * AX.rowmap[offx + lane % 3] + rs[Y] * AY.rowmap[offy + lane / 3];
+  }
   double Hsum[SGEO ? 5 : 1][4];      // SGEO: the first-order sums of the next element's points, from its flush-phase half to its MFMA-phase half
   auto geometry = [&](int ei) {   // control points, NURBS weights of the lane's basis functions and the metric of element wh + ei
     if constexpr (GEO) {
@@ -1996,13 +2130,14 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       if constexpr (STATE) {
         // this lane's node (aw, ay, ax) = (lane>>4, (lane>>2)&3, lane&3): coefficient of U, or the Dirichlet value there
         const int aw = lane >> 4, ay = (lane >> 2) & 3, ax = lane & 3;
-        double uc = 0.0;
+        double uc = 0.0, vc = 0.0;
         if (aw < NB && ay < NB && ax < NB) {
           const int li = ei + aw;                 // (one new node layer per element: AW.off[wh + ei] - T.lay0 = ei)
           const long long urow = (long long)T.rho[li] * rs[W] + rs[X] * AX.rowmap[offx + ax] + rs[Y] * AY.rowmap[offy + ay];
           uc = out.U[urow];
+          if constexpr (RESID) vc = out.V ? out.V[urow] : 0.0;
           double fv = 0;
-          if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) uc = S.fixtable ? S.fixtable[urow] : fv;     // (IGASetFixTable: the value by row)
+          if (bc.any && pencil_fixed<P, false>(bc, ax, ay, T.lay0 + li, fv)) { uc = S.fixtable ? S.fixtable[urow] : fv; vc = 0.0; }     // (IGASetFixTable: the value by row; IGAElementDelValues for V)
         }
         if constexpr (SGEO) {
           pencil_sgeo_ctrl<P>(geo, S, lane, AW.off[ew(ei)], offx, offy, uc);
@@ -2011,7 +2146,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
         double xpar[3] = {0, 0, 0};
         const int gqx = lane & 3, gqy = (lane >> 2) & 3;
         if (gqx < NB && gqy < NB && gqw < NB) { xpar[0] = AW.pt[ew(ei) * NB + gqw]; xpar[1] = AX.pt[elx * NB + gqx]; xpar[2] = AY.pt[ely * NB + gqy]; }
-        pencil_state_eval<P, Form>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
+        pencil_state_eval<P, Form, RESID>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), uc, prm, out.shift, out.t, xpar);
+        if constexpr (RESID) vscr[lane] = vc;      // (u_t of this element is summed at the head of its MFMA phase: pencil_resid_ut)
         }
       } else
       if constexpr (is_builtin_gram<Form>::v) pencil_geo_eval<P>(geo, lane, uxr, vyr, geo + GEO_Z, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), pa.forcing, rational, out.errflag);
@@ -2045,6 +2181,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (kDebug && pa.debug_buf) tw_loop = __builtin_readcyclecounter();
   for (int ei = 0; ei < ne; ++ei) {
     lay = T.lay0 + ei;          // walk condition: one new layer per element, local basis a_w sits in tile slot a_w
+    if constexpr (PKIDX) { int z = 0; asm volatile("" : "+s"(z)); K2.o = z; }      // (P2kLaneT<true>: the window indices are decoded per element)
     const double *zt = T.zt + ei * 32, *wqs = T.wq + ei * 4;
     long long tq0 = 0, tq1 = 0, tq2 = 0, tq3 = 0;
     if (kDebug && pa.debug_buf) tq0 = __builtin_readcyclecounter();
@@ -2062,15 +2199,17 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       pencil_sgeo_point<P, RAT, Form>(geo, lane, Hsum, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), prm, out.shift, out.t, out.errflag);
       if constexpr (PACK) {
         d4_t pk[4];
-        pencil_mfma_state_geo_p2k<RAT, Form>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
+        pencil_mfma_state_geo_p2k<RAT, Form, P2kLaneT<PKIDX>>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
         pencil_winc_add_ns(hold, pk, K2, ei);
       } else
       pencil_mfma_state_geo_p2<RAT, Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     }
     else if constexpr (STATE && PACK) {
       d4_t pk[4];
-      pencil_mfma_state_p2k<Form>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
+      if constexpr (RESID) pencil_resid_ut<P, Form>(geo, vscr, lane, uxr, vyr, ztg);
+      pencil_mfma_state_p2k<Form, RESID, P2kLaneT<PKIDX>>(pk, uxr, vyr, ztg, d2w, geo, K2, lane);
       pencil_win_add_ns(hold, pk, K2, ei);      // (measured: in the flush phase instead, behind the barrier, 130.4 -> 125.8 M el/s at 128^3)
+      if constexpr (RESID) pencil_rwin_add(rwin, pk, K2, ei, lane);
     }
     else if constexpr (STATE && P == 2) pencil_mfma_state_p2<Form>(acc, uxr, vyr, ztg, d2w, geo, lane);
     else if constexpr (STATE) pencil_mfma_state<NB, Form>(acc, L.u0, L.u1, u2, L.vy, d2w + 16 + ((lane >> 2) & 3) * 4, ztg, d2w + 32, geo, lane);
@@ -2099,14 +2238,18 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     __builtin_amdgcn_s_setprio(3);
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
+    if constexpr (RESID) pencil_rwin_leave<P>(rwin, lane, T, nl, out, S.fixtable, lay, own_lo, own_hi, bc, held[0], rs[W]);
+    if (kDebug && pa.debug_buf && pa.debug_noflush == 2) tq0 = __builtin_readcyclecounter();      // (IGX_DEBUG_NOFLUSH=2: the stamps split the flush phase: Residual's leave | band row's leave | next element's state)
     if constexpr (W == 0) pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, WINMODE>(acc, Facc, hold, lane, L, T, nl, out, lay, own_lo, own_hi, T0, T10, bc, held[0], fxt);
     else pencil_leave<SYSTEM, W>(acc, Facc, L, T, nl, out, lay, own_lo, own_hi, T0, T10, rs[W]);
+    if (kDebug && pa.debug_buf && pa.debug_noflush == 2) tq1 = __builtin_readcyclecounter();
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
     held[NB - 1] = 0;
     if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
     __builtin_amdgcn_s_setprio(0);
-    if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if ((wave & 3) == 0 && wave < 8 && lane == 0 && ei < 62) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
+    if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if (pa.debug_noflush == 2) { const long long a = tq0, b = tq1; tq0 = tq2; tq1 = a; tq2 = b; }      // (columns: "mfma" = the Residual's leave, "wait" = the band row's leave, "flush" = the next element's state)
+      if ((wave & 3) == 0 && wave < 8 && lane == 0 && ei < 62) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
     if (pingpong) __builtin_amdgcn_s_barrier();
   }
   if (kDebug && pa.debug_buf) tw_loopend = __builtin_readcyclecounter();
@@ -2120,6 +2263,7 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
   if (seg == pa.nseg - 1 && !alias0 && !pa.open_hi)       // the last segment also owns what is still in the window (wrapped axis: the first segment does)
     for (int k = 1; k <= P; ++k) {
       if constexpr (W == 0) {
+        if constexpr (RESID) pencil_rwin_leave<P>(rwin, lane, T, nl, out, S.fixtable, lay + k, own_lo, own_hi, bc, held[0], rs[W]);
         pencil0_leave<SYSTEM, P, FIXT, STATE, SYSTEM || STATE, (GEO && SYSTEM && P == 3) ? 2 : P + 1, WINMODE>(acc, Facc, hold, lane, L, T, nl, out, lay + k, own_lo, own_hi, T0, T10, bc, held[0], fxt);
 #pragma unroll
         for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
@@ -2178,6 +2322,14 @@ state_pencil_k(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
 }
 
 // ... and on a mapped geometry (p = 2: pencil_sgeo_sums / pencil_sgeo_point / pencil_mfma_state_geo_p2)
+// ... with the Residual on the same MFMAs (one pass for IFunction + IJacobian: IGXComputeIFunctionIJacobian)
+template <class Form>
+__global__ void __launch_bounds__(512, 2)
+state_pencil_kr(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {
+  static_assert(pencil_resid_of<Form>::v, "state_pencil_kr: the form declares PENCIL_NCR, pencil_coef_r and pencil_resid");
+  gram_pencil_body<false, 0, 2, true, false, false, Form, true, -1, true, true>(S, out, pa, prm.v);
+}
+
 template <bool RAT, class Form>
 __global__ void __launch_bounds__(512, 2)
 state_pencil_geo_k(SpaceDev S, OutDev out, PencilArgs pa, ParamsDev prm) {      // packed tiles, the compact window of band rows

@@ -42,6 +42,9 @@ struct EnvSwitches {
   int vec_sumfact = 1;       // IGX_VEC_SUMFACT=0: the vector-only drivers stay on the feature kernel (vec_sumfact.hpp)
   int free_run = -1;         // IGX_FREE_RUN=0/1: the pencil walk with / without its s_barrier ping-pong (-1: the launcher's choice)
   int p2_pack = 1;           // IGX_P2_PACK=0: the p = 2 walks keep one tile per pair of node layers (round 4) instead of the packed tiles
+  int fuse_resid = 0;        // IGX_FUSE_RESID=1: IGXComputeIFunctionIJacobian takes the fused walk (state_pencil_kr) where it exists; default: the two
+                             // drivers one after the other -- measured in round 6: the fused launch costs 2.5 ms more than the Tangent's, the
+                             // Residual's own pass 2.1 ms per launch
   int combine = -1;          // IGX_COMBINE: element bricks of the feature kernel (-1 = automatic, 0 = one element per workgroup)
   int debug_feature = 0, debug_noflush = 0, debug_timing = 0;   // only honoured by -DIGX_DEBUG builds
 };

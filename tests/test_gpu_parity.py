@@ -646,6 +646,7 @@ def test_pencil_first_touch_needs_no_zeroing(p, N, size):
 
 
 @pytest.mark.parametrize("size,form,N,periodic", [(4, "ch", (6, 7, 8), (0, 0, 0)), (8, "ch", (8, 8, 8), (0, 0, 0)), (2, "ns", (9, 3, 8), (1, 0, 1)), (4, "ns", (9, 4, 8), (1, 0, 1)),
+                                                  (2, "ch", (16, 4, 6), (0, 0, 0)), (4, "ch", (9, 6, 10), (1, 0, 0)),      # boxes the pencil walk takes: the fused pass on a rank's share
                                                   (27, "ch", (3, 4, 3), (0, 0, 0)),       # one element of degree 2 per rank and axis: ghost values come from two ranks up
                                                   (2, "chg", (24, 6, 6), (0, 0, 0)), (4, "chg", (20, 12, 5), (0, 0, 0))])      # Cahn-Hilliard on a NURBS patch: state_pencil_geo + vec_sumfact on a partition
 def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic):
@@ -655,6 +656,7 @@ def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic
     import torch
     import scipy.sparse as sp
     import petiga_amd as P
+    monkeypatch.setenv("IGX_FUSE_RESID", "1")      # (read at IGXCreate: the fused pass is checked on every rank's box below)
     periodic = [bool(x) for x in periodic]
     geo = form == "chg"
     form = "ch" if geo else form
@@ -729,6 +731,16 @@ def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic
         g.compute_ijacobian(2.0, Vs[r], 0.1, Us[r], A)
         if geo and os.environ.get("IGX_KERNEL") == "0":
             assert "state_pencil<CahnHilliard>" in g.kernel_name() and "mapped geometry" in g.kernel_name(), g.kernel_name()
+        if form == "ch" and not geo and os.environ.get("IGX_KERNEL") == "0":
+            # the fused pass (IGXComputeIFunctionIJacobian: the Residual on the Tangent's MFMAs) on this rank's box -- ghost rows,
+            # halo segments, rows zeroed for the neighbours' columns -- gives what the two drivers gave
+            A2, b2 = g.create_mat(), g.create_vec()
+            _poison(A2)
+            g.compute_ifunction_ijacobian(2.0, Vs[r], 0.1, Us[r], b2, A2)
+            g.synchronize()
+            assert ("+Residual>" in g.kernel_name()) == (g.sizes()["elem_width"][0] >= 8), g.kernel_name()      # (a box the walk does not take: the two drivers, one after the other)
+            assert np.abs(b2.get() - b.get()).max() <= 1e-12 * np.abs(b.get()).max()
+            assert np.abs(A2.host(True) - A.host(True)).max() <= 1e-12 * np.abs(A.host(True)).max()
         for k, (peer, m, v) in enumerate(g.neighbors(True)):
             buf = torch.empty(m + v, dtype=torch.float64, device="cuda")
             g.pack_ghost_rows(A, b, k, buf.data_ptr()); send[(r, peer)] = buf

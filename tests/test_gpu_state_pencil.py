@@ -206,3 +206,113 @@ def test_switch_and_fallbacks(monkeypatch):
             with pytest.raises(P.IGXError) as e:
                 eng.compute_ijacobian(10.0, Vv, 0.0, Uv, J)
             assert e.value.code == 56 and "p = 2 only" in str(e.value), str(e.value)
+
+
+@pytest.mark.parametrize("form,N,periodic,bc,nseg,fixtable", [
+    ("ch", (9, 4, 5), (False, False, False), False, 0, False),        # config 4's discretisation
+    ("ch", (12, 3, 4), (False, False, False), True, 0, False),        # Dirichlet values on four faces: F_k = nelem (u - v), V dropped at fixed nodes
+    ("ch", (17, 4, 3), (False, False, False), True, 3, True),         # three segments, the values from a fix table
+    ("ch", (8, 5, 6), (False, True, True), False, 0, False),
+    ("ch", (19, 5, 5), (True, False, True), True, 3, False),          # the walk axis wrapped inside the rank
+    ("bratu", (9, 5, 4), (False, False, False), True, 0, False),
+    ("bratu", (11, 4, 6), (False, False, True), True, 2, False),
+    ("bratu-snes", (9, 5, 4), (False, False, False), True, 0, False),  # Function + Jacobian (no V)
+])
+def test_fused_function_and_jacobian_vs_oracle(form, N, periodic, bc, nseg, fixtable, monkeypatch):
+    """IGXComputeIFunctionIJacobian (state_pencil_kr): the Residual rides on the Tangent's MFMAs as operand column 27 of tile 1 and is
+    summed over the pencil in a ring of its own.  F against the oracle's IFunction (demo/CahnHilliard3D.c:55-109 through
+    src/petigats.c:23-90: FixValues / DelValues / FixFunction), J against its IJacobian, both from ONE call; then the same call with
+    IGX_FUSE_RESID=0 semantics (the two drivers) through the separate entry points gives the same numbers."""
+    monkeypatch.setenv("IGX_FUSE_RESID", "1")        # (read at IGXCreate; the default runs the two drivers: the fused walk measured 3 % slower)
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 1, 2, list(N), periodic=list(periodic))
+    if bc:
+        for g in (orc, eng):
+            if not periodic[0]:
+                g.set_boundary_value(0, 0, 0, 0.6)
+                g.set_boundary_value(0, 1, 0, 0.66)
+            if not periodic[1]:
+                g.set_boundary_value(1, 1, 0, 0.61)
+            if not periodic[2]:
+                g.set_boundary_value(2, 0, 0, 0.65)
+    rng = np.random.default_rng(21)
+    n = orc.global_size()
+    V = rng.standard_normal(n)
+    if fixtable:
+        tab = 0.63 + 0.04 * (2 * rng.random(n) - 1)
+        orc.set_fixtable(tab)
+        eng.set_fixtable(eng.create_vec().set(tab))
+    shift = 250.0
+    if form == "ch":
+        U = 0.63 + 0.05 * (2 * rng.random(n) - 1)
+        eng.set_form("cahnhilliard", CH)
+        ctx = O.CahnHilliardCtx(*CH)
+        F_o = orc.compute_ifunction("orc_form_ch_residual", ctx, shift, V, 0.0, U)
+        J_o = orc.compute_ijacobian("orc_form_ch_tangent", ctx, shift, V, 0.0, U)
+    else:
+        U = 0.3 * rng.standard_normal(n)
+        eng.set_form("bratu", (3.5,))
+        lam = C.c_double(3.5)
+        if form == "bratu":
+            F_o = orc.compute_ifunction("orc_form_bratu_ifunction", lam, shift, V, 0.0, U)
+            J_o = orc.compute_ijacobian("orc_form_bratu_ijacobian", lam, shift, V, 0.0, U)
+        else:
+            F_o = orc.compute_function("orc_form_bratu_function", lam, U)
+            J_o = orc.compute_jacobian("orc_form_bratu_jacobian", lam, U)
+    Uv, Vv, J, F = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat(), eng.create_vec()
+    F.set(np.full(n, 7.0))          # the driver zeroes F itself
+    _poison(J)
+    if form == "bratu-snes":
+        eng.compute_function_jacobian(Uv, F, J)
+    else:
+        eng.compute_ifunction_ijacobian(shift, Vv, 0.0, Uv, F, J)
+    eng.synchronize()
+    assert "+Residual>" in eng.kernel_name() and "packed tiles" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-11)
+    scale = np.abs(F_o).max()
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * scale, np.abs(F.get() - F_o).max() / scale
+    # bit-repeatable, and the two-call path agrees
+    Fb, vals = F.get().copy(), J.to_coo_global()[2].copy()
+    _poison(J)
+    if form == "bratu-snes":
+        eng.compute_function_jacobian(Uv, F, J)
+    else:
+        eng.compute_ifunction_ijacobian(shift, Vv, 0.0, Uv, F, J)
+    assert np.array_equal(F.get(), Fb) and np.array_equal(J.to_coo_global()[2], vals)
+    F2, J2 = eng.create_vec(), eng.create_mat()
+    if form == "bratu-snes":
+        eng.compute_function(Uv, F2); eng.compute_jacobian(Uv, J2)
+    else:
+        eng.compute_ifunction(shift, Vv, 0.0, Uv, F2); eng.compute_ijacobian(shift, Vv, 0.0, Uv, J2)
+    eng.synchronize()
+    assert np.abs(F2.get() - Fb).max() <= 1e-12 * scale
+    assert np.abs(J2.to_coo_global()[2] - vals).max() <= 1e-12 * np.abs(vals).max()
+
+
+def test_fused_call_falls_back_to_the_two_drivers(monkeypatch):
+    """Where no fused kernel covers the case (p = 3; a mapped geometry) or it is not asked for (the default) the call runs IFunction and
+    IJacobian one after the other: same results, both kernels named."""
+    for p, geo, fuse in ((3, False, "1"), (2, True, "1"), (2, False, None)):
+        if fuse:
+            monkeypatch.setenv("IGX_FUSE_RESID", fuse)
+        else:
+            monkeypatch.delenv("IGX_FUSE_RESID", raising=False)
+        orc, eng = make_pair(3, 1, p, [9, 4, 4])
+        if geo:
+            from common import warped_geometry
+            X, W = warped_geometry(orc, 3, seed=6, rational=True, amp=0.05)
+            orc.set_geometry(X, W); eng.set_geometry(X, W)
+        rng = np.random.default_rng(2)
+        n = orc.global_size()
+        U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+        eng.set_form("cahnhilliard", CH)
+        ctx = O.CahnHilliardCtx(*CH)
+        F_o = orc.compute_ifunction("orc_form_ch_residual", ctx, 250.0, V, 0.0, U)
+        J_o = orc.compute_ijacobian("orc_form_ch_tangent", ctx, 250.0, V, 0.0, U)
+        Uv, Vv, J, F = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat(), eng.create_vec()
+        eng.compute_ifunction_ijacobian(250.0, Vv, 0.0, Uv, F, J)
+        eng.synchronize()
+        assert " | " in eng.kernel_name() and "vec_sumfact" in eng.kernel_name() and "state_pencil" in eng.kernel_name(), eng.kernel_name()
+        compare_mats(J, J_o, 1e-10)
+        assert np.abs(F.get() - F_o).max() <= 1e-10 * np.abs(F_o).max()
