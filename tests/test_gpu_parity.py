@@ -649,7 +649,7 @@ def test_pencil_first_touch_needs_no_zeroing(p, N, size):
                                                   (2, "ch", (16, 4, 6), (0, 0, 0)), (4, "ch", (9, 6, 10), (1, 0, 0)),      # boxes the pencil walk takes: the fused pass on a rank's share
                                                   (27, "ch", (3, 4, 3), (0, 0, 0)),       # one element of degree 2 per rank and axis: ghost values come from two ranks up
                                                   (2, "chg", (24, 6, 6), (0, 0, 0)), (4, "chg", (20, 12, 5), (0, 0, 0))])      # Cahn-Hilliard on a NURBS patch: state_pencil_geo + vec_sumfact on a partition
-def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic):
+def test_multirank_nonlinear_assembly_with_ghost_refresh(size, form, N, periodic, monkeypatch):
     """Nonlinear drivers on a partition (configs 4 and 5 are multi-GPU): every rank knows the state only on the nodes
     it owns, the owner -> ghost refresh (IGXPackOwnerValues / IGXUnpackGhostValues, the reverse of the ghost-row
     reduction) fills its ghost rows, then IFunction / IJacobian + ghost-row reduction reproduce the single-rank oracle."""
