@@ -73,6 +73,7 @@ typedef enum {
   IGX_FORM_NITSCHE     = 10,/* System: demo/NitscheMethod.c:69-110  Poisson with Nitsche terms on visited faces (normals,
                                normal mesh size through IGAPointFormInvGradGeomMap); params: {max degree k} */
   IGX_FORM_BRATU       = 11,/* Function/Jacobian and IFunction/IJacobian: demo/Bratu.c, demo/BratuFJ.F90:23-176  params: {lambda} */
+  IGX_FORM_ELASTICITY_F = 12,/* System: demo/Elasticity3D.c's K with a body force, F[a][i] = N_a f_i   params: {lambda, mu, fx, fy, fz} */
   IGX_FORM_SOURCE      = 100 /* a user form compiled at run time: IGXSetFormSource */
 } IGXFormKind;
 

@@ -200,6 +200,20 @@ int orc_form_elasticity(OrcPoint *p,double *K,double *F,void *ctx)
   return 0;
 }
 
+/* The same K with a body force f: F[a][i] = N_a f_i.  Not a reference demo (demo/Elasticity3D.c:43-45 writes F = 0); it exercises
+ * what the reference's System path does with ANY callback's F (src/petigapoint.c:427-450 AddVec, src/petigaelem.c:1377-1387
+ * FixSystem: F -= K[:,k] v, F[k] = v) for a multi-field form.  ctx: {lambda, mu, f[3]} */
+int orc_form_elasticity_f(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  const double *c = (const double*)ctx;
+  OrcElasticityCtx user; int a,i,nen=p->nen;
+  const double *N0 = p->shape[0];
+  user.lambda = c[0]; user.mu = c[1];
+  orc_form_elasticity(p,K,F,&user);
+  for (a=0; a<nen; a++) for (i=0; i<3; i++) F[a*3+i] = N0[a]*c[2+i];
+  return 0;
+}
+
 /* demo/CahnHilliard3D.c:11-16 (Mobility), :39-53 (ChemicalPotential); dim-generic over the
  * diagonal second derivatives (the 2-D demo, demo/CahnHilliard2D.c, uses 3*alpha scaling instead:
  * selected by L0 <= 0) */

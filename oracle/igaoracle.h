@@ -175,6 +175,7 @@ int orc_form_boundary_integral(OrcPoint*,double*,double*,void*);  /* demo/Bounda
 int orc_form_nitsche(OrcPoint*,double*,double*,void*);            /* demo/NitscheMethod.c System; ctx = int* degree */
 int orc_form_errnorm   (OrcPoint*,double*,double*,void*);  /* test/IGAErrNorm.c System (dof=4) */
 int orc_form_elasticity(OrcPoint*,double*,double*,void*);  /* demo/Elasticity3D.c System */
+int orc_form_elasticity_f(OrcPoint*,double*,double*,void*);  /* the same K with a body force; ctx: double[5] = {lambda, mu, fx, fy, fz} */
 int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ch_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ns_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);

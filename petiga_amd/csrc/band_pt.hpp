@@ -71,6 +71,7 @@ struct BandArgs {
   int first_touch, nelx, nely, fty_lo, fty_hi, fty_blocked;
   int wrap2;                         // axis 2 periodic and wrapped inside the rank (first-touch rule without clipping)
   double *pts;                       // element records of this launch: [pencil][element on axis 0][bpt_rec]
+  int prio_layers, rmw_prio;         // schedule switches (IGX_BAND_PRIO, IGX_BAND_RMW_PRIO): s_setprio 2 through a workgroup's first layers; s_setprio 3 through a read-add-write
   int debug, dbg_block;
   long long *dbg_buf;                // -DIGX_DEBUG builds, IGX_DEBUG_TIMING: cycle stamps [workgroup][wave][layer][6]
 };
@@ -433,6 +434,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
     const int li = li_lo + it, lay = lay_first + li;
     // the element that enters the window with the next layer: its slot was last read in layer li - 1, which every wave has left
     if (it + 1 < nlay) load_element(li + 1);
+    if (pa.prio_layers > 0) { if (it < pa.prio_layers) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
     const int c0 = __builtin_amdgcn_readfirstlane(Lcnt[it]);
     const int held = alias0 ? P + 1 : (min(li, pa.nel0 - 1) - max(li - P, 0) + 1);
     const bool bcrow = bc.any && (bc.on[2] || bc.on[3] || bc.on[4] || bc.on[5] || (lay >= bc.wlo - P && lay <= bc.wlo + P) || (lay >= bc.whi - P && lay <= bc.whi + P));
@@ -466,6 +468,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       if (kDebug && pa.dbg_buf) stamp[1 + 2 * half] = __builtin_readcyclecounter();
       if (kDebug && (pa.debug & 1)) continue;
       // ---- read-add-write of the lane's four blocks (r = row slot on axis 2): a block is one 128-byte line
+      if (pa.rmw_prio) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
       for (int r = 0; r < NB; ++r) {
         if (!lane_ok) continue;
@@ -491,6 +494,7 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
 #pragma unroll
         for (int k = 0; k < BS / 2; ++k) { bp_d2_t w; w[0] = oldv[k][0] + K[2 * k]; w[1] = oldv[k][1] + K[2 * k + 1]; *reinterpret_cast<bp_d2_t *>(gp + 2 * k) = w; }
       }
+      if (pa.rmw_prio) { if (it < pa.prio_layers) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
       if (kDebug && pa.dbg_buf) stamp[2 + 2 * half] = __builtin_readcyclecounter();
     }
     if (kDebug && pa.dbg_buf) stamp[5] = __builtin_readcyclecounter();
@@ -590,6 +594,7 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
       if (s.env.nseg > 0) nseg = std::max((NL + max_len - 1) / max_len, std::min(s.env.nseg, std::max(1, NL / 2)));
       pa.seg_len = (NL + nseg - 1) / nseg; pa.nseg = (NL + pa.seg_len - 1) / pa.seg_len;
       pa.debug = s.env.debug_feature; pa.dbg_block = 7 + s.env.debug_noflush;
+      pa.prio_layers = s.env.band_prio; pa.rmw_prio = s.env.band_rmw_prio;
       const size_t need = (size_t)pencils * pa.nel0 * rec * sizeof(double);
       if (pool_alloc(reinterpret_cast<void **>(&pa.pts), need, stream) != hipSuccess) { err = "device allocation of the point records failed"; rc = IGX_ERR_MEM; return; }
       const long long nelem = pencils * pa.nel0;

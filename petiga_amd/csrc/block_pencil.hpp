@@ -535,7 +535,7 @@ static int launch_boundary_loads_fields(const Space &s, const OutDev &out, hipSt
 // constant-coefficient form with F = 0, axis 0 walkable (one new node layer per element, not wrapped inside the rank), axes 1, 2
 // with consecutive column positions (not wrapped inside the rank).
 template <class Form> constexpr bool bp_form_ok() {
-  return mat_pair_mask_of<Form>::v != 0ull && vec_zero_of<Form>::v && Form::DOF <= 3 && Form::DOF >= 2 && shape_order_of<Form>::v < 2 && Form::ORDER < 2 &&
+  return mat_pair_mask_of<Form>::v != 0ull && Form::DOF <= 3 && Form::DOF >= 2 && shape_order_of<Form>::v < 2 && Form::ORDER < 2 &&
          !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0;
 }
 static bool block_pencil_covers_space(const Space &s, const SpaceDev &S, const OutDev &out, int dof) {
@@ -568,6 +568,21 @@ static int try_block_pencil(const Space &s, const SpaceDev &S, const ParamsDev &
   if constexpr (!bp_form_ok<Form>()) return 0;
   else {
   if (!block_pencil_covers<Form>(s, S, out)) return 0;
+  if constexpr (!vec_zero_of<Form>::v) {
+    // F != 0 (a body force): the form's own vec() comes from a vector-only pass ahead of the band rows -- sum factorisation, 64 evaluations
+    // of vec() per element -- with the fixed rows left at zero; the band-row kernel then ADDS the Dirichlet lifting and value x
+    // multiplicity of IGAElementFixSystem as it does for F = 0 (src/petigaelem.c:1377-1387 is linear in F_e).
+    if (out.op == OP_SYSTEM) {
+#ifdef IGX_HAVE_VEC_SUMFACT
+      OutDev ov = out; ov.vec_mode = 2; ov.op = OP_VECTOR; ov.val = nullptr; ov.browptr = nullptr;
+      bool vdone = false; int vl = 0; std::string vk;
+      if (int rc = try_vec_sumfact<Form>(s, S, prm, ov, stream, vk, vl, vdone)) { err = "vec_sumfact kernel launch failed"; return rc; }
+      if (!vdone) return 0;
+#else
+      return 0;
+#endif
+    }
+  }
   return block_pencil_run(s, S, out, stream, kname, launches, err, done, dom, zero_matrix, slab_done, Form::DOF, fm_popcount(mat_pair_mask_of<Form>::v),
                           [&](bool sys, unsigned grid, size_t lds, const BlockPencilArgs &pa) {
                             auto kern = sys ? block_pencil<Form, 3, true> : block_pencil<Form, 3, false>;

@@ -1024,6 +1024,11 @@ static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
       if constexpr (DIM == 3) return launch_generic<FormElasticity, 3>(g, S, out);
       else return fail(IGX_ERR_ARG_WRONG, "Elasticity3D form needs dim = 3");
     } else return IGX_NOT_MINE;
+  case IGX_FORM_ELASTICITY_F:
+    if constexpr (GROUP < 0 || GROUP == 1) {
+      if constexpr (DIM == 3) return launch_generic<FormElasticityF, 3>(g, S, out);
+      else return fail(IGX_ERR_ARG_WRONG, "Elasticity3D form needs dim = 3");
+    } else return IGX_NOT_MINE;
   case IGX_FORM_CAHNHILLIARD:
     if constexpr (GROUP < 0 || GROUP == 2) {
       if constexpr (DIM >= 2) return launch_generic<FormCahnHilliard<DIM>, DIM>(g, S, out);

@@ -133,6 +133,34 @@ struct FormElasticity {
   }
   static __device__ __forceinline__ void vec(const PtView &, const double *, double *R) { R[0] = 0; R[1] = 0; R[2] = 0; }
 };
+// ... with a body force: the same K, F[a][i] = N_a f_i (the callback path of the reference is uniform in what a System callback puts
+// into F: demo/Elasticity3D.c:43-45 writes zeros, src/petigapoint.c:427-450 adds whatever it finds); params {lambda, mu, fx, fy, fz}
+struct FormElasticityF : FormElasticity {
+  static constexpr bool VEC_ZERO = false;
+  static constexpr unsigned VEC_TEST_MASK = 1u;      // vec() reads N only
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * p.prm[2]; R[1] = Na[0] * p.prm[3]; R[2] = Na[0] * p.prm[4]; }
+};
+
+// The VECTOR of IGAComputeSystem of a linear form without its K_e (the band-row kernels never hold one): per element
+//   F_e = vec - sum_k K_e[:, k] v_k over the fixed dofs k,  F_e[k] = v_k          (IGAElementFixSystem, src/petigaelem.c:1377-1387)
+// and mat() is linear in N_b, so sum_k K_e[a][k] v_k = sum_q JW mat(p, N_a, u_D) with u_D the field that holds v on the element's fixed
+// dofs and 0 elsewhere -- a vector-only pass (vec_sumfact.hpp, OutDev::vec_mode 1: the state is u_D, a fixed row takes v).
+template <class Form> struct SystemVectorOf {
+  static constexpr int DOF = Form::DOF, ORDER = Form::ORDER;
+  static constexpr unsigned NEED = Form::NEED | NEED_U | NEED_GU;
+  static_assert(Form::ORDER < 2, "first-order forms (the lifting reads u_D and its gradient)");
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    Form::vec(p, Na, R);
+#pragma unroll
+    for (int j = 0; j < DOF; ++j) {      // column j of the blocks, the trial function's features replaced by those of field j of u_D
+      const double Nb[4] = {p.u[j], p.gu[j * 3 + 0], p.gu[j * 3 + 1], p.gu[j * 3 + 2]};
+      double T[DOF * DOF];
+      Form::mat(p, Na, Nb, T);
+#pragma unroll
+      for (int i = 0; i < DOF; ++i) R[i] -= T[i * DOF + j];
+    }
+  }
+};
 
 // demo/CahnHilliard3D.c:11-16,39-53,55-179 (Residual / Tangent); 2-D: demo/CahnHilliard2D.c.
 // params {theta, alpha, cbar, L0, lambda, tau}; L0 <= 0 selects the 2-D demo's 3*alpha scaling.

@@ -42,6 +42,7 @@ struct EnvSwitches {
   int vec_sumfact = 1;       // IGX_VEC_SUMFACT=0: the vector-only drivers stay on the feature kernel (vec_sumfact.hpp)
   int free_run = -1;         // IGX_FREE_RUN=0/1: the pencil walk with / without its s_barrier ping-pong (-1: the launcher's choice)
   int p2_pack = 1;           // IGX_P2_PACK=0: the p = 2 walks keep one tile per pair of node layers (round 4) instead of the packed tiles
+  int band_prio = 0, band_rmw_prio = 0;      // IGX_BAND_PRIO=k: band_pt raises the priority of a workgroup's first k layers; IGX_BAND_RMW_PRIO=1: ... of its read-add-writes
   int fuse_resid = 0;        // IGX_FUSE_RESID=1: IGXComputeIFunctionIJacobian takes the fused walk (state_pencil_kr) where it exists; default: the two
                              // drivers one after the other -- measured in round 6: the fused launch costs 2.5 ms more than the Tangent's, the
                              // Residual's own pass 2.1 ms per launch
@@ -190,6 +191,8 @@ struct OutDev {
   long long *dbg;          // experiment: s_memtime stamps of workgroup 0 per phase (IGX_DEBUG_FEATURE & 8)
   int ft2_lo, ft2_hi, ft2_blocked;   // feature kernel, assembly in two passes over axis 2 (upper face first): first-touch rule of the pass; ft2_hi = 0: one pass
   int64_t elem_base;       // OP_SCALAR: index of this launch's first element in the per-element partial sums (vec)
+  int vec_mode;            // vec_sumfact as a part of IGAComputeSystem next to a band-row kernel: 1 the whole vector (lifting of the Dirichlet values through
+                           // SystemVectorOf<Form>, a fixed row takes its value), 2 the form's vec() alone with the fixed rows left at 0 (block_pencil lifts itself)
 };
 
 constexpr int MAXPARAM = 8;

@@ -186,7 +186,8 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   const int il[3] = {i0, i1, i2};
   const int op = out.op;
   const bool geo = GEO && S.nsd > 0, rat = GEO && S.rational != 0;
-  const bool useU = out.U != nullptr, useV = out.V != nullptr;
+  const bool sysvec = out.vec_mode == 1, sysbody = out.vec_mode == 2;      // parts of a System assembly (igx.hpp: OutDev::vec_mode)
+  const bool readU = out.U != nullptr && !sysvec && !sysbody, useU = readU || sysvec, useV = out.V != nullptr && !sysvec && !sysbody;
   int nb[3], nq[3], off[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) { nb[d] = S.ax[d].nen; nq[d] = S.ax[d].nqp; off[d] = S.ax[d].off[el[d]]; }
@@ -208,8 +209,8 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
     wgt = rat ? S.W[g] : 1.0;
     if (geo) for (int c = 0; c < 3; ++c) Xw[c] = S.X[g * 3 + c] * wgt;
 #pragma unroll
-    for (int f = 0; f < DOF; ++f) { if (useU) Uv[f] = out.U[row * DOF + f]; if (useV) Vv[f] = out.V[row * DOF + f]; }
-    if (op != OP_VECTOR) {
+    for (int f = 0; f < DOF; ++f) { if (readU) Uv[f] = out.U[row * DOF + f]; if (useV) Vv[f] = out.V[row * DOF + f]; }
+    if (op != OP_VECTOR || sysvec || sysbody) {
       for (int d = 0; d < 3; ++d) {
         const AxisDev &A = S.ax[d];
         if (A.periodic) continue;
@@ -417,7 +418,9 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
     double F = SECOND_T ? vs_backward<2, KMASK, NS>(Cq[f], buf, tab0, tab1, tab2, lane, VL) : vs_backward<1, KMASK, NS>(Cq[f], buf, tab0, tab1, tab2, lane, VL);
     F *= wgt;
     if (isnode) {
-      if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
+      if (fixed[f] && sysvec) F = ufix[f];                       // IGAElementFixSystem: F_e[k] = v
+      else if (fixed[f] && sysbody) F = 0.0;                     // (the band-row kernel that follows adds v per element itself)
+      else if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
       if (F != 0.0) out.vec[row * DOF + f] += F;
     }
   }
@@ -432,11 +435,11 @@ static bool vec_sumfact_covers(const Space &s, const OutDev &out) {
   if constexpr (nscalar_of<Form>::v > 0 || has_boundary_of<Form>::v) return false;
   else {
     if (s.env.vec_sumfact == 0) return false;
-    if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION) return false;
+    if (out.op != OP_VECTOR && out.op != OP_FUNCTION && out.op != OP_IFUNCTION && !out.vec_mode) return false;
     if (s.dim != 3 || s.dof != Form::DOF || (s.nsd != 0 && s.nsd != 3)) return false;
     for (int d = 0; d < 3; ++d) {
       if (s.basis[d].nen > 4 || s.basis[d].nqp > 4) return false;
-      for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && s.load[d][sd].count) return false; }
+      for (int sd = 0; sd < 2; ++sd) { if (s.visit[d][sd]) return false; if (out.op != OP_VECTOR && !out.vec_mode && s.load[d][sd].count) return false; }      // (vec_mode: the band-row launchers add the loads themselves)
     }
     return true;
   }

@@ -78,6 +78,39 @@ def test_elasticity_vs_oracle(N, bc, nseg, monkeypatch):
     compare_mats(A, A_o2, 1e-12)
 
 
+@pytest.mark.parametrize("N,bc,nseg", [((8, 4, 4), "demo", 0), ((9, 5, 6), "all", 0), ((8, 4, 9), "partial", 0), ((13, 5, 4), "none", 0), ((16, 4, 4), "all", 3)])
+def test_elasticity_with_a_body_force(N, bc, nseg, monkeypatch):
+    """F != 0 on the band-row kernel (round 6: the review's third request): demo/Elasticity3D.c's K with F[a][i] = N_a f_i.  The form's
+    vec() comes from a sum-factorised vector pass ahead of the band rows (vec_sumfact, fixed rows left at zero); the band-row
+    kernel adds the Dirichlet lifting and value x multiplicity of IGAElementFixSystem (src/petigaelem.c:1377-1387) as for F = 0."""
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 3, 3, list(N))
+    _bc((orc, eng), bc, 3)
+    prm = (2.5, 0.7, 0.3, -1.25, 2.0)
+    A_o, b_o = orc.compute_system("orc_form_elasticity_f", (C.c_double * 5)(*prm))
+    eng.set_form("elasticity_f", prm)
+    eng.set_kernel(4)
+    A, b = eng.create_mat(), eng.create_vec()
+    _poison(A)
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "block_pencil" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(A, A_o, 1e-12)
+    _close(b.get(), b_o, 1e-12)
+    eng.set_kernel(0)               # the automatic choice takes the same path
+    A2, b2 = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A2, b2)
+    eng.synchronize()
+    assert "block_pencil" in eng.kernel_name(), eng.kernel_name()
+    assert np.array_equal(b2.get(), b.get())
+    eng.compute_vector(b2)          # IGAComputeVector: no fix-up at all
+    eng.synchronize()
+    orc.clear_boundary()
+    _, b_o2 = orc.compute_system("orc_form_elasticity_f", (C.c_double * 5)(*prm))
+    _close(b2.get(), b_o2, 1e-12)
+
+
 @pytest.mark.parametrize("N,bc,nseg", [((8, 4, 4), "demo", 0), ((9, 5, 6), "all", 0), ((11, 4, 5), "override", 3)])
 def test_elasticity_with_a_fix_table(N, bc, nseg, monkeypatch):
     """IGASetFixTable (src/petigaform.c:273-298): the Dirichlet values of the fixed dofs come from a vector, per node and field.  The
