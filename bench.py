@@ -255,7 +255,7 @@ def _state(vec_like_mat, sizes, dof, amp, base):
     return out.reshape(-1)
 
 
-def build_problem(P, name, size, degree, world, rank, kernel, geometry, source=False):
+def build_problem(P, name, size, degree, world, rank, kernel, geometry, source=False, body_force=False):
     import numpy as np
     w = WORKLOADS[name]
     dof, p = w["dof"], (degree if name == "poisson" else w["p"])
@@ -287,7 +287,10 @@ def build_problem(P, name, size, degree, world, rank, kernel, geometry, source=F
     if source:
         g.set_form_source(USER_POISSON_SOURCE, "UserPoisson", (1.0,))
     else:
-        g.set_form(w["form"], params)
+        if body_force and name == "elasticity":
+            g.set_form("elasticity_f", tuple(params) + (0.3, -1.25, 2.0))
+        else:
+            g.set_form(w["form"], params)
     g.set_kernel(kernel)
     A, b = g.create_mat(), g.create_vec()
     U = V = None
@@ -346,6 +349,7 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 MFMA pencil, 3 feature")
     ap.add_argument("--geometry", action="store_true", help="mapped rational geometry (default for nsvms)")
     ap.add_argument("--source", action="store_true", help="poisson only: the form is given as run-time source (IGXSetFormSource), not as the built-in struct")
+    ap.add_argument("--body-force", action="store_true", help="elasticity only: the same K with F[a][i] = N_a f_i (IGX_FORM_ELASTICITY_F); the CPU baseline keeps the demo's form")
     ap.add_argument("--two-calls", action="store_true", help="tangent workloads: IFunction and IJacobian as two calls (two passes of the element loop) instead of IGXComputeIFunctionIJacobian")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the N>1 checksum against a single-rank assembly on rank 0")
@@ -403,7 +407,7 @@ def main():
     import petiga_amd as P
     from petiga_amd import exchange
     assert not args.source or args.form == "poisson", "--source is the metric configuration's form given as source"
-    g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry, args.source)
+    g, A, b, U, V, p = build_problem(P, args.form, size, args.degree, world, rank, args.kernel, geometry, args.source, args.body_force)
     # the library's own exchange: RCCL (or the gloo test transport).  IGX_BENCH_TRANSPORT=rccl keeps the library on its grouped
     # ncclSend / ncclRecv path while torch.distributed stays on gloo: with IGX_RCCL_LIB naming tests/fake_rccl's double, N ranks
     # that share one GPU run the product transport's schedule (tests/test_gpu_bench_ranks.py).
@@ -541,7 +545,7 @@ def main():
                 cs_n = cs
             else:           # every rank assembles its share of the reduced mesh through the same exchange
                 A = b = None            # (their memory goes back before the reduced meshes are created)
-                gk, Ak, bk, Uk, Vk, _ = build_problem(P, args.form, csize, args.degree, world, rank, args.kernel, geometry, args.source)
+                gk, Ak, bk, Uk, Vk, _ = build_problem(P, args.form, csize, args.degree, world, rank, args.kernel, geometry, args.source, args.body_force)
                 exchange.init_comm(gk, transport="rccl" if transport == "rccl" else "host")
                 assemble(gk, Ak, bk, Uk, Vk)
                 gk.synchronize()
@@ -550,7 +554,7 @@ def main():
                 cs_n = tk.cpu().numpy()
                 Ak = bk = gk = None
             if rank == 0:
-                g1, A1, b1, U1, V1, _ = build_problem(P, args.form, csize, args.degree, 1, 0, args.kernel, geometry, args.source)
+                g1, A1, b1, U1, V1, _ = build_problem(P, args.form, csize, args.degree, 1, 0, args.kernel, geometry, args.source, args.body_force)
                 assemble(g1, A1, b1, U1, V1)
                 g1.synchronize()
                 ref = g1.checksum(A1, b1)

@@ -57,8 +57,20 @@ template <class Form> __host__ __device__ constexpr unsigned bpt_acc_mask(int n)
 // gradient (n, d_0, d_1, d_2) of w_a N_a to the physical ones: R = g0 n, d_i R = h_i n + sum_b Gm[i][b] d_b, with g0 = 1/W,
 // Gm[i][b] = du_b/dx_i / W, h_i = -sum_b Gm[i][b] dW_b/W (Rationalize + ShapeFunctions, src/petigarat.f90.in:3-57,
 // petigamapshf.f90.in:30-58, in one 4 x 4 matrix) | u | the form's point coefficients
-template <class F, class = void> struct band_ncoef_of { static constexpr int v = F::NCOEF; };
+template <class F, class = void> struct band_ncoef_base { static constexpr int v = 0; };      // (a constant-coefficient form has none)
+template <class F> struct band_ncoef_base<F, decltype((void)F::NCOEF)> { static constexpr int v = F::NCOEF; };
+template <class F, class = void> struct band_ncoef_of { static constexpr int v = band_ncoef_base<F>::v; };
 template <class F> struct band_ncoef_of<F, decltype((void)F::BAND_NCOEF)> { static constexpr int v = F::BAND_NCOEF; };      // (band_coef instead of point_coef)
+// Round 6: constant-coefficient forms with 2 or 3 fields (MAT_PAIR_MASK: demo/Elasticity3D.c) on a MAPPED geometry.  block_pencil.hpp
+// builds their Gram operands from the three 1-D rows -- identity geometry only; here the operands are the PHYSICAL features of the
+// point records, the accumulators are the Gram pairs M_fg = sum_q JW d_f N_a d_g N_b (one MFMA per pair and k-step) and the
+// coefficient transform K^{ij} = sum_fg C^{ij}_fg M_fg is block_pencil's own (bp_transform), lane-local at the end of a tile's
+// products; a lane then holds whole blocks of dof^2 values and adds them to the matrix itself, 72 contiguous bytes at dof 3.
+#ifndef BPT_PREFETCH
+#define BPT_PREFETCH 1
+#endif
+template <class Form> constexpr bool bpt_pairs() { return mat_pair_mask_of<Form>::v != 0ull && !has_point_coef<Form>::v; }
+template <class Form> constexpr int bpt_nacc() { if constexpr (bpt_pairs<Form>()) return bp_nacc<Form>(); else return band_nacc_of<Form>::v; }
 template <class F, class = void> struct band_neg5_of { static constexpr bool v = false; };
 template <class F> struct band_neg5_of<F, decltype((void)F::BAND_NEG_FEAT5)> { static constexpr bool v = F::BAND_NEG_FEAT5; };
 template <class Form> constexpr int bpt_npd() { return 1 + 13 + Form::DOF + band_ncoef_of<Form>::v; }
@@ -214,7 +226,7 @@ band_points(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       for (int i = 0; i < 3; ++i) G[a * 3 + i] = E[a][i] / L3[a];
     PtView p; p.x = nullptr; p.u = u; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = G; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
     p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
-    if constexpr (band_nacc_of<Form>::own) Form::band_coef(p, rec + 14 + DOF); else Form::point_coef(p, rec + 14 + DOF);
+    if constexpr (band_nacc_of<Form>::own) Form::band_coef(p, rec + 14 + DOF); else if constexpr (has_point_coef<Form>::v) Form::point_coef(p, rec + 14 + DOF);
   }
   double *dst = pa.pts + (size_t)elem * REC;
 #pragma unroll
@@ -241,8 +253,8 @@ __device__ __forceinline__ int bpt_slot(int eu) { const int m = eu % 5; return m
 
 // the MFMAs of one test feature F at one k-step: the trial-side values of the accumulators whose mask names F
 template <class Form, int F>
-__device__ __forceinline__ void bpt_feature(d4_t (&acc)[band_nacc_of<Form>::v], const double *cf, const PtView &p, const double (&na)[5], const double (&nb)[4]) {
-  constexpr int NACC = band_nacc_of<Form>::v;
+__device__ __forceinline__ void bpt_feature(d4_t (&acc)[bpt_nacc<Form>()], const double *cf, const PtView &p, const double (&na)[5], const double (&nb)[4]) {
+  constexpr int NACC = bpt_nacc<Form>();
   double T[NACC];
   if constexpr (band_nacc_of<Form>::own) Form::template mat_acc<F>(cf, p, nb, T);
   else if constexpr (band_nfeat_of<Form>::v == 5) Form::template mat_unit5<F>(cf, p, nb, T);
@@ -262,7 +274,7 @@ __device__ __forceinline__ void bpt_feature(d4_t (&acc)[band_nacc_of<Form>::v], 
 
 // one tile product: acc[n] += A_F(e, ta)^T B^n_F(e, tb) over the element's 64 points; k-step (qw, qy), k slot qx = lane >> 4
 template <class Form, bool GEO, bool RAT, int NB>
-__device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
+__device__ __forceinline__ void bpt_product(d4_t (&acc)[bpt_nacc<Form>()], const double *rec, int ta, int tb, const double (&uxy)[4][3], int lane, const double *prm, double shift) {
   constexpr int DOF = Form::DOF, NPD = bpt_npd<Form>();
   const double *zt = rec + 64 * NPD, *wts = zt + 32;
   const int qx = lane >> 4;
@@ -299,6 +311,16 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
       na[4] = 0.0;
       PtView p; p.x = nullptr; p.u = pd + 14; p.ut = nullptr; p.gu = nullptr; p.hu = nullptr; p.G = nullptr; p.prm = prm; p.shift = shift; p.t = 0.0;
       p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
+      if constexpr (bpt_pairs<Form>()) {      // the Gram pairs of a constant-coefficient form: one MFMA per (test feature f, trial feature g)
+        constexpr unsigned long long PAIRS = mat_pair_mask_of<Form>::v;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            if (!((PAIRS >> (f * 8 + g)) & 1ull)) continue;
+            acc[fm_pair_index(PAIRS, f, g)] = __builtin_amdgcn_mfma_f64_16x16x4f64(na[f], nb[g], acc[fm_pair_index(PAIRS, f, g)], 0, 0, 0);
+          }
+      } else {
       const double *cf = pd + 14 + DOF;
       bpt_feature<Form, 0>(acc, cf, p, na, nb);
       bpt_feature<Form, 1>(acc, cf, p, na, nb);
@@ -309,6 +331,7 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
         else na[4] = pd[14] * na[1] + pd[15] * na[2] + pd[16] * na[3];
         bpt_feature<Form, 4>(acc, cf, p, na, nb);
       }
+      }
     }
   }
 }
@@ -316,9 +339,11 @@ __device__ __forceinline__ void bpt_product(d4_t (&acc)[band_nacc_of<Form>::v], 
 template <class Form, bool GEO, bool RAT, int P = 3>
 __global__ void __launch_bounds__(256, 2)
 band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
-  constexpr int NB = P + 1, BW = 2 * P + 1, DOF = Form::DOF, BS = DOF * DOF, NACC = band_nacc_of<Form>::v, REC = bpt_rec<Form>();
+  constexpr int NB = P + 1, BW = 2 * P + 1, DOF = Form::DOF, BS = DOF * DOF, NACC = bpt_nacc<Form>(), REC = bpt_rec<Form>();
+  constexpr bool PAIRF = bpt_pairs<Form>();
   static_assert(P == 2 || P == 3, "degrees 2 and 3 (p = 2 in the 4 x 4 tile slots, zero padded)");
-  static_assert(DOF == 4 && has_point_coef<Form>::v, "128-byte blocks; the form separates its point coefficients (NCOEF, point_coef, mat_c)");
+  static_assert((DOF == 4 && has_point_coef<Form>::v) || (PAIRF && (DOF == 2 || DOF == 3)),
+                "128-byte blocks of a form that separates its point coefficients (NCOEF, point_coef, mat_c), or the Gram pairs of a constant-coefficient form with 2 or 3 fields");
   static_assert(NACC >= BS && NACC <= 20, "accumulators: the block entries first, shared parts behind them");
   extern __shared__ __attribute__((aligned(16))) double bpt_sm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -450,6 +475,23 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
       if (d == NONE) continue;
       const int p0d = __builtin_amdgcn_readfirstlane(LP[it * 8 + d + P]);
       if (p0d < 0) continue;          // the column layer does not exist (ends of a non-periodic axis)
+      // The Gram pairs of a constant-coefficient form are 9 MFMAs per k-step, not 34: a layer's products (37k cycles of issue per
+      // wave) are no longer than its two read-add-writes and its barrier, and the old values' round trip to memory would be a third of
+      // the layer.  So the loads of a band tile's old blocks go out BEFORE its products (36 doubles per lane at dof 3: the accumulators
+      // are 72 registers, not 136) and are consumed behind them.
+      constexpr bool PREF = PAIRF && BPT_PREFETCH;
+      double pre[PREF ? NB : 1][PREF ? BS : 1];
+      if constexpr (PREF) {
+#pragma unroll
+        for (int r = 0; r < NB; ++r) {
+          const long long pos = pbase[r] + (long long)pcc[r] * ps0 + (long long)ppp[r] * c0 + p0d;
+          const double *gp = out.val + pos * BS;
+          const bool ld = lane_ok && !((ftm >> r) & 1u) && !(kDebug && (pa.debug & 1));
+#pragma unroll
+          for (int k = 0; k < BS / 2; ++k) { const d2u_t x = ld ? *reinterpret_cast<const d2u_t *>(gp + 2 * k) : (d2u_t){0.0, 0.0}; pre[r][2 * k] = x[0]; pre[r][2 * k + 1] = x[1]; }
+          if constexpr (BS & 1) pre[r][BS - 1] = ld ? gp[BS - 1] : 0.0;
+        }
+      }
       d4_t acc[NACC];
 #pragma unroll
       for (int n = 0; n < NACC; ++n) acc[n] = (d4_t){0, 0, 0, 0};
@@ -463,7 +505,12 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
           bpt_product<Form, GEO, RAT, NB>(acc, ring + bpt_slot(eu) * REC, ta, tb, uxy, lane, prm.v, out.shift);
         }
       }
-      if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc, prm.v);
+      if constexpr (PAIRF) {      // Gram sums -> blocks, in place (block_pencil.hpp: the form's constants C = mat(e_f, e_g))
+        PtView p0; p0.x = nullptr; p0.u = nullptr; p0.ut = nullptr; p0.gu = nullptr; p0.hu = nullptr; p0.G = nullptr; p0.prm = prm.v; p0.shift = out.shift; p0.t = out.t;
+        p0.normal = nullptr; p0.atboundary = 0; p0.boundary_id = -1;
+        bp_transform<Form>(acc, p0);
+      }
+      else if constexpr (band_nacc_of<Form>::own) Form::band_finish(acc, prm.v);
       else if constexpr (band_nfeat_of<Form>::v == 5) Form::template band_combine<0>(acc);
       if (kDebug && pa.dbg_buf) stamp[1 + 2 * half] = __builtin_readcyclecounter();
       if (kDebug && (pa.debug & 1)) continue;
@@ -475,9 +522,17 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
         const long long pos = pbase[r] + (long long)pcc[r] * ps0 + (long long)ppp[r] * c0 + p0d;
         double *gp = out.val + pos * BS;
         const bool first = (ftm >> r) & 1u;
-        bp_d2_t oldv[BS / 2];
+        // (a block of 9 values starts on an 8-byte boundary: d2u_t is the pair type without the 16-byte promise)
+        d2u_t oldv[BS / 2]; double oldl = 0.0;
+        if constexpr (PREF) {      // (read ahead of the products, above)
 #pragma unroll
-        for (int k = 0; k < BS / 2; ++k) oldv[k] = first ? (bp_d2_t){0.0, 0.0} : *reinterpret_cast<const bp_d2_t *>(gp + 2 * k);
+          for (int k = 0; k < BS / 2; ++k) { oldv[k][0] = pre[r][2 * k]; oldv[k][1] = pre[r][2 * k + 1]; }
+          if constexpr (BS & 1) oldl = pre[r][BS - 1];
+        } else {
+#pragma unroll
+        for (int k = 0; k < BS / 2; ++k) oldv[k] = first ? (d2u_t){0.0, 0.0} : *reinterpret_cast<const d2u_t *>(gp + 2 * k);
+        if constexpr (BS & 1) oldl = first ? 0.0 : gp[BS - 1];
+        }
         double K[BS];
 #pragma unroll
         for (int n = 0; n < BS; ++n) K[n] = acc[n][r];
@@ -492,7 +547,8 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
             }
         }
 #pragma unroll
-        for (int k = 0; k < BS / 2; ++k) { bp_d2_t w; w[0] = oldv[k][0] + K[2 * k]; w[1] = oldv[k][1] + K[2 * k + 1]; *reinterpret_cast<bp_d2_t *>(gp + 2 * k) = w; }
+        for (int k = 0; k < BS / 2; ++k) { d2u_t w; w[0] = oldv[k][0] + K[2 * k]; w[1] = oldv[k][1] + K[2 * k + 1]; *reinterpret_cast<d2u_t *>(gp + 2 * k) = w; }
+        if constexpr (BS & 1) gp[BS - 1] = oldl + K[BS - 1];
       }
       if (pa.rmw_prio) { if (it < pa.prio_layers) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0); }
       if (kDebug && pa.dbg_buf) stamp[2 + 2 * half] = __builtin_readcyclecounter();
@@ -520,12 +576,16 @@ band_pt(SpaceDev S, ParamsDev prm, OutDev out, BandArgs pa) {
 // ---- host side
 // the form qualifies (also evaluated inside a run-time module: rtc.hpp reads it back)
 template <class Form> constexpr bool bpt_form_ok() {
-  if constexpr (!has_point_coef<Form>::v) return false;
+  if constexpr (bpt_pairs<Form>())      // (round 6) the Gram pairs of a constant-coefficient form with 2 or 3 fields, first order
+    return (Form::DOF == 2 || Form::DOF == 3) && shape_order_of<Form>::v < 2 && Form::ORDER < 2 && !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0 &&
+           (mat_pair_mask_of<Form>::v >> 32) == 0ull && ((mat_pair_mask_of<Form>::v >> 4) & 0x0f0f0f0full) == 0ull && (mat_need_of<Form>::v & ~(NEED_U | NEED_G)) == 0u;
+  else if constexpr (!has_point_coef<Form>::v) return false;
   else return Form::DOF == 4 && shape_order_of<Form>::v < 2 && !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0 && mat_pair_mask_of<Form>::v == 0ull &&
               (mat_need_of<Form>::v & ~(NEED_U | NEED_G)) == 0u;
 }
 // MFMAs per k-step: one per (accumulator, test feature) product
 template <class Form> constexpr int bpt_products() {
+  if constexpr (bpt_pairs<Form>()) return fm_popcount(mat_pair_mask_of<Form>::v);
   int nm = 0;
   for (int n = 0; n < band_nacc_of<Form>::v; ++n) for (int f = 0; f < band_nfeat_of<Form>::v; ++f) if ((bpt_acc_mask<Form>(n) >> f) & 1u) nm++;
   return nm;
@@ -535,10 +595,12 @@ template <class Form> constexpr int bpt_products() {
 // 3-D, p = 3 with 4 Gauss points per axis, 4 fields, matrix-only drivers (Matrix / Jacobian / IJacobian); axis 0: one new node layer
 // per element (a periodic axis wrapped inside the rank is taken: layers and elements modulo nel, at least 2p+1 of them); axis 1 not
 // wrapped inside the rank; axis 2 either way; any geometry (none / polynomial / NURBS) of dimension 3
-static bool band_pt_covers_space(const Space &s, const SpaceDev &S, const OutDev &out) {
+// (dof 4: the matrix-only drivers; dof 2, 3 -- the Gram pairs of a constant-coefficient form -- also the System driver, whose vector comes from a
+//  pass of its own: try_band_pt)
+static bool band_pt_covers_space(const Space &s, const SpaceDev &S, const OutDev &out, int dof = 4, bool system_too = false) {
   if (s.env.block_pencil == 0) return false;
-  if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN) return false;
-  if (s.dim != 3 || s.dof != 4 || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
+  if (out.op != OP_MATRIX && out.op != OP_JACOBIAN && out.op != OP_IJACOBIAN && !(system_too && out.op == OP_SYSTEM)) return false;
+  if (s.dim != 3 || s.dof != dof || (s.nsd != 0 && s.nsd != 3) || S.fixtable) return false;
   const int p = s.axis[0].p;
   if (p != 2 && p != 3) return false;
   for (int d = 0; d < 3; ++d) {
@@ -554,7 +616,7 @@ static bool band_pt_covers_space(const Space &s, const SpaceDev &S, const OutDev
 template <class Form>
 static bool band_pt_covers(const Space &s, const SpaceDev &S, const OutDev &out) {
   if constexpr (!bpt_form_ok<Form>()) return false;
-  else return band_pt_covers_space(s, S, out);
+  else return band_pt_covers_space(s, S, out, Form::DOF, bpt_pairs<Form>());
 }
 
 // the launches of an assembly; `launch(points, grid, lds_bytes, geo, rat, degree, args)` starts band_points (points = true: 256 threads, four
@@ -671,7 +733,7 @@ static int band_pt_run(const Space &s, const SpaceDev &S, const OutDev &out, hip
   dom.name = std::string("band_pt<p=") + char('0' + P) + ">"; dom.launches = launches;
   dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2];
   dom.flop_per_element = 2048.0 * products * (P + 1) * (P + 1) * (P + 1) * (P + 1);      // (P+1)^2 tile products of (P+1)^2 k-steps per layer
-  kname = std::string("band_pt(mfma_f64_16x16x4,p=") + char('0' + P) + std::string(",dof=4,band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
+  kname = std::string("band_pt(mfma_f64_16x16x4,p=") + char('0' + P) + ",dof=" + char('0' + s.dof) + std::string(",band rows by node layer,point records,whole blocks per lane") + (geo ? (rat ? ",NURBS geometry)" : ",mapped geometry)") : ")");
   done = true;
   return 0;
 }
@@ -684,6 +746,24 @@ static int try_band_pt(const Space &s, const SpaceDev &S, const ParamsDev &prm, 
   else {
   if (!band_pt_covers<Form>(s, S, out)) return 0;
   if constexpr (band_nacc_of<Form>::own) { if (!Form::band_params_ok(prm.v)) return 0; }
+  if constexpr (bpt_pairs<Form>()) {
+    // The System driver of a constant-coefficient form: the matrix below (rows and columns of the fixed dofs emptied, the diagonal
+    // counting the elements: IGAElementFixSystem's K part is IGAElementFixJacobian's), the VECTOR from a sum-factorised pass of its
+    // own that never sees a K_e -- vec() minus the lifting of the Dirichlet values through the form's linearity in N_b, a fixed row
+    // taking its value once per element (forms.hpp: SystemVectorOf; vec_sumfact.hpp, OutDev::vec_mode 1).  Boundary loads on a mapped
+    // geometry stay with the feature kernel.
+    if (out.op == OP_SYSTEM) {
+      for (int d = 0; d < 3; ++d) for (int sd = 0; sd < 2; ++sd) if (s.load[d][sd].count) return 0;
+#ifdef IGX_HAVE_VEC_SUMFACT
+      OutDev ov = out; ov.vec_mode = 1; ov.op = OP_FUNCTION; ov.val = nullptr; ov.browptr = nullptr; ov.U = nullptr; ov.V = nullptr;
+      bool vdone = false; int vl = 0; std::string vk;
+      if (int rc = try_vec_sumfact<SystemVectorOf<Form>>(s, S, prm, ov, stream, vk, vl, vdone)) { err = "vec_sumfact kernel launch failed"; return rc; }
+      if (!vdone) return 0;
+#else
+      return 0;
+#endif
+    }
+  }
   return band_pt_run(s, S, out, stream, kname, launches, err, done, dom, zero_matrix, slab_done, bpt_rec<Form>(), bpt_products<Form>(),
                      [&](bool points, unsigned grid, size_t lds, bool geo, bool rat, int deg, const BandArgs &pa) {
                        if (points) { hipLaunchKernelGGL((deg == 2 ? band_points<Form, 2> : band_points<Form, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, pa); return; }

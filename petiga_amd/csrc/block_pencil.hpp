@@ -539,7 +539,7 @@ template <class Form> constexpr bool bp_form_ok() {
          !has_boundary_of<Form>::v && nscalar_of<Form>::v == 0;
 }
 static bool block_pencil_covers_space(const Space &s, const SpaceDev &S, const OutDev &out, int dof) {
-  if (s.env.block_pencil == 0) return false;
+  if (s.env.block_pencil == 0 || s.env.block_pencil == 2) return false;      // (2: band_pt only -- an experiment switch: the identity geometry through the point-record kernel)
   if (out.op != OP_SYSTEM && out.op != OP_MATRIX) return false;
   if (s.dim != 3 || s.dof != dof || s.nsd != 0) return false;      // (a fix table is read in the fix-up: bp_fixed)
   for (int d = 0; d < 3; ++d) {

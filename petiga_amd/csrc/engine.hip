@@ -22,8 +22,9 @@
 #include "block_pencil.hpp"      // (the host launcher, for run-time forms: rtc.hpp; no kernel of it is instantiated in this unit)
 #include "band_pt.hpp"           // (likewise: band_pt_run)
 #elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)
-#include "block_pencil.hpp"
+#include "band_pt.hpp"           // (includes block_pencil.hpp; the constant-coefficient multi-field forms take band_pt on a mapped geometry)
 #define IGX_HAVE_BLOCK_PENCIL 1
+#define IGX_HAVE_BAND_PT 1
 #elif IGX_TU_DIM == 3 && IGX_TU_GROUP == 2
 #include "band_pt.hpp"
 #define IGX_HAVE_BAND_PT 1
@@ -884,7 +885,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
     if (done) return 0;
   }
 #endif
-  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields and F = 0; band_pt: 3-D, p = 2 or 3, matrix-only driver of a 4-field form with separated point coefficients)");
+  if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields; band_pt: 3-D, p = 2 or 3, any geometry: matrix-only driver of a 4-field form with separated point coefficients, System / Matrix driver of a constant-coefficient form with 2 or 3 fields without boundary loads)");
   if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;

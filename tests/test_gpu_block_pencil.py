@@ -186,18 +186,83 @@ def test_automatic_choice_and_repeatability():
 
 
 def test_uncovered_cases_are_refused_not_rerouted():
-    """Forced kernel 4 on a case it does not cover (p = 2; a scalar form) fails with PETSC_ERR_SUP."""
+    """Forced kernel 4 on a case no band-row kernel covers (p = 4; boundary loads on a mapped geometry) fails with PETSC_ERR_SUP."""
     import petiga_amd as P
-    g = P.IGX(3, 3)
-    for i in range(3):
-        g.axis_uniform(i, 2, 8)
-    g.setup()
-    g.set_form("elasticity", (1.0, 1.0))
-    g.set_kernel(4)
-    A, b = g.create_mat(), g.create_vec()
-    with pytest.raises(P.IGXError) as e:
-        g.compute_system(A, b)
-    assert e.value.code == 56
+    from common import warped_geometry
+    for case in ("degree", "loads"):
+        orc, g = make_pair(3, 3, 4 if case == "degree" else 3, [8, 4, 4])
+        if case == "loads":
+            X, W = warped_geometry(orc, 3, seed=1, rational=True, amp=0.05)
+            g.set_geometry(X, W)
+            g.set_boundary_load(1, 1, 0, 1.0)
+        g.set_form("elasticity", (1.0, 1.0))
+        g.set_kernel(4)
+        A, b = g.create_mat(), g.create_vec()
+        with pytest.raises(P.IGXError) as e:
+            g.compute_system(A, b)
+        assert e.value.code == 56
+
+
+@pytest.mark.parametrize("form,dof,N,geo,bc,p", [
+    ("elasticity", 3, (8, 4, 4), "nurbs", "demo", 3),          # demo/Elasticity3D.c on a NURBS patch: the canonical IGA case
+    ("elasticity", 3, (9, 5, 4), "poly", "all", 3),            # every face, every field fixed: the lifting through SystemVectorOf
+    ("elasticity", 3, (10, 4, 5), "nurbs", "override", 3),
+    ("elasticity_f", 3, (8, 5, 4), "nurbs", "all", 3),         # ... with a body force
+    ("elasticity_f", 3, (9, 4, 4), "none", "demo", 3),         # (the identity geometry through the same kernel: IGX_BLOCK_PENCIL=... not needed, kernel 4 + no block pencil below)
+    ("mass", 2, (8, 4, 5), "nurbs", "demo2", 3),               # two fields, F = N: vec() and the lifting in one vector pass
+    ("elasticity", 3, (9, 4, 5), "nurbs", "demo", 2),          # p = 2 (on request: the 27 functions in 4 x 4 x 4 tile slots)
+])
+def test_constant_coefficient_forms_on_a_mapped_geometry(form, dof, N, geo, bc, p, monkeypatch):
+    """Round 6 (asked for in rounds 3, 4, 5): 2- and 3-field constant-coefficient forms off the identity geometry take a band-row
+    kernel -- band_pt's point records and physical operands, the Gram pairs as accumulators, block_pencil's coefficient transform,
+    whole blocks of dof^2 values per lane -- instead of the feature kernel.  The System driver's vector comes from a sum-factorised
+    pass that never sees a K_e (SystemVectorOf: vec() minus the lifting of the Dirichlet values; a fixed row takes its value per
+    element).  Engine vs oracle: pattern bit-exact, values to 2e-11 of max|K| over the free rows (mapped geometry)."""
+    from common import warped_geometry
+    if geo == "none":
+        monkeypatch.setenv("IGX_BLOCK_PENCIL", "2")      # (2: band_pt only -- the identity geometry is block_pencil's otherwise)
+    orc, eng = make_pair(3, dof, p, list(N))
+    if geo != "none":
+        X, W = warped_geometry(orc, 3, seed=4, rational=(geo == "nurbs"), amp=0.07)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    if bc == "demo2":
+        for g in (orc, eng):
+            g.set_boundary_value(0, 0, 0, 0.5); g.set_boundary_value(0, 0, 1, -0.25); g.set_boundary_value(2, 1, 1, 1.5)
+    else:
+        _bc((orc, eng), bc, dof)
+    if form == "elasticity":
+        octx, prm, oname = O.ElasticityCtx(2.5, 0.7), (2.5, 0.7), "orc_form_elasticity"
+    elif form == "elasticity_f":
+        prm = (2.5, 0.7, 0.3, -1.25, 2.0); octx, oname = (C.c_double * 5)(*prm), "orc_form_elasticity_f"
+    else:
+        octx, prm, oname = None, (), "orc_form_mass"
+    A_o, b_o = orc.compute_system(oname, octx)
+    eng.set_form(form, prm)
+    eng.set_kernel(4)
+    A, b = eng.create_mat(), eng.create_vec()
+    _poison(A)
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "band_pt" in eng.kernel_name() and "dof=%d" % dof in eng.kernel_name(), eng.kernel_name()
+    tol = 1e-12 if geo == "none" else 2e-11
+    compare_mats(A, A_o, tol)
+    _close(b.get(), b_o, tol)
+    if p == 3 and geo != "none":      # the automatic choice takes it too
+        eng.set_kernel(0)
+        A2, b2 = eng.create_mat(), eng.create_vec()
+        eng.compute_system(A2, b2)
+        eng.synchronize()
+        assert "band_pt" in eng.kernel_name(), eng.kernel_name()
+        assert np.array_equal(A2.host(True), A.host(True)) and np.array_equal(b2.get(), b.get())
+    # Matrix driver: no fix-up
+    orc.clear_boundary()
+    A_o2, _ = orc.compute_system(oname, octx)
+    _poison(A)
+    eng.set_kernel(4)
+    eng.compute_matrix(A)
+    eng.synchronize()
+    assert "band_pt" in eng.kernel_name()
+    compare_mats(A, A_o2, tol)
 
 
 def test_matches_feature_kernel_on_a_larger_mesh(monkeypatch):
