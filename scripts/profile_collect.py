@@ -18,9 +18,9 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ONLY = set(sys.argv[2:])
 SRC, DST = "gpurun_out/prof", "profiles"
-SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96, "cahnhilliard_nurbs": 128}
-KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil"}
-FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson", "cahnhilliard_nurbs": "cahnhilliard"}
+SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96, "cahnhilliard_nurbs": 128, "elasticity_nurbs": 64}
+KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil", "elasticity_nurbs": "band_pt<"}
+FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson", "cahnhilliard_nurbs": "cahnhilliard", "elasticity_nurbs": "elasticity"}
 
 
 def pmc(dirs):
@@ -41,7 +41,7 @@ def write_pmc(path, agg):
 
 
 configs = []
-for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "cahnhilliard", "nsvms", "cahnhilliard_nurbs"):
+for form in ("poisson", "poisson_p2", "poisson_p2_nurbs", "elasticity", "elasticity_nurbs", "cahnhilliard", "nsvms", "cahnhilliard_nurbs"):
     lf = "%s/line_%s.json" % (SRC, form)
     if ONLY and form not in ONLY:
         continue

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the evidence behind bench.py's lines on the GPU box (run through gpurun from the repo root), round 4:
+# Collects the evidence behind bench.py's lines on the GPU box (run through gpurun from the repo root), rounds 4-6:
 #   for each workload tag (poisson = the metric; poisson_p2 = config 2; poisson_p2_nurbs = config 2 on the bench's NURBS map;
 #   elasticity, cahnhilliard, nsvms = configs 3, 4, 5; cahnhilliard_nurbs = config 4's forms at 128^3 on the bench's NURBS map; TAGS="..."
 #   runs a subset and skips the secondary timings):
@@ -11,13 +11,14 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 [ -n "$TAGS" ] && ONLY_TAGS=1
-TAGS="${TAGS:-poisson poisson_p2 poisson_p2_nurbs elasticity cahnhilliard nsvms cahnhilliard_nurbs}"
+TAGS="${TAGS:-poisson poisson_p2 poisson_p2_nurbs elasticity elasticity_nurbs cahnhilliard nsvms cahnhilliard_nurbs}"
 args_of() {
   case $1 in
     poisson) echo "--form poisson" ;;
     poisson_p2) echo "--form poisson --degree 2 --size 128" ;;
     poisson_p2_nurbs) echo "--form poisson --degree 2 --size 96 --geometry" ;;
     cahnhilliard_nurbs) echo "--form cahnhilliard --size 128 --geometry" ;;
+    elasticity_nurbs) echo "--form elasticity --size 64 --geometry" ;;
     *) echo "--form $1" ;;
   esac
 }
