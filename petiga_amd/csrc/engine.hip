@@ -19,6 +19,7 @@
 #endif
 #ifndef IGX_TU_DISPATCH
 #include "gram_mfma.hpp"
+#include "gram_patch.hpp"
 #include "block_pencil.hpp"      // (the host launcher, for run-time forms: rtc.hpp; no kernel of it is instantiated in this unit)
 #include "band_pt.hpp"           // (likewise: band_pt_run)
 #elif IGX_TU_DIM == 3 && (IGX_TU_GROUP < 0 || IGX_TU_GROUP == 1)

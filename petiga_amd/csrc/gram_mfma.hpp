@@ -2723,6 +2723,17 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
 // zero_matrix: MatZeroEntries of the caller; called before the first launch unless the axis-0 walk stores first touches
 // slab_done (may be empty): called between the two passes of an assembly that forms the elements next to the upper face of axis
 // 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
+// gram_patch.hpp (round 6): the p = 2 walk of patches of pencils
+static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, int &launches);
+// one rank, no axis wrapped inside it, one new node per element on axes 1 and 2 (a patch's nodes are consecutive)
+static bool patch_walk_covers(const Space &s) {
+  if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] != 1) return false;
+  for (int d = 0; d < 3; ++d) if (s.lay[d].alias) return false;
+  for (int d = 1; d < 3; ++d)
+    for (int e = 0; e + 1 < s.elem_width[d]; ++e) if (s.basis[d].offset[s.elem_start[d] + e + 1] != s.basis[d].offset[s.elem_start[d] + e] + 1) return false;
+  return true;
+}
+
 static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, bool forced,
                          std::string &kname, int &launches, std::string &err, bool &done, DomInfo &dom, const std::function<void()> &zero_matrix,
                          const std::function<void()> &slab_done = std::function<void()>(), const PencilModule *mod = nullptr,
@@ -2764,6 +2775,20 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   // boundary loads first: F is zeroed and only added to, so the order is free -- and the ghost rows of the upper face of axis 2
   // must be complete when the first pass of a multi-rank assembly ends (slab_done below)
   if (sys) { if (int rc = launch_boundary_loads(s, S, out, stream, err)) return rc; }
+  // (round 6, experiment: IGX_PATCH=1) p = 2 on the identity geometry, Matrix driver, one rank: the walk of 4 x 3 patches of pencils with one
+  // shared window (gram_patch.hpp) on a zeroed matrix
+  if (deg == 2 && walk_axis == 0 && s.env.patch && !geo && !mod && !fixt && out.op == OP_MATRIX && patch_walk_covers(s)) {
+    zero_matrix();
+    if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
+    launch_patches_p2(s, S, out, stream, launches);
+    if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
+    if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
+    if (hipGetLastError() != hipSuccess) { err = "gram_patch kernel launch failed"; return IGX_ERR_LIB; }
+    dom.name = "gram_patch<p=2>"; dom.launches = launches; dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2]; dom.flop_per_element = 2048.0 * 21 * 3;
+    kname = "gram_patch(mfma_f64_16x16x4,p=2,walk=0,packed tiles,4x3 pencils per workgroup,one window)";
+    done = true;
+    return 0;
+  }
   if (!walk) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
     if (sys) launch_elements<true>(s, S, out, stream, all, ga, launches); else launch_elements<false>(s, S, out, stream, all, ga, launches);
