@@ -2724,7 +2724,7 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
 // slab_done (may be empty): called between the two passes of an assembly that forms the elements next to the upper face of axis
 // 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
 // gram_patch.hpp (round 6): the p = 2 walk of patches of pencils
-static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, int &launches);
+static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, int &launches, double forcing, bool first_touch);
 // one rank, no axis wrapped inside it, one new node per element on axes 1 and 2 (a patch's nodes are consecutive)
 static bool patch_walk_covers(const Space &s) {
   if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] != 1) return false;
@@ -2775,12 +2775,11 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
   // boundary loads first: F is zeroed and only added to, so the order is free -- and the ghost rows of the upper face of axis 2
   // must be complete when the first pass of a multi-rank assembly ends (slab_done below)
   if (sys) { if (int rc = launch_boundary_loads(s, S, out, stream, err)) return rc; }
-  // (round 6, experiment: IGX_PATCH=1) p = 2 on the identity geometry, Matrix driver, one rank: the walk of 4 x 3 patches of pencils with one
-  // shared window (gram_patch.hpp) on a zeroed matrix
-  if (deg == 2 && walk_axis == 0 && s.env.patch && !geo && !mod && !fixt && out.op == OP_MATRIX && patch_walk_covers(s)) {
-    zero_matrix();
+  // (round 6: IGX_PATCH=1) p = 2 on the identity geometry, one rank: the walk of 4 x 3 patches of pencils whose band rows leave through the whole
+  // workgroup (gram_patch.hpp): 4 colours, 190 instead of 405 entries per element read-add-written
+  if (deg == 2 && walk_axis == 0 && s.env.patch && !geo && !mod && !fixt && (out.op == OP_MATRIX || out.op == OP_SYSTEM) && patch_walk_covers(s)) {
     if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
-    launch_patches_p2(s, S, out, stream, launches);
+    launch_patches_p2(s, S, out, stream, launches, ga.forcing, first_touch);
     if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
     if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
     if (hipGetLastError() != hipSuccess) { err = "gram_patch kernel launch failed"; return IGX_ERR_LIB; }

@@ -43,7 +43,8 @@ struct EnvSwitches {
   int free_run = -1;         // IGX_FREE_RUN=0/1: the pencil walk with / without its s_barrier ping-pong (-1: the launcher's choice)
   int p2_pack = 1;           // IGX_P2_PACK=0: the p = 2 walks keep one tile per pair of node layers (round 4) instead of the packed tiles
   int band_prio = 0, band_rmw_prio = 0;      // IGX_BAND_PRIO=k: band_pt raises the priority of a workgroup's first k layers; IGX_BAND_RMW_PRIO=1: ... of its read-add-writes
-  int patch = 0;             // IGX_PATCH=1: the p = 2 Gram walk in patches of 4 x 3 pencils with one shared window (gram_patch.hpp; round 6)
+  int patch = 1;             // IGX_PATCH=0: the p = 2 Gram walk keeps one pencil and one window per wavefront (bit-repeatable) instead of the patches of
+                             // 4 x 3 pencils with one shared window (gram_patch.hpp, round 6: + 23 % on config 2, the order of its LDS adds is not fixed)
   int fuse_resid = 0;        // IGX_FUSE_RESID=1: IGXComputeIFunctionIJacobian takes the fused walk (state_pencil_kr) where it exists; default: the two
                              // drivers one after the other -- measured in round 6: the fused launch costs 2.5 ms more than the Tangent's, the
                              // Residual's own pass 2.1 ms per launch

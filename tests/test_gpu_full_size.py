@@ -143,7 +143,8 @@ def test_poisson_full_size_properties(p, N):
     assert A.nbrows == n ** 3 and A.nblocks == (n * (2 * p + 1) - p * (p + 1)) ** 3      # 17 373 979 rows / 5 841 725 401 nnz at p=3
     # --- no Dirichlet data: every row sums to zero (partition of unity), F_a = integral of N_a (closed form)
     g.compute_system(A, b); g.synchronize()
-    assert "pencil" in g.kernel_name()
+    assert "pencil" in g.kernel_name() or "gram_patch" in g.kernel_name()
+    patch = "gram_patch" in g.kernel_name()      # config 2's default since round 6: up to nine wavefronts add to a window entry, in no fixed order
     rp, ci, val = _views(A)
     scale = float(val.abs().max())
     rowsum = _rowsums(rp, val)
@@ -161,7 +162,10 @@ def test_poisson_full_size_properties(p, N):
     keep = val.clone(); bk = b.get()
     val.fill_(float("nan"))
     g.compute_system(A, b); g.synchronize()
-    assert torch.equal(val, keep) and np.array_equal(b.get(), bk)
+    if patch:      # stale values never survive, and two assemblies agree to a few ulps of the largest entry (the pencil walks: bit for bit)
+        assert bool(torch.isfinite(val).all()) and float((val - keep).abs().max()) <= 4e-15 * float(keep.abs().max()) and np.abs(b.get() - bk).max() <= 4e-15 * np.abs(bk).max()
+    else:
+        assert torch.equal(val, keep) and np.array_equal(b.get(), bk)
     del keep
     idx = np.arange(n ** 3)
     i0, i1, i2 = idx % n, (idx // n) % n, idx // (n * n)

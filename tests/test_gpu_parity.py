@@ -532,6 +532,7 @@ def test_mfma_pencil_degree2(N, bc, pack, monkeypatch):
     tiles, band rows combined in an LDS window) and, with IGX_P2_PACK=0, the kernel they replaced (the 3x3x3 basis zero-padded into
     4x4 tile slots, one tile per pair of node layers) -- still the code of p = 2 on mapped geometries, so it stays tested."""
     monkeypatch.setenv("IGX_P2_PACK", str(pack))      # (read when an IGX is created)
+    monkeypatch.setenv("IGX_PATCH", "0")              # (the pencil walk itself: since round 6 the patch walk takes these cases by default, tests/test_gpu_patch.py)
     orc, eng = make_pair(3, 1, 2, list(N))
     for g in (orc, eng):
         if bc == "all1":
@@ -615,10 +616,11 @@ def test_feature_mfma_kernel_is_selected_and_matches(case):
 
 
 @pytest.mark.parametrize("p,N,size", [(3, (9, 10, 11), 1), (3, (16, 5, 4), 1), (2, (8, 9, 10), 1), (3, (12, 9, 10), 2), (3, (16, 9, 20), 2), (3, (16, 16, 16), 8), (2, (9, 3, 1), 1)])
-def test_pencil_first_touch_needs_no_zeroing(p, N, size):
+def test_pencil_first_touch_needs_no_zeroing(p, N, size, monkeypatch):
     """The axis-0 pencil walk stores the first contribution of every entry (no MatZeroEntries): poisoned matrices
     must come out identical to freshly zeroed ones, on every rank of a partition."""
     import petiga_amd as P
+    monkeypatch.setenv("IGX_PATCH", "0")      # (the bit-repeatable pencil walk; the patch walk's first touch: tests/test_gpu_patch.py)
     for r in range(size):
         g = P.IGX(3, 1)
         for i in range(3):

@@ -223,8 +223,8 @@ def test_boundary_loads_on_the_pencil_kernel(p, N, stretch, geo, kernel_family):
     A, b = eng.create_mat(), eng.create_vec()
     eng.compute_system(A, b)
     eng.synchronize()
-    if kernel_family == "auto":
-        assert "gram_pencil" in eng.kernel_name()
+    if kernel_family == "auto":      # (p = 2 on the identity geometry: the patch walk since round 6; the per-face load kernel is the same)
+        assert "gram_pencil" in eng.kernel_name() or "gram_patch" in eng.kernel_name()
     tol = 1e-12 if geo == "none" else 1e-11
     compare_mats(A, A_o, tol)
     _vec_close(b.get(), b_o, tol)
@@ -257,8 +257,8 @@ def test_fix_table_on_the_pencil_kernel(p, N, faces, geo, kernel_family):
     A, b = eng.create_mat(), eng.create_vec()
     eng.compute_system(A, b)
     eng.synchronize()
-    if kernel_family == "auto":
-        assert "gram_pencil" in eng.kernel_name()
+    if kernel_family == "auto":      # (p = 2 on the identity geometry: the patch walk since round 6; the per-face load kernel is the same)
+        assert "gram_pencil" in eng.kernel_name() or "gram_patch" in eng.kernel_name()
     tol = 1e-12 if geo == "none" else 1e-11
     compare_mats(A, A_o, tol)
     _vec_close(b.get(), b_o, tol)
