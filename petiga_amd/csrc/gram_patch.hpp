@@ -284,7 +284,9 @@ gram_patch_p2(SpaceDev S, OutDev out, PatchArgs A) {
   };
   Run run; run.on = false;
   fetch(0, run);
+  long long st_mfma = 0, st_wait = 0, st_leave = 0, st_t0 = 0; const long long st_wall0 = (kDebug && pa.debug_buf) ? wall_clock64() : 0;
   for (int ei = 0; ei < ne; ++ei) {
+    if (kDebug && pa.debug_buf) st_t0 = __builtin_readcyclecounter();
     if (valid) {
       d4_t pk[3];
       pencil_mfma_p2k(pk, uxs, vys, T.zt + ei * 32, K, lane);
@@ -305,10 +307,19 @@ gram_patch_p2(SpaceDev S, OutDev out, PatchArgs A) {
       if (fslot < NB && !(A.dbg & 1)) Facc += sxy * sw;
       if (!(A.dbg & 2)) f_stage(ei);
     }
+    long long st_t1 = 0, st_t2 = 0;
+    if (kDebug && pa.debug_buf) st_t1 = __builtin_readcyclecounter();
     __syncthreads();      // every wavefront's element ei is in the window: layer ei is complete (and its F sums are staged)
+    if (kDebug && pa.debug_buf) st_t2 = __builtin_readcyclecounter();
     leave(ei, run);
     if (ei >= 1 && !(A.dbg & 4)) leave_f(ei - 1);      // (a step behind: the liftings of its runs were staged before this barrier)
     fetch(ei + 1, run);
+    if (kDebug && pa.debug_buf) { const long long t3 = __builtin_readcyclecounter(); st_mfma += st_t1 - st_t0; st_wait += st_t2 - st_t1; st_leave += t3 - st_t2; }
+  }
+  if (kDebug && pa.debug_buf && lane == 0) {      // -DIGX_DEBUG: per wavefront [MFMAs + window adds | wait at the barrier | leave + next fetch] summed over the walk, elements; workgroup record
+    long long *d = pa.debug_buf + ((size_t)blockIdx.x * PATCH_W + wave) * 4;
+    d[0] = st_mfma; d[1] = st_wait; d[2] = st_leave; d[3] = ne;
+    if (wave == 0) { long long *w = pa.debug_buf + (size_t)gridDim.x * PATCH_W * 4 + (size_t)blockIdx.x * 4; w[0] = st_wall0; w[1] = wall_clock64(); w[2] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 4); w[3] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20); }
   }
   if constexpr (SYSTEM) { __syncthreads(); leave_f(ne - 1); }
   if (seg == pa.nseg - 1 && !pa.open_hi)
@@ -352,7 +363,41 @@ static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &o
     if (lds > (size_t)160 * 1024) { pencil_launch_error() = "the patch walk's tables do not fit the LDS"; return; }
     auto kern = sys ? gram_patch_p2<true> : gram_patch_p2<false>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static int dbg_done = 0, dbg_seen = 0;      // -DIGX_DEBUG, IGX_DEBUG_TIMING=n: the n-th patch launch of the process is stamped
+    const bool dbg_t = kDebug && s.env.debug_timing && !dbg_done && ++dbg_seen >= std::max(1, atoi(getenv("IGX_DEBUG_TIMING") ? getenv("IGX_DEBUG_TIMING") : "1"));
+    const size_t nwg = (size_t)(patches * pa.nseg), dbg_n = nwg * PATCH_W * 4 + nwg * 4;
+    if (dbg_t) { (void)hipMalloc((void **)&pa.debug_buf, dbg_n * 8); (void)hipMemset(pa.debug_buf, 0, dbg_n * 8); }
     hipLaunchKernelGGL(kern, dim3((unsigned)(patches * pa.nseg)), dim3(PATCH_W * 64), lds, stream, S, out, A);
+    if (dbg_t) {
+      dbg_done = 1;
+      (void)hipStreamSynchronize(stream);
+      std::vector<long long> h(dbg_n);
+      (void)hipMemcpy(h.data(), pa.debug_buf, dbg_n * 8, hipMemcpyDeviceToHost);
+      double sm[3][3] = {{0}}; long long cnt[3] = {0}; double el = 0;
+      for (size_t b = 0; b < nwg; ++b) for (int w = 0; w < PATCH_W; ++w) {
+        const long long *d = &h[(b * PATCH_W + w) * 4];
+        if (!d[3]) continue;
+        const int k = w < 7 ? 0 : (w < PATCH_W - 1 ? 1 : 2);      // wavefronts whose every lane owns a run | partly or none | the one with the F rows
+        for (int c = 0; c < 3; ++c) sm[k][c] += (double)d[c] / (double)d[3];
+        cnt[k]++; el += (double)d[3];
+      }
+      const char *nm[3] = {"wavefronts 0-6 (64 runs each)", "wavefronts 7-10 (8 runs / none)", "wavefront 11 (the F rows)"};
+      fprintf(stderr, "[igx patch timing] colour (%d,%d): %zu workgroups, seg_len %d nseg %d; cycles per element and wavefront:\n", cx, cy, nwg, pa.seg_len, pa.nseg);
+      for (int k = 0; k < 3; ++k) if (cnt[k]) fprintf(stderr, "[igx patch timing]   %s: MFMAs + window adds %.0f | wait at the barrier %.0f | leave + next fetch %.0f | period %.0f\n", nm[k], sm[k][0] / cnt[k], sm[k][1] / cnt[k], sm[k][2] / cnt[k], (sm[k][0] + sm[k][1] + sm[k][2]) / cnt[k]);
+      {   // the launch as a per-CU timeline on the 100 MHz clock (as launch_pencils prints it)
+        const long long *wr = &h[nwg * PATCH_W * 4];
+        long long t0 = LLONG_MAX, t1 = 0; std::map<long long, std::vector<std::pair<long long, long long>>> cu;
+        for (size_t b = 0; b < nwg; ++b) { const long long *w = wr + b * 4; if (!w[0] || !w[1]) continue; t0 = std::min(t0, w[0]); t1 = std::max(t1, w[1]);
+          const long long hw = w[2]; cu[((w[3] & 15) << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)].push_back({w[0], w[1]}); }
+        if (t1 > t0 && !cu.empty()) {
+          double busy = 0; int rmax = 0;
+          for (auto &kv : cu) { rmax = std::max(rmax, (int)kv.second.size()); for (auto &iv : kv.second) busy += (double)(iv.second - iv.first); }
+          fprintf(stderr, "[igx patch timing]   timeline: span %.1f us (walks only) over %d CUs, at most %d workgroups on one CU; CU-time inside a walk %.3f of span x 256 CUs\n",
+                  (t1 - t0) * 0.01, (int)cu.size(), rmax, busy / ((double)(t1 - t0) * 256.0));
+        }
+      }
+      (void)hipFree(pa.debug_buf); pa.debug_buf = nullptr;
+    }
     launches++;
   }
 }

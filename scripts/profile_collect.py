@@ -19,7 +19,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ONLY = set(sys.argv[2:])
 SRC, DST = "gpurun_out/prof", "profiles"
 SIZES = {"poisson": 256, "poisson_p2": 128, "poisson_p2_nurbs": 96, "elasticity": 128, "cahnhilliard": 256, "nsvms": 96, "cahnhilliard_nurbs": 128, "elasticity_nurbs": 64}
-KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_pencil", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil", "elasticity_nurbs": "band_pt<"}
+KEY = {"poisson": "gram_pencil", "poisson_p2": "gram_p", "poisson_p2_nurbs": "gram_pencil", "elasticity": "block_pencil", "cahnhilliard": "state_pencil", "nsvms": "band_pt<", "cahnhilliard_nurbs": "state_pencil", "elasticity_nurbs": "band_pt<"}
 FORM = {"poisson_p2": "poisson", "poisson_p2_nurbs": "poisson", "cahnhilliard_nurbs": "cahnhilliard", "elasticity_nurbs": "elasticity"}
 
 
