@@ -212,14 +212,23 @@ gram_patch_p2(SpaceDev S, OutDev out, PatchArgs A) {
   }
 
   // the run of layer li: its five old values are requested a step ahead (fetch) and consumed when the layer is complete (leave)
-  struct Run { long long base; double o[5]; int p0[5]; bool on; };
+  struct Run { long long base; double o[5]; int p0[5]; bool on, full; };
   auto fetch = [&](int li, Run &r) {
     const int lay = T.lay0 + li;
     r.on = unit && li >= 0 && li < nl && T.cnt[li] > 0 && lay >= own_lo && lay < own_hi;
     if (!r.on) return;
     r.base = RA + (long long)RB * T.pre[li] + (long long)RC * T.cnt[li];
+    r.full = true;
 #pragma unroll
-    for (int d = 0; d < 5; ++d) { r.p0[d] = T.P[li * 8 + d]; r.o[d] = (r.p0[d] >= 0 && !ufirst) ? out.val[r.base + r.p0[d]] : 0.0; }
+    for (int d = 0; d < 5; ++d) { r.p0[d] = T.P[li * 8 + d]; r.full = r.full && r.p0[d] == d; }
+    if (r.full) {      // an interior layer: the run is 40 contiguous bytes
+      const double *p = out.val + r.base;
+      if (ufirst) { r.o[0] = r.o[1] = r.o[2] = r.o[3] = r.o[4] = 0.0; }
+      else { const d2u_t a = *reinterpret_cast<const d2u_t *>(p), b = *reinterpret_cast<const d2u_t *>(p + 2); r.o[0] = a[0]; r.o[1] = a[1]; r.o[2] = b[0]; r.o[3] = b[1]; r.o[4] = p[4]; }
+    } else {
+#pragma unroll
+      for (int d = 0; d < 5; ++d) r.o[d] = (r.p0[d] >= 0 && !ufirst) ? out.val[r.base + r.p0[d]] : 0.0;
+    }
   };
   // elements of the walk that hold layer li (the diagonal of a fixed row counts them: each sets K_kk = 1)
   auto held_w = [&](int li) { return min(li, ne - 1) - max(li - P, 0) + 1; };
@@ -246,8 +255,14 @@ gram_patch_p2(SpaceDev S, OutDev out, PatchArgs A) {
       // (this path is the one that is not bit-repeatable anyway: the row's lifting is summed with LDS atomics too, by the runs that have any)
       if (corr != 0.0) (void)__hip_atomic_fetch_add(corrp + (li % 3) * PATCH_NODES + uyr * PATCH_NX + uxr, corr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    if (r.full) {
+      double *p = out.val + r.base;
+      d2u_t a, b; a[0] = r.o[0] + v[0]; a[1] = r.o[1] + v[1]; b[0] = r.o[2] + v[2]; b[1] = r.o[3] + v[3];
+      *reinterpret_cast<d2u_t *>(p) = a; *reinterpret_cast<d2u_t *>(p + 2) = b; p[4] = r.o[4] + v[4];
+    } else {
 #pragma unroll
-    for (int d = 0; d < 5; ++d) if (r.p0[d] >= 0) out.val[r.base + r.p0[d]] = r.o[d] + v[d];
+      for (int d = 0; d < 5; ++d) if (r.p0[d] >= 0) out.val[r.base + r.p0[d]] = r.o[d] + v[d];
+    }
   };
   // F of layer li: thread t < 30 = patch node (yr, xr): the pencils' sums (Fp) and its runs' liftings (corrp), each in a fixed order
   auto leave_f = [&](int li) {
