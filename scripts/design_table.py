@@ -8,7 +8,7 @@ import sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 ROWS = [("poisson", "metric: Poisson p=3 256³ System"), ("poisson_p2", "config 2: Poisson p=2 128³ System"), ("elasticity", "config 3: Elasticity p=3 128³ System"),
         ("cahnhilliard", "config 4: Cahn–Hilliard p=2 256³ IFunction + IJacobian"), ("nsvms", "config 5 (one GPU's share): NS-VMS p=3 96³ on the NURBS net, IFunction + IJacobian"),
-        ("poisson_p2_nurbs", "Poisson p=2 96³ on the NURBS net"), ("cahnhilliard_nurbs", "Cahn–Hilliard p=2 128³ on the NURBS net, pair")]
+        ("poisson_p2_nurbs", "Poisson p=2 96³ on the NURBS net"), ("cahnhilliard_nurbs", "Cahn–Hilliard p=2 128³ on the NURBS net, pair"), ("elasticity_nurbs", "Elasticity p=3 64³ on the NURBS net, System")]
 traffic = {c["tag"]: c for c in json.load(open("profiles/traffic.json"))["configs"]}
 print("| workload | dominant kernel | M el/s | ms per step | launch ms | executed fraction of 78.6 TF | algorithmic fraction | MFMA busy (PMC) | HBM KB per element | CPU port, el/s (cores) |")
 print("|---|---|---|---|---|---|---|---|---|---|")
