@@ -1193,6 +1193,7 @@ static int compute(IGX g, int op, IGXMat A, IGXVec b, IGXVec U, IGXVec V, double
         if (s.form == IGX_FORM_CAHNHILLIARD) { st.kfn = fused ? state_pencil_kr<FormCahnHilliard<3>> : state_pencil_k<FormCahnHilliard<3>>; st.flop_per_element = 2048.0 * FormCahnHilliard<3>::PENCIL_NFEAT * 7 * 4; }
         else { st.kfn = fused ? state_pencil_kr<FormBratu<3>> : state_pencil_k<FormBratu<3>>; st.flop_per_element = 2048.0 * FormBratu<3>::PENCIL_NFEAT * 7 * 4; }
         if (fused) st.name += "+Residual";
+        else st.patch_kfn = s.form == IGX_FORM_CAHNHILLIARD ? reinterpret_cast<const void *>(state_patch_p2<FormCahnHilliard<3>>) : reinterpret_cast<const void *>(state_patch_p2<FormBratu<3>>);
       }
       if (st.kfn) { st.state = true; st.extra_lds = pencil_state_bytes() + (fused ? (size_t)8 * (RWIN_DOUBLES + 128) * 8 : 0) /* fused: the Residual's ring and the scratch of its u_t sums, per wavefront */; for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) st.prm.v[i] = s.params[i]; }
     }

@@ -2368,7 +2368,8 @@ typedef void (*PencilKernel)(SpaceDev, OutDev, PencilArgs, ParamsDev);
 struct PencilPass { int ftx[3] = {0, 0x7fffffff, 0x7fffffff}; int halo_lo = -1; bool open_hi = false; };
 struct PencilModule { hipFunction_t fn = nullptr; ParamsDev prm; std::string name; PencilKernel kfn = nullptr; size_t extra_lds = 0; bool state = false; double flop_per_element = 0;
                       bool state_geo = false;         // state_geo: the instantiation is state_pencil_geo (evaluates the geometry itself)
-                      int pack = 0; };                // pack: packed tiles, the window of band rows in the place of the hold areas (1: state_pencil_k; 2: the compact window, state_pencil_geo_k)
+                      int pack = 0;
+                      const void *patch_kfn = nullptr; };      // gram_patch.hpp: state_patch_p2<Form> of the same form (p = 2, no geometry)                // pack: packed tiles, the window of band rows in the place of the hold areas (1: state_pencil_k; 2: the compact window, state_pencil_geo_k)
 
 static inline int nseg_min_lds(int nw) { return std::max(1, (nw + 159) / 160); }
 // a launch that could not be made (the LDS of the chosen segments beyond the device's, a module launch refused): try_gram_mfma
@@ -2725,6 +2726,7 @@ static int launch_boundary_loads(const Space &s, const SpaceDev &S, const OutDev
 // 2 first -- the ghost rows of that face are complete then and their exchange can run under the rest of the launches
 // gram_patch.hpp (round 6): the p = 2 walk of patches of pencils
 static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, int &launches, double forcing, bool first_touch);
+static void launch_state_patches_p2(const Space &s, const SpaceDev &S, const OutDev &out, hipStream_t stream, int &launches, bool first_touch, const void *kernel, const ParamsDev &prm);
 // one rank, no axis wrapped inside it, one new node per element on axes 1 and 2 (a patch's nodes are consecutive)
 static bool patch_walk_covers(const Space &s) {
   if (s.proc_sizes[0] * s.proc_sizes[1] * s.proc_sizes[2] != 1) return false;
@@ -2785,6 +2787,18 @@ static int try_gram_mfma(const Space &s, const SpaceDev &S, const OutDev &out, h
     if (hipGetLastError() != hipSuccess) { err = "gram_patch kernel launch failed"; return IGX_ERR_LIB; }
     dom.name = "gram_patch<p=2>"; dom.launches = launches; dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2]; dom.flop_per_element = 2048.0 * 21 * 3;
     kname = "gram_patch(mfma_f64_16x16x4,p=2,walk=0,packed tiles,4x3 pencils per workgroup,one window)";
+    done = true;
+    return 0;
+  }
+  // ... and of a Tangent (IGX_PATCH_STATE=1): 4 x 2 pencils per workgroup, state_patch_p2
+  if (deg == 2 && walk_axis == 0 && s.env.patch_state && state && !geo && mod->patch_kfn && patch_walk_covers(s)) {
+    if (dom.ev0) (void)hipEventRecord(dom.ev0, stream);
+    launch_state_patches_p2(s, S, out, stream, launches, first_touch, mod->patch_kfn, mod->prm);
+    if (dom.ev1) (void)hipEventRecord(dom.ev1, stream);
+    if (pencil_launch_error()) { err = pencil_launch_error(); pencil_launch_error() = nullptr; (void)hipGetLastError(); return IGX_ERR_LIB; }
+    if (hipGetLastError() != hipSuccess) { err = "state_patch kernel launch failed"; return IGX_ERR_LIB; }
+    dom.name = "state_patch<p=2>"; dom.launches = launches; dom.elements = (long long)s.elem_width[0] * s.elem_width[1] * s.elem_width[2]; dom.flop_per_element = mod->flop_per_element;
+    kname = "state_patch<" + mod->name + ">(mfma_f64_16x16x4,p=2,walk=0,packed tiles,4x2 pencils per workgroup,one window)";
     done = true;
     return 0;
   }

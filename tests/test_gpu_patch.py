@@ -79,3 +79,50 @@ def test_system_driver_vs_oracle(N, bc, nseg, monkeypatch):
     eng.compute_system(A, b)
     eng.synchronize()
     assert np.abs(A.host(True) - vals).max() <= 4e-15 * np.abs(vals).max() and np.abs(b.get() - bv).max() <= 4e-15 * max(np.abs(bv).max(), 1.0)
+
+
+CH = (1.5, 200.0, 0.63, 1.0, 1.0 / 48.0, 1.0)      # (the parameters of tests/test_gpu_state_pencil.py)
+
+
+@pytest.mark.parametrize("form,N,bc,nseg", [
+    ("cahnhilliard", (9, 8, 6), False, 0),        # whole patches of 4 x 2 pencils
+    ("cahnhilliard", (10, 9, 7), True, 0),        # partial patches on both axes, Dirichlet values on four faces
+    ("cahnhilliard", (17, 5, 3), True, 3),        # three segments along the walk
+    ("cahnhilliard", (8, 4, 2), False, 0),        # one patch
+    ("bratu", (12, 13, 11), True, 2),
+    ("bratu", (9, 5, 4), False, 0),
+])
+def test_tangent_patch_walk_vs_oracle(form, N, bc, nseg, monkeypatch):
+    """state_patch_p2: the Tangent of demo/CahnHilliard3D.c:111-179 / demo/Bratu.c through IGAComputeIJacobian on patches of 4 x 2 pencils
+    (IGX_PATCH_STATE=1), IGAElementFixJacobian on the combined runs, first-touch stores on a NaN-poisoned matrix."""
+    import oracle_api as O
+    monkeypatch.setenv("IGX_PATCH_STATE", "1")
+    if nseg:
+        monkeypatch.setenv("IGX_NSEG", str(nseg))
+    orc, eng = make_pair(3, 1, 2, list(N))
+    if bc:
+        for g in (orc, eng):
+            g.set_boundary_value(0, 0, 0, 0.6); g.set_boundary_value(0, 1, 0, 0.66)
+            g.set_boundary_value(1, 1, 0, 0.61); g.set_boundary_value(2, 0, 0, 0.65)
+    rng = np.random.default_rng(5)
+    n = orc.global_size()
+    U, V = 0.63 + 0.05 * (2 * rng.random(n) - 1), rng.standard_normal(n)
+    Uv, Vv, J = eng.create_vec().set(U), eng.create_vec().set(V), eng.create_mat()
+    if form == "cahnhilliard":
+        eng.set_form("cahnhilliard", CH)
+        J_o = orc.compute_ijacobian("orc_form_ch_tangent", O.CahnHilliardCtx(*CH), 250.0, V, 0.0, U)
+        shift = 250.0
+    else:
+        eng.set_form("bratu", (3.5,))
+        J_o = orc.compute_ijacobian("orc_form_bratu_ijacobian", C.c_double(3.5), 4.0, V, 0.0, U)
+        shift = 4.0
+    _poison(J)
+    eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert "state_patch" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(J, J_o, 1e-11)
+    vals = J.host(True).copy()
+    _poison(J)
+    eng.compute_ijacobian(shift, Vv, 0.0, Uv, J)
+    eng.synchronize()
+    assert np.abs(J.host(True) - vals).max() <= 4e-15 * np.abs(vals).max()      # (not bit-repeatable, like gram_patch)
