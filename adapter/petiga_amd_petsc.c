@@ -160,6 +160,7 @@ static PetscErrorCode IGAGetAmd(IGA iga,IGAAmdCtx **out)
     }
     t.nsd = (int)iga->geometry; t.rational = (int)iga->rational;
     t.geometryX = iga->geometryX; t.rationalW = iga->rationalW;      /* ghosted local arrays, src/petigaelem.c:733-747 */
+    t.property = (int)iga->property; t.propertyA = iga->propertyA;   /* include/petiga.h:350-353 (PetscScalar = double: real builds) */
     IGXCHK(comm,IGXCreateFromTables(&t,&c->igx));
     IGXCHK(comm,IGXCreateMat(c->igx,&c->A));
     IGXCHK(comm,IGXCreateVec(c->igx,&c->b));

@@ -74,6 +74,10 @@ typedef enum {
                                normal mesh size through IGAPointFormInvGradGeomMap); params: {max degree k} */
   IGX_FORM_BRATU       = 11,/* Function/Jacobian and IFunction/IJacobian: demo/Bratu.c, demo/BratuFJ.F90:23-176  params: {lambda} */
   IGX_FORM_ELASTICITY_F = 12,/* System: demo/Elasticity3D.c's K with a body force, F[a][i] = N_a f_i   params: {lambda, mu, fx, fy, fz} */
+  IGX_FORM_DER3 = 13,        /* System / Function on third derivatives (p->shape[3], IGAPointFormDer3: test/IGAGeometryMap.c:179,221): K = N N + k3 d3N : d3N,
+                              * F = N (1 + |x|^2) + f3 c : d3N + u3 N c : d3u; params {k3, f3, u3}; the general kernel (order-3 tabulation) */
+  IGX_FORM_PROPERTY = 14,    /* System: Poisson with conductivity A[..][0] and source A[..][npd-1] of the property array (IGXSetProperty), interpolated
+                              * at the point from p->property; the general kernel */
   IGX_FORM_SOURCE      = 100 /* a user form compiled at run time: IGXSetFormSource */
 } IGXFormKind;
 
@@ -107,6 +111,17 @@ int IGXSetUp(IGX iga);                                     /* IGASetUp          
  * and optional NURBS weights W (NULL = polynomial).  Stands for IGASetGeometryDim + the arrays
  * iga->geometryX / iga->rationalW that IGALoadGeometry fills (src/petigaio.c:201-356). */
 int IGXSetGeometry(IGX iga,int nsd,const double X[],const double W[]);
+/* Derivative order (IGASetOrder, src/petiga.c:463): forms that read third derivatives -- p->shape[3] ([nen][dim][dim][dim], include/petiga.h:657)
+ * as the dim^3 numbers behind the Hessian in Na / Nb, IGAPointFormDer3 (include/petiga.h:731) as p.d3u with NEED_D3U -- declare ORDER = 3
+ * and need IGXSetOrder(iga,3) (the default order is the largest degree, src/petiga.c:1472-1475); they run on the point-form kernel, which
+ * then tabulates K2, Rationalize, GeometryMap, InverseMap and ShapeFunctions at order 3 (src/petigamapinv.f90.in:49-60,
+ * src/petigamapshf.f90.in:60-72).  Every other form is tabulated as far as it reads, whatever the order set here. */
+/* Property array: npd numbers per node of the geometry grid (natural order, [node][npd]); npd = 0 drops it.  Stands for
+ * IGASetPropertyDim + iga->propertyA as IGALoadProperty fills it (src/petigaio.c:359-458).  A point's form sees the values of its
+ * element's nodes as p->property [nen][npd] (IGAElementBuildClosure, src/petigaelem.c:745-752; include/petiga.h:662): forms that
+ * read them (NEED_PROP) run on the general kernel.  IGXRead / IGXWrite carry the array (info bit 1 of the file, src/petigaio.c:38,105). */
+int IGXSetProperty(IGX iga,int npd,const double A[]);
+int IGXGetPropertyDim(IGX iga,int *npd);   /* IGAGetPropertyDim src/petigaio.c:384 */
 
 int IGXSetBoundaryValue(IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryValue src/petigaform.c:324 */
 int IGXSetBoundaryLoad (IGX iga,int axis,int side,int field,double value); /* IGASetBoundaryLoad  src/petigaform.c:340 */
@@ -228,6 +243,8 @@ typedef struct {
   int rational;                              /* iga->rational                                     */
   const double *geometryX;                   /* ghosted local [gw2][gw1][gw0][nsd]  (iga->geometryX) */
   const double *rationalW;                   /* ghosted local [gw2][gw1][gw0]       (iga->rationalW) */
+  int property;                              /* iga->property: numbers per node (0 = none), include/petiga.h:350 */
+  const double *propertyA;                   /* ghosted local [gw2][gw1][gw0][npd]  (iga->propertyA, include/petiga.h:353) */
 } IGXTables;
 
 int IGXCreateFromTables(const IGXTables *t,IGX *iga);

@@ -64,6 +64,42 @@ int orc_form_poisson_f(OrcPoint *p,double *K,double *F,void *ctx)
   return 0;
 }
 
+/* A form on the third derivatives p->shape[3] ([nen][dim][dim][dim], include/petiga.h:657; read as test/IGAGeometryMap.c:179,221 does) and
+ * IGAPointFormDer3 (include/petiga.h:731; demo/AutoDiff/CahnHilliardPrimalFAD.cxx:51): the engine's IGX_FORM_DER3.  ctx = {k3, f3, u3}:
+ * K_ab = N_a N_b + k3 d3N_a : d3N_b,  F_a = N_a (1 + |x|^2) + f3 c : d3N_a [+ u3 N_a c : d3u],  c_ijk = 1/(1 + i + 2j + 3k). */
+static int der3_body(OrcPoint *p,const double *U,double *K,double *F,void *ctx)
+{
+  const double *prm = (const double*)ctx;
+  int a,b,i,j,k,f,nen=p->nen,dim=p->dim,d3=dim*dim*dim; const double *N0=p->shape[0],*N3=p->shape[3];
+  double x[3]={0,0,0},x2=0,su=0,u3[27];
+  orc_point_geommap(p,x); for (i=0;i<dim;i++) x2 += x[i]*x[i];
+  if (U) { orc_point_der3(p,U,u3); for (i=0;i<dim;i++) for (j=0;j<dim;j++) for (k=0;k<dim;k++) su += u3[(i*dim+j)*dim+k]/(1.0+i+2.0*j+3.0*k); }
+  for (a=0; a<nen; a++) {
+    double s = 0;
+    if (K) for (b=0; b<nen; b++) { double t=0; for (f=0;f<d3;f++) t += N3[a*d3+f]*N3[b*d3+f]; K[a*nen+b] = N0[a]*N0[b] + prm[0]*t; }
+    for (i=0;i<dim;i++) for (j=0;j<dim;j++) for (k=0;k<dim;k++) s += N3[a*d3+(i*dim+j)*dim+k]/(1.0+i+2.0*j+3.0*k);
+    F[a] = N0[a]*(1.0+x2) + prm[1]*s + prm[2]*N0[a]*su;
+  }
+  return 0;
+}
+int orc_form_der3(OrcPoint *p,double *K,double *F,void *ctx) { return der3_body(p,NULL,K,F,ctx); }
+int orc_form_der3_function(OrcPoint *p,const double *U,double *F,void *ctx) { return der3_body(p,U,NULL,F,ctx); }
+
+/* Poisson with the conductivity A[.][0] and the source A[.][npd-1] of the property array, interpolated at the point from the
+ * element's nodal values p->property [nen][npd] (IGAElementBuildClosure, src/petigaelem.c:745-752): the engine's IGX_FORM_PROPERTY */
+int orc_form_property(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  int a,b,i,nen=p->nen,dim=p->dim,npd=p->npd; const double *N0=p->shape[0],*N1=p->shape[1],*A=p->property; double kq=0,fq=0;
+  (void)ctx;
+  if (!A || npd < 1) return 73;   /* PETSC_ERR_ARG_WRONGSTATE: "No property set" (src/petigaelem.c:300) */
+  for (a=0; a<nen; a++) { kq += N0[a]*A[a*npd]; fq += N0[a]*A[a*npd+npd-1]; }
+  for (a=0; a<nen; a++) {
+    for (b=0; b<nen; b++) { double s=0; for (i=0;i<dim;i++) s += N1[a*dim+i]*N1[b*dim+i]; K[a*nen+b] = kq*s; }
+    F[a] = N0[a]*fq;
+  }
+  return 0;
+}
+
 /* test/IGAErrNorm.c:26-52 (Exact) for the four fields 1, sum x, sum x^2, prod x */
 static void errnorm_exact(const OrcPoint *p,int order,double *v)
 {

@@ -417,7 +417,7 @@ void orc_destroy(OrcIGA *iga)
   if (!iga) return;
   for (i=0; i<3; i++) { axis_free(&iga->axis[i]); basis_free(&iga->basis[i]); }
   for (i=0; i<3; i++) { free(iga->rule_x[i]); free(iga->rule_w[i]); }
-  free(iga->geometryX); free(iga->rationalW); free(iga->fixtableU);
+  free(iga->geometryX); free(iga->rationalW); free(iga->fixtableU); free(iga->propertyA);
   free(iga);
 }
 
@@ -472,6 +472,7 @@ int orc_setup(OrcIGA *iga)
   iga->nsd = 0; iga->rational = 0;
   free(iga->geometryX); iga->geometryX = NULL;
   free(iga->rationalW); iga->rationalW = NULL;
+  free(iga->propertyA); iga->propertyA = NULL; iga->property = 0;   /* src/petiga.c:1296-1299 */
   free(iga->fixtableU); iga->fixtableU = NULL; iga->fixtable = 0;
   if (iga->order < 0) { int o = 0; for (i=0; i<dim; i++) if (iga->axis[i].p > o) o = iga->axis[i].p; orc_set_order(iga,o); }
   for (i=0; i<dim; i++) {
@@ -517,6 +518,27 @@ int orc_set_geometry(OrcIGA *iga,int nsd,const double *X,const double *W)
         if (W) iga->rationalW[pos] = W[g];
       }
   iga->nsd = nsd; iga->rational = W ? 1 : 0;
+  return 0;
+}
+
+/* IGASetPropertyDim + IGALoadProperty (src/petigaio.c:359-458): the ghosted-local box of the natural-order array [node][npd] */
+int orc_set_property(OrcIGA *iga,int npd,const double *A)
+{
+  int gs[3]={1,1,1},i,j,k,c,dim=iga->dim;
+  const int *g0 = iga->node_gstart,*gw = iga->node_gwidth;
+  size_t pos = 0;
+  if (!iga->setup) ORC_ERR("setup first");
+  if (npd < 0) ORC_ERR("Number of properties must be nonnegative");
+  free(iga->propertyA); iga->propertyA = NULL; iga->property = npd;
+  if (!npd) return 0;
+  for (i=0; i<dim; i++) gs[i] = iga->axis[i].span[iga->axis[i].nel-1] + 1;
+  iga->propertyA = (double*)xcalloc((size_t)gw[0]*gw[1]*gw[2]*npd,sizeof(double));
+  for (k=g0[2]; k<g0[2]+gw[2]; k++)
+    for (j=g0[1]; j<g0[1]+gw[1]; j++)
+      for (i=g0[0]; i<g0[0]+gw[0]; i++,pos++) {
+        size_t g = (size_t)i + (size_t)gs[0]*((size_t)j + (size_t)gs[1]*(size_t)k);
+        for (c=0; c<npd; c++) iga->propertyA[pos*npd+c] = A[g*npd+c];
+      }
   return 0;
 }
 
@@ -652,7 +674,7 @@ typedef struct {
   int count,index,ID[3],sqp[3];
   int atboundary,boundary_id;
   int *mapping;            /* ghosted-local node index per a */
-  double *rationalW,*geometryX;
+  double *rationalW,*geometryX,*propertyA; int npd;
   double *weight,*detJac,*normal,*detX,*detS;
   double *basis[5],*shape[5],*mapU[5],*mapX[5];
   int nfix; int *ifix; double *vfix,*ufix;
@@ -674,6 +696,7 @@ static Elem *elem_create(OrcIGA *iga)
   e->mapping   = (int*)xcalloc((size_t)nen,sizeof(int));
   e->rationalW = (double*)xcalloc((size_t)nen,sizeof(double));
   e->geometryX = (double*)xcalloc((size_t)nen*nsd,sizeof(double));
+  e->npd = iga->property; e->propertyA = (double*)xcalloc((size_t)nen*(iga->property ? iga->property : 1),sizeof(double));   /* src/petigaelem.c:155,199 */
   e->weight = (double*)xcalloc((size_t)nqp,sizeof(double));
   e->detJac = (double*)xcalloc((size_t)nqp,sizeof(double));
   e->normal = (double*)xcalloc((size_t)nqp*nsd,sizeof(double));
@@ -709,7 +732,7 @@ static Elem *elem_create(OrcIGA *iga)
 static void elem_destroy(Elem *e)
 {
   int k;
-  free(e->mapping); free(e->rationalW); free(e->geometryX);
+  free(e->mapping); free(e->rationalW); free(e->geometryX); free(e->propertyA);
   free(e->weight); free(e->detJac); free(e->normal); free(e->detX); free(e->detS);
   for (k=0; k<5; k++) { free(e->basis[k]); free(e->shape[k]); free(e->mapU[k]); free(e->mapX[k]); }
   free(e->ifix); free(e->vfix); free(e->ufix); free(e->iflux); free(e->vflux);
@@ -736,6 +759,7 @@ static void elem_closure(Elem *e)
   }
   if (iga->rational) for (a=0; a<e->nen; a++) e->rationalW[a] = iga->rationalW[e->mapping[a]];
   if (iga->nsd) { int i,nsd=e->nsd; for (a=0; a<e->nen; a++) for (i=0; i<nsd; i++) e->geometryX[i+a*nsd] = iga->geometryX[(size_t)e->mapping[a]*nsd+i]; }
+  if (iga->property && iga->propertyA) { int i,npd=e->npd; for (a=0; a<e->nen; a++) for (i=0; i<npd; i++) e->propertyA[i+a*npd] = iga->propertyA[(size_t)e->mapping[a]*npd+i]; }   /* src/petigaelem.c:745-752 */
 }
 
 /* ------------------------------------------------------------------ */
@@ -1187,6 +1211,7 @@ static int elem_begin_point(Elem *e)
   p->neq = e->nen; p->nen = e->nen; p->dof = e->dof; p->dim = e->dim; p->nsd = e->nsd;
   p->rational = e->iga->rational ? e->rationalW : NULL;
   p->geometry = e->iga->nsd ? e->geometryX : NULL;
+  p->property = (e->iga->property && e->iga->propertyA) ? e->propertyA : NULL; p->npd = p->property ? e->npd : 0;   /* src/petigaelem.c:370 */
   p->ID[0]=e->ID[0]; p->ID[1]=e->ID[1]; p->ID[2]=e->ID[2];
   return elem_tabulate(e);
 }
@@ -1445,6 +1470,7 @@ static void eval(int nen,int dof,int nc,const double *N,const double *U,double *
 void orc_point_value(const OrcPoint *p,const double *U,double *u) { eval(p->nen,p->dof,1,p->shape[0],U,u); }
 void orc_point_grad (const OrcPoint *p,const double *U,double *u) { eval(p->nen,p->dof,p->dim,p->shape[1],U,u); }
 void orc_point_hess (const OrcPoint *p,const double *U,double *u) { eval(p->nen,p->dof,p->dim*p->dim,p->shape[2],U,u); }
+void orc_point_der3 (const OrcPoint *p,const double *U,double *u) { eval(p->nen,p->dof,p->dim*p->dim*p->dim,p->shape[3],U,u); }
 void orc_point_del2 (const OrcPoint *p,const double *U,double *u)
 {
   int a,c,i,dim=p->dim,dof=p->dof,d2=dim*dim;

@@ -78,6 +78,8 @@ struct OrcPoint {
   double *mapU[5], *mapX[5];
   double *detX, *detS;
   int     ID[3];
+  const double *property;                /* element A[nen][npd] or NULL (include/petiga.h:662) */
+  int     npd;
 };
 
 struct OrcIGA {
@@ -99,6 +101,8 @@ struct OrcIGA {
   int   rule_type[3];      /* IGARuleType: 0 Legendre, 1 Lobatto, 3 user (include/petiga.h:82-87) */
   int   rule_user_n[3];
   double *rule_x[3], *rule_w[3];   /* user-defined rule on [-1,1] */
+  int    property;         /* iga->property: numbers per node, 0 = none (include/petiga.h:350) */
+  double *propertyA;       /* ghosted local [gw2][gw1][gw0][npd] (include/petiga.h:353) */
 };
 
 /* global (natural-order) CSR: rows = node*dof + c, i0 fastest */
@@ -123,6 +127,7 @@ int     orc_set_order(OrcIGA*,int order);
 int     orc_set_partition(OrcIGA*,int size,int rank);
 int     orc_setup(OrcIGA*);
 int     orc_set_geometry(OrcIGA*,int nsd,const double *Xglobal,const double *Wglobal);
+int     orc_set_property(OrcIGA*,int npd,const double *Aglobal);   /* IGASetPropertyDim + the array IGALoadProperty fills (src/petigaio.c:359-458) */
 int     orc_set_boundary_value(OrcIGA*,int axis,int side,int field,double v);
 int     orc_set_boundary_load (OrcIGA*,int axis,int side,int field,double v);
 int     orc_set_boundary_form (OrcIGA*,int axis,int side,int flag);
@@ -175,6 +180,9 @@ int orc_form_boundary_integral(OrcPoint*,double*,double*,void*);  /* demo/Bounda
 int orc_form_nitsche(OrcPoint*,double*,double*,void*);            /* demo/NitscheMethod.c System; ctx = int* degree */
 int orc_form_errnorm   (OrcPoint*,double*,double*,void*);  /* test/IGAErrNorm.c System (dof=4) */
 int orc_form_elasticity(OrcPoint*,double*,double*,void*);  /* demo/Elasticity3D.c System */
+int orc_form_der3      (OrcPoint*,double*,double*,void*);  /* third derivatives p->shape[3] (test/IGAGeometryMap.c:179,221); ctx: double[3] = {k3, f3, u3} */
+int orc_form_der3_function(OrcPoint*,const double*,double*,void*);  /* ... with IGAPointFormDer3 of U (demo/AutoDiff/CahnHilliardPrimalFAD.cxx:51) */
+int orc_form_property  (OrcPoint*,double*,double*,void*);  /* Poisson with conductivity / source from p->property (include/petiga.h:662) */
 int orc_form_elasticity_f(OrcPoint*,double*,double*,void*);  /* the same K with a body force; ctx: double[5] = {lambda, mu, fx, fy, fz} */
 int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);
 int orc_form_ch_tangent (OrcPoint*,double,const double*,double,const double*,double*,void*);
@@ -193,6 +201,7 @@ int orc_scalar_volume   (OrcPoint*,const double*,int,double*,void*); /* test/IGA
 void orc_point_value(const OrcPoint*,const double*U,double*u);
 void orc_point_grad (const OrcPoint*,const double*U,double*u);
 void orc_point_hess (const OrcPoint*,const double*U,double*u);
+void orc_point_der3 (const OrcPoint*,const double*U,double*u);   /* IGAPointFormDer3, include/petiga.h:731 */
 void orc_point_del2 (const OrcPoint*,const double*U,double*u);
 void orc_point_geommap(const OrcPoint*,double*x);
 void orc_point_invgradgeommap(const OrcPoint*,double*G);

@@ -42,7 +42,8 @@ class OrcIGAStruct(C.Structure):
                 ("geometryX", c_dp), ("rationalW", c_dp),
                 ("value", (OrcBC * 2) * 3), ("load", (OrcBC * 2) * 3), ("visit", (C.c_int * 2) * 3),
                 ("fixtable", C.c_int), ("fixtableU", c_dp), ("setup", C.c_int),
-                ("rule_type", C.c_int * 3), ("rule_user_n", C.c_int * 3), ("rule_x", c_dp * 3), ("rule_w", c_dp * 3)]
+                ("rule_type", C.c_int * 3), ("rule_user_n", C.c_int * 3), ("rule_x", c_dp * 3), ("rule_w", c_dp * 3),
+                ("property", C.c_int), ("propertyA", c_dp)]
 
 
 class OrcMat(C.Structure):
@@ -93,6 +94,7 @@ def lib():
         L.orc_set_partition.argtypes = [P, C.c_int, C.c_int]
         L.orc_setup.argtypes = [P]
         L.orc_set_geometry.argtypes = [P, C.c_int, c_dp, c_dp]
+        L.orc_set_property.argtypes = [P, C.c_int, c_dp]
         L.orc_set_boundary_value.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_double]
         L.orc_set_boundary_load.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_double]
         L.orc_set_boundary_form.argtypes = [P, C.c_int, C.c_int, C.c_int]
@@ -259,6 +261,13 @@ class OracleIGA:
         W = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
         self._keep = (X, W)
         self._ck(self.L.orc_set_geometry(self.p, X.shape[-1], _dp(X), _dp(W)))
+
+    def set_property(self, A):
+        if A is None:
+            self._ck(self.L.orc_set_property(self.p, 0, None)); return
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        self._keep_prop = A
+        self._ck(self.L.orc_set_property(self.p, A.shape[-1], _dp(A)))
 
     def set_boundary_value(self, axis, side, field, value):
         self._ck(self.L.orc_set_boundary_value(self.p, axis, side, field, value))

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SCALARS = dict(volume=1, x2err=2, errnorm=3)
-FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10, bratu=11, elasticity_f=12)
+FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10, bratu=11, elasticity_f=12, der3=13, property=14)
 RULE_TYPES = dict(legendre=0, lobatto=1, reduced=2, user=3)      # IGARuleType, include/petiga.h:82-87
 
 _dp = C.POINTER(C.c_double)
@@ -34,7 +34,8 @@ class IGXTables(C.Structure):
                 ("elem_sizes", C.c_int * 3), ("elem_start", C.c_int * 3), ("elem_width", C.c_int * 3),
                 ("node_sizes", C.c_int * 3), ("node_lstart", C.c_int * 3), ("node_lwidth", C.c_int * 3),
                 ("node_gstart", C.c_int * 3), ("node_gwidth", C.c_int * 3),
-                ("nsd", C.c_int), ("rational", C.c_int), ("geometryX", _dp), ("rationalW", _dp)]
+                ("nsd", C.c_int), ("rational", C.c_int), ("geometryX", _dp), ("rationalW", _dp),
+                ("property", C.c_int), ("propertyA", _dp)]
 
 
 # IGXTransportFn (include/petiga_amd.h): the host-callback transport of the ghost-row exchange
@@ -76,7 +77,7 @@ def lib(build_if_needed=False):
         "IGXGetBasis": [V, C.c_int, _ip, _ip, _ip, _ip, _dp, _dp, _dp, _dp], "IGXSetProcessors": [V, C.c_int, C.c_int],
         "IGXSetComm": [V, C.c_int, C.c_int], "IGXAxisSetDegree": [V, C.c_int, C.c_int], "IGXAxisSetPeriodic": [V, C.c_int, C.c_int],
         "IGXAxisInitUniform": [V, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int], "IGXAxisSetKnots": [V, C.c_int, C.c_int, _dp],
-        "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp],
+        "IGXSetUp": [V], "IGXSetGeometry": [V, C.c_int, _dp, _dp], "IGXSetProperty": [V, C.c_int, _dp], "IGXGetPropertyDim": [V, C.POINTER(C.c_int)],
         "IGXComputeScalar": [V, V, C.c_int, _dp, C.c_int, C.c_int, _dp],
         "IGXComputeScalarSource": [V, V, C.c_char_p, C.c_char_p, _dp, C.c_int, C.c_int, _dp],
         "IGXRead": [V, C.c_char_p], "IGXWrite": [V, C.c_char_p], "IGXWriteVec": [V, V, C.c_char_p], "IGXReadVec": [V, V, C.c_char_p],
@@ -341,6 +342,16 @@ class IGX:
         X = np.ascontiguousarray(X, dtype=np.float64)
         Wp = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
         _ck(lib().IGXSetGeometry(self.h, X.shape[-1], X.ctypes.data_as(_dp), None if Wp is None else Wp.ctypes.data_as(_dp)))
+
+    def set_property(self, A):
+        """IGASetPropertyDim + the property array on the geometry grid, natural order [..][npd] (None drops it)."""
+        if A is None:
+            _ck(lib().IGXSetProperty(self.h, 0, None)); return
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        _ck(lib().IGXSetProperty(self.h, A.shape[-1], A.ctypes.data_as(_dp)))
+
+    def property_dim(self):
+        n = C.c_int(0); _ck(lib().IGXGetPropertyDim(self.h, C.byref(n))); return n.value
 
     def set_boundary_value(self, axis, side, field, value): _ck(lib().IGXSetBoundaryValue(self.h, axis, side, field, value))
     def set_boundary_load(self, axis, side, field, value): _ck(lib().IGXSetBoundaryLoad(self.h, axis, side, field, value))

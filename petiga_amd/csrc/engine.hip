@@ -75,7 +75,7 @@ struct _p_IGX {
   Space s;
   bool on_device = false;
   AxisBufs ab[3];
-  DevBuf X, W, fixtable, errflag, scratch;
+  DevBuf X, W, A, fixtable, errflag, scratch;
   hipStream_t stream = nullptr;
   int kernel_choice = 0;
   _p_IGX() { s.env = read_env_switches(); kernel_choice = s.env.kernel; }   // environment switches are read here, once per IGX
@@ -127,7 +127,7 @@ extern "C" int IGXDestroy(IGX *iga) {
 #define NEEDIGA(g) do { if (!(g)) return fail(IGX_ERR_ARG_WRONG, "null IGX"); } while (0)
 #define AXISCK(g, i) do { NEEDIGA(g); if ((i) < 0 || (i) >= 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Index must be in range [0,2]"); } while (0)
 static void touch(IGX g) { g->s.setup = false; g->on_device = false; }
-static void drop_net(IGX g) { g->s.netX.clear(); g->s.netW.clear(); g->s.net_nsd = 0; }
+static void drop_net(IGX g) { g->s.netX.clear(); g->s.netW.clear(); g->s.net_nsd = 0; g->s.netA.clear(); g->s.npd = 0; }
 
 extern "C" int IGXSetDim(IGX g, int dim) { NEEDIGA(g); if (dim < 1 || dim > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of parametric dimensions must be in range [1,3]"); g->s.dim = dim; touch(g); return 0; }
 extern "C" int IGXSetDof(IGX g, int dof) { NEEDIGA(g); if (dof < 1) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of DOFs per node must be greater than one"); if (dof > MAXBC) return fail(IGX_ERR_SUP, "device path supports dof <= 8"); g->s.dof = dof; touch(g); return 0; }
@@ -170,9 +170,11 @@ extern "C" int IGXAxisSetPeriodic(IGX g, int i, int flag) { AXISCK(g, i); g->s.a
 extern "C" int IGXAxisInitUniform(IGX g, int i, int N, double Ui, double Uf, int C) { AXISCK(g, i); std::string e; int rc = axis_init_uniform(g->s.axis[i], N, Ui, Uf, C, e); touch(g); drop_net(g); return rc ? fail(rc, e) : 0; }
 extern "C" int IGXAxisSetKnots(IGX g, int i, int m, const double U[]) { AXISCK(g, i); if (!U) return fail(IGX_ERR_ARG_WRONG, "null knots"); std::string e; int rc = axis_set_knots(g->s.axis[i], m, U, e); touch(g); drop_net(g); return rc ? fail(rc, e) : 0; }
 static int apply_geometry(IGX g);
+static int apply_property(IGX g);
 extern "C" int IGXSetUp(IGX g) {
   NEEDIGA(g); std::string e; int rc = space_setup(g->s, e); g->on_device = false;
   if (rc) return fail(rc, e);
+  if (int rp = apply_property(g)) return rp;
   return apply_geometry(g);   // a control net given by IGXRead / an earlier IGXSetGeometry survives re-partitioning
 }
 
@@ -200,6 +202,40 @@ static int apply_geometry(IGX g) {
   g->on_device = false;
   return 0;
 }
+
+// ... and of the property array (IGALoadProperty's scatters, src/petigaio.c:393-458)
+static int apply_property(IGX g) {
+  Space &s = g->s;
+  s.propA.clear();
+  if (!s.npd) return 0;
+  int gs[3] = {1, 1, 1};
+  for (int i = 0; i < s.dim; ++i) gs[i] = s.axis[i].span[s.axis[i].nel - 1] + 1;
+  const size_t nnet = (size_t)gs[0] * gs[1] * gs[2], npd = (size_t)s.npd;
+  if (s.netA.size() != nnet * npd) return fail(IGX_ERR_ARG_WRONG, "property array does not match the knot vectors");
+  const int *g0 = s.node_gstart, *gw = s.node_gwidth;
+  s.propA.assign((size_t)gw[0] * gw[1] * gw[2] * npd, 0.0);
+  size_t pos = 0;
+  for (int k = g0[2]; k < g0[2] + gw[2]; ++k) for (int j = g0[1]; j < g0[1] + gw[1]; ++j) for (int i = g0[0]; i < g0[0] + gw[0]; ++i, ++pos) {
+    const size_t gi = (size_t)i + (size_t)gs[0] * ((size_t)j + (size_t)gs[1] * (size_t)k);
+    for (size_t c = 0; c < npd; ++c) s.propA[pos * npd + c] = s.netA[gi * npd + c];
+  }
+  g->on_device = false;
+  return 0;
+}
+// IGASetPropertyDim + the array IGALoadProperty fills (src/petigaio.c:359-458): npd numbers per node of the geometry grid, natural order; npd = 0 drops it
+extern "C" int IGXSetProperty(IGX g, int npd, const double A[]) {
+  NEEDIGA(g); Space &s = g->s;
+  if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
+  if (npd < 0) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of properties must be nonnegative");
+  if (npd > 64) return fail(IGX_ERR_SUP, "device path supports at most 64 properties per node");
+  if (npd == 0) { s.npd = 0; s.netA.clear(); return apply_property(g); }
+  if (!A) return fail(IGX_ERR_ARG_WRONG, "null property array");
+  size_t nnet = 1;
+  for (int i = 0; i < s.dim; ++i) nnet *= (size_t)(s.axis[i].span[s.axis[i].nel - 1] + 1);
+  s.netA.assign(A, A + nnet * (size_t)npd); s.npd = npd;
+  return apply_property(g);
+}
+extern "C" int IGXGetPropertyDim(IGX g, int *npd) { NEEDIGA(g); if (!npd) return fail(IGX_ERR_ARG_WRONG, "null pointer"); *npd = g->s.npd; return 0; }
 
 extern "C" int IGXSetGeometry(IGX g, int nsd, const double X[], const double W[]) {
   NEEDIGA(g); Space &s = g->s;
@@ -311,6 +347,12 @@ extern "C" int IGXCreateFromTables(const IGXTables *t, IGX *out) {
     s.geomX.assign(t->geometryX, t->geometryX + n * t->nsd); s.nsd = t->nsd;
     if (t->rational) { if (!t->rationalW) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set"); s.geomW.assign(t->rationalW, t->rationalW + n); s.rational = 1; }
   }
+  if (t->property) {      // iga->property / iga->propertyA
+    if (!t->propertyA) return fail(IGX_ERR_ARG_WRONGSTATE, "No property set");
+    if (t->property < 0 || t->property > 64) return fail(IGX_ERR_SUP, "device path supports at most 64 properties per node");
+    const size_t n = (size_t)s.node_gwidth[0] * s.node_gwidth[1] * s.node_gwidth[2];
+    s.npd = t->property; s.propA.assign(t->propertyA, t->propertyA + n * (size_t)t->property);
+  }
   *out = g.release(); igx_pool_acquire();
   return 0;
 }
@@ -357,7 +399,7 @@ static int ensure_device(IGX g) {
         B.rcnt.upload(L.rcnt) || B.P.upload(L.P) || B.rcol.upload(L.rcol) || B.prefix.upload(prefix))
       return fail(IGX_ERR_MEM, "device allocation of axis tables failed");
   }
-  if (g->X.upload(s.geomX) || g->W.upload(s.geomW)) return fail(IGX_ERR_MEM, "device allocation of geometry failed");
+  if (g->X.upload(s.geomX) || g->W.upload(s.geomW) || g->A.upload(s.propA)) return fail(IGX_ERR_MEM, "device allocation of geometry failed");
   if (!g->errflag.p) { if (g->errflag.alloc(sizeof(int))) return fail(IGX_ERR_MEM, "device allocation failed"); HIPCK(hipMemset(g->errflag.p, 0, sizeof(int))); }
   g->nbrows = (int64_t)s.lay[0].nrow * s.lay[1].nrow * s.lay[2].nrow;
   {
@@ -385,6 +427,7 @@ static SpaceDev make_spacedev(IGX g) {
     A.prefix = B.prefix.as<int64_t>(); A.tot = 0; for (int r = 0; r < L.nrow; ++r) A.tot += L.rcnt[r];
   }
   S.X = s.nsd ? g->X.as<double>() : nullptr; S.W = s.rational ? g->W.as<double>() : nullptr;
+  S.npd = s.propA.empty() ? 0 : s.npd; S.A = S.npd ? g->A.as<double>() : nullptr;
   for (int a = 0; a < 3; ++a) for (int sd = 0; sd < 2; ++sd) {
     auto cp = [&](const BC &h, BCDev &dv) { dv.count = 0; for (int k = 0; k < h.count && dv.count < MAXBC; ++k) if (h.field[k] < s.dof) { dv.field[dv.count] = h.field[k]; dv.value[dv.count] = h.value[k]; dv.count++; } };
     cp(s.value[a][sd], S.bcv[a][sd]); cp(s.load[a][sd], S.bcl[a][sd]);
@@ -854,11 +897,16 @@ template <class Form, int DIM>
 static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   const Space &s = g->s;
   constexpr int DOF = Form::DOF;
-  constexpr bool SECOND = Form::ORDER >= 2;
-  constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
+  constexpr bool SECOND = Form::ORDER >= 2, THIRD = Form::ORDER >= 3;
+  constexpr int NF = nfeat<DIM>(Form::ORDER), D2 = DIM * DIM, D3 = D2 * DIM;
   constexpr int NS = nscalar_of<Form>::v;
+  // third-order tabulation, the property array and the point's shape table exist in the general kernel only
+  constexpr bool GENERAL = general_only_of<Form>::v;
+  if (GENERAL && g->kernel_choice != 0 && g->kernel_choice != 1) return fail(IGX_ERR_SUP, "a form of order 3 or one that reads the property array runs on the general kernel only");
+  if ((Form::NEED & NEED_PROP) && !S.npd) return fail(IGX_ERR_ARG_WRONGSTATE, "No property set");      // src/petigaelem.c:300
+  if (THIRD && s.order < 3) return fail(IGX_ERR_ARG_WRONGSTATE, "the form reads third derivatives (p->shape[3]): call IGASetOrder(iga,3) first");
 #ifdef IGX_HAVE_VEC_SUMFACT
-  if constexpr (DIM == 3) if (g->kernel_choice == 0) {   // vector-only drivers: sum factorisation both ways (vec_sumfact.hpp)
+  if constexpr (DIM == 3 && !GENERAL) if (g->kernel_choice == 0) {   // vector-only drivers: sum factorisation both ways (vec_sumfact.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -867,7 +915,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   }
 #endif
 #ifdef IGX_HAVE_BLOCK_PENCIL
-  if constexpr (DIM == 3) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer (block_pencil.hpp)
+  if constexpr (DIM == 3 && !GENERAL) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer (block_pencil.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -878,7 +926,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
 #ifdef IGX_HAVE_BAND_PT
   // (p = 2 only on request: the 27-function element in 4 x 4 x 4 tile slots wastes two thirds of the MFMAs there -- NS-VMS 48^3: 7.7 M el/s, the
   //  feature kernel's 2 x 2 tiles are as fast -- so the automatic choice keeps the feature kernel at p = 2)
-  if constexpr (DIM == 3) if ((g->kernel_choice == 0 && s.axis[0].p == 3) || g->kernel_choice == 4) {   // band rows by node layer, point-dependent coefficients (band_pt.hpp)
+  if constexpr (DIM == 3 && !GENERAL) if ((g->kernel_choice == 0 && s.axis[0].p == 3) || g->kernel_choice == 4) {   // band rows by node layer, point-dependent coefficients (band_pt.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -887,14 +935,14 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   }
 #endif
   if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields; band_pt: 3-D, p = 2 or 3, any geometry: matrix-only driver of a 4-field form with separated point coefficients, System / Matrix driver of a constant-coefficient form with 2 or 3 fields without boundary loads)");
-  if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
+  if constexpr (!GENERAL) if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;
     if (done) return 0;
     if (g->kernel_choice == 3) return fail(IGX_ERR_SUP, "the feature-GEMM kernel does not cover this case (needs dim >= 2 and nen <= 64; in 3-D nen <= 128 / 256 for forms with at most two / one accumulator set)");
   }
   if (g->zero_matrix) g->zero_matrix();
-  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  const bool fields = (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_D3U)) != 0;
   if (s.dof != DOF && (NS == 0 || fields)) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
@@ -906,6 +954,8 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
   cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
   cv.G = take((Form::NEED & NEED_G) ? NQ * D2 : 0);
+  cv.E3 = take((s.nsd && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
+  cv.d3u = take((THIRD && (Form::NEED & NEED_D3U)) ? NQ * DOF * D3 : 0); cv.gA = take(NE * S.npd);
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((Form::NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
@@ -1010,6 +1060,8 @@ static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
   case IGX_FORM_L2PROJ_X2: IGX_GROUP(0, (launch_generic<FormL2ProjX2<DIM>, DIM>(g, S, out)));
   case IGX_FORM_BOUNDARYINTEGRAL: IGX_GROUP(0, (launch_generic<FormBoundaryIntegral<DIM>, DIM>(g, S, out)));
   case IGX_FORM_NITSCHE:          IGX_GROUP(0, (launch_generic<FormNitsche<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_DER3:      IGX_GROUP(0, (launch_generic<FormDer3<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_PROPERTY:  IGX_GROUP(0, (launch_generic<FormProperty<DIM>, DIM>(g, S, out)));
   case IGX_FORM_ERRNORM:   IGX_GROUP(1, (launch_generic<FormErrNorm<DIM>, DIM>(g, S, out)));
   case IGX_FORM_MASS:
     if constexpr (GROUP < 0 || GROUP == 1) {

@@ -68,7 +68,18 @@ static int igx_read_into(Space &s, FILE *f, const Space &keep) {
     if (!((wmax - wmin) > 100 * DBL_EPSILON)) s.netW.clear();   // iga->rational, src/petigaio.c:253-255
     s.net_nsd = nsd;
   }
-  // property arrays (info & 2) are not on the assembly path: ignored
+  if (info & 0x2) {      // IGALoad, src/petigaio.c:65-70: the property dimension, then the Vec in natural order [node][npd] (IGALoadProperty :393-458)
+    int npd = 0, vid = 0, n = 0;
+    if (!rd_int(f, npd) || npd < 1 || npd > 64) return fail(66, "bad property dimension");
+    if (!rd_int(f, vid) || vid != VEC_FILE_CLASSID_ || !rd_int(f, n) || n < 0) return fail(66, "bad property Vec header");
+    size_t nnet = 1;
+    for (int i = 0; i < dim; ++i) nnet *= (size_t)(s.axis[i].m - s.axis[i].p);
+    if ((size_t)n != nnet * (size_t)npd) return fail(IGX_ERR_ARG_WRONG, "property Vec size does not match the knot vectors");
+    if ((long long)n * 8 > bytes_left(f)) return fail(66, "truncated property array");
+    s.netA.assign((size_t)n, 0.0);
+    if (!rd_dbl(f, s.netA.data(), s.netA.size())) return fail(66, "truncated property array");
+    s.npd = npd;
+  }
   return 0;
 }
 
@@ -93,7 +104,8 @@ extern "C" int IGXWrite(IGX g, const char filename[]) {   // IGAWrite -> IGASave
   if (s.dim < 1) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetDim() first");
   FileCloser fc{fopen(filename, "wb")};
   if (!fc.f) return fail(65, std::string("cannot open ") + filename);
-  bool ok = wr_int(fc.f, IGA_FILE_CLASSID_) && wr_int(fc.f, s.net_nsd ? 1 : 0) && wr_int(fc.f, s.dim);
+  const bool prop = s.npd > 0 && !s.netA.empty();
+  bool ok = wr_int(fc.f, IGA_FILE_CLASSID_) && wr_int(fc.f, (s.net_nsd ? 1 : 0) | (prop ? 2 : 0)) && wr_int(fc.f, s.dim);
   for (int i = 0; i < s.dim && ok; ++i) ok = wr_int(fc.f, s.axis[i].p) && wr_int(fc.f, s.axis[i].m + 1) && wr_dbl(fc.f, s.axis[i].U.data(), s.axis[i].U.size());
   if (ok && s.net_nsd) {
     const int nsd = s.net_nsd; const size_t nnet = s.netX.size() / nsd;
@@ -105,6 +117,7 @@ extern "C" int IGXWrite(IGX g, const char filename[]) {   // IGAWrite -> IGASave
     }
     ok = wr_int(fc.f, nsd) && wr_int(fc.f, VEC_FILE_CLASSID_) && wr_int(fc.f, (int)xw.size()) && wr_dbl(fc.f, xw.data(), xw.size());
   }
+  if (ok && prop) ok = wr_int(fc.f, s.npd) && wr_int(fc.f, VEC_FILE_CLASSID_) && wr_int(fc.f, (int)s.netA.size()) && wr_dbl(fc.f, s.netA.data(), s.netA.size());      // IGASave, src/petigaio.c:130-135
   return ok ? 0 : fail(67 /*PETSC_ERR_FILE_WRITE*/, "write failed");
 }
 

@@ -11,7 +11,9 @@
 
 namespace igx {
 
-enum : unsigned { NEED_X = 1u, NEED_U = 2u, NEED_UT = 4u, NEED_GU = 8u, NEED_HU = 16u, NEED_G = 32u };
+enum : unsigned { NEED_X = 1u, NEED_U = 2u, NEED_UT = 4u, NEED_GU = 8u, NEED_HU = 16u, NEED_G = 32u, NEED_D3U = 64u, NEED_PROP = 128u };
+// a form of ORDER 3, or one that reads the property array / the point's shape table, runs on the general kernel only
+template <class Form> struct general_only_of { static constexpr bool v = Form::ORDER >= 3 || (Form::NEED & (NEED_PROP | NEED_D3U)) != 0; };
 
 struct PtView {
   const double *x;     // physical point [DIM] (parametric point when there is no geometry)
@@ -20,6 +22,11 @@ struct PtView {
   const double *gu;    // gradient          [dof][DIM]
   const double *hu;    // hessian           [dof][DIM][DIM]
   const double *G;     // IGAPointFormInvGradGeomMap [DIM][DIM] (src/petigapoint.c:269-294)
+  // the general kernel only (forms of ORDER 3 or with NEED_PROP are routed there):
+  const double *d3u = nullptr;       // third derivatives [dof][DIM][DIM][DIM] (IGAPointFormDer3, include/petiga.h:731; NEED_D3U)
+  const double *property = nullptr;  // p->property: the property array of the element's nodes [nen][npd] (include/petiga.h:662); npd = 0 without one
+  const double *shape = nullptr;     // the point's shape functions [nen][nf] (value, gradient, ... laid out as a form's Na), e.g. to interpolate the properties
+  int npd = 0, nen = 0, nf = 0;
   const double *prm;   // form parameters (replaces ctx)
   double shift, t;
   const double *normal;  // unit outward normal [DIM] at a boundary-form point (p->normal), else null
@@ -106,6 +113,49 @@ template <int DIM> struct FormErrNorm {
     for (int i = 0; i < DIM; ++i) { s1 += p.x[i]; s2 += p.x[i] * p.x[i]; pr *= p.x[i]; }
     R[0] = Na[0] * 1.0; R[1] = Na[0] * s1; R[2] = Na[0] * s2; R[3] = Na[0] * pr;
   }
+};
+
+// A form on the third derivatives (IGASetOrder(iga,3): p->shape[3] as test/IGAGeometryMap.c:179,221 reads it, IGAPointFormDer3 as
+// demo/AutoDiff/CahnHilliardPrimalFAD.cxx:51 does).  params {k3, f3, u3}:
+//   K_ab = N_a N_b + k3 sum_ijk d_ijk N_a d_ijk N_b,   F_a = N_a (1 + |x|^2) + f3 sum_ijk c_ijk d_ijk N_a + u3 N_a sum_ijk c_ijk d_ijk u,
+// c_ijk = 1 / (1 + i + 2 j + 3 k); the last term through the Function / IFunction drivers (u = 0 under the System driver).
+template <int DIM> struct FormDer3 {
+  static constexpr int DOF = 1, ORDER = 3; static constexpr unsigned NEED = NEED_X | NEED_U | NEED_D3U;
+  static constexpr int O3 = 1 + DIM + DIM * DIM;
+  static __device__ __forceinline__ double c3(int i, int j, int k) { return 1.0 / (1.0 + i + 2.0 * j + 3.0 * k); }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double s = 0;
+#pragma unroll
+    for (int f = 0; f < DIM * DIM * DIM; ++f) s += Na[O3 + f] * Nb[O3 + f];
+    T[0] = Na[0] * Nb[0] + p.prm[0] * s;
+  }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) {
+    double x2 = 0, s = 0, su = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) x2 += p.x[i] * p.x[i];
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k) { const double c = c3(i, j, k); s += c * Na[O3 + (i * DIM + j) * DIM + k]; su += c * p.d3u[(i * DIM + j) * DIM + k]; }
+    R[0] = Na[0] * (1.0 + x2) + p.prm[1] * s + p.prm[2] * Na[0] * su;
+  }
+};
+
+// A Poisson problem whose conductivity and source live on the control net as a property array (IGASetPropertyDim, include/petiga.h:350-353;
+// the point sees its element's nodal values, p->property [nen][npd], and interpolates them with its own shape functions p->shape[0]):
+//   k(q) = sum_a N_a(q) A_a[0],  f(q) = sum_a N_a(q) A_a[npd - 1],   K_ab = k grad N_a . grad N_b,   F_a = N_a f.
+template <int DIM> struct FormProperty {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_PROP;
+  static __device__ __forceinline__ double interp(const PtView &p, int c) { double s = 0; for (int a = 0; a < p.nen; ++a) s += p.shape[a * p.nf] * p.property[a * p.npd + c]; return s; }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i];
+    T[0] = interp(p, 0) * s;
+  }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * interp(p, p.npd - 1); }
 };
 
 // demo/Elasticity3D.c:13-46 System; params {lambda, mu}.  The reference's [1][1] block carries an

@@ -19,12 +19,14 @@ struct Carve {          // offsets (in doubles) into the dynamic LDS block; -1 =
   int t1d[3], w1d[3];
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
+  int E3, W3, d3u;      // order 3 (Form::ORDER >= 3): third-order inverse map, third derivatives of the NURBS denominator and of the fields
+  int gA;               // property array of the element's nodes [nen][npd] (IGAElementBuildClosure, src/petigaelem.c:745-752)
   int u, ut, gu, hu, lift, phi;
   int nrm;              // [nqp][DIM] outward unit normals of a boundary-form pass
   int total;            // doubles
 };
 
-template <int DIM> __device__ __forceinline__ constexpr int nfeat(int order) { return order >= 2 ? 1 + DIM + DIM * DIM : 1 + DIM; }
+template <int DIM> __host__ __device__ __forceinline__ constexpr int nfeat(int order) { return order >= 3 ? 1 + DIM + DIM * DIM + DIM * DIM * DIM : (order >= 2 ? 1 + DIM + DIM * DIM : 1 + DIM); }
 
 __device__ __forceinline__ double det3(const double *A, int d) {   // A row-major [d][d]
   if (d == 1) return A[0];
@@ -41,16 +43,16 @@ __device__ __forceinline__ void inv3(const double *A, int d, double det, double 
 
 // parametric tensor-product basis value + derivatives of basis function a=(a0,a1,a2) at point q=(q0,q1,q2)
 // (K2, src/petiga3d.F90:32-233) read from the LDS copies of the three 1-D rows.
-template <int DIM, bool SECOND>
+template <int DIM, bool SECOND, bool THIRD = false>
 __device__ __forceinline__ void tensor_basis(const double *const t[3], const int na[3], const int aq[3], const int qq[3],
-                                             double &b0, double *b1, double *b2) {
-  double n[3][3];
+                                             double &b0, double *b1, double *b2, double *b3 = nullptr) {
+  double n[3][4];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     if (d < DIM) {
       const double *r = t[d] + (qq[d] * na[d] + aq[d]) * NDER;
-      n[d][0] = r[0]; n[d][1] = r[1]; n[d][2] = SECOND ? r[2] : 0.0;
-    } else { n[d][0] = 1; n[d][1] = 0; n[d][2] = 0; }
+      n[d][0] = r[0]; n[d][1] = r[1]; n[d][2] = SECOND ? r[2] : 0.0; n[d][3] = THIRD ? r[3] : 0.0;
+    } else { n[d][0] = 1; n[d][1] = 0; n[d][2] = 0; n[d][3] = 0; }
   }
   b0 = n[0][0] * n[1][0] * n[2][0];
 #pragma unroll
@@ -62,8 +64,34 @@ __device__ __forceinline__ void tensor_basis(const double *const t[3], const int
       for (int j = 0; j < DIM; ++j)
         b2[i * DIM + j] = n[0][(i == 0) + (j == 0)] * n[1][(i == 1) + (j == 1)] * n[2][(i == 2) + (j == 2)];
   }
+  if constexpr (THIRD) {      // K2 at order 3 (src/petiga3d.F90:32-233): N3(c,b,a) = the product of the 1-D derivatives of the orders the three indices count
+#pragma unroll
+    for (int i = 0; i < DIM; ++i)
+#pragma unroll
+      for (int j = 0; j < DIM; ++j)
+#pragma unroll
+        for (int k = 0; k < DIM; ++k)
+          b3[(i * DIM + j) * DIM + k] = n[0][(i == 0) + (j == 0) + (k == 0)] * n[1][(i == 1) + (j == 1) + (k == 1)] * n[2][(i == 2) + (j == 2) + (k == 2)];
+  }
 }
 
+// Rationalize (src/petigarat.f90.in:3-57) of one basis function at one point: b_k in, R_k out (in place); w its weight, W_k the
+// derivatives of the denominator there.  Orders 2 and 3 use the rationalised lower orders.
+template <int DIM, bool SECOND, bool THIRD>
+__device__ __forceinline__ void rationalize(double w, double w0, const double *W1, const double *W2, const double *W3, double &b0, double *b1, double *b2, double *b3) {
+  const double r0 = w * b0 / w0;
+  double r1[3];
+  for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[i]) / w0;
+  if (SECOND)
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
+      b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[i * DIM + j] - r1[i] * W1[j] - r1[j] * W1[i]) / w0;
+  if constexpr (THIRD)
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) for (int k = 0; k < DIM; ++k)
+      b3[(i * DIM + j) * DIM + k] = (w * b3[(i * DIM + j) * DIM + k] - r0 * W3[(i * DIM + j) * DIM + k]
+                                     - r1[i] * W2[j * DIM + k] - r1[j] * W2[i * DIM + k] - r1[k] * W2[i * DIM + j]
+                                     - b2[j * DIM + k] * W1[i] - b2[i * DIM + k] * W1[j] - b2[i * DIM + j] * W1[k]) / w0;
+  b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
+}
 
 // Local numbering of an element's basis functions in the kernels' LDS arrays.  Natural: a = a0 + na0*(a1 + na1*a2)
 // (IGAElementBuildClosure, src/petigaelem.c:711-719).  WALK (feature kernel's pencil mode, 4x4x4 functions): the axis-0 index
@@ -143,9 +171,9 @@ template <class Form, int DIM>
 __global__ void __launch_bounds__(256)
 generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv, double *phi_global, size_t phi_stride) {
   constexpr int DOF = Form::DOF;
-  constexpr bool SECOND = Form::ORDER >= 2;
-  constexpr int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM;
-  constexpr int D2 = DIM * DIM;
+  constexpr bool SECOND = Form::ORDER >= 2, THIRD = Form::ORDER >= 3;      // (IGASetOrder: the tabulation goes as far as the form says it reads)
+  constexpr int NF = nfeat<DIM>(Form::ORDER);
+  constexpr int D2 = DIM * DIM, D3 = D2 * DIM;
   constexpr int NS = nscalar_of<Form>::v;   // > 0: a scalar functional (OP_SCALAR), no matrix / vector phases
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -185,6 +213,8 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
   double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
   double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
+  double *E3 = smem + cv.E3, *W3 = smem + cv.W3, *fd3u = smem + cv.d3u, *gA = smem + cv.gA;
+  const int npd = S.npd;
   double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift, *nrm = smem + cv.nrm;
   double *phi = (cv.phi >= 0) ? smem + cv.phi : phi_global + (size_t)blockIdx.x * phi_stride;
   __shared__ int s_anyfix;
@@ -209,6 +239,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     const size_t row = (size_t)S.ax[0].rowmap[i0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[i1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[i2]);
     if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
     if (rat) gW[a] = S.W[g];
+    for (int c = 0; c < npd; ++c) gA[a * npd + c] = S.A[g * npd + c];
     if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
     if (useV) for (int c = 0; c < DOF; ++c) Ve[a * DOF + c] = out.V[row * DOF + c];
     // IGAElementBuildFix (src/petigaelem.c:1214-1283): faces in (dir, side) order, later faces override
@@ -258,48 +289,43 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   for (int q = tid; q < NQ; q += nthr) {
     const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
     double detX = 1.0;
-    double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0};
-    double x0[3], X1[9], X2[27];
+    double w0 = 1, w1[3] = {0, 0, 0}, w2[9] = {0}, w3[THIRD ? 27 : 1] = {0};
+    double x0[3], X1[9], X2[27], X3[THIRD ? 81 : 1];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) x0[d] = (d == baxis) ? S.ax[d].bndpt[bside] : S.ax[d].pt[el[d] * nq[d] + qq[d]];
     if (rat) {
       w0 = 0;
       for (int a = 0; a < NE; ++a) {
         const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
-        double b0, b1[3], b2[9];
-        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
+        double b0, b1[3], b2[9], b3[THIRD ? 27 : 1];
+        tensor_basis<DIM, SECOND, THIRD>(t1d, na, aq, qq, b0, b1, b2, b3);
         const double w = gW[a];
         w0 += w * b0;
         for (int i = 0; i < DIM; ++i) w1[i] += w * b1[i];
         if (SECOND) for (int i = 0; i < D2; ++i) w2[i] += w * b2[i];
+        if constexpr (THIRD) for (int i = 0; i < D3; ++i) w3[i] += w * b3[i];
       }
       W0[q] = w0;
       for (int i = 0; i < DIM; ++i) W1[q * DIM + i] = w1[i];
       if (SECOND) for (int i = 0; i < D2; ++i) W2[q * D2 + i] = w2[i];
+      if constexpr (THIRD) for (int i = 0; i < D3; ++i) W3[q * D3 + i] = w3[i];
     }
     if (geo) {
       for (int i = 0; i < DIM; ++i) x0[i] = 0;
       for (int i = 0; i < D2; ++i) X1[i] = 0;
       if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
+      if constexpr (THIRD) for (int i = 0; i < D3 * DIM; ++i) X3[i] = 0;
       for (int a = 0; a < NE; ++a) {
         const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
-        double b0, b1[3], b2[9];
-        tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-        if (rat) {   // Rationalize, src/petigarat.f90.in:3-57
-          const double w = gW[a];
-          const double r0 = w * b0 / w0;
-          double r1[3];
-          for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * w1[i]) / w0;
-          if (SECOND)
-            for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-              b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * w2[i * DIM + j] - r1[i] * w1[j] - r1[j] * w1[i]) / w0;
-          b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
-        }
+        double b0, b1[3], b2[9], b3[THIRD ? 27 : 1];
+        tensor_basis<DIM, SECOND, THIRD>(t1d, na, aq, qq, b0, b1, b2, b3);
+        if (rat) rationalize<DIM, SECOND, THIRD>(gW[a], w0, w1, w2, w3, b0, b1, b2, b3);   // Rationalize, src/petigarat.f90.in:3-57
         for (int i = 0; i < DIM; ++i) {
           const double x = gX[a * DIM + i];
           x0[i] += x * b0;
           for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
           if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
+          if constexpr (THIRD) for (int f = 0; f < D3; ++f) X3[i * D3 + f] += x * b3[f];
         }
       }
       detX = det3(X1, DIM);
@@ -312,6 +338,19 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
           for (int k = 0; k < DIM; ++k) for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b)
             s -= X2[k * D2 + a * DIM + b] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
           E2[(q * DIM + c) * D2 + i * DIM + j] = s;
+        }
+      }
+      if constexpr (THIRD) {   // InverseMap order 3, src/petigamapinv.f90.in:49-60: the third derivatives of the parametric coordinates
+        const double *e2 = E2 + (size_t)q * DIM * D2;      // [c][i][j], written by this thread just above
+        for (int dd = 0; dd < DIM; ++dd) for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) for (int k = 0; k < DIM; ++k) {
+          double s = 0;
+          for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b) for (int l = 0; l < DIM; ++l) {
+            double t = 0;
+            for (int c = 0; c < DIM; ++c) t += X3[l * D3 + (a * DIM + b) * DIM + c] * e1[a * DIM + i] * e1[b * DIM + j] * e1[c * DIM + k];
+            t += X2[l * D2 + a * DIM + b] * (e1[a * DIM + i] * e2[b * D2 + j * DIM + k] + e1[b * DIM + j] * e2[a * D2 + i * DIM + k] + e1[b * DIM + k] * e2[a * D2 + i * DIM + j]);
+            s -= t * e1[dd * DIM + l];
+          }
+          E3[((size_t)q * DIM + dd) * D3 + (i * DIM + j) * DIM + k] = s;
         }
       }
       if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
@@ -355,23 +394,15 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     const int q = idx / NE, a = idx - q * NE;
     const int qq[3] = {q % nq[0], (q / nq[0]) % nq[1], q / (nq[0] * nq[1])};
     const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
-    double b0, b1[3], b2[9];
-    tensor_basis<DIM, SECOND>(t1d, na, aq, qq, b0, b1, b2);
-    if (rat) {
-      const double w = gW[a], w0 = W0[q];
-      const double r0 = w * b0 / w0;
-      double r1[3];
-      for (int i = 0; i < DIM; ++i) r1[i] = (w * b1[i] - r0 * W1[q * DIM + i]) / w0;
-      if (SECOND)
-        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j)
-          b2[i * DIM + j] = (w * b2[i * DIM + j] - r0 * W2[q * D2 + i * DIM + j] - r1[i] * W1[q * DIM + j] - r1[j] * W1[q * DIM + i]) / w0;
-      b0 = r0; for (int i = 0; i < DIM; ++i) b1[i] = r1[i];
-    }
+    double b0, b1[3], b2[9], b3[THIRD ? 27 : 1];
+    tensor_basis<DIM, SECOND, THIRD>(t1d, na, aq, qq, b0, b1, b2, b3);
+    if (rat) rationalize<DIM, SECOND, THIRD>(gW[a], W0[q], W1 + q * DIM, W2 + q * D2, W3 + q * D3, b0, b1, b2, b3);
     double *o = phi + (size_t)idx * NF;
     o[0] = b0;
     if (!geo) {
       for (int i = 0; i < DIM; ++i) o[1 + i] = b1[i];
       if (SECOND) for (int i = 0; i < D2; ++i) o[1 + DIM + i] = b2[i];
+      if constexpr (THIRD) for (int i = 0; i < D3; ++i) o[1 + DIM + D2 + i] = b3[i];
     } else {   // ShapeFunctions, src/petigamapshf.f90.in:30-58
       const double *e1 = E1 + q * D2;
       for (int i = 0; i < DIM; ++i) { double s = 0; for (int al = 0; al < DIM; ++al) s += b1[al] * e1[al * DIM + i]; o[1 + i] = s; }
@@ -386,15 +417,29 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
           o[1 + DIM + i * DIM + j] = s;
         }
       }
+      if constexpr (THIRD) {   // ShapeFunctions order 3, src/petigamapshf.f90.in:60-72
+        const double *e2 = E2 + (size_t)q * DIM * D2, *e3 = E3 + (size_t)q * DIM * D3;
+        for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) for (int k = 0; k < DIM; ++k) {
+          double s = 0;
+          for (int al = 0; al < DIM; ++al) {
+            for (int be = 0; be < DIM; ++be) {
+              for (int ga = 0; ga < DIM; ++ga) s += b3[(al * DIM + be) * DIM + ga] * e1[al * DIM + i] * e1[be * DIM + j] * e1[ga * DIM + k];
+              s += b2[al * DIM + be] * (e1[al * DIM + i] * e2[be * D2 + j * DIM + k] + e1[be * DIM + j] * e2[al * D2 + i * DIM + k] + e1[be * DIM + k] * e2[al * D2 + i * DIM + j]);
+            }
+            s += b1[al] * e3[al * D3 + (i * DIM + j) * DIM + k];
+          }
+          o[1 + DIM + D2 + (i * DIM + j) * DIM + k] = s;
+        }
+      }
     }
   }
   __syncthreads();
 
   // ---- phase 3: field values at the points (src/petigaval.F90:182-232)
-  if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) {
+  if (Form::NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_D3U)) {
     for (int idx = tid; idx < NQ * DOF; idx += nthr) {
       const int q = idx / DOF, c = idx - q * DOF;
-      double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0};
+      double u = 0, ut = 0, g[3] = {0, 0, 0}, h[9] = {0}, t3[THIRD ? 27 : 1] = {0};
       for (int a = 0; a < NE; ++a) {
         const double *f = phi + ((size_t)q * NE + a) * NF;
         const double Ua = useU ? Ue[a * DOF + c] : 0.0;
@@ -402,10 +447,12 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         if (useV) ut += f[0] * Ve[a * DOF + c];
         if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) g[i] += f[1 + i] * Ua;
         if (SECOND && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) h[i] += f[1 + DIM + i] * Ua;
+        if constexpr (THIRD) if (Form::NEED & NEED_D3U) for (int i = 0; i < D3; ++i) t3[i] += f[1 + DIM + D2 + i] * Ua;      // IGAPointFormDer3, src/petigapoint.c (IGA_GetDer3)
       }
       fu[idx] = u; fut[idx] = ut;
       if (Form::NEED & NEED_GU) for (int i = 0; i < DIM; ++i) fgu[idx * DIM + i] = g[i];
       if (SECOND && (Form::NEED & NEED_HU)) for (int i = 0; i < D2; ++i) fhu[idx * D2 + i] = h[i];
+      if constexpr (THIRD) if (Form::NEED & NEED_D3U) for (int i = 0; i < D3; ++i) fd3u[idx * D3 + i] = t3[i];
     }
   }
   if constexpr (NS > 0) {
@@ -414,7 +461,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     for (int q = tid; q < NQ; q += nthr) {
       PtView p;
       p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-      p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
+      p.G = Gq + q * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
       double Sq[NS];
       Form::scalar(p, Sq);
       const double jw = JW[q];
@@ -443,7 +490,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   auto point = [&](int q) {
     PtView p;
     p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-    p.G = Gq + q * D2; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
+    p.G = Gq + q * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
     return p;
   };
   const int W0s = 2 * S.ax[0].p + 1, W1s = 2 * S.ax[1].p + 1, W2s = 2 * S.ax[2].p + 1;

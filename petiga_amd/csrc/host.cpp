@@ -430,7 +430,7 @@ int space_setup(Space &s, std::string &err) {
     s.elem_sizes[i] = 1; s.elem_start[i] = 0; s.elem_width[i] = 1;
     s.node_sizes[i] = 1; s.node_lstart[i] = 0; s.node_lwidth[i] = 1; s.node_gstart[i] = 0; s.node_gwidth[i] = 1;
   }
-  s.nsd = 0; s.rational = 0; s.geomX.clear(); s.geomW.clear();   // src/petiga.c:1290-1298
+  s.nsd = 0; s.rational = 0; s.geomX.clear(); s.geomW.clear(); s.propA.clear();   // src/petiga.c:1290-1299
   if (s.order < 0) { int o = 0; for (int i = 0; i < dim; ++i) o = std::max(o, s.axis[i].p); s.order = std::min(std::max(o, 1), 4); }
   for (int i = 0; i < dim; ++i) {
     const int q = s.rule_nqp[i] > 0 ? s.rule_nqp[i] : s.axis[i].p + 1;   // src/petigabasis.c:103

@@ -124,6 +124,8 @@ struct Space {
   int nsd = 0, rational = 0;
   std::vector<double> geomX, geomW;       // ghosted local
   std::vector<double> netX, netW;         // global control net (geometry grid, natural order) kept for IGXWrite / re-partitioning
+  int npd = 0;                            // iga->property: numbers per node of the property array (0: none)
+  std::vector<double> netA, propA;        // ... on the global net [node][npd] (natural order) / ghosted local (iga->propertyA, include/petiga.h:350-353)
   int net_nsd = 0;
   BC value[3][2], load[3][2];
   bool visit[3][2] = {{false, false}, {false, false}, {false, false}};   // IGAFormSetBoundaryForm, src/petigaform.c:134
@@ -173,6 +175,8 @@ struct SpaceDev {
   const double *W;     // ghosted local or null
   BCDev bcv[3][2], bcl[3][2];
   const double *fixtable;  // row-indexed [nrows][dof] or null
+  const double *A;         // property array, ghosted local [.][npd], or null
+  int npd;
 };
 
 struct ColorRange { int start[3], step[3], count[3]; };

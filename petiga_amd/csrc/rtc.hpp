@@ -713,6 +713,13 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   const int DOF = F.meta[0];
   if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "a struct with NSCALAR is a functional: IGXComputeScalarSource");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
+  // a struct of ORDER 3, or one that reads the property array / the point's shape table / third derivatives of the state: the general kernel (as launch_generic)
+  if (F.meta[1] >= 3 || ((unsigned)F.meta[2] & (NEED_PROP | NEED_D3U))) {
+    if (g->kernel_choice != 0 && g->kernel_choice != 1) return fail(IGX_ERR_SUP, "a form of order 3 or one that reads the property array runs on the general kernel only");
+    if (((unsigned)F.meta[2] & NEED_PROP) && !S.npd) return fail(IGX_ERR_ARG_WRONGSTATE, "No property set");
+    if (g->zero_matrix) g->zero_matrix();
+    return rtc_generic_launch(g, F, S, out);
+  }
   if (g->kernel_choice == 0) {   // vector-only drivers in 3-D: sum factorisation both ways (vec_sumfact.hpp)
     bool done = false;
     if (int rc = launch_vecsf_rtc(g, F, S, out, done)) return rc;
@@ -754,9 +761,9 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
 // (NSCALAR > 0: one sweep, a row of partial sums per element, as launch_generic does for the built-in ones)
 static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &out) {
   Space &s = g->s;
-  const int DOF = F.meta[0], DIM = s.dim, NS = F.meta[3]; const bool SECOND = F.meta[1] >= 2; const unsigned NEED = (unsigned)F.meta[2];
-  const int NF = SECOND ? 1 + DIM + DIM * DIM : 1 + DIM, D2 = DIM * DIM;
-  const bool fields = (NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU)) != 0;
+  const int DOF = F.meta[0], DIM = s.dim, NS = F.meta[3]; const bool SECOND = F.meta[1] >= 2, THIRD = F.meta[1] >= 3; const unsigned NEED = (unsigned)F.meta[2];
+  const int D2 = DIM * DIM, D3 = D2 * DIM, NF = 1 + DIM + (SECOND ? D2 : 0) + (THIRD ? D3 : 0);
+  const bool fields = (NEED & (NEED_U | NEED_UT | NEED_GU | NEED_HU | NEED_D3U)) != 0;
   int nq[3], na[3]; int NQ = 1, NE = 1;
   for (int d = 0; d < 3; ++d) { nq[d] = s.basis[d].nqp; na[d] = s.basis[d].nen; NQ *= nq[d]; NE *= na[d]; }
   Carve cv; int pos = 0;
@@ -767,6 +774,8 @@ static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
   cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
   cv.G = take((NEED & NEED_G) ? NQ * D2 : 0);
+  cv.E3 = take((s.nsd && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
+  cv.d3u = take((THIRD && (NEED & NEED_D3U)) ? NQ * DOF * D3 : 0); cv.gA = take(NE * S.npd);
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));

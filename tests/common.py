@@ -95,9 +95,10 @@ def compare_mats(eng_mat, orc_mat, tol):
 IGA_FILE_CLASSID, VEC_FILE_CLASSID = 1211299, 1211214
 
 
-def iga_file_bytes(degrees, knots, X=None, W=None):
-    """Big-endian: classid, info, dim, {p, nk, U}, [nsd, Vec(classid, n, (x*w.., w) per control point)]."""
-    out = [np.array([IGA_FILE_CLASSID, 1 if X is not None else 0, len(degrees)], dtype=">i4").tobytes()]
+def iga_file_bytes(degrees, knots, X=None, W=None, A=None):
+    """Big-endian: classid, info, dim, {p, nk, U}, [nsd, Vec(classid, n, (x*w.., w) per control point)], [npd, Vec(classid, n, A[node][npd])]
+    (IGASave, src/petigaio.c:75-139: info bit 0 geometry, bit 1 property)."""
+    out = [np.array([IGA_FILE_CLASSID, (1 if X is not None else 0) | (2 if A is not None else 0), len(degrees)], dtype=">i4").tobytes()]
     for p, U in zip(degrees, knots):
         out.append(np.array([p, len(U)], dtype=">i4").tobytes())
         out.append(np.asarray(U, dtype=">f8").tobytes())
@@ -108,6 +109,10 @@ def iga_file_bytes(degrees, knots, X=None, W=None):
         xw = np.concatenate([X * w[:, None], w[:, None]], axis=1)
         out.append(np.array([nsd, VEC_FILE_CLASSID, xw.size], dtype=">i4").tobytes())
         out.append(xw.astype(">f8").tobytes())
+    if A is not None:
+        A = np.asarray(A, dtype=np.float64)
+        out.append(np.array([A.shape[-1], VEC_FILE_CLASSID, A.size], dtype=">i4").tobytes())
+        out.append(A.astype(">f8").tobytes())
     return b"".join(out)
 
 

@@ -36,6 +36,31 @@ def test_read_then_write_is_identity(tmp_path, dim, p, N, rational):
         assert got == src
 
 
+@pytest.mark.parametrize("dim,p,N,geo", [(2, 2, 4, True), (3, 2, 3, False), (1, 3, 5, True)])
+def test_property_array_travels_with_the_file(tmp_path, dim, p, N, geo):
+    """IGASave / IGALoad with info bit 1 (src/petigaio.c:38,65-70,105,130-135): the property dimension and the Vec in natural order
+    behind the geometry block."""
+    _, U, X, W = _case(dim, p, N, True)
+    rng = np.random.default_rng(11)
+    A = rng.standard_normal((len(X), 3))
+    src = iga_file_bytes([p] * dim, U, X if geo else None, W if geo else None, A)
+    f = tmp_path / "prop.dat"; f.write_bytes(src)
+    g = P.IGX(); g.set_dof(1); g.read(f); g.setup()
+    assert g.property_dim() == 3
+    out = tmp_path / "out.dat"; g.write(out)
+    got = out.read_bytes()
+    assert len(got) == len(src) and got[-8 * A.size:] == src[-8 * A.size:]      # the array itself bit for bit
+    assert got[:12] == src[:12]
+    g.set_property(None)                                                          # dropped: the file loses bit 1
+    assert g.property_dim() == 0
+    g.write(out)
+    assert out.read_bytes()[4:8] == np.array([1 if geo else 0], dtype=">i4").tobytes()
+    trunc = tmp_path / "t.dat"; trunc.write_bytes(src[:-8])
+    with pytest.raises(P.IGXError) as e:
+        P.IGX().read(trunc)
+    assert e.value.code == 66
+
+
 def test_no_geometry_and_header_checks(tmp_path):
     U = [np.array([0, 0, 0, .25, .5, .5, 1, 1, 1.])]
     f = tmp_path / "a.dat"; f.write_bytes(iga_file_bytes([2], U))

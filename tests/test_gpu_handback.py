@@ -44,6 +44,7 @@ def tables_from_oracle(orc, P):
         for i in range(3):
             getattr(t, name)[i] = getattr(s, name)[i]
     t.nsd, t.rational, t.geometryX, t.rationalW = s.nsd, s.rational, s.geometryX, s.rationalW
+    t.property, t.propertyA = s.property, s.propertyA
     return t
 
 

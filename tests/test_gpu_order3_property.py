@@ -1,0 +1,178 @@
+"""Order-3 tabulation and property arrays on the general kernel (round 6).
+ * IGASetOrder(iga,3): p->shape[3] -- K2 at order 3 (src/petiga3d.F90:32-233), Rationalize order 3 (src/petigarat.f90.in), GeometryMap,
+   InverseMap order 3 (src/petigamapinv.f90.in:49-60), ShapeFunctions order 3 (src/petigamapshf.f90.in:60-72) -- and IGAPointFormDer3
+   (include/petiga.h:731), read by IGX_FORM_DER3 and by a struct given as source; the oracle holds the restated chain, pinned by
+   test/IGAGeometryMap.c's identities (tests/test_oracle_known_answers.py).
+ * IGASetPropertyDim / iga->propertyA (include/petiga.h:350-353, gathered per element at src/petigaelem.c:745-752, p->property).
+Engine vs oracle: pattern bit-exact, values to 1e-11 of the largest free entry (third derivatives reach 1e3-1e5 on these meshes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import petiga_amd as P
+from common import compare_mats, iga_file_bytes, make_pair, warped_geometry
+
+pytestmark = pytest.mark.gpu
+PRM = (0.01, 0.5, 0.25)
+
+
+def _prm(v): return (C.c_double * 3)(*v)
+
+
+def _bc(orc, eng, dim):
+    for g in (orc, eng):
+        g.set_boundary_value(0, 0, 0, 0.5)
+        if dim > 1:
+            g.set_boundary_value(1, 1, 0, -1.0)
+        g.set_boundary_load(dim - 1, 0, 0, 1.5)
+
+
+@pytest.mark.parametrize("dim,p,N,geo,bc", [(1, 3, [6], None, True), (2, 3, [4, 3], None, False), (2, 2, [4, 5], "nurbs", True), (3, 3, [3, 2, 2], "nurbs", True),
+                                            (3, 2, [3, 3, 2], "poly", False), (3, 3, [2, 3, 2], None, True), (2, 4, [3, 3], "nurbs", False)])
+def test_third_order_system_vs_oracle(dim, p, N, geo, bc):
+    orc, eng = make_pair(dim, 1, p, N, order=3)
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=5, rational=geo == "nurbs")
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    if bc:
+        _bc(orc, eng, dim)
+    A_o, b_o = orc.compute_system("orc_form_der3", _prm(PRM))
+    eng.set_form("der3", PRM)
+    A, b = eng.create_mat(), eng.create_vec()
+    eng.compute_system(A, b)
+    eng.synchronize()
+    assert "generic" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(A, A_o, 1e-11)
+    assert np.abs(b.get() - b_o).max() <= 1e-11 * max(np.abs(b_o).max(), 1.0)
+    # the third derivatives carry the result: without them K is the mass matrix
+    A0, _ = orc.compute_system("orc_form_der3", _prm((0.0, 0.0, 0.0)))
+    assert np.abs(A_o.val - A0.val).max() > 1e-3 * np.abs(A0.val).max()
+
+
+@pytest.mark.parametrize("dim,p,N,geo", [(2, 3, [4, 3], "nurbs"), (3, 2, [3, 2, 3], "nurbs"), (3, 3, [2, 2, 3], None)])
+def test_third_derivatives_of_the_state_vs_oracle(dim, p, N, geo):
+    """IGAPointFormDer3 through the Function driver; a field linear in x has none (test/IGAGeometryMap.c:221-255 through the engine)."""
+    orc, eng = make_pair(dim, 1, p, N, order=3)
+    X = None
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=6, rational=True)
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    _bc(orc, eng, dim)
+    rng = np.random.default_rng(9)
+    U = rng.standard_normal(orc.global_size())
+    F_o = orc.compute_function("orc_form_der3_function", _prm(PRM), U)
+    eng.set_form("der3", PRM)
+    Uv, F = eng.create_vec().set(U), eng.create_vec()
+    eng.compute_function(Uv, F)
+    eng.synchronize()
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * np.abs(F_o).max()
+    if X is not None:
+        eng.clear_boundary()
+        Ux = eng.create_vec().set(X[:, 0].copy())
+        F1, F0 = eng.create_vec(), eng.create_vec()
+        eng.compute_function(Ux, F1)
+        eng.set_form("der3", (PRM[0], PRM[1], 0.0))
+        eng.compute_function(Ux, F0)
+        assert np.abs(F1.get() - F0.get()).max() <= 1e-9 * np.abs(F0.get()).max()
+
+
+def test_order_and_kernel_rules():
+    _, eng = make_pair(2, 1, 2, [4, 4])                     # default order = max degree = 2 (src/petiga.c:1472-1475)
+    eng.set_form("der3", PRM)
+    A, b = eng.create_mat(), eng.create_vec()
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_system(A, b)
+    assert e.value.code == 73 and "IGASetOrder" in str(e.value)      # PETSC_ERR_ARG_WRONGSTATE
+    eng.set_order(3)
+    eng.compute_system(A, b)
+    eng.set_kernel(3)
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_system(A, b)
+    assert e.value.code == 56                                         # PETSC_ERR_SUP: the general kernel only
+    eng.set_kernel(0)
+    eng.set_form("property")
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_system(A, b)
+    assert e.value.code == 73 and "No property set" in str(e.value)   # src/petigaelem.c:300
+
+
+@pytest.mark.parametrize("dim,p,N,geo,npd", [(2, 2, [5, 4], None, 2), (3, 2, [3, 4, 3], "nurbs", 3), (3, 3, [3, 2, 2], "poly", 1), (1, 3, [7], None, 2)])
+def test_property_array_system_vs_oracle(dim, p, N, geo, npd, tmp_path):
+    orc, eng = make_pair(dim, 1, p, N)
+    X = W = None
+    if geo:
+        X, W = warped_geometry(orc, dim, seed=8, rational=geo == "nurbs")
+        orc.set_geometry(X, W); eng.set_geometry(X, W)
+    rng = np.random.default_rng(12)
+    A = 1.0 + rng.random((orc.global_size(), npd))          # (positive conductivity; one rank, no periodic axis: the net is the node grid)
+    orc.set_property(A); eng.set_property(A)
+    assert eng.property_dim() == npd
+    _bc(orc, eng, dim)
+    K_o, F_o = orc.compute_system("orc_form_property")
+    eng.set_form("property")
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    eng.synchronize()
+    assert "generic" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(K, K_o, 1e-12)
+    assert np.abs(F.get() - F_o).max() <= 1e-12 * max(np.abs(F_o).max(), 1.0)
+    # ... and read from a file (IGALoad, src/petigaio.c:65-70): the same system
+    U = [np.array(orc.axis(i)["U"]) for i in range(dim)]
+    f = tmp_path / "prop.dat"; f.write_bytes(iga_file_bytes([p] * dim, U, X, W, A))
+    eng2 = P.IGX(); eng2.set_dof(1); eng2.read(f); eng2.setup()
+    _bc(orc, eng2, dim)
+    eng2.set_form("property")
+    K2, F2 = eng2.create_mat(), eng2.create_vec()
+    eng2.compute_system(K2, F2)
+    compare_mats(K2, K_o, 1e-12)
+
+
+USER_DER3 = r"""
+// a struct of ORDER 3 given as source: the third derivatives behind the second ones in Na, IGAPointFormDer3 in p.d3u; and one that
+// reads the property array (NEED_PROP)
+template <int DIM> struct UserDer3 {
+  static constexpr int DOF = 1, ORDER = 3; static constexpr unsigned NEED = NEED_X | NEED_U | NEED_D3U;
+  static constexpr int O3 = 1 + DIM + DIM * DIM;
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double s = 0; for (int f = 0; f < DIM * DIM * DIM; ++f) s += Na[O3 + f] * Nb[O3 + f];
+    T[0] = Na[0] * Nb[0] + p.prm[0] * s;
+  }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) {
+    double x2 = 0, s = 0, su = 0;
+    for (int i = 0; i < DIM; ++i) x2 += p.x[i] * p.x[i];
+    for (int i = 0; i < DIM; ++i) for (int j = 0; j < DIM; ++j) for (int k = 0; k < DIM; ++k) {
+      const double c = 1.0 / (1.0 + i + 2.0 * j + 3.0 * k); s += c * Na[O3 + (i * DIM + j) * DIM + k]; su += c * p.d3u[(i * DIM + j) * DIM + k]; }
+    R[0] = Na[0] * (1.0 + x2) + p.prm[1] * s + p.prm[2] * Na[0] * su;
+  }
+};
+template <int DIM> struct UserProperty {
+  static constexpr int DOF = 1, ORDER = 1; static constexpr unsigned NEED = NEED_PROP;
+  static __device__ double at(const PtView &p, int c) { double s = 0; for (int a = 0; a < p.nen; ++a) s += p.shape[a * p.nf] * p.property[a * p.npd + c]; return s; }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) { double s = 0; for (int i = 0; i < DIM; ++i) s += Na[1 + i] * Nb[1 + i]; T[0] = at(p, 0) * s; }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) { R[0] = Na[0] * at(p, p.npd - 1); }
+};
+"""
+
+
+@pytest.mark.parametrize("kind", ["der3", "property"])
+def test_user_source_of_order_three_and_with_properties(kind):
+    dim, p, N = 3, 2, [3, 2, 3]
+    orc, eng = make_pair(dim, 1, p, N, order=3)
+    X, W = warped_geometry(orc, dim, seed=3, rational=True)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    _bc(orc, eng, dim)
+    if kind == "der3":
+        K_o, F_o = orc.compute_system("orc_form_der3", _prm(PRM))
+        eng.set_form_source(USER_DER3, "UserDer3<3>", PRM)
+    else:
+        A = 1.0 + np.random.default_rng(1).random((orc.global_size(), 2))
+        orc.set_property(A); eng.set_property(A)
+        K_o, F_o = orc.compute_system("orc_form_property")
+        eng.set_form_source(USER_DER3, "UserProperty<3>")
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    eng.synchronize()
+    assert "generic_assemble" in eng.kernel_name() and "hiprtc" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(K, K_o, 1e-11)
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * max(np.abs(F_o).max(), 1.0)

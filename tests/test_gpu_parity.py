@@ -411,7 +411,9 @@ def _rank_matrix_rows(eng, A, b):
                                                              (2, 3, 1, 3, (9, 4, 8), (0, 0, 0), "poisson+nurbs"), (4, 3, 1, 2, (10, 6, 8), (0, 0, 0), "poisson+nurbs"),
                                                              # ranks thinner than p elements: a ghost layer reaches two (three) ranks up
                                                              (5, 1, 1, 3, (10,), (0,), "poisson"), (6, 2, 1, 3, (6, 8), (0, 0), "poisson"), (7, 1, 2, 3, (7,), (0,), "mass"),
-                                                             (27, 3, 1, 2, (3, 4, 3), (0, 0, 0), "poisson"), (12, 3, 1, 3, (4, 6, 5), (0, 0, 0), "poisson+nurbs")])
+                                                             (27, 3, 1, 2, (3, 4, 3), (0, 0, 0), "poisson"), (12, 3, 1, 3, (4, 6, 5), (0, 0, 0), "poisson+nurbs"),
+                                                             # the property array's ghosted box on every rank (IGALoadProperty's scatters, src/petigaio.c:441-446)
+                                                             (4, 3, 1, 2, (6, 7, 5), (0, 0, 0), "property+nurbs"), (3, 2, 1, 3, (11, 4), (0, 0), "property")])
 def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
     """Every rank assembles its own element box, ghost rows are packed / added through the C ABI exactly as
     petiga_amd/exchange.py does between processes; the owned rows of all ranks together must be the
@@ -427,6 +429,10 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
         orc.set_geometry(X, W)
     if form == "poisson":
         dirichlet_all((orc,), dim, 1.0)
+    PA = None
+    if form == "property":
+        PA = 1.0 + np.random.default_rng(21).random((orc.global_size(), 2))
+        orc.set_property(PA)
     octx, prm = (O.ElasticityCtx(1.3, 0.8), (1.3, 0.8)) if form == "elasticity" else (None, ())
     A_o, b_o = orc.compute_system("orc_form_" + form, octx)
     engs, mats, vecs, sendbufs = [], [], [], {}
@@ -438,6 +444,8 @@ def test_multirank_ghost_row_reduction(size, dim, dof, p, N, periodic, form):
         g.setup()
         if geo:
             g.set_geometry(X, W)          # the global control net; the rank keeps its ghosted box
+        if PA is not None:
+            g.set_property(PA)
         if form == "poisson":
             dirichlet_all((g,), dim, 1.0)
         g.set_form(form, prm)
@@ -497,18 +505,22 @@ def _tables_from_oracle(orc, dim, dof, keep):
             getattr(t, name)[i] = getattr(s, name)[i]
     t.nsd, t.rational = s.nsd, s.rational
     t.geometryX, t.rationalW = s.geometryX, s.rationalW
+    t.property, t.propertyA = s.property, s.propertyA
     keep.append(t)
     return t
 
 
 @pytest.mark.parametrize("dim,dof,p,N,geo,form", [(3, 1, 3, (9, 6, 7), None, "poisson"), (3, 1, 2, (5, 6, 4), "nurbs", "poisson"),
-                                                   (2, 2, 3, (7, 6), None, "mass"), (3, 3, 2, (4, 4, 3), None, "elasticity")])
+                                                   (2, 2, 3, (7, 6), None, "mass"), (3, 3, 2, (4, 4, 3), None, "elasticity"),
+                                                   (3, 1, 2, (4, 3, 5), "nurbs", "property")])      # iga->property / iga->propertyA handed over with the tables
 def test_create_from_tables_matches_oracle(dim, dof, p, N, geo, form):
     import petiga_amd as P
     orc, _ = make_pair(dim, dof, p, list(N), engine=False)
     if geo:
         X, W = warped_geometry(orc, dim, seed=3, rational=True)
         orc.set_geometry(X, W)
+    if form == "property":
+        orc.set_property(1.0 + np.random.default_rng(4).random((orc.global_size(), 2)))
     keep = []
     eng = P.IGX.from_tables(_tables_from_oracle(orc, dim, dof, keep))
     ctx, params = None, ()

@@ -268,3 +268,41 @@ def test_mass_solve_gives_one(dim, dof, periodic, degree):
     assert x.max() - x.min() < 1e-9 and abs(x.mean() - 1) < 1e-9
     vol = g.compute_scalar("orc_scalar_volume", 2)
     assert abs(vol[0] - 1.0) < 1e-13
+
+
+# ---------------------------------------------------------------- order-3 tabulation and property arrays (round 6)
+def test_third_derivatives_known_answers():
+    """p->shape[3] (src/petigamapshf.f90.in:60-72 behind InverseMap order 3, src/petigamapinv.f90.in:49-60) through a form: the sum over
+    the element's functions of d3 N_a vanishes at every point (partition of unity), so the c : d3N term of orc_form_der3 leaves the
+    sum of F unchanged; and IGAPointFormDer3 of a field that is linear in x (U_a = x_a) is zero (test/IGAGeometryMap.c:221-255)."""
+    import ctypes as C
+    from common import make_pair, warped_geometry
+    orc, _ = make_pair(3, 1, 3, [3, 2, 2], order=3, engine=False)
+    X, W = warped_geometry(orc, 3, seed=4, rational=True)
+    orc.set_geometry(X, W)
+    prm = lambda *v: (C.c_double * 3)(*v)
+    _, F0 = orc.compute_system("orc_form_der3", prm(0.0, 0.0, 0.0))
+    _, F1 = orc.compute_system("orc_form_der3", prm(0.0, 1.0, 0.0))
+    assert np.abs(F1 - F0).max() > 1e-3                       # the third derivatives are there ...
+    assert abs(F1.sum() - F0.sum()) < TIGHT * np.abs(F1).sum()      # ... and sum to zero over the functions
+    U = X[:, 0].copy()                                         # (one rank, no periodic axis: the net is the node grid)
+    G0 = orc.compute_function("orc_form_der3_function", prm(0.0, 0.0, 0.0), U)
+    G1 = orc.compute_function("orc_form_der3_function", prm(0.0, 0.0, 1.0), U)
+    assert np.abs(G1 - G0).max() < 1e-9 * np.abs(G0).max()    # d3(x) = 0 (the warped net's third-order terms reach 1e2: relative to them 1e-12)
+    V = np.random.default_rng(2).standard_normal(U.size)
+    G2 = orc.compute_function("orc_form_der3_function", prm(0.0, 0.0, 1.0), V)
+    assert np.abs(G2 - G0).max() > 1e-3
+
+
+def test_property_array_known_answers():
+    """p->property (src/petigaelem.c:745-752): constant properties k = 2, f = 3 turn orc_form_property into 2 K_Poisson and 3 F_Poisson."""
+    from common import make_pair
+    orc, _ = make_pair(2, 1, 2, [4, 3], engine=False)
+    with pytest.raises(RuntimeError):
+        orc.compute_system("orc_form_property")               # "No property set" (src/petigaelem.c:300)
+    n = orc.global_size()
+    A = np.tile([2.0, -1.0, 3.0], (n, 1))
+    orc.set_property(A)
+    K, F = orc.compute_system("orc_form_property")
+    K0, F0 = orc.compute_system("orc_form_poisson")
+    assert np.abs(K.val - 2.0 * K0.val).max() < TIGHT and np.abs(F - 3.0 * F0).max() < TIGHT
