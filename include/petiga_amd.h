@@ -76,6 +76,8 @@ typedef enum {
   IGX_FORM_ELASTICITY_F = 12,/* System: demo/Elasticity3D.c's K with a body force, F[a][i] = N_a f_i   params: {lambda, mu, fx, fy, fz} */
   IGX_FORM_DER3 = 13,        /* System / Function on third derivatives (p->shape[3], IGAPointFormDer3: test/IGAGeometryMap.c:179,221): K = N N + k3 d3N : d3N,
                               * F = N (1 + |x|^2) + f3 c : d3N + u3 N c : d3u; params {k3, f3, u3}; the general kernel (order-3 tabulation) */
+  IGX_FORM_SURFACE = 15,     /* System on a curve / surface in space (IGXSetGeometry with nsd > dim; demo/ClassicalShell.c:57-80 reads p->mapX the same way):
+                              * Laplace-Beltrami + mass, load |H| (mean-curvature vector from p->mapX[1], p->mapX[2]); dim 1, 2; the general kernel */
   IGX_FORM_PROPERTY = 14,    /* System: Poisson with conductivity A[..][0] and source A[..][npd-1] of the property array (IGXSetProperty), interpolated
                               * at the point from p->property; the general kernel */
   IGX_FORM_SOURCE      = 100 /* a user form compiled at run time: IGXSetFormSource */
@@ -109,7 +111,10 @@ int IGXSetUp(IGX iga);                                     /* IGASetUp          
 
 /* Geometry: control net on the geometry grid (n+1 points per axis, i0 fastest), Cartesian X[...][nsd]
  * and optional NURBS weights W (NULL = polynomial).  Stands for IGASetGeometryDim + the arrays
- * iga->geometryX / iga->rationalW that IGALoadGeometry fills (src/petigaio.c:201-356). */
+ * iga->geometryX / iga->rationalW that IGALoadGeometry fills (src/petigaio.c:201-356).
+ * dim <= nsd <= 3.  nsd > dim (a curve or a surface in space, demo/ClassicalShell.c:154): the geometry map is tabulated, the inverse
+ * map is not -- shape functions and measure stay parametric, a face's normal is its axis (src/petigaelem.c:966-1029) -- and the form
+ * reads p->mapX[1], p->mapX[2] (NEED_MAPX: p.X1 [nsd][dim], p.X2 [nsd][dim][dim]); such assemblies run on the general kernel. */
 int IGXSetGeometry(IGX iga,int nsd,const double X[],const double W[]);
 /* Derivative order (IGASetOrder, src/petiga.c:463): forms that read third derivatives -- p->shape[3] ([nen][dim][dim][dim], include/petiga.h:657)
  * as the dim^3 numbers behind the Hessian in Na / Nb, IGAPointFormDer3 (include/petiga.h:731) as p.d3u with NEED_D3U -- declare ORDER = 3

@@ -85,6 +85,41 @@ static int der3_body(OrcPoint *p,const double *U,double *K,double *F,void *ctx)
 int orc_form_der3(OrcPoint *p,double *K,double *F,void *ctx) { return der3_body(p,NULL,K,F,ctx); }
 int orc_form_der3_function(OrcPoint *p,const double *U,double *F,void *ctx) { return der3_body(p,U,NULL,F,ctx); }
 
+/* A form on a curve / surface in space (IGASetGeometryDim with nsd != dim, demo/ClassicalShell.c:154): the metric is built in the callback
+ * from p->mapX[1] [nsd][dim] and p->mapX[2] [nsd][dim][dim] (demo/ClassicalShell.c:57-80), the shape functions are the parametric basis:
+ *   g = F^T F,  a = sqrt det g,  K_ab = (N_a N_b + d_alpha N_a g^{alpha beta} d_beta N_b) a,  F_a = N_a |H| a,
+ * H = g^{alpha beta} (d_alpha d_beta x - Gamma^gamma_{alpha beta} d_gamma x) the mean-curvature vector (1/R on a circle, 2/R on a sphere):
+ * the engine's IGX_FORM_SURFACE.  ctx (optional) = double gs: K_ab += gs N_a N_b sum_{alpha i} G_{alpha i}^2 with G of IGAPointFormInvGradGeomMap
+ * (src/petigapoint.c:269-294; nsd != dim: the pseudo-inverse of IGA_GetInvGradGeomMap, src/petigaval.F90:124-142). */
+int orc_form_surface(OrcPoint *p,double *K,double *F,void *ctx)
+{
+  int a,b,i,al,be,ga,de,nen=p->nen,dim=p->dim,nsd=p->nsd,d2=dim*dim;
+  const double *N0=p->basis[0],*N1=p->basis[1],*X1=p->mapX[1],*X2=p->mapX[2];
+  double g[4]={0,0,0,0},gi[4],detg,ar,H[3]={0,0,0},Hn=0,gs = ctx ? *(const double*)ctx : 0.0,G[9],G2=0;
+  if (!p->geometry) return 73;   /* "No geometry set" */
+  orc_point_invgradgeommap(p,G); for (i=0;i<dim*nsd;i++) G2 += G[i]*G[i];
+  for (al=0;al<dim;al++) for (be=0;be<dim;be++) { double t=0; for (i=0;i<nsd;i++) t += X1[i*dim+al]*X1[i*dim+be]; g[al*dim+be] = t; }
+  if (dim == 1) { detg = g[0]; gi[0] = 1/g[0]; }
+  else { detg = g[0]*g[3]-g[1]*g[2]; gi[0] = g[3]/detg; gi[1] = -g[1]/detg; gi[2] = -g[2]/detg; gi[3] = g[0]/detg; }
+  ar = sqrt(detg);
+  for (al=0;al<dim;al++) for (be=0;be<dim;be++) {
+    double Gam[2]={0,0};
+    for (ga=0;ga<dim;ga++) for (de=0;de<dim;de++) { double t=0; for (i=0;i<nsd;i++) t += X1[i*dim+de]*X2[i*d2+al*dim+be]; Gam[ga] += gi[ga*dim+de]*t; }
+    for (i=0;i<nsd;i++) { double h = X2[i*d2+al*dim+be]; for (ga=0;ga<dim;ga++) h -= Gam[ga]*X1[i*dim+ga]; H[i] += gi[al*dim+be]*h; }
+  }
+  for (i=0;i<nsd;i++) Hn += H[i]*H[i];
+  Hn = sqrt(Hn);
+  for (a=0; a<nen; a++) {
+    for (b=0; b<nen; b++) {
+      double s = 0;
+      for (al=0;al<dim;al++) for (be=0;be<dim;be++) s += N1[a*dim+al]*gi[al*dim+be]*N1[b*dim+be];
+      K[a*nen+b] = (N0[a]*N0[b] + s)*ar + gs*N0[a]*N0[b]*G2;
+    }
+    F[a] = N0[a]*Hn*ar;
+  }
+  return 0;
+}
+
 /* Poisson with the conductivity A[.][0] and the source A[.][npd-1] of the property array, interpolated at the point from the
  * element's nodal values p->property [nen][npd] (IGAElementBuildClosure, src/petigaelem.c:745-752): the engine's IGX_FORM_PROPERTY */
 int orc_form_property(OrcPoint *p,double *K,double *F,void *ctx)

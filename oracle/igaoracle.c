@@ -505,7 +505,7 @@ int orc_set_geometry(OrcIGA *iga,int nsd,const double *X,const double *W)
   const int *g0 = iga->node_gstart,*gw = iga->node_gwidth;
   size_t pos = 0;
   if (!iga->setup) ORC_ERR("setup first");
-  if (nsd != dim) ORC_ERR("only nsd == dim is restated");
+  if (nsd < dim || nsd > 3) ORC_ERR("Number of space dimensions must be in range [dim,3]");   /* IGASetGeometryDim, src/petigaio.c:187 */
   for (i=0; i<dim; i++) gs[i] = iga->axis[i].span[iga->axis[i].nel-1] + 1;
   free(iga->geometryX); free(iga->rationalW);
   iga->geometryX = (double*)xcalloc((size_t)gw[0]*gw[1]*gw[2]*nsd,sizeof(double));
@@ -1024,9 +1024,9 @@ static int elem_tabulate(Elem *e)
       k_rationalize(ord,dim,nen,e->rationalW,e->basis[0]+(size_t)q*nen,e->basis[1]+(size_t)q*nen*d1,e->basis[2]+(size_t)q*nen*d2,e->basis[3]+(size_t)q*nen*d3,e->basis[4]+(size_t)q*nen*d4);
   }
   if (iga->nsd) {
-    if (dim != nsd) ORC_ERR("dim != nsd not restated");
+    /* src/petigaelem.c:940-964: the same sums for any nsd (IGA_GeometryMap, src/petigaval.F90:10-43) */
     for (q=0; q<nqp; q++) k_geometrymap(ord,dim,nsd,nen,e->geometryX,e->basis,e->mapX,(size_t)q);
-    {
+    if (dim == nsd) {   /* src/petigaelem.c:966: inverse map and physical shape functions only when the map is square */
       int d1=dim,d2=dim*dim,d3=d2*dim,d4=d3*dim;
       for (q=0; q<nqp; q++)
         k_inversemap(ord,dim,e->mapX[1]+(size_t)q*d2,e->mapX[2]+(size_t)q*d3,e->mapX[3]+(size_t)q*d4,&e->detX[q],
@@ -1039,10 +1039,10 @@ static int elem_tabulate(Elem *e)
     }
   }
   if (e->atboundary) {
-    if (iga->nsd) for (q=0; q<nqp; q++) k_normal(dim,axis,side,e->mapX[1]+(size_t)q*nsd*dim,&e->detS[q],e->normal+(size_t)q*nsd);
+    if (iga->nsd && dim == nsd) for (q=0; q<nqp; q++) k_normal(dim,axis,side,e->mapX[1]+(size_t)q*nsd*dim,&e->detS[q],e->normal+(size_t)q*nsd);   /* src/petigaelem.c:1016-1021 */
     else { memset(e->normal,0,sizeof(double)*(size_t)nqp*nsd); for (q=0; q<nqp; q++) { e->detS[q] = 1.0; e->normal[q*nsd+axis] = side ? 1.0 : -1.0; } }
   }
-  if (iga->nsd) {
+  if (iga->nsd && dim == nsd) {   /* src/petigaelem.c:1024 */
     if (!e->atboundary) for (q=0; q<nqp; q++) e->detJac[q] *= e->detX[q];
     else                for (q=0; q<nqp; q++) e->detJac[q] *= e->detS[q];
   }
@@ -1449,7 +1449,7 @@ int orc_element_tabulate(OrcIGA *iga,const int ID[3],int boundary_id,OrcElemView
   out->weight=e->weight; out->detJac=e->detJac; out->point=e->mapU[0]; out->normal=e->normal; out->detX=e->detX; out->detS=e->detS;
   for (k=0; k<5; k++) {
     out->basis[k]=e->basis[k];
-    out->shape[k]=(iga->nsd)?e->shape[k]:e->basis[k];
+    out->shape[k]=(iga->nsd && e->dim==e->nsd)?e->shape[k]:e->basis[k];
     out->mapU[k]=e->mapU[k];
     out->mapX[k]=(iga->nsd)?e->mapX[k]:e->mapU[k];
   }
@@ -1487,6 +1487,12 @@ void orc_point_invgradgeommap(const OrcPoint *p,double *G)
 {
   int a,i,dim=p->dim,nsd=p->nsd; double L[3]={1,1,1};
   for (i=0; i<dim; i++) L[i] = p->iga->basis[i].detJac[p->ID[i]];
-  if (p->geometry) { memcpy(G,p->mapU[1],sizeof(double)*(size_t)dim*nsd); for (a=0;a<dim;a++) for (i=0;i<nsd;i++) G[a*nsd+i] /= L[a]; }
+  if (p->geometry && dim != nsd) {   /* IGA_GetInvGradGeomMap, src/petigaval.F90:124-142: G = ((F^T F)^-1 F^T)^T, F = mapX[1] [nsd][dim] */
+    const double *F = p->mapX[1]; double M[9]={0,0,0,0,0,0,0,0,0},Mi[9]; int b;
+    for (a=0;a<dim;a++) for (b=0;b<dim;b++) { double t=0; for (i=0;i<nsd;i++) t += F[i*dim+a]*F[i*dim+b]; M[a+dim*b] = t; }
+    k_inv(dim,k_det(dim,M),M,Mi);
+    for (a=0;a<dim;a++) for (i=0;i<nsd;i++) { double t=0; for (b=0;b<dim;b++) t += Mi[a+dim*b]*F[i*dim+b]; G[a*nsd+i] = t/L[a]; }
+  }
+  else if (p->geometry) { memcpy(G,p->mapU[1],sizeof(double)*(size_t)dim*nsd); for (a=0;a<dim;a++) for (i=0;i<nsd;i++) G[a*nsd+i] /= L[a]; }
   else { memset(G,0,sizeof(double)*(size_t)dim*dim); for (i=0;i<dim;i++) G[i*(dim+1)] = 1/L[i]; }
 }

@@ -182,6 +182,7 @@ int orc_form_errnorm   (OrcPoint*,double*,double*,void*);  /* test/IGAErrNorm.c 
 int orc_form_elasticity(OrcPoint*,double*,double*,void*);  /* demo/Elasticity3D.c System */
 int orc_form_der3      (OrcPoint*,double*,double*,void*);  /* third derivatives p->shape[3] (test/IGAGeometryMap.c:179,221); ctx: double[3] = {k3, f3, u3} */
 int orc_form_der3_function(OrcPoint*,const double*,double*,void*);  /* ... with IGAPointFormDer3 of U (demo/AutoDiff/CahnHilliardPrimalFAD.cxx:51) */
+int orc_form_surface   (OrcPoint*,double*,double*,void*);  /* Laplace-Beltrami + mass and a curvature load from p->mapX[1], p->mapX[2] (as demo/ClassicalShell.c:57-80 reads them), nsd != dim */
 int orc_form_property  (OrcPoint*,double*,double*,void*);  /* Poisson with conductivity / source from p->property (include/petiga.h:662) */
 int orc_form_elasticity_f(OrcPoint*,double*,double*,void*);  /* the same K with a body force; ctx: double[5] = {lambda, mu, fx, fy, fz} */
 int orc_form_ch_residual(OrcPoint*,double,const double*,double,const double*,double*,void*);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 SCALARS = dict(volume=1, x2err=2, errnorm=3)
-FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10, bratu=11, elasticity_f=12, der3=13, property=14)
+FORMS = dict(none=0, poisson=1, mass=2, l2proj_x2=3, poisson_f=4, errnorm=5, elasticity=6, cahnhilliard=7, nsvms=8, boundary_integral=9, nitsche=10, bratu=11, elasticity_f=12, der3=13, property=14, surface=15)
 RULE_TYPES = dict(legendre=0, lobatto=1, reduced=2, user=3)      # IGARuleType, include/petiga.h:82-87
 
 _dp = C.POINTER(C.c_double)

@@ -183,7 +183,7 @@ static int apply_geometry(IGX g) {
   Space &s = g->s;
   const int nsd = s.net_nsd;
   if (!nsd) return 0;
-  if (nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+  if (nsd < s.dim || nsd > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of space dimensions must be in range [dim,3]");
   int gs[3] = {1, 1, 1};
   for (int i = 0; i < s.dim; ++i) gs[i] = s.axis[i].span[s.axis[i].nel - 1] + 1;
   const size_t nnet = (size_t)gs[0] * gs[1] * gs[2];
@@ -240,7 +240,7 @@ extern "C" int IGXGetPropertyDim(IGX g, int *npd) { NEEDIGA(g); if (!npd) return
 extern "C" int IGXSetGeometry(IGX g, int nsd, const double X[], const double W[]) {
   NEEDIGA(g); Space &s = g->s;
   if (!s.setup) return fail(IGX_ERR_ARG_WRONGSTATE, "Must call IGASetUp() first");
-  if (nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+  if (nsd < s.dim || nsd > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of space dimensions must be in range [dim,3]");      // (IGASetGeometryDim, src/petigaio.c:187: [1,3]; below dim there is no map)
   if (!X) return fail(IGX_ERR_ARG_WRONG, "null control points");
   size_t nnet = 1;
   for (int i = 0; i < s.dim; ++i) nnet *= (size_t)(s.axis[i].span[s.axis[i].nel - 1] + 1);
@@ -341,7 +341,7 @@ extern "C" int IGXCreateFromTables(const IGXTables *t, IGX *out) {
   if (int rc = space_layout(s, e)) return fail(rc, e);
   s.setup = true;
   if (t->nsd) {
-    if (t->nsd != s.dim) return fail(IGX_ERR_SUP, "only geometry dimension == parametric dimension is supported");
+    if (t->nsd < s.dim || t->nsd > 3) return fail(IGX_ERR_ARG_OUTOFRANGE, "Number of space dimensions must be in range [dim,3]");
     if (!t->geometryX) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set");
     const size_t n = (size_t)s.node_gwidth[0] * s.node_gwidth[1] * s.node_gwidth[2];
     s.geomX.assign(t->geometryX, t->geometryX + n * t->nsd); s.nsd = t->nsd;
@@ -904,9 +904,13 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   constexpr bool GENERAL = general_only_of<Form>::v;
   if (GENERAL && g->kernel_choice != 0 && g->kernel_choice != 1) return fail(IGX_ERR_SUP, "a form of order 3 or one that reads the property array runs on the general kernel only");
   if ((Form::NEED & NEED_PROP) && !S.npd) return fail(IGX_ERR_ARG_WRONGSTATE, "No property set");      // src/petigaelem.c:300
+  // a geometry of another dimension than the parametric one: tabulated by the general kernel only (no inverse map: src/petigaelem.c:966)
+  const bool emb = s.nsd && s.nsd != DIM;
+  if (emb && g->kernel_choice != 0 && g->kernel_choice != 1) return fail(IGX_ERR_SUP, "a geometry with nsd != dim runs on the general kernel only");
+  if ((Form::NEED & NEED_MAPX) && !s.nsd) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set");
   if (THIRD && s.order < 3) return fail(IGX_ERR_ARG_WRONGSTATE, "the form reads third derivatives (p->shape[3]): call IGASetOrder(iga,3) first");
 #ifdef IGX_HAVE_VEC_SUMFACT
-  if constexpr (DIM == 3 && !GENERAL) if (g->kernel_choice == 0) {   // vector-only drivers: sum factorisation both ways (vec_sumfact.hpp)
+  if constexpr (DIM == 3 && !GENERAL) if (g->kernel_choice == 0 && !emb) {   // vector-only drivers: sum factorisation both ways (vec_sumfact.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -915,7 +919,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   }
 #endif
 #ifdef IGX_HAVE_BLOCK_PENCIL
-  if constexpr (DIM == 3 && !GENERAL) if (g->kernel_choice == 0 || g->kernel_choice == 4) {   // band rows by node layer (block_pencil.hpp)
+  if constexpr (DIM == 3 && !GENERAL) if ((g->kernel_choice == 0 || g->kernel_choice == 4) && !emb) {   // band rows by node layer (block_pencil.hpp)
     bool done = false;
     ParamsDev prm; memset(&prm, 0, sizeof(prm));
     for (size_t i = 0; i < s.params.size() && i < MAXPARAM; ++i) prm.v[i] = s.params[i];
@@ -935,7 +939,7 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   }
 #endif
   if (g->kernel_choice == 4) return fail(IGX_ERR_SUP, "the band-row kernels do not cover this case (block_pencil: 3-D, p = 3, identity geometry, System / Matrix driver of a constant-coefficient form with 2 or 3 fields; band_pt: 3-D, p = 2 or 3, any geometry: matrix-only driver of a 4-field form with separated point coefficients, System / Matrix driver of a constant-coefficient form with 2 or 3 fields without boundary loads)");
-  if constexpr (!GENERAL) if (g->kernel_choice != 1) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
+  if constexpr (!GENERAL) if (g->kernel_choice != 1 && !emb) {   // matrix-producing ops: the dense contraction goes to the matrix cores when covered
     bool done = false;
     if (int rc = launch_feature<Form, DIM>(g, S, out, done)) return rc;
     if (done) return 0;
@@ -949,17 +953,19 @@ static int launch_generic(IGX g, const SpaceDev &S, const OutDev &out) {
   Carve cv; int pos = 0;
   auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };   // keep 16-byte alignment
   for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(nq[d]); }
-  cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
+  const int nsd = s.nsd ? s.nsd : DIM;
+  cv.gX = take(NE * nsd); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
   cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
-  cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
+  cv.JW = take(NQ); cv.xq = take(NQ * nsd); cv.E1 = take((s.nsd && !emb) ? NQ * D2 : 0); cv.E2 = take((s.nsd && !emb && SECOND) ? NQ * DIM * D2 : 0);
   cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
-  cv.G = take((Form::NEED & NEED_G) ? NQ * D2 : 0);
-  cv.E3 = take((s.nsd && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
+  cv.G = take((Form::NEED & NEED_G) ? NQ * DIM * nsd : 0);
+  cv.X1m = take((Form::NEED & NEED_MAPX) ? NQ * nsd * DIM : 0); cv.X2m = take(((Form::NEED & NEED_MAPX) && SECOND) ? NQ * nsd * D2 : 0);
+  cv.E3 = take((s.nsd && !emb && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
   cv.d3u = take((THIRD && (Form::NEED & NEED_D3U)) ? NQ * DOF * D3 : 0); cv.gA = take(NE * S.npd);
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((Form::NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((Form::NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
-  cv.nrm = take(NQ * DIM);
+  cv.nrm = take(NQ * nsd);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   // Phi in LDS up to 64 KiB per workgroup, in an HBM slice beyond: a 131 KiB Phi (p = 3) in LDS leaves one workgroup per CU and
   // measured slower than the HBM slice with two (Poisson p=3 48^3: 0.91 vs 1.71 M elements/s, Elasticity 0.80 vs 1.28)
@@ -1062,6 +1068,11 @@ static int dispatch_dim(IGX g, const SpaceDev &S, const OutDev &out) {
   case IGX_FORM_NITSCHE:          IGX_GROUP(0, (launch_generic<FormNitsche<DIM>, DIM>(g, S, out)));
   case IGX_FORM_DER3:      IGX_GROUP(0, (launch_generic<FormDer3<DIM>, DIM>(g, S, out)));
   case IGX_FORM_PROPERTY:  IGX_GROUP(0, (launch_generic<FormProperty<DIM>, DIM>(g, S, out)));
+  case IGX_FORM_SURFACE:
+    if constexpr (GROUP < 0 || GROUP == 0) {
+      if constexpr (DIM <= 2) return launch_generic<FormSurface<DIM>, DIM>(g, S, out);
+      else return fail(IGX_ERR_ARG_WRONG, "the surface form needs dim = 1 or 2 (a curve or a surface in space)");
+    } else return IGX_NOT_MINE;
   case IGX_FORM_ERRNORM:   IGX_GROUP(1, (launch_generic<FormErrNorm<DIM>, DIM>(g, S, out)));
   case IGX_FORM_MASS:
     if constexpr (GROUP < 0 || GROUP == 1) {

@@ -11,9 +11,9 @@
 
 namespace igx {
 
-enum : unsigned { NEED_X = 1u, NEED_U = 2u, NEED_UT = 4u, NEED_GU = 8u, NEED_HU = 16u, NEED_G = 32u, NEED_D3U = 64u, NEED_PROP = 128u };
+enum : unsigned { NEED_X = 1u, NEED_U = 2u, NEED_UT = 4u, NEED_GU = 8u, NEED_HU = 16u, NEED_G = 32u, NEED_D3U = 64u, NEED_PROP = 128u, NEED_MAPX = 256u };
 // a form of ORDER 3, or one that reads the property array / the point's shape table, runs on the general kernel only
-template <class Form> struct general_only_of { static constexpr bool v = Form::ORDER >= 3 || (Form::NEED & (NEED_PROP | NEED_D3U)) != 0; };
+template <class Form> struct general_only_of { static constexpr bool v = Form::ORDER >= 3 || (Form::NEED & (NEED_PROP | NEED_D3U | NEED_MAPX)) != 0; };
 
 struct PtView {
   const double *x;     // physical point [DIM] (parametric point when there is no geometry)
@@ -27,6 +27,11 @@ struct PtView {
   const double *property = nullptr;  // p->property: the property array of the element's nodes [nen][npd] (include/petiga.h:662); npd = 0 without one
   const double *shape = nullptr;     // the point's shape functions [nen][nf] (value, gradient, ... laid out as a form's Na), e.g. to interpolate the properties
   int npd = 0, nen = 0, nf = 0;
+  // a geometry of another dimension than the parametric one (IGASetGeometryDim, nsd != dim: x, normal and G then have nsd columns, the
+  // shape functions stay parametric) and forms with NEED_MAPX: the geometry map's derivatives at the point, p->mapX[1] / p->mapX[2]
+  // (IGAPointFormGradGeomMap / HessGeomMap, src/petigapoint.c:243-263) [nsd][dim] / [nsd][dim][dim]; X2 for forms of ORDER >= 2
+  int nsd = 0;
+  const double *X1 = nullptr, *X2 = nullptr;
   const double *prm;   // form parameters (replaces ctx)
   double shift, t;
   const double *normal;  // unit outward normal [DIM] at a boundary-form point (p->normal), else null
@@ -141,6 +146,42 @@ template <int DIM> struct FormDer3 {
         for (int k = 0; k < DIM; ++k) { const double c = c3(i, j, k); s += c * Na[O3 + (i * DIM + j) * DIM + k]; su += c * p.d3u[(i * DIM + j) * DIM + k]; }
     R[0] = Na[0] * (1.0 + x2) + p.prm[1] * s + p.prm[2] * Na[0] * su;
   }
+};
+
+// A form on a curve or a surface in space (IGASetGeometryDim with nsd != dim, demo/ClassicalShell.c:154): the shape functions are the
+// parametric basis, the metric is built here from p->mapX[1], p->mapX[2] as demo/ClassicalShell.c:57-80 does:
+//   g = F^T F, a = sqrt det g,  K_ab = (N_a N_b + d_al N_a g^{al be} d_be N_b) a,  F_a = N_a |H| a,
+// H = g^{al be} (d_al d_be x - Gamma^ga_{al be} d_ga x) the mean-curvature vector (1/R on a circle, 2/R on a sphere).  DIM = 1, 2.
+// params {gs}: K_ab += gs N_a N_b sum G^2, G of IGAPointFormInvGradGeomMap (the pseudo-inverse when nsd != dim, src/petigaval.F90:124-142).
+template <int DIM> struct FormSurface {
+  static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_MAPX | NEED_G;
+  struct Metric { double gi[4], ar, Hn; };
+  static __device__ __forceinline__ Metric metric(const PtView &p) {
+    constexpr int D2 = DIM * DIM;
+    const int nsd = p.nsd; const double *X1 = p.X1, *X2 = p.X2;
+    Metric m; double g[4] = {0, 0, 0, 0}, detg, H[3] = {0, 0, 0};
+    for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be) { double t = 0; for (int i = 0; i < nsd; ++i) t += X1[i * DIM + al] * X1[i * DIM + be]; g[al * DIM + be] = t; }
+    if (DIM == 1) { detg = g[0]; m.gi[0] = 1 / g[0]; }
+    else { detg = g[0] * g[3] - g[1] * g[2]; m.gi[0] = g[3] / detg; m.gi[1] = -g[1] / detg; m.gi[2] = -g[2] / detg; m.gi[3] = g[0] / detg; }
+    m.ar = sqrt(detg);
+    for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be) {
+      double Gam[2] = {0, 0};
+      for (int ga = 0; ga < DIM; ++ga) for (int de = 0; de < DIM; ++de) { double t = 0; for (int i = 0; i < nsd; ++i) t += X1[i * DIM + de] * X2[i * D2 + al * DIM + be]; Gam[ga] += m.gi[ga * DIM + de] * t; }
+      for (int i = 0; i < nsd; ++i) { double h = X2[i * D2 + al * DIM + be]; for (int ga = 0; ga < DIM; ++ga) h -= Gam[ga] * X1[i * DIM + ga]; H[i] += m.gi[al * DIM + be] * h; }
+    }
+    double hn = 0; for (int i = 0; i < nsd; ++i) hn += H[i] * H[i];
+    m.Hn = sqrt(hn);
+    return m;
+  }
+  static __device__ __forceinline__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    const Metric m = metric(p);
+    double s = 0;
+    for (int al = 0; al < DIM; ++al) for (int be = 0; be < DIM; ++be) s += Na[1 + al] * m.gi[al * DIM + be] * Nb[1 + be];
+    double G2 = 0;
+    for (int i = 0; i < DIM * p.nsd; ++i) G2 += p.G[i] * p.G[i];
+    T[0] = (Na[0] * Nb[0] + s) * m.ar + p.prm[0] * Na[0] * Nb[0] * G2;
+  }
+  static __device__ __forceinline__ void vec(const PtView &p, const double *Na, double *R) { const Metric m = metric(p); R[0] = Na[0] * m.Hn * m.ar; }
 };
 
 // A Poisson problem whose conductivity and source live on the control net as a property array (IGASetPropertyDim, include/petiga.h:350-353;

@@ -19,6 +19,7 @@ struct Carve {          // offsets (in doubles) into the dynamic LDS block; -1 =
   int t1d[3], w1d[3];
   int gX, gW, Ue, Ve, ufix, fixval, fixflag, flux;
   int JW, xq, E1, E2, W0, W1, W2, G;
+  int X1m, X2m;         // NEED_MAPX: the geometry map's first / second derivatives at the points [nqp][nsd][dim] / [nqp][nsd][dim][dim] (p->mapX[1], [2])
   int E3, W3, d3u;      // order 3 (Form::ORDER >= 3): third-order inverse map, third derivatives of the NURBS denominator and of the fields
   int gA;               // property array of the element's nodes [nen][npd] (IGAElementBuildClosure, src/petigaelem.c:745-752)
   int u, ut, gu, hu, lift, phi;
@@ -108,7 +109,7 @@ template <bool WALK> __device__ __forceinline__ void slot_decode(int a, const in
 // knot coordinate, the routine's own Rationalize.  Called by the few threads of a face element that carry a load.
 template <int DIM, bool WALK = false>
 __device__ inline double face_dS(const double *const t1d[3], const double *const w1d[3], const int nq[3], const int na[3],
-                                 const double *gX, const double *gW, bool rat, int dir, int side) {
+                                 const double *gX, const double *gW, bool rat, int dir, int side, int nsd = DIM) {
   if constexpr (DIM == 1) return 1.0;
   else {
     constexpr int FD = DIM - 1;
@@ -133,10 +134,10 @@ __device__ inline double face_dS(const double *const t1d[3], const double *const
         const int la = ctrl(a0, a1);
         double N0 = r0[0] * v1, N1[2] = {r0[1] * v1, r0[0] * d1};
         if (rat) { const double w = gW[la]; N0 = w * N0 / W0; for (int r = 0; r < FD; ++r) N1[r] = (w * N1[r] - N0 * S1[r]) / W0; }
-        for (int r = 0; r < FD; ++r) for (int c = 0; c < DIM; ++c) F[r][c] += N1[r] * gX[la * DIM + c];
+        for (int r = 0; r < FD; ++r) for (int c = 0; c < nsd; ++c) F[r][c] += N1[r] * gX[la * nsd + c];
       }
       double M[2][2] = {{0, 0}, {0, 0}};
-      for (int r = 0; r < FD; ++r) for (int s = 0; s < FD; ++s) for (int c = 0; c < DIM; ++c) M[r][s] += F[r][c] * F[s][c];
+      for (int r = 0; r < FD; ++r) for (int s = 0; s < FD; ++s) for (int c = 0; c < nsd; ++c) M[r][s] += F[r][c] * F[s][c];
       const double det = (FD == 1) ? M[0][0] : M[0][0] * M[1][1] - M[0][1] * M[1][0];
       dS += sqrt(fabs(det)) * w1d[ax[0]][q0] * ((FD == 2) ? w1d[ax[1]][q1] : 1.0);
     }
@@ -148,7 +149,7 @@ __device__ inline double face_dS(const double *const t1d[3], const double *const
 // gathers are visible.  aa-decoding as in the kernels: a = a0 + na0*(a1 + na1*a2).
 template <int DIM, int DOF, bool WALK = false>
 __device__ inline void add_mapped_flux(const SpaceDev &S, const int ID[3], const int el[3], const double *const t1d[3], const double *const w1d[3],
-                                       const int nq[3], const int na[3], const double *gX, const double *gW, bool rat, double *flux, int tid, int nthr) {
+                                       const int nq[3], const int na[3], const double *gX, const double *gW, bool rat, double *flux, int tid, int nthr, int nsd = DIM) {
   const int NE = na[0] * na[1] * na[2];
   for (int d = 0; d < DIM; ++d) {
     if (S.ax[d].periodic) continue;
@@ -160,7 +161,7 @@ __device__ inline void add_mapped_flux(const SpaceDev &S, const int ID[3], const
         if (aa[d] != (side ? na[d] - 1 : 0)) continue;
         double A = 1;
         for (int i = 0; i < DIM; ++i) if (i != d) A *= S.ax[i].J[el[i]] / (double)na[i];
-        A *= face_dS<DIM, WALK>(t1d, w1d, nq, na, gX, gW, rat, d, side);
+        A *= face_dS<DIM, WALK>(t1d, w1d, nq, na, gX, gW, rat, d, side, nsd);
         for (int k = 0; k < bl.count; ++k) { const int c = bl.field[k]; if (c < DOF) flux[a * DOF + c] += bl.value[k] * A; }
       }
     }
@@ -205,6 +206,12 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   const bool hasV = (op == OP_SYSTEM || op == OP_VECTOR || op == OP_FUNCTION || op == OP_IFUNCTION);
   const bool useU = out.U != nullptr, useV = out.V != nullptr;
   const bool geo = S.nsd > 0, rat = S.rational != 0;
+  // dim != nsd (a curve or a surface in space, IGASetGeometryDim: demo/ClassicalShell.c:154): the geometry map is tabulated
+  // (IGA_GeometryMap, src/petigaval.F90:10-43), the inverse map and the physical shape functions are not -- p->shape stays the
+  // parametric basis, detJac keeps the parametric measure, a face's normal is the axis (src/petigaelem.c:966-1029) -- and the form
+  // builds its metric from p->mapX[1], p->mapX[2] (NEED_MAPX: p.X1, p.X2)
+  const int nsd = geo ? S.nsd : DIM;
+  const bool emb = geo && nsd != DIM;
 
   double *t1d[3] = {smem + cv.t1d[0], smem + cv.t1d[1], smem + cv.t1d[2]};
   double *w1d[3] = {smem + cv.w1d[0], smem + cv.w1d[1], smem + cv.w1d[2]};
@@ -213,6 +220,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   int *fixflag = reinterpret_cast<int *>(smem + cv.fixflag);
   double *JW = smem + cv.JW, *xq = smem + cv.xq, *E1 = smem + cv.E1, *E2 = smem + cv.E2;
   double *W0 = smem + cv.W0, *W1 = smem + cv.W1, *W2 = smem + cv.W2, *Gq = smem + cv.G;
+  double *X1m = smem + cv.X1m, *X2m = smem + cv.X2m;
   double *E3 = smem + cv.E3, *W3 = smem + cv.W3, *fd3u = smem + cv.d3u, *gA = smem + cv.gA;
   const int npd = S.npd;
   double *fu = smem + cv.u, *fut = smem + cv.ut, *fgu = smem + cv.gu, *fhu = smem + cv.hu, *lift = smem + cv.lift, *nrm = smem + cv.nrm;
@@ -237,7 +245,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     const int i0 = off[0] + a0, i1 = off[1] + a1, i2 = off[2] + a2;
     const size_t g = (size_t)i0 + (size_t)gw0 * ((size_t)i1 + (size_t)gw1 * (size_t)i2);
     const size_t row = (size_t)S.ax[0].rowmap[i0] + (size_t)nr0 * ((size_t)S.ax[1].rowmap[i1] + (size_t)nr1 * (size_t)S.ax[2].rowmap[i2]);
-    if (geo) for (int c = 0; c < DIM; ++c) gX[a * DIM + c] = S.X[g * DIM + c];
+    if (geo) for (int c = 0; c < nsd; ++c) gX[a * nsd + c] = S.X[g * nsd + c];
     if (rat) gW[a] = S.W[g];
     for (int c = 0; c < npd; ++c) gA[a * npd + c] = S.A[g * npd + c];
     if (useU) for (int c = 0; c < DOF; ++c) Ue[a * DOF + c] = out.U[row * DOF + c];
@@ -274,7 +282,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
   }
   __syncthreads();
   const bool anyfix = s_anyfix != 0;
-  if (geo && DIM > 1 && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr);
+  if (geo && DIM > 1 && !bpass && op != OP_MATRIX && op != OP_VECTOR && op != OP_SCALAR) add_mapped_flux<DIM, DOF>(S, ID, el, t1d, w1d, nq, na, gX, gW, rat, flux, tid, nthr, nsd);
   // IGAElementFixValues / DelValues (src/petigaelem.c:1327-1358)
   if (anyfix && (useU || useV)) {
     for (int k = tid; k < NE * DOF; k += nthr)
@@ -311,25 +319,30 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
       if constexpr (THIRD) for (int i = 0; i < D3; ++i) W3[q * D3 + i] = w3[i];
     }
     if (geo) {
-      for (int i = 0; i < DIM; ++i) x0[i] = 0;
-      for (int i = 0; i < D2; ++i) X1[i] = 0;
-      if (SECOND) for (int i = 0; i < D2 * DIM; ++i) X2[i] = 0;
-      if constexpr (THIRD) for (int i = 0; i < D3 * DIM; ++i) X3[i] = 0;
+      for (int i = 0; i < 3; ++i) x0[i] = 0;
+      for (int i = 0; i < 9; ++i) X1[i] = 0;
+      if (SECOND) for (int i = 0; i < 27; ++i) X2[i] = 0;
+      if constexpr (THIRD) for (int i = 0; i < 81; ++i) X3[i] = 0;
       for (int a = 0; a < NE; ++a) {
         const int aq[3] = {a % na[0], (a / na[0]) % na[1], a / (na[0] * na[1])};
         double b0, b1[3], b2[9], b3[THIRD ? 27 : 1];
         tensor_basis<DIM, SECOND, THIRD>(t1d, na, aq, qq, b0, b1, b2, b3);
         if (rat) rationalize<DIM, SECOND, THIRD>(gW[a], w0, w1, w2, w3, b0, b1, b2, b3);   // Rationalize, src/petigarat.f90.in:3-57
-        for (int i = 0; i < DIM; ++i) {
-          const double x = gX[a * DIM + i];
+        for (int i = 0; i < nsd; ++i) {      // GeometryMap, src/petigamapgeo.f90.in:3-71: X_k(i, :) = sum_a X(i, a) M_k(:, a), i < nsd
+          const double x = gX[a * nsd + i];
           x0[i] += x * b0;
           for (int al = 0; al < DIM; ++al) X1[i * DIM + al] += x * b1[al];
           if (SECOND) for (int f = 0; f < D2; ++f) X2[i * D2 + f] += x * b2[f];
           if constexpr (THIRD) for (int f = 0; f < D3; ++f) X3[i * D3 + f] += x * b3[f];
         }
       }
+      if (Form::NEED & NEED_MAPX) {
+        for (int i = 0; i < nsd * DIM; ++i) X1m[q * nsd * DIM + i] = X1[i];
+        if (SECOND) for (int i = 0; i < nsd; ++i) for (int f = 0; f < D2; ++f) X2m[(q * nsd + i) * D2 + f] = X2[i * D2 + f];
+      }
+      double e1[9] = {0};
+      if (!emb) {
       detX = det3(X1, DIM);
-      double e1[9];
       inv3(X1, DIM, detX, e1);           // e1[al][i] = du_al/dx_i
       for (int i = 0; i < D2; ++i) E1[q * D2 + i] = e1[i];
       if (SECOND) {   // InverseMap order 2, src/petigamapinv.f90.in:32-45: E2[c][i][j] = -X2[k][a][b] e1[a][i] e1[b][j] e1[c][k]
@@ -354,10 +367,11 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         }
       }
       if (!(detX > 0.0)) atomicExch(out.errflag, IGX_ERR_USER);   // src/petigaelem.c:989-993
+      }      // !emb
     }
     if (bpass) {   // K7: IGA_GetNormal, src/petigaval.F90:45-99; detJac *= detS instead of detX (src/petigaelem.c:1012-1029)
       double n[3] = {0, 0, 0}, dS = 1;
-      if (!geo || DIM == 1) n[baxis] = 1.0;
+      if (!geo || DIM == 1 || emb) n[baxis] = 1.0;      // (dim != nsd: src/petigaelem.c:1017-1020)
       else if (DIM == 3) {
         const int r1 = (baxis + 1) % 3, r2 = (baxis + 2) % 3;
         const double s0 = X1[0 * DIM + r1], s1 = X1[1 * DIM + r1], s2 = X1[2 * DIM + r1];
@@ -372,15 +386,21 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
         dS = sqrt(n[0] * n[0] + n[1] * n[1]);
         n[0] /= dS; n[1] /= dS;
       }
-      for (int i = 0; i < DIM; ++i) nrm[q * DIM + i] = bside ? n[i] : -n[i];
+      for (int i = 0; i < nsd; ++i) nrm[q * nsd + i] = bside ? n[i] : -n[i];
       detX = dS;
     }
     double w = 1;
 #pragma unroll
     for (int d = 0; d < 3; ++d) w *= w1d[d][qq[d]];
     JW[q] = (Jel * detX) * w;          // detJac[q] *= detX[q]; JW = detJac*weight (src/petigaelem.c:1024, petigapoint.c:461)
-    for (int i = 0; i < DIM; ++i) xq[q * DIM + i] = x0[i];
+    for (int i = 0; i < nsd; ++i) xq[q * nsd + i] = x0[i];
     if (Form::NEED & NEED_G) {           // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+      if (emb) {      // IGA_GetInvGradGeomMap, src/petigaval.F90:124-142: G = ((F^T F)^-1 F^T)^T with F = X1 [nsd][dim]
+        double M[9] = {0}, Mi[9];
+        for (int a = 0; a < DIM; ++a) for (int b = 0; b < DIM; ++b) { double t = 0; for (int i = 0; i < nsd; ++i) t += X1[i * DIM + a] * X1[i * DIM + b]; M[a * DIM + b] = t; }
+        inv3(M, DIM, det3(M, DIM), Mi);
+        for (int a = 0; a < DIM; ++a) for (int i = 0; i < nsd; ++i) { double t = 0; for (int b = 0; b < DIM; ++b) t += Mi[a * DIM + b] * X1[i * DIM + b]; Gq[(q * DIM + a) * nsd + i] = t / S.ax[a].J[el[a]]; }
+      } else
       for (int a = 0; a < DIM; ++a) for (int i = 0; i < DIM; ++i) {
         const double L = S.ax[a].J[el[a]];
         Gq[q * D2 + a * DIM + i] = geo ? E1[q * D2 + a * DIM + i] / L : ((a == i) ? 1 / L : 0.0);
@@ -399,7 +419,7 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     if (rat) rationalize<DIM, SECOND, THIRD>(gW[a], W0[q], W1 + q * DIM, W2 + q * D2, W3 + q * D3, b0, b1, b2, b3);
     double *o = phi + (size_t)idx * NF;
     o[0] = b0;
-    if (!geo) {
+    if (!geo || emb) {
       for (int i = 0; i < DIM; ++i) o[1 + i] = b1[i];
       if (SECOND) for (int i = 0; i < D2; ++i) o[1 + DIM + i] = b2[i];
       if constexpr (THIRD) for (int i = 0; i < D3; ++i) o[1 + DIM + D2 + i] = b3[i];
@@ -460,8 +480,8 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
     __syncthreads();
     for (int q = tid; q < NQ; q += nthr) {
       PtView p;
-      p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-      p.G = Gq + q * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
+      p.x = xq + q * nsd; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
+      p.G = Gq + q * DIM * nsd; p.nsd = nsd; p.X1 = X1m + q * nsd * DIM; p.X2 = X2m + q * nsd * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * nsd : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
       double Sq[NS];
       Form::scalar(p, Sq);
       const double jw = JW[q];
@@ -489,8 +509,8 @@ generic_assemble(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, Carve cv,
 
   auto point = [&](int q) {
     PtView p;
-    p.x = xq + q * DIM; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
-    p.G = Gq + q * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * DIM : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
+    p.x = xq + q * nsd; p.u = fu + q * DOF; p.ut = fut + q * DOF; p.gu = fgu + q * DOF * DIM; p.hu = fhu + q * DOF * D2;
+    p.G = Gq + q * DIM * nsd; p.nsd = nsd; p.X1 = X1m + q * nsd * DIM; p.X2 = X2m + q * nsd * D2; p.d3u = fd3u + q * DOF * D3; p.property = gA; p.npd = npd; p.shape = phi + (size_t)q * NE * NF; p.nen = NE; p.nf = NF; p.prm = prm.v; p.shift = out.shift; p.t = out.t; p.normal = bpass ? nrm + q * nsd : nullptr; p.atboundary = bpass ? 1 : 0; p.boundary_id = bid;
     return p;
   };
   const int W0s = 2 * S.ax[0].p + 1, W1s = 2 * S.ax[1].p + 1, W2s = 2 * S.ax[2].p + 1;

@@ -714,9 +714,11 @@ static int launch_generic_rtc(IGX g, const SpaceDev &S, const OutDev &out) {
   if (F.meta[3] > 0) return fail(IGX_ERR_SUP, "a struct with NSCALAR is a functional: IGXComputeScalarSource");
   if (s.dof != DOF) return fail(IGX_ERR_ARG_WRONG, "form does not match the number of fields (dof)");
   // a struct of ORDER 3, or one that reads the property array / the point's shape table / third derivatives of the state: the general kernel (as launch_generic)
-  if (F.meta[1] >= 3 || ((unsigned)F.meta[2] & (NEED_PROP | NEED_D3U))) {
+  if (F.meta[1] >= 3 || ((unsigned)F.meta[2] & (NEED_PROP | NEED_D3U | NEED_MAPX)) || (s.nsd && s.nsd != s.dim)) {      // (... or a geometry with nsd != dim)
     if (g->kernel_choice != 0 && g->kernel_choice != 1) return fail(IGX_ERR_SUP, "a form of order 3 or one that reads the property array runs on the general kernel only");
     if (((unsigned)F.meta[2] & NEED_PROP) && !S.npd) return fail(IGX_ERR_ARG_WRONGSTATE, "No property set");
+    if (((unsigned)F.meta[2] & NEED_MAPX) && !s.nsd) return fail(IGX_ERR_ARG_WRONGSTATE, "No geometry set");
+    if (F.meta[1] >= 3 && s.order < 3) return fail(IGX_ERR_ARG_WRONGSTATE, "the form reads third derivatives (p->shape[3]): call IGASetOrder(iga,3) first");
     if (g->zero_matrix) g->zero_matrix();
     return rtc_generic_launch(g, F, S, out);
   }
@@ -769,17 +771,19 @@ static int rtc_generic_launch(IGX g, RtcForm &F, const SpaceDev &S, const OutDev
   Carve cv; int pos = 0;
   auto take = [&](int n) { int o = pos; pos += (n + 1) & ~1; return o; };
   for (int d = 0; d < 3; ++d) { cv.t1d[d] = take(nq[d] * na[d] * NDER); cv.w1d[d] = take(nq[d]); }
-  cv.gX = take(NE * DIM); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
+  const int nsd = s.nsd ? s.nsd : DIM; const bool emb = s.nsd && s.nsd != DIM;
+  cv.gX = take(NE * nsd); cv.gW = take(NE); cv.Ue = take(NE * DOF); cv.Ve = take(NE * DOF);
   cv.ufix = take(NE * DOF); cv.fixval = take(NE * DOF); cv.fixflag = take(NE * DOF); cv.flux = take(NE * DOF);
-  cv.JW = take(NQ); cv.xq = take(NQ * DIM); cv.E1 = take(s.nsd ? NQ * D2 : 0); cv.E2 = take((s.nsd && SECOND) ? NQ * DIM * D2 : 0);
+  cv.JW = take(NQ); cv.xq = take(NQ * nsd); cv.E1 = take((s.nsd && !emb) ? NQ * D2 : 0); cv.E2 = take((s.nsd && !emb && SECOND) ? NQ * DIM * D2 : 0);
   cv.W0 = take(s.rational ? NQ : 0); cv.W1 = take(s.rational ? NQ * DIM : 0); cv.W2 = take((s.rational && SECOND) ? NQ * D2 : 0);
-  cv.G = take((NEED & NEED_G) ? NQ * D2 : 0);
-  cv.E3 = take((s.nsd && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
+  cv.G = take((NEED & NEED_G) ? NQ * DIM * nsd : 0);
+  cv.X1m = take((NEED & NEED_MAPX) ? NQ * nsd * DIM : 0); cv.X2m = take(((NEED & NEED_MAPX) && SECOND) ? NQ * nsd * D2 : 0);
+  cv.E3 = take((s.nsd && !emb && THIRD) ? NQ * DIM * D3 : 0); cv.W3 = take((s.rational && THIRD) ? NQ * D3 : 0);
   cv.d3u = take((THIRD && (NEED & NEED_D3U)) ? NQ * DOF * D3 : 0); cv.gA = take(NE * S.npd);
   cv.u = take(fields ? NQ * DOF : 0); cv.ut = take(fields ? NQ * DOF : 0);
   cv.gu = take((NEED & NEED_GU) ? NQ * DOF * DIM : 0); cv.hu = take((NEED & NEED_HU) ? NQ * DOF * D2 : 0);
   cv.lift = take(NS > 0 ? NQ * NS : (out.op == OP_SYSTEM ? NQ * DOF * NF : 0));
-  cv.nrm = take(NQ * DIM);
+  cv.nrm = take(NQ * nsd);
   const size_t phi_doubles = (size_t)NQ * NE * NF;
   const size_t lds_limit = 64 * 1024;   // as launch_generic: beyond it Phi goes to an HBM slice and two workgroups share a CU
   const bool phi_in_lds = ((size_t)pos + phi_doubles) * sizeof(double) <= lds_limit;

@@ -176,3 +176,111 @@ def test_user_source_of_order_three_and_with_properties(kind):
     assert "generic_assemble" in eng.kernel_name() and "hiprtc" in eng.kernel_name(), eng.kernel_name()
     compare_mats(K, K_o, 1e-11)
     assert np.abs(F.get() - F_o).max() <= 1e-11 * max(np.abs(F_o).max(), 1.0)
+
+
+# ---------------------------------------------------------------- a geometry of another dimension than the parametric one (nsd != dim)
+def _lifted(orc, dim, nsd, seed, rational=True):
+    """A curve / surface in space: the warped net of the parametric dimension with nsd - dim smooth coordinates more."""
+    X, W = warped_geometry(orc, dim, seed=seed, rational=rational)
+    cols = [X]
+    for k in range(nsd - dim):
+        z = 0.3 * np.sin(2.0 * X[:, 0] + k) + (0.2 * np.cos(3.0 * X[:, 1]) if dim > 1 else 0.1 * X[:, 0] ** 2)
+        cols.append(z[:, None])
+    return np.concatenate(cols, axis=1), W
+
+
+@pytest.mark.parametrize("dim,nsd,p,N,rational,bc,gs", [(1, 2, 2, [6], True, True, 0.0), (1, 3, 3, [5], False, False, 0.3), (2, 3, 2, [4, 5], True, True, 0.2),
+                                                        (2, 3, 3, [3, 4], True, False, 0.0), (2, 3, 2, [5, 3], False, True, 0.1)])
+def test_curve_and_surface_system_vs_oracle(dim, nsd, p, N, rational, bc, gs, tmp_path):
+    """IGASetGeometryDim(nsd) with nsd != dim (demo/ClassicalShell.c:154): IGA_GeometryMap (src/petigaval.F90:10-43) tabulated, no inverse
+    map, parametric shape functions and measure, axis normals (src/petigaelem.c:940-1029); the form reads p->mapX[1], p->mapX[2] and
+    IGAPointFormInvGradGeomMap's pseudo-inverse (src/petigaval.F90:124-142); the boundary load goes through BoundaryArea's geometry
+    branch with nsd columns (src/petigaelem.c:1133-1160)."""
+    orc, eng = make_pair(dim, 1, p, N)
+    X, W = _lifted(orc, dim, nsd, seed=13, rational=rational)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    if bc:
+        _bc(orc, eng, dim)
+    K_o, F_o = orc.compute_system("orc_form_surface", C.c_double(gs))
+    eng.set_form("surface", (gs,))
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    eng.synchronize()
+    assert "generic" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(K, K_o, 1e-12)
+    assert np.abs(F.get() - F_o).max() <= 1e-12 * max(np.abs(F_o).max(), 1.0)
+    # any other form on such a geometry: the general kernel, parametric gradients, no detX -- what the reference computes
+    A_o, b_o = orc.compute_system("orc_form_poisson")
+    eng.set_form("poisson")
+    eng.compute_system(K, F)
+    assert "generic" in eng.kernel_name(), eng.kernel_name()
+    compare_mats(K, A_o, 1e-12)
+    assert np.abs(F.get() - b_o).max() <= 1e-12 * max(np.abs(b_o).max(), 1.0)
+    eng.set_kernel(3)
+    with pytest.raises(P.IGXError) as e:
+        eng.compute_system(K, F)
+    assert e.value.code == 56
+    # ... and read from a file whose geometry block says nsd (IGALoad, src/petigaio.c:58-63)
+    U = [np.array(orc.axis(i)["U"]) for i in range(dim)]
+    f = tmp_path / "surf.dat"; f.write_bytes(iga_file_bytes([p] * dim, U, X, W))
+    eng2 = P.IGX(); eng2.set_dof(1); eng2.read(f); eng2.setup()
+    if bc:
+        _bc(orc, eng2, dim)
+    eng2.set_form("surface", (gs,))
+    K2, F2 = eng2.create_mat(), eng2.create_vec()
+    eng2.compute_system(K2, F2)
+    compare_mats(K2, K_o, 1e-11)      # (the file holds x w: one rounding more)
+
+
+def test_quarter_cylinder_known_answers_through_the_engine():
+    R, h = 1.75, 0.8
+    orc, eng = make_pair(2, 1, [2, 1], [1, 2], nqp=[10, 2])
+    arc = [(R, 0.0), (R, R), (0.0, R)]; wts = [1.0, np.sqrt(0.5), 1.0]
+    X = np.array([[x, y, h * k / 2] for k in range(3) for (x, y) in arc]); W = np.array(wts * 3)
+    eng.set_geometry(X, W)
+    eng.set_form("surface")
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    area = np.pi * R / 2 * h
+    assert abs(K.to_coo_global()[2].sum() - area) < 1e-12 and abs(F.get().sum() - area / R) < 1e-12
+    with pytest.raises(P.IGXError):
+        eng.set_geometry(X[:, :1], W)      # nsd below dim
+
+
+USER_SHELL = r"""
+// a struct that reads the geometry map's derivatives like demo/ClassicalShell.c:57-80 (NEED_MAPX): the Lame parameters A1, A2 of the
+// parametric lines and the normal curvatures b1, b2 there, on the parametric basis
+struct UserShell {
+  static constexpr int DOF = 1, ORDER = 2; static constexpr unsigned NEED = NEED_MAPX;
+  static __device__ void lame(const PtView &p, double &A1, double &A2, double &b1, double &b2) {
+    const double (*g)[2] = (const double (*)[2])p.X1; const double (*h)[2][2] = (const double (*)[2][2])p.X2;
+    double n[3] = {g[1][0] * g[2][1] - g[2][0] * g[1][1], -(g[0][0] * g[2][1] - g[2][0] * g[0][1]), g[0][0] * g[1][1] - g[1][0] * g[0][1]};
+    const double r = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]); n[0] *= r; n[1] *= r; n[2] *= r;
+    A1 = sqrt(g[0][0] * g[0][0] + g[1][0] * g[1][0] + g[2][0] * g[2][0]); A2 = sqrt(g[0][1] * g[0][1] + g[1][1] * g[1][1] + g[2][1] * g[2][1]);
+    b1 = -1.0 / (A1 * A1) * (n[0] * h[0][0][0] + n[1] * h[1][0][0] + n[2] * h[2][0][0]);
+    b2 = -1.0 / (A2 * A2) * (n[0] * h[0][1][1] + n[1] * h[1][1][1] + n[2] * h[2][1][1]);
+  }
+  static __device__ void mat(const PtView &p, const double *Na, const double *Nb, double *T) {
+    double A1, A2, b1, b2; lame(p, A1, A2, b1, b2);
+    T[0] = (Na[1] * Nb[1] / (A1 * A1) + Na[2] * Nb[2] / (A2 * A2) + (b1 * b1 + b2 * b2) * Na[0] * Nb[0]) * A1 * A2;
+  }
+  static __device__ void vec(const PtView &p, const double *Na, double *R) { double A1, A2, b1, b2; lame(p, A1, A2, b1, b2); R[0] = Na[0] * (b1 + b2) * A1 * A2; }
+};
+"""
+
+
+def test_user_shell_struct_on_the_cylinder():
+    """p->mapX[1], p->mapX[2] in a struct given as source, read as demo/ClassicalShell.c:57-80 does: on the quarter cylinder the
+    parametric lines are lines of curvature, A1 A2 is the area element, b1 = 1/R (outward normal: -1/R ... the sign of the demo's
+    formula), b2 = 0: sum F = -+ area / R, sum K = the (b1^2 + b2^2)-weighted area."""
+    R, h = 1.75, 0.8
+    orc, eng = make_pair(2, 1, [2, 1], [1, 2], nqp=[10, 2])
+    arc = [(R, 0.0), (R, R), (0.0, R)]; wts = [1.0, np.sqrt(0.5), 1.0]
+    X = np.array([[x, y, h * k / 2] for k in range(3) for (x, y) in arc]); W = np.array(wts * 3)
+    eng.set_geometry(X, W)
+    eng.set_form_source(USER_SHELL, "UserShell")
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    assert "generic_assemble" in eng.kernel_name()
+    area = np.pi * R / 2 * h
+    assert abs(abs(F.get().sum()) - area / R) < 1e-12 and abs(K.to_coo_global()[2].sum() - area / R ** 2) < 1e-12

@@ -306,3 +306,26 @@ def test_property_array_known_answers():
     K, F = orc.compute_system("orc_form_property")
     K0, F0 = orc.compute_system("orc_form_poisson")
     assert np.abs(K.val - 2.0 * K0.val).max() < TIGHT and np.abs(F - 3.0 * F0).max() < TIGHT
+
+
+@pytest.mark.parametrize("dim", [1, 2])
+def test_curve_and_surface_in_space_known_answers(dim):
+    """IGASetGeometryDim with nsd != dim (src/petigaelem.c:940-1029: geometry map only, parametric shape functions and measure):
+    a quarter circle of radius R as a NURBS curve in the plane (dim 1, nsd 2), extruded to a quarter cylinder (dim 2, nsd 3).
+    orc_form_surface builds the metric from p->mapX[1], p->mapX[2]: sum K = length / area (partition of unity), sum F = that
+    times the curvature 1 / R, which is the same at every point."""
+    from common import make_pair
+    R, h = 1.75, 0.8
+    orc, _ = make_pair(dim, 1, [2, 1][:dim], [1, 2][:dim], nqp=[10, 2][:dim], engine=False)
+    arc = [(R, 0.0), (R, R), (0.0, R)]; wts = [1.0, SQ2 / 2, 1.0]
+    if dim == 1:
+        X, W = np.array(arc), np.array(wts)
+    else:
+        X = np.array([[x, y, h * k / 2] for k in range(3) for (x, y) in arc]); W = np.array(wts * 3)
+    orc.set_geometry(X, W)
+    K, F = orc.compute_system("orc_form_surface")
+    size = np.pi * R / 2 * (h if dim == 2 else 1.0)
+    assert abs(K.val.sum() - size) < TIGHT and abs(F.sum() - size / R) < TIGHT
+    e = orc.element([0] * dim)
+    assert np.allclose(np.hypot(e["mapX0"][:, 0], e["mapX0"][:, 1]), R, atol=TIGHT)      # on the circle
+    assert e["mapX1"].shape[1:] == (dim + 1, dim) and np.all(e["detX"] == 0)              # [nsd][dim]; no inverse map, no detX
