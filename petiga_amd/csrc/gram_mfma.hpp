@@ -2385,13 +2385,16 @@ static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bo
   const long long bps = (pencils + wpb - 1) / wpb;
   int nseg = std::max(1, (nw + 159) / 160);
   long long best = -1; int best_n = nseg;
-  for (int n = nseg; n <= std::max(nseg, nw / 8); ++n) {
+  // (round 6: segments down to two elements.  A pencil's elements are sequential -- 12.8 us of MFMA issue each at p = 3 -- so on a small
+  //  mesh, where the CUs outnumber the workgroups, the walk's LENGTH is the launch's duration: 32^3 took 365 us per launch with the old
+  //  floor of eight elements per segment, 250 us with four.  The "+ 1" is a workgroup's set-up in units of a step.)
+  for (int n = nseg; n <= std::max(nseg, nw / 2); ++n) {
     const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
     const size_t lds_n = pencil_lds_bytes(len + 3, geo, wpb) + (walk0 ? pencil_hold_bytes(P) * wpb / 8 : 0) + (geo ? pencil_geo_bytes() : 0) + extra_lds;
     // (next to the metric areas of a mapped geometry the tables of 128 + 3 elements no longer fit: 256^3 takes three segments there)
     if (lds_n > (size_t)160 * 1024) { if (best < 0) best_n = n + 1; continue; }
     const long long slots = (long long)ncu * std::max<long long>(1, std::min<long long>(2, (long long)(160 * 1024) / (long long)lds_n));   // resident workgroups
-    const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || halo_always) ? P : 0));
+    const long long cost = ((bps * ns + slots - 1) / slots) * (len + ((ns > 1 || halo_always) ? P : 0) + 1);
     if (best < 0 || cost < best) { best = cost; best_n = n; }
   }
   if (cost_out) *cost_out = best < 0 ? 0 : best;
@@ -2460,7 +2463,7 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     const size_t win_bytes = (mod && mod->pack == 2) ? pencil_winc_bytes(pa.wpb) : pencil_win_bytes(pa.wpb);
     const size_t win_extra = W == 0 ? pencil_win_extra(s, P, GEO, FIXT, mod, pa.wpb) : 0;
     int nseg = pencil_segments(pencils, nw, P, GEO, W == 0, (mod ? mod->extra_lds : 0) + win_extra, (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]), nullptr, pa.wpb);
-    if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 4)));   // experiment switch
+    if (s.env.nseg > 0) nseg = std::max(nseg_min_lds(nw), std::min(s.env.nseg, std::max(1, nw / 2)));   // experiment switch
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
     pa.blocks_per_seg = (int)((pencils + pa.wpb - 1) / pa.wpb);

@@ -625,13 +625,13 @@ static void launch_patches_p2(const Space &s, const SpaceDev &S, const OutDev &o
     const long long patches = (long long)A.px_count * A.py_count;
     // segments: the count with the fewest rounds x (length + halo), one workgroup per CU
     int best = 1; long long bc = -1;
-    for (int n = 1; n <= std::max(1, nw / 8); ++n) {
+    for (int n = 1; n <= std::max(1, nw / 2); ++n) {      // (down to two elements per segment: pencil_segments)
       const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
       if (patch_lds_bytes(len + 3) > (size_t)160 * 1024) continue;
-      const long long cost = ((patches * ns + ncu - 1) / ncu) * (len + (ns > 1 ? 2 : 0));
+      const long long cost = ((patches * ns + ncu - 1) / ncu) * (len + (ns > 1 ? 2 : 0) + 1);
       if (bc < 0 || cost < bc) { bc = cost; best = n; }
     }
-    if (s.env.nseg > 0) best = std::min(s.env.nseg, std::max(1, nw / 4));
+    if (s.env.nseg > 0) best = std::min(s.env.nseg, std::max(1, nw / 2));
     pa.seg_len = (nw + best - 1) / best; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.blocks_per_seg = (int)patches; pa.ne_max = pa.seg_len + 3;
     const size_t lds = patch_lds_bytes(pa.ne_max);
@@ -694,13 +694,13 @@ static void launch_state_patches_p2(const Space &s, const SpaceDev &S, const Out
     pa.nelx = nx; pa.nely = ny; pa.w_lo = 0; pa.w_hi = nw; pa.w_halo_lo = 0; pa.open_hi = 0; pa.wpb = SPATCH_W;
     const long long patches = (long long)A.px_count * A.py_count;
     int best = 1; long long bc = -1;
-    for (int n = 1; n <= std::max(1, nw / 8); ++n) {
+    for (int n = 1; n <= std::max(1, nw / 2); ++n) {      // (down to two elements per segment: pencil_segments)
       const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
       if (spatch_lds_bytes(len + 3) > (size_t)160 * 1024) continue;
-      const long long cost = ((patches * ns + ncu - 1) / ncu) * (len + (ns > 1 ? 2 : 0));
+      const long long cost = ((patches * ns + ncu - 1) / ncu) * (len + (ns > 1 ? 2 : 0) + 1);
       if (bc < 0 || cost < bc) { bc = cost; best = n; }
     }
-    if (s.env.nseg > 0) best = std::min(s.env.nseg, std::max(1, nw / 4));
+    if (s.env.nseg > 0) best = std::min(s.env.nseg, std::max(1, nw / 2));
     pa.seg_len = (nw + best - 1) / best; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.blocks_per_seg = (int)patches; pa.ne_max = pa.seg_len + 3;
     const size_t lds = spatch_lds_bytes(pa.ne_max);

@@ -25,6 +25,7 @@ def _poison(mat):
                                     ((10, 9, 7), 0),       # partial patches on both axes (9 = 2 x 4 + 1, 7 = 2 x 3 + 1)
                                     ((17, 5, 4), 3),       # three segments along the walk: halo elements, owned rows
                                     ((8, 4, 3), 0),        # one patch
+                                    ((8, 5, 4), 4),        # segments of two elements (the floor since round 6: small meshes are bound by the walk's length)
                                     ((12, 13, 11), 2)])
 def test_matrix_driver_vs_oracle(N, nseg, monkeypatch):
     monkeypatch.setenv("IGX_PATCH", "1")
@@ -48,7 +49,7 @@ def test_matrix_driver_vs_oracle(N, nseg, monkeypatch):
     assert np.abs(A.host(True) - vals).max() <= 4e-15 * np.abs(vals).max()
 
 
-@pytest.mark.parametrize("N,bc,nseg", [((9, 8, 6), "all", 0), ((10, 9, 7), "all", 0), ((17, 5, 4), "some", 3), ((12, 13, 11), "all", 2), ((9, 5, 4), "none", 0)])
+@pytest.mark.parametrize("N,bc,nseg", [((9, 8, 6), "all", 0), ((10, 9, 7), "all", 0), ((17, 5, 4), "some", 3), ((12, 13, 11), "all", 2), ((9, 5, 4), "none", 0), ((8, 5, 4), "all", 4)])
 def test_system_driver_vs_oracle(N, bc, nseg, monkeypatch):
     """demo/Poisson3D.c:37-51: Dirichlet values on the faces (IGAElementFixSystem on the combined runs: fixed rows and columns emptied, the
     diagonal counting the elements of the patch's walk that hold the node, the lifting of a row gathered from its runs), F = N * 1, a
@@ -89,6 +90,7 @@ CH = (1.5, 200.0, 0.63, 1.0, 1.0 / 48.0, 1.0)      # (the parameters of tests/te
     ("cahnhilliard", (10, 9, 7), True, 0),        # partial patches on both axes, Dirichlet values on four faces
     ("cahnhilliard", (17, 5, 3), True, 3),        # three segments along the walk
     ("cahnhilliard", (8, 4, 2), False, 0),        # one patch
+    ("cahnhilliard", (9, 4, 3), True, 4),         # segments of three, three and three elements, two of halo each
     ("bratu", (12, 13, 11), True, 2),
     ("bratu", (9, 5, 4), False, 0),
 ])

@@ -111,6 +111,8 @@ def test_repeatable_and_matches_the_feature_kernel_on_a_larger_mesh():
     (3, (21, 8, 4), (True, True, False), 3, "system"),       # ... in three segments, a second wrapped axis
     (2, (8, 5, 7), (True, False, True), 0, "matrix"),
     (2, (17, 4, 4), (True, False, False), 2, "system"),
+    (3, (8, 4, 4), (True, False, False), 4, "system"),       # segments of two elements, shorter than their halo of p (the floor since round 6)
+    (3, (9, 4, 5), (False, False, False), 4, "system"),      # ... on an open axis: lengths 3, 3, 3
 ])
 def test_walk_axis_wrapped_inside_the_rank(p, N, periodic, nseg, driver, monkeypatch):
     """gram_pencil on a periodic axis 0 held by one rank: elements and node layers modulo the axis, every segment re-computes the p

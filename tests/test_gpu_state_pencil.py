@@ -28,6 +28,8 @@ def _poison(mat):
     (2, (9, 4, 5), (False, False, False), False, 0),        # demo/CahnHilliard3D.c at p = 2 (config 4's discretisation)
     (2, (12, 3, 4), (False, False, False), True, 0),        # Dirichlet values on four faces: FixValues + FixJacobian inside the walk
     (2, (17, 4, 3), (False, False, False), True, 3),        # three segments along the walk
+    (2, (8, 4, 3), (False, False, False), True, 4),         # segments of two elements (the floor since round 6)
+    (3, (9, 3, 4), (False, False, False), True, 4),         # p = 3: segments of three elements, the halo as long
     (2, (8, 5, 6), (False, True, True), False, 0),          # the demo's periodic box on the two axes the walk does not follow
     (3, (9, 4, 4), (False, False, False), False, 0),
     (3, (10, 3, 5), (False, False, True), True, 2),
