@@ -93,8 +93,10 @@ int IGXSetDof(IGX iga,int dof);                            /* IGASetDof         
 int IGXSetOrder(IGX iga,int order);                        /* IGASetOrder        src/petiga.c:463  (clipped to [1,4]) */
 int IGXSetQuadrature(IGX iga,int i,int q);                 /* IGASetQuadrature   src/petiga.c:530  */
 /* Quadrature rule of an axis (IGARuleType, include/petiga.h:82-87).  LEGENDRE (q = 1..10) and LOBATTO (q = 2..10) carry the
- * doubles of the reference's tables (src/petigarule.c:182-319, :321-459); USER takes any rule on [-1,1]; REDUCED (a point
- * count that varies along the axis, src/petigabasis.c:144-171) is refused with PETSC_ERR_SUP at IGXSetUp. */
+ * doubles of the reference's tables (src/petigarule.c:182-319, :321-459); USER takes any rule on [-1,1]; REDUCED is Gauss-Legendre
+ * with q points on the first and the last element of the axis and q - 1 on the others (src/petigabasis.c:144-171): the engine keeps
+ * q slots per element and gives the last one of an interior element weight 0 (the reference trims it, src/petigaelem.c:764-776),
+ * so the results are the reference's and the cost is that of the full rule. */
 typedef enum { IGX_RULE_LEGENDRE = 0, IGX_RULE_LOBATTO = 1, IGX_RULE_REDUCED = 2, IGX_RULE_USER = 3 } IGXRuleType;
 int IGXSetRuleType(IGX iga,int i,IGXRuleType type);        /* IGASetRuleType     src/petiga.c:500  */
 int IGXSetRuleSize(IGX iga,int i,int nqp);                 /* IGASetRuleSize     src/petiga.c:515  */

@@ -267,13 +267,17 @@ static void basis_free(OrcBasis *b)
 static int basis_init_quadrature(OrcBasis *bs,const OrcAxis *ax,int nqp,int type,const double *ux,const double *uw)
 {
   int p=ax->p, m=ax->m, n=m-p-1, nel=ax->nel, nen=p+1, d=(p<4)?p:4, e,q;
-  double X[64],W[64];
+  double X[64],W[64],Xr[64],Wr[64]; int nr = nqp;
   const double *U = ax->U;
   if (nqp > 64) ORC_ERR("rule size not implemented");
   if (type == 0)      { if (orc_gauss_legendre(nqp,X,W)) ORC_ERR("rule size not implemented"); }
   else if (type == 1) { if (orc_gauss_lobatto(nqp,X,W))  ORC_ERR("rule size not implemented"); }
   else if (type == 3) { if (!ux || !uw) ORC_ERR("user rule not set"); for (q=0; q<nqp; q++) { X[q]=ux[q]; W[q]=uw[q]; } }
-  else ORC_ERR("reduced rules are not restated");
+  else {   /* IGA_RULE_REDUCED, src/petigabasis.c:144-171: Gauss-Legendre with nqp points on the first and the last element, with
+            * nqp-1 on the others (the last slot: weight 0, point PETSC_MAX_REAL, no basis values; IGA_Quadrature_SIZE trims it) */
+    if (orc_gauss_legendre(nqp,X,W)) ORC_ERR("rule size not implemented");
+    if (nel > 2 && nqp > 1) { nr = nqp-1; if (orc_gauss_legendre(nr,Xr,Wr)) ORC_ERR("rule size not implemented"); }
+  }
   basis_free(bs);
   bs->nel=nel; bs->nqp=nqp; bs->nen=nen;
   bs->offset = (int*)   xcalloc((size_t)nel,sizeof(int));
@@ -286,6 +290,10 @@ static int basis_init_quadrature(OrcBasis *bs,const OrcAxis *ax,int nqp,int type
     double u0 = U[k], u1 = U[k+1], J = (u1-u0)/2;
     bs->detJac[e] = J;
     bs->offset[e] = k - p;
+    if (type == 2 && nr < nqp && e > 0 && e < nel-1) {
+      for (q=0; q<nr; q++) { bs->weight[e*nqp+q] = Wr[q]; bs->point[e*nqp+q] = (Xr[q] + 1)*J + u0; }
+      for (q=nr; q<nqp; q++) { bs->weight[e*nqp+q] = 0; bs->point[e*nqp+q] = 1.797693134862315708e308; }
+    } else
     for (q=0; q<nqp; q++) {
       bs->weight[e*nqp+q] = W[q];
       bs->point [e*nqp+q] = (X[q] + 1)*J + u0;

@@ -241,7 +241,7 @@ class OracleIGA:
         self._ck(self.L.orc_set_quadrature(self.p, i, q))
 
     def set_rule_type(self, i, kind):
-        self._ck(self.L.orc_set_rule_type(self.p, i, dict(legendre=0, lobatto=1)[kind] if isinstance(kind, str) else kind))
+        self._ck(self.L.orc_set_rule_type(self.p, i, dict(legendre=0, lobatto=1, reduced=2)[kind] if isinstance(kind, str) else kind))
 
     def set_rule(self, i, x, w):
         x, w = np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(w, dtype=np.float64)

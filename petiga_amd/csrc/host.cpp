@@ -105,8 +105,8 @@ int rule_setup(const Rule1D &r, int nqp, double *X, double *W, std::string &err)
       if ((int)r.x.size() != nqp) { err = "user-defined rule has a different number of points"; return IGX_ERR_ARG_WRONGSTATE; }
       for (int q = 0; q < nqp; ++q) { X[q] = r.x[q]; W[q] = r.w[q]; }
       break;
-    default:   // IGA_RULE_REDUCED changes the number of points from element to element (src/petigabasis.c:144-171, petigaelem.c:764-776)
-      err = "reduced Gauss-Legendre rules (a point count that varies along the axis) are not supported"; return IGX_ERR_SUP;
+    default:   // IGA_RULE_REDUCED: Gauss-Legendre; basis_init gives the interior elements one point less (src/petigabasis.c:144-171)
+      rc = gauss_legendre(nqp, X, W); break;
   }
   if (rc) { err = "Number of quadrature points not implemented"; return IGX_ERR_ARG_OUTOFRANGE; }
   return 0;
@@ -231,6 +231,15 @@ int basis_init(Basis1D &b, const Axis &ax, const Rule1D &rule, int nqp, std::str
   if (int rc = rule_setup(rule, nqp, X, W, err)) return rc;
   if (ax.p > 7) { err = "degree > 7 not supported"; return IGX_ERR_SUP; }
   const int p = ax.p, nel = ax.nel, nen = p + 1, d = std::min(p, 4);
+  // IGA_RULE_REDUCED (src/petigabasis.c:144-171): the first and the last element keep the nqp points, the others take the rule with
+  // nqp - 1.  The reference pads the last slot with weight 0 and trims it per element (IGA_Quadrature_SIZE, src/petigaelem.c:764-776);
+  // the kernels here keep one point count per axis, so the padded slot stays in the tables with weight 0 -- it adds an exact zero --
+  // and sits at the element's midpoint, where every form is finite (the reference leaves PETSC_MAX_REAL and no basis values there).
+  std::vector<double> Xr, Wr;
+  if (rule.type == IGX_RULE_REDUCED && nel > 2 && nqp > 1) {
+    Xr.assign(std::max(nqp, 10), 0.0); Wr.assign(std::max(nqp, 10), 0.0);
+    if (gauss_legendre(nqp - 1, Xr.data(), Wr.data())) { err = "Number of quadrature points not implemented"; return IGX_ERR_ARG_OUTOFRANGE; }
+  }
   b.nel = nel; b.nqp = nqp; b.nen = nen;
   b.offset.assign(nel, 0); b.detJac.assign(nel, 0.0);
   b.weight.assign((size_t)nel * nqp, 0.0); b.point.assign((size_t)nel * nqp, 0.0);
@@ -240,9 +249,11 @@ int basis_init(Basis1D &b, const Axis &ax, const Rule1D &rule, int nqp, std::str
     const double u0 = ax.U[k], u1 = ax.U[k + 1], J = (u1 - u0) / 2;
     b.detJac[e] = J;
     b.offset[e] = k - p;
+    const bool reduced = !Xr.empty() && e > 0 && e < nel - 1;
     for (int q = 0; q < nqp; ++q) {
-      b.weight[(size_t)e * nqp + q] = W[q];
-      const double u = (X[q] + 1) * J + u0;
+      const bool pad = reduced && q == nqp - 1;
+      b.weight[(size_t)e * nqp + q] = reduced ? (pad ? 0.0 : Wr[q]) : W[q];
+      const double u = ((reduced ? (pad ? 0.0 : Xr[q]) : X[q]) + 1) * J + u0;
       b.point[(size_t)e * nqp + q] = u;
       bspline_ders(k, u, p, d, ax.U.data(), &b.value[((size_t)e * nqp + q) * nen * 5]);
     }

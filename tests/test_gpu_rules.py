@@ -17,8 +17,8 @@ def _pair(dim, dof, p, N, rule, nq=None):
     orc, eng = make_pair(dim, dof, p, N)
     for g in (orc, eng):
         for i in range(dim):
-            if rule == "lobatto":
-                g.set_rule_type(i, "lobatto")
+            if rule in ("lobatto", "reduced"):
+                g.set_rule_type(i, rule)
                 if nq:
                     g.set_quadrature(i, nq)
             else:
@@ -30,7 +30,10 @@ def _pair(dim, dof, p, N, rule, nq=None):
 @pytest.mark.parametrize("kernel", [0, 1])
 @pytest.mark.parametrize("dim,p,N,rule,nq,geo", [(2, 2, [7, 6], "lobatto", None, "none"), (2, 2, [6, 5], "lobatto", 5, "nurbs"), (3, 3, [9, 4, 4], "lobatto", None, "none"),
                                                  (3, 2, [9, 5, 4], "lobatto", None, "nurbs"), (3, 3, [8, 4, 5], "user", 4, "poly"), (3, 2, [10, 5, 4], "user", 3, "none"),
-                                                 (1, 3, [9], "lobatto", 6, "none")])
+                                                 (1, 3, [9], "lobatto", 6, "none"),
+                                                 # IGA_RULE_REDUCED (src/petigabasis.c:144-171): one point less on the interior elements of every axis
+                                                 (3, 3, [9, 4, 5], "reduced", None, "none"), (3, 2, [9, 5, 4], "reduced", None, "nurbs"), (2, 3, [6, 7], "reduced", 5, "poly"),
+                                                 (3, 2, [8, 2, 5], "reduced", None, "none"), (1, 2, [7], "reduced", 2, "none")])
 def test_poisson_system_with_other_rules(dim, p, N, rule, nq, geo, kernel):
     orc, eng = _pair(dim, 1, p, N, rule, nq)
     eng.set_kernel(kernel)
@@ -54,10 +57,11 @@ def test_poisson_system_with_other_rules(dim, p, N, rule, nq, geo, kernel):
     assert np.abs(b.get() - b_o).max() <= tol * max(np.abs(b_o).max(), 1.0)
 
 
+@pytest.mark.parametrize("rule", ["lobatto", "reduced"])
 @pytest.mark.parametrize("form,dof", [("elasticity", 3), ("cahnhilliard", 1)])
-def test_multi_field_and_nonlinear_forms_with_lobatto(form, dof):
+def test_multi_field_and_nonlinear_forms_with_lobatto(form, dof, rule):
     p = 3 if form == "elasticity" else 2
-    orc, eng = _pair(3, dof, p, [9, 4, 4], "lobatto")
+    orc, eng = _pair(3, dof, p, [9, 4, 4], rule)
     if form == "elasticity":
         import ctypes as C
         import oracle_api as O
