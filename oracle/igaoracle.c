@@ -1070,7 +1070,8 @@ static double boundary_area_dS(const Elem *e,int dir,int side)
   int ax[2]={0,0}, nq[2]={1,1}, na[2]={1,1}, m[3]={1,1,1}, i,k,q0,q1,a0,a1,c,r,s2;
   const double *W[2]={NULL,NULL}, *N[2]={NULL,NULL}; double dS=0;
   for (i=0; i<dim; i++) m[i] = iga->basis[i].nen;
-  for (k=0,i=0; i<dim; i++) { if (i==dir) continue; ax[k]=i; nq[k]=iga->basis[i].nqp; na[k]=iga->basis[i].nen;
+  int qs[3]; quad_size(iga->basis,e->ID,qs);   /* IGA_Quadrature_SIZE(BD,ID,qshape), src/petigaelem.c:1137: the trimmed counts of a reduced rule */
+  for (k=0,i=0; i<dim; i++) { if (i==dir) continue; ax[k]=i; nq[k]=qs[i]; na[k]=iga->basis[i].nen;
     W[k] = iga->basis[i].weight + (size_t)e->ID[i]*iga->basis[i].nqp; N[k] = iga->basis[i].value + (size_t)e->ID[i]*iga->basis[i].nqp*na[k]*5; k++; }
   for (q1=0; q1<nq[1]; q1++) for (q0=0; q0<nq[0]; q0++) {
     double N0[64], N1[2][64], Xw[64], F[2][3], M[2][2]={{0,0},{0,0}}, detJ=1, W0=0, S1[2]={0,0}; int nen = na[0]*na[1];
