@@ -423,6 +423,11 @@ static SpaceDev make_spacedev(IGX g) {
     A.tab = B.tab.as<double>(); A.w = B.w.as<double>(); A.J = B.J.as<double>(); A.pt = B.pt.as<double>();
     A.bnd = B.bnd.as<double>();
     if (d < s.dim && !s.axis[d].U.empty() && !s.axis[d].span.empty()) { const Axis &ax = s.axis[d]; A.bndpt[0] = ax.U[ax.span[0]]; A.bndpt[1] = ax.U[ax.span[ax.nel - 1] + 1]; }
+    {
+      const Basis1D &bd = s.basis[d]; const int e0 = s.elem_start[d], ne = s.elem_width[d];
+      A.off_lin = 1; A.off0 = ne > 0 ? bd.offset[e0] - L.gstart : 0;
+      for (int e = 0; e < ne; ++e) if (bd.offset[e0 + e] - L.gstart != A.off0 + e) { A.off_lin = 0; break; }
+    }
     A.off = B.off.as<int>(); A.rowmap = B.rowmap.as<int>(); A.rwrap = L.alias ? s.axis[d].nnp : 0x7fffffff; A.rcnt = B.rcnt.as<int>(); A.P = B.P.as<int>();
     A.prefix = B.prefix.as<int64_t>(); A.tot = 0; for (int r = 0; r < L.nrow; ++r) A.tot += L.rcnt[r];
   }

@@ -166,6 +166,7 @@ struct AxisDev {
   const int *P;        // [gwidth][2p+1]
   const int64_t *prefix;  // [nrow+1] exclusive prefix sums of rcnt
   int64_t tot;         // sum of rcnt
+  int off_lin, off0;   // off in closed form: off[e] = off0 + e for every element of the rank (one new basis function per element: maximal continuity); else off_lin = 0
 };
 
 struct SpaceDev {

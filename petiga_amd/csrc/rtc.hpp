@@ -504,7 +504,8 @@ static int launch_vecsf_rtc(IGX g, RtcForm &F, const SpaceDev &S, const OutDev &
     args.cr = cr; args.nelem = (long long)cr.count[0] * cr.count[1] * cr.count[2];
     size_t asz = sizeof(args);
     void *cfg[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END};
-    HIPCK(hipModuleLaunchKernel(K->func[0], (unsigned)((args.nelem + (three ? 7 : 3)) / (three ? 8 : 4)), 1, 1, 256, 1, 1, 0, g->stream, nullptr, cfg));
+    const unsigned want = (unsigned)((args.nelem + (three ? 7 : 3)) / (three ? 8 : 4));      // (a wavefront walks a sequence of elements: vec_sumfact.hpp, round 6)
+    HIPCK(hipModuleLaunchKernel(K->func[0], want, 1, 1, 256, 1, 1, 0, g->stream, nullptr, cfg));
     launches++;
   }
   g->last_launches = launches;

@@ -151,8 +151,10 @@ __device__ __forceinline__ constexpr unsigned vs_kmask_ident(unsigned vmask) {
 
 // GEO: a mapped geometry and / or NURBS weights; without them the geometry chain is the identity at compile time (no E1 / E2
 // products, no quotient rule) and the kernel needs half the registers
+// the pipelined walk of round 6 (see the kernel): scalar forms without a geometry, where its registers fit four wavefronts per SIMD
+template <class Form, bool GEO> __host__ __device__ constexpr bool vs_pipe() { return !GEO && Form::DOF == 1; }
 template <class Form, bool GEO, int NS = 4>
-__global__ void __launch_bounds__(256, 2)      // (two waves per SIMD: the geometry variants of NS-VMS and Cahn-Hilliard need 290-350 VGPRs uncapped, one wave per SIMD)
+__global__ void __launch_bounds__(256, (vs_pipe<Form, GEO>() ? 4 : 2))      // (two waves per SIMD: the geometry variants of NS-VMS and Cahn-Hilliard need 290-350 VGPRs uncapped, one wave per SIMD)
 vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nelem) {
   constexpr int EPW = NS == 3 ? 2 : 1, NL = NS * NS * NS;               // elements per wavefront, lanes per element
   constexpr int DOF = Form::DOF;
@@ -168,18 +170,24 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard: 33 KB per workgroup, four workgroups per CU, two elements per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int esub = (EPW == 2 && lane >= NL) ? 1 : 0;                    // which of the wavefront's elements this lane works on
-  const long long w0 = ((long long)blockIdx.x * 4 + wave) * EPW, w = w0 + esub;
-  if (w0 >= nelem) return;
-  const bool live = lane < EPW * NL && w < nelem;                       // (an odd count leaves the second half of the last wavefront idle)
+  // Round 6 (PIPE: scalar forms without a geometry): every global load of the unit -- the 1-D rows, the node's state and old F, the
+  // point's weights -- leaves at its start, behind closed forms for the element's offset and the row map.  A wavefront's life was a
+  // chain of dependent round trips (offset -> row map -> state; the rows; the point's weights; F read-add-write at the end, each
+  // behind a wavefront fence the compiler does not move loads across) around 2-3 us of arithmetic: 9.3 us with four wavefronts per
+  // SIMD to hide it, 7.7 us now.  (The colour makes the early read of F safe: no other element of the launch touches these rows.)
+  // Off for the geometry variants: they are at their 256 registers already.
+  constexpr bool PIPE = vs_pipe<Form, GEO>();
+  constexpr int TPL = (EPW * 3 * 48 + 63) / 64;                          // table entries per lane
+  const long long nunits = (nelem + EPW - 1) / EPW, ustride = (long long)gridDim.x * 4;
+  long long unit = (long long)blockIdx.x * 4 + wave;
+  if (unit >= nunits) return;
   double *buf = sm_all[wave], *tab0 = buf + NBUF * 64 + esub * 144, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
-  auto element_of = [&](long long ww, int (&e3)[3]) {
-    long long b = ww < nelem ? ww : w0;
+  auto element_at = [&](long long ww, long long wfirst, int (&e3)[3]) {
+    long long b = ww < nelem ? ww : wfirst;
     const int t0 = (int)(b % cr.count[0]); b /= cr.count[0];
     const int t1 = (int)(b % cr.count[1]); b /= cr.count[1];
     e3[0] = cr.start[0] + t0 * cr.step[0]; e3[1] = cr.start[1] + t1 * cr.step[1]; e3[2] = cr.start[2] + (int)b * cr.step[2];
   };
-  int el[3];
-  element_of(w, el);
   const int ll = lane < EPW * NL ? lane - esub * NL : 0;                 // (the lanes beyond the last element idle on lane 0's indices)
   const int i0 = NS == 4 ? (ll & 3) : ll % 3, i1 = NS == 4 ? ((ll >> 2) & 3) : (ll / 3) % 3, i2 = NS == 4 ? (ll >> 4) : ll / 9;
   const VsLane VL = {i0, i1, i2, esub * NL};
@@ -188,39 +196,95 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   const bool geo = GEO && S.nsd > 0, rat = GEO && S.rational != 0;
   const bool sysvec = out.vec_mode == 1, sysbody = out.vec_mode == 2;      // parts of a System assembly (igx.hpp: OutDev::vec_mode)
   const bool readU = out.U != nullptr && !sysvec && !sysbody, useU = readU || sysvec, useV = out.V != nullptr && !sysvec && !sysbody;
-  int nb[3], nq[3], off[3];
+  int nb[3], nq[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) { nb[d] = S.ax[d].nen; nq[d] = S.ax[d].nqp; off[d] = S.ax[d].off[el[d]]; }
-  // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4
-  for (int i = lane; i < EPW * 3 * 48; i += 64) {
-    const int es = i / 144, r = i - es * 144, d = r / 48, j = r - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
-    int e3[3]; element_of(w0 + es, e3);
-    buf[NBUF * 64 + i] = (q < nq[d] && a < nb[d]) ? S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v] : 0.0;
-  }
-  // this lane's node: control point, state, Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
-  const bool isnode = live && i0 < nb[0] && i1 < nb[1] && i2 < nb[2];
-  const bool ispoint = live && i0 < nq[0] && i1 < nq[1] && i2 < nq[2];
-  size_t row = 0; double Xw[3] = {0, 0, 0}, wgt = 0.0, Uv[DOF], Vv[DOF], ufix[DOF]; bool fixed[DOF];
+  for (int d = 0; d < 3; ++d) { nb[d] = S.ax[d].nen; nq[d] = S.ax[d].nqp; }
+  const bool lanenode = i0 < nb[0] && i1 < nb[1] && i2 < nb[2], lanepoint = i0 < nq[0] && i1 < nq[1] && i2 < nq[2];
+  // what an element needs from memory, in two steps: its offsets (A), then everything addressed through them (B)
+  struct Pre { int el[3], off[3]; bool live; size_t row; double tab[TPL], U[DOF], V[DOF], Fo[DOF], fx[DOF], wgt, X[3], pt[3], wq[3], Jd[3]; };
+  auto stageA = [&](long long un, Pre &P) {
+    const long long w0n = un * EPW, wn = w0n + esub;
+    P.live = lane < EPW * NL && wn < nelem;                             // (an odd count leaves the second half of the last wavefront idle)
+    element_at(wn, w0n, P.el);
 #pragma unroll
-  for (int f = 0; f < DOF; ++f) { Uv[f] = 0; Vv[f] = 0; ufix[f] = 0; fixed[f] = false; }
+    for (int d = 0; d < 3; ++d) P.off[d] = S.ax[d].off_lin ? S.ax[d].off0 + P.el[d] : S.ax[d].off[P.el[d]];      // (closed form: the loads behind it leave with the first round trip)
+  };
+  auto stageB = [&](long long un, Pre &P) {
+    const long long w0n = un * EPW;
+#pragma unroll
+    for (int k = 0; k < TPL; ++k) {      // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4
+      const int i = lane + 64 * k;
+      P.tab[k] = 0.0;
+      if (i < EPW * 3 * 48) {
+        const int es = i / 144, r = i - es * 144, d = r / 48, j = r - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
+        int e3[3]; element_at(w0n + es, w0n, e3);
+        if (q < nq[d] && a < nb[d]) P.tab[k] = S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v];
+      }
+    }
+    P.row = 0; P.wgt = 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P.X[c] = 0.0;
+#pragma unroll
+    for (int f = 0; f < DOF; ++f) { P.U[f] = 0; P.V[f] = 0; P.Fo[f] = 0; P.fx[f] = 0; }
+    if (P.live && lanenode) {      // this lane's node: control point, state, old F (rowmap in closed form: AxisDev::rwrap)
+      const int n0 = P.off[0] + i0, n1 = P.off[1] + i1, n2 = P.off[2] + i2;
+      const size_t g = (size_t)n0 + (size_t)S.ax[0].gwidth * ((size_t)n1 + (size_t)S.ax[1].gwidth * (size_t)n2);
+      const int r0 = n0 < S.ax[0].rwrap ? n0 : n0 - S.ax[0].rwrap, r1 = n1 < S.ax[1].rwrap ? n1 : n1 - S.ax[1].rwrap, r2 = n2 < S.ax[2].rwrap ? n2 : n2 - S.ax[2].rwrap;
+      P.row = (size_t)r0 + (size_t)S.ax[0].nrow * ((size_t)r1 + (size_t)S.ax[1].nrow * (size_t)r2);
+      P.wgt = rat ? S.W[g] : 1.0;
+      if (geo) for (int c = 0; c < 3; ++c) P.X[c] = S.X[g * 3 + c];
+#pragma unroll
+      for (int f = 0; f < DOF; ++f) {
+        if (readU) P.U[f] = out.U[P.row * DOF + f];
+        if (useV) P.V[f] = out.V[P.row * DOF + f];
+        if (S.fixtable) P.fx[f] = S.fixtable[P.row * DOF + f];
+        if constexpr (PIPE) P.Fo[f] = out.vec[P.row * DOF + f];
+      }
+    }
+    if constexpr (PIPE) {      // (the geometry variants read these where they use them: no register to spare)
+      const bool on = P.live && lanepoint;
+      P.pt[0] = on ? S.ax[0].pt[P.el[0] * nq[0] + i0] : 0.0; P.pt[1] = on ? S.ax[1].pt[P.el[1] * nq[1] + i1] : 0.0; P.pt[2] = on ? S.ax[2].pt[P.el[2] * nq[2] + i2] : 0.0;
+      P.wq[0] = on ? S.ax[0].w[P.el[0] * nq[0] + i0] : 0.0; P.wq[1] = on ? S.ax[1].w[P.el[1] * nq[1] + i1] : 0.0; P.wq[2] = on ? S.ax[2].w[P.el[2] * nq[2] + i2] : 0.0;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) P.Jd[d] = S.ax[d].J[P.el[d]];
+    }
+  };
+  Pre cur, nxt;
+  if (PIPE) { stageA(unit, cur); stageB(unit, cur); }
+  // One unit per wavefront.  Measured in round 6 (config 4's Residual, 256^3, 18.9 ms before): a wavefront walking a SEQUENCE of units with
+  // the next one's loads in flight held 228 registers -- two wavefronts per SIMD -- and took 24.6 ms; TWO units as straight-line code
+  // spilled 71 registers under the cap of 128 and took 32.6 ms; this, every load of the unit issued at its start, takes 15.6 ms.
+  constexpr int UNITS = 1;
+#pragma unroll
+  for (int it = 0; it < UNITS; ++it) {
+  const long long unext = unit + ustride; const bool more = PIPE && it + 1 < UNITS && unext < nunits;
+  if (!PIPE) { stageA(unit, cur); stageB(unit, cur); }
+  const bool live = cur.live;
+  int el[3] = {cur.el[0], cur.el[1], cur.el[2]};
+  VS_SYNC();      // (the previous element's readers of the rows are done)
+#pragma unroll
+  for (int k = 0; k < TPL; ++k) { const int i = lane + 64 * k; if (i < EPW * 3 * 48) buf[NBUF * 64 + i] = cur.tab[k]; }
+  if (PIPE && more) stageA(unext, nxt);
+  // Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
+  const bool isnode = live && lanenode;
+  const bool ispoint = live && lanepoint;
+  const size_t row = cur.row; double Xw[3] = {cur.X[0] * cur.wgt, cur.X[1] * cur.wgt, cur.X[2] * cur.wgt}; const double wgt = cur.wgt; double Uv[DOF], Vv[DOF], ufix[DOF], Fold[DOF]; bool fixed[DOF];
+#pragma unroll
+  for (int f = 0; f < DOF; ++f) { Uv[f] = cur.U[f]; Vv[f] = cur.V[f]; Fold[f] = cur.Fo[f]; ufix[f] = 0; fixed[f] = false; }
   if (isnode) {
-    const size_t g = (size_t)(off[0] + i0) + (size_t)S.ax[0].gwidth * ((size_t)(off[1] + i1) + (size_t)S.ax[1].gwidth * (size_t)(off[2] + i2));
-    row = (size_t)S.ax[0].rowmap[off[0] + i0] + (size_t)S.ax[0].nrow * ((size_t)S.ax[1].rowmap[off[1] + i1] + (size_t)S.ax[1].nrow * (size_t)S.ax[2].rowmap[off[2] + i2]);
-    wgt = rat ? S.W[g] : 1.0;
-    if (geo) for (int c = 0; c < 3; ++c) Xw[c] = S.X[g * 3 + c] * wgt;
-#pragma unroll
-    for (int f = 0; f < DOF; ++f) { if (readU) Uv[f] = out.U[row * DOF + f]; if (useV) Vv[f] = out.V[row * DOF + f]; }
     if (op != OP_VECTOR || sysvec || sysbody) {
-      for (int d = 0; d < 3; ++d) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {      // (unrolled: el[d] / il[d] stay registers -- indexed at run time the arrays went to scratch and LDS)
         const AxisDev &A = S.ax[d];
         if (A.periodic) continue;
+#pragma unroll
         for (int sd = 0; sd < 2; ++sd) {
           if (el[d] + A.estart != (sd ? A.esizes - 1 : 0) || il[d] != (sd ? nb[d] - 1 : 0)) continue;
           const BCDev &bv = S.bcv[d][sd];
           for (int k = 0; k < bv.count; ++k) {
             const int f = bv.field[k];
 #pragma unroll
-            for (int ff = 0; ff < DOF; ++ff) if (ff == f) { fixed[ff] = true; ufix[ff] = S.fixtable ? S.fixtable[row * DOF + ff] : bv.value[k]; }
+            for (int ff = 0; ff < DOF; ++ff) if (ff == f) { fixed[ff] = true; ufix[ff] = S.fixtable ? cur.fx[ff] : bv.value[k]; }
           }
         }
       }
@@ -233,7 +297,8 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   for (int i = 0; i < 9; ++i) { E1[i] = (i % 4 == 0) ? 1.0 : 0.0; o2[i] = 0.0; }
 #pragma unroll
   for (int i = 0; i < 27; ++i) E2[i] = 0.0;
-  x[0] = ispoint ? S.ax[0].pt[el[0] * nq[0] + i0] : 0.0; x[1] = ispoint ? S.ax[1].pt[el[1] * nq[1] + i1] : 0.0; x[2] = ispoint ? S.ax[2].pt[el[2] * nq[2] + i2] : 0.0;
+  if constexpr (PIPE) { x[0] = cur.pt[0]; x[1] = cur.pt[1]; x[2] = cur.pt[2]; }
+  else { x[0] = ispoint ? S.ax[0].pt[el[0] * nq[0] + i0] : 0.0; x[1] = ispoint ? S.ax[1].pt[el[1] * nq[1] + i1] : 0.0; x[2] = ispoint ? S.ax[2].pt[el[2] * nq[2] + i2] : 0.0; }
   // index of the second derivative (a, b) among the 10
   auto k2 = [](int a, int b) { const int lo = a < b ? a : b, hi = a < b ? b : a; return 4 + (lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)); };
   if constexpr (GEO) if (geo || rat) {
@@ -340,17 +405,19 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       ut[f] = D[0] * iw;
     }
   }
+  // the next element's loads go out here: its offsets have arrived, and the point stage and the way back lie ahead
+  if (PIPE && more) stageB(unext, nxt);
   // ---- point: JW and the form's vec() on the unit test features
   double JW = 0.0, G[9];
   if (ispoint) {
     JW = detX;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) JW *= S.ax[d].w[el[d] * nq[d] + il[d]] * S.ax[d].J[el[d]];
+    for (int d = 0; d < 3; ++d) JW *= PIPE ? cur.wq[d] * cur.Jd[d] : S.ax[d].w[el[d] * nq[d] + il[d]] * S.ax[d].J[el[d]];
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int i = 0; i < 3; ++i) G[a * 3 + i] = E1[a * 3 + i] / S.ax[a].J[el[a]];      // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
+    for (int i = 0; i < 3; ++i) G[a * 3 + i] = E1[a * 3 + i] / (PIPE ? cur.Jd[a] : S.ax[a].J[el[a]]);      // IGAPointFormInvGradGeomMap, src/petigapoint.c:269-294
   PtView p; p.x = x; p.u = u; p.ut = ut; p.gu = gu; p.hu = hu; p.G = G; p.prm = prm.v; p.shift = out.shift; p.t = out.t;
   p.normal = nullptr; p.atboundary = 0; p.boundary_id = -1;
   double Cq[DOF][10];
@@ -421,9 +488,13 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       if (fixed[f] && sysvec) F = ufix[f];                       // IGAElementFixSystem: F_e[k] = v
       else if (fixed[f] && sysbody) F = 0.0;                     // (the band-row kernel that follows adds v per element itself)
       else if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
-      if (F != 0.0) out.vec[row * DOF + f] += F;
+      if (F != 0.0) { if constexpr (PIPE) out.vec[row * DOF + f] = Fold[f] + F; else out.vec[row * DOF + f] += F; }
     }
   }
+  if (!more) break;
+  if (PIPE) cur = nxt;
+  unit = unext;
+  }      // the wavefront's next element
 }
 #undef VS_SYNC
 
@@ -469,12 +540,13 @@ static int try_vec_sumfact(const Space &s, const SpaceDev &S, const ParamsDev &p
     bool three = !s.env.no_vec_pairs;
     for (int d = 0; d < 3; ++d) three = three && s.basis[d].nen <= 3 && s.basis[d].nqp <= 3;
     const bool g1 = s.nsd > 0 || s.rational;
+    const bool onepass = true;      // (UNITS = 1 in the kernel)      // (one pass per wavefront: the launch has a wavefront per unit)
     if (three) {
-      const unsigned grid = (unsigned)((nelem + 7) / 8);
+      const unsigned grid = onepass ? (unsigned)((nelem + 7) / 8) : (unsigned)((nelem + 15) / 16);
       if (g1) hipLaunchKernelGGL((vec_sumfact<Form, true, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
       else hipLaunchKernelGGL((vec_sumfact<Form, false, 3>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
     } else {
-      const unsigned grid = (unsigned)((nelem + 3) / 4);
+      const unsigned grid = onepass ? (unsigned)((nelem + 3) / 4) : (unsigned)((nelem + 7) / 8);
       if (g1) hipLaunchKernelGGL((vec_sumfact<Form, true, 4>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
       else hipLaunchKernelGGL((vec_sumfact<Form, false, 4>), dim3(grid), dim3(256), 0, stream, S, prm, out, cr, nelem);
     }
