@@ -2161,7 +2161,48 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
       }
     }
   };
-  geometry(0);
+  // Round 6 (a Tangent on the identity geometry): the global loads of the NEXT element's state -- its walk-axis rows, the lane's
+  // coefficient of U, the point's walk coordinate -- leave at the START of the flush phase, ahead of the band row's read-add-write,
+  // instead of behind it: the two round trips overlap (each sat behind a wavefront fence the compiler does not move loads across).
+  constexpr bool SPLIT = STATE && IDENT && !SGEO;
+  struct StatePre { double zv, uc, vc, xw; };
+  const int sp_aw = lane >> 4, sp_ay = (lane >> 2) & 3, sp_ax = lane & 3;
+  const bool sp_node = sp_aw < NB && sp_ay < NB && sp_ax < NB;
+  long long sp_rowxy = 0; double sp_x1 = 0, sp_x2 = 0;
+  if constexpr (SPLIT) {
+    if (sp_node) sp_rowxy = rs[X] * AX.rowmap[offx + sp_ax] + rs[Y] * AY.rowmap[offy + sp_ay];
+    if (sp_ax < NB && sp_ay < NB) { sp_x1 = AX.pt[elx * NB + sp_ax]; sp_x2 = AY.pt[ely * NB + sp_ay]; }      // (this lane's point (q_x, q_y) = (lane & 3, (lane >> 2) & 3): constant along the walk)
+  }
+  auto state_load = [&](int ei, StatePre &sp) {
+    sp.zv = 0.0; sp.uc = 0.0; sp.vc = 0.0; sp.xw = 0.0;
+    if constexpr (SPLIT) {
+    if (lane < 32) { const int q = lane >> 3, a = (lane >> 1) & 3, k = lane & 1; if (q < NB && a < NB) sp.zv = AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + k]; }
+    else if (lane < 48) { const int l2 = lane - 32, q = l2 >> 2, a = l2 & 3; if (q < NB && a < NB) sp.zv = AW.tab[((size_t)ew(ei) * NB * NB + q * NB + a) * NDER + 2]; }
+    if (sp_node) {
+      const int li = ei + sp_aw;
+      const long long urow = (long long)T.rho[li] * rs[W] + sp_rowxy;
+      sp.uc = out.U[urow];
+      if constexpr (RESID) sp.vc = out.V ? out.V[urow] : 0.0;
+      double fv = 0;
+      if (bc.any && pencil_fixed<P, false>(bc, sp_ax, sp_ay, T.lay0 + li, fv)) { sp.uc = S.fixtable ? S.fixtable[urow] : fv; sp.vc = 0.0; }
+    }
+    if (sp_aw < NB) sp.xw = AW.pt[ew(ei) * NB + sp_aw];
+    }
+  };
+  auto state_eval = [&](int ei, const StatePre &sp) {
+    if constexpr (SPLIT) {
+    if (lane < 32) geo[GZ + lane] = sp.zv;
+    else if (lane < 48) d2w[lane] = sp.zv;
+    __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    double xpar[3] = {0, 0, 0};
+    const int gqw = lane >> 4;
+    if (sp_ax < NB && sp_ay < NB && gqw < NB) { xpar[0] = sp.xw; xpar[1] = sp_x1; xpar[2] = sp_x2; }
+    pencil_state_eval<P, Form, RESID>(geo, d2w, lane, uxr, vyr, geo + GZ, wjxy * (gqw < NB ? T.wq[ei * 4 + gqw] : 0.0), sp.uc, prm, out.shift, out.t, xpar);
+    if constexpr (RESID) vscr[lane] = sp.vc;
+    }
+  };
+  if constexpr (SPLIT) { StatePre sp0; state_load(0, sp0); state_eval(0, sp0); }
+  else geometry(0);
 
   PencilFix<FIXT> fxt;
   if constexpr (FIXT) { fxt.table = S.fixtable; fxt.rmx = AX.rowmap + offx; fxt.rmy = AY.rowmap + offy; fxt.sx = rs[X]; fxt.sy = rs[Y]; fxt.rho = T.rho; fxt.lay0 = T.lay0; fxt.nl = nl; }
@@ -2236,6 +2277,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
     // the partner wavefront on this SIMD now streams MFMAs (one issue slot per 64 cycles); without priority
     // the younger wavefront's address arithmetic only gets the left-over VALU slots (measured: 12k vs 60k cycles)
     __builtin_amdgcn_s_setprio(3);
+    StatePre spn;
+    if constexpr (SPLIT) { if (ei + 1 < ne) state_load(ei + 1, spn); }
 #pragma unroll
     for (int t = 0; t < NB; ++t) held[t]++;
     if constexpr (RESID) pencil_rwin_leave<P>(rwin, lane, T, nl, out, S.fixtable, lay, own_lo, own_hi, bc, held[0], rs[W]);
@@ -2246,7 +2289,8 @@ __device__ __forceinline__ void gram_pencil_body(const SpaceDev &S, const OutDev
 #pragma unroll
     for (int t = 0; t < NB - 1; ++t) held[t] = held[t + 1];
     held[NB - 1] = 0;
-    if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
+    if constexpr (SPLIT) { if (ei + 1 < ne) state_eval(ei + 1, spn); }
+    else if (GEO && ei + 1 < ne) geometry(ei + 1);   // the next element's metric, while the partner wavefront streams its MFMAs
     __builtin_amdgcn_s_setprio(0);
     if (kDebug && pa.debug_buf) { tq3 = __builtin_readcyclecounter(); if (pa.debug_noflush == 2) { const long long a = tq0, b = tq1; tq0 = tq2; tq1 = a; tq2 = b; }      // (columns: "mfma" = the Residual's leave, "wait" = the band row's leave, "flush" = the next element's state)
       if ((wave & 3) == 0 && wave < 8 && lane == 0 && ei < 62) { long long *d = pa.debug_buf + (((size_t)blockIdx.x * 2 + (wave >> 2)) * 64 + ei) * 4; d[0] = tq0; d[1] = tq1; d[2] = tq2; d[3] = tq3; } }
