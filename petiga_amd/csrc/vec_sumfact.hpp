@@ -177,6 +177,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // SIMD to hide it, 7.7 us now.  (The colour makes the early read of F safe: no other element of the launch touches these rows.)
   // Off for the geometry variants: they are at their 256 registers already.
   constexpr bool PIPE = vs_pipe<Form, GEO>();
+  constexpr bool EF = GEO && Form::DOF == 1;      // ... scalar forms on a geometry: old F and the product of the point's weights (three registers) leave early too
   constexpr int TPL = (EPW * 3 * 48 + 63) / 64;                          // table entries per lane
   const long long nunits = (nelem + EPW - 1) / EPW, ustride = (long long)gridDim.x * 4;
   long long unit = (long long)blockIdx.x * 4 + wave;
@@ -238,7 +239,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
         if (readU) P.U[f] = out.U[P.row * DOF + f];
         if (useV) P.V[f] = out.V[P.row * DOF + f];
         if (S.fixtable) P.fx[f] = S.fixtable[P.row * DOF + f];
-        if constexpr (PIPE) P.Fo[f] = out.vec[P.row * DOF + f];
+        if constexpr (PIPE || EF) P.Fo[f] = out.vec[P.row * DOF + f];
       }
     }
     if constexpr (PIPE) {      // (the geometry variants read these where they use them: no register to spare)
@@ -247,6 +248,9 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       P.wq[0] = on ? S.ax[0].w[P.el[0] * nq[0] + i0] : 0.0; P.wq[1] = on ? S.ax[1].w[P.el[1] * nq[1] + i1] : 0.0; P.wq[2] = on ? S.ax[2].w[P.el[2] * nq[2] + i2] : 0.0;
 #pragma unroll
       for (int d = 0; d < 3; ++d) P.Jd[d] = S.ax[d].J[P.el[d]];
+    } else if constexpr (EF) {
+      const bool on = P.live && lanepoint;
+      P.wq[0] = on ? (S.ax[0].w[P.el[0] * nq[0] + i0] * S.ax[0].J[P.el[0]]) * (S.ax[1].w[P.el[1] * nq[1] + i1] * S.ax[1].J[P.el[1]]) * (S.ax[2].w[P.el[2] * nq[2] + i2] * S.ax[2].J[P.el[2]]) : 0.0;
     }
   };
   Pre cur, nxt;
@@ -411,8 +415,11 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   double JW = 0.0, G[9];
   if (ispoint) {
     JW = detX;
+    if constexpr (EF && !PIPE) JW *= cur.wq[0];
+    else {
 #pragma unroll
     for (int d = 0; d < 3; ++d) JW *= PIPE ? cur.wq[d] * cur.Jd[d] : S.ax[d].w[el[d] * nq[d] + il[d]] * S.ax[d].J[el[d]];
+    }
   }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
@@ -488,7 +495,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
       if (fixed[f] && sysvec) F = ufix[f];                       // IGAElementFixSystem: F_e[k] = v
       else if (fixed[f] && sysbody) F = 0.0;                     // (the band-row kernel that follows adds v per element itself)
       else if (fixed[f] && (op == OP_FUNCTION || op == OP_IFUNCTION)) F = Uv[f] - ufix[f];
-      if (F != 0.0) { if constexpr (PIPE) out.vec[row * DOF + f] = Fold[f] + F; else out.vec[row * DOF + f] += F; }
+      if (F != 0.0) { if constexpr (PIPE || EF) out.vec[row * DOF + f] = Fold[f] + F; else out.vec[row * DOF + f] += F; }
     }
   }
   if (!more) break;
