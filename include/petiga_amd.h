@@ -147,9 +147,12 @@ int IGXSetForm(IGX iga,IGXFormKind kind,const double params[],int nparams);
  * `struct_name` with the contract of the built-in forms (petiga_amd/csrc/forms.hpp, the device restatement of
  * include/petiga.h:153-197 + src/petigapoint.c:427-462):
  *     struct MyForm {
- *       static constexpr int DOF = 1, ORDER = 1;          // fields per node; 2 if second derivatives of N or of U are read
+ *       static constexpr int DOF = 1, ORDER = 1;          // fields per node; 2 if second derivatives of N or of U are read, 3 for third
+ *                                                         // ones (p->shape[3]: dim^3 numbers behind the Hessian in Na / Nb; IGXSetOrder(3))
  *       static constexpr unsigned NEED = NEED_X | NEED_U; // point data read: NEED_X x, NEED_U u, NEED_UT du/dt, NEED_GU grad u,
- *                                                         // NEED_HU hess u, NEED_G IGAPointFormInvGradGeomMap
+ *                                                         // NEED_HU hess u, NEED_G IGAPointFormInvGradGeomMap; on the point-form kernel
+ *                                                         // only: NEED_D3U p.d3u (IGAPointFormDer3), NEED_PROP p.property [nen][npd] with
+ *                                                         // the point's shape table p.shape [nen][nf], NEED_MAPX p.X1 / p.X2 (p->mapX[1], [2])
  *       static __device__ void mat(const PtView &p,const double *Na,const double *Nb,double *T); // T[i*DOF+j]: K block of (a,b)
  *       static __device__ void vec(const PtView &p,const double *Na,double *R);                  // R[i]: F entries of a
  *     };
