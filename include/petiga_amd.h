@@ -253,6 +253,8 @@ typedef struct {
   int rational;                              /* iga->rational                                     */
   const double *geometryX;                   /* ghosted local [gw2][gw1][gw0][nsd]  (iga->geometryX) */
   const double *rationalW;                   /* ghosted local [gw2][gw1][gw0]       (iga->rationalW) */
+  /* appended in round 6 -- zero the whole struct before filling it (the adapter does: PetscMemzero), so that a field this header
+   * grows later reads as "absent" */
   int property;                              /* iga->property: numbers per node (0 = none), include/petiga.h:350 */
   const double *propertyA;                   /* ghosted local [gw2][gw1][gw0][npd]  (iga->propertyA, include/petiga.h:353) */
 } IGXTables;
