@@ -2424,8 +2424,12 @@ inline const char *&pencil_launch_error() { static thread_local const char *e = 
 // elements -- but enough workgroups for the CUs.  One 8-pencil workgroup per CU at a time (LDS; two where the tables are small), so a
 // launch takes ceil(workgroups / slots) rounds of (segment length + halo): the count with the least rounds x length.  Returns the
 // count; *cost = that product (element-steps of the launch's critical path).
-static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bool walk0, size_t extra_lds, bool halo_always, long long *cost_out = nullptr, int wpb = 8) {
+static inline int pencil_cus() {
   static const int ncu = [] { int dev = 0; hipDeviceProp_t pr; return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }();
+  return ncu;
+}
+static inline int pencil_segments(long long pencils, int nw, int P, bool geo, bool walk0, size_t extra_lds, bool halo_always, long long *cost_out = nullptr, int wpb = 8) {
+  const int ncu = pencil_cus();
   const long long bps = (pencils + wpb - 1) / wpb;
   int nseg = std::max(1, (nw + 159) / 160);
   long long best = -1; int best_n = nseg;
@@ -2511,6 +2515,34 @@ static void launch_pencils(const Space &s, const SpaceDev &S, const OutDev &out,
     pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
     pa.w_lo = bx.lo[W]; pa.w_hi = bx.hi[W];
     pa.blocks_per_seg = (int)((pencils + pa.wpb - 1) / pa.wpb);
+    // Launches that do not fill the chip (small and medium meshes), the plain Gram walk: segments AND workgroup size from a model of the
+    // step -- measured at p = 3 (profiles/r06_small_meshes.txt): a step of the walk takes 20 us with one wavefront on the SIMD (its
+    // MFMAs, then its flush), 31 us with two (the ping-pong pair), 14 us per wavefront beyond; four-wavefront workgroups (one per SIMD,
+    // free-running) spread the pencils over twice the CUs.  time = rounds x (length + halo + 1) x step(wavefronts per SIMD on the
+    // fullest CU).  Large meshes come out as before (eight wavefronts, the fewest segments that fit the LDS).  IGX_SMALL_WPB=0: off;
+    // IGX_NSEG forces the segments and keeps the eight.
+    if (W == 0 && !GEO && !mod && pa.wpb == 8 && s.env.small_wpb && s.env.nseg <= 0) {
+      const int ncu = pencil_cus();
+      const bool halo_always = (W == 0 && s.lay[0].alias) || (pass && pass->halo_lo >= 0 && pass->halo_lo < bx.lo[W]);
+      double best = 1e300; int bn = nseg, bw = 8;
+      for (int wc = 8; wc >= 4; wc -= 4)
+        for (int n = nseg_min_lds(nw); n <= std::max(nseg_min_lds(nw), nw / 2); ++n) {
+          const int len = (nw + n - 1) / n, ns = (nw + len - 1) / len;
+          const size_t lds_n = pencil_lds_bytes(len + 3, false, wc) + pencil_hold_bytes(P) * wc / 8;
+          if (lds_n > (size_t)160 * 1024) continue;
+          const long long rmax = std::max<long long>(1, std::min<long long>(wc == 8 ? 2 : 4, (long long)(160 * 1024) / (long long)lds_n));
+          const long long wgs = ((pencils + wc - 1) / wc) * ns, m = (wgs + ncu - 1) / ncu, rounds = (m + rmax - 1) / rmax;
+          const long long wsimd = std::min(m, rmax) * wc / 4;
+          double step = wsimd <= 1 ? 20.0 : (wsimd == 2 ? 31.0 : 14.0 * (double)wsimd);
+          if (wc == 4 && wsimd >= 2) step *= 1.08;      // (without the barriers the p = 3 walk loses 6-8 % once wavefronts share a SIMD)
+          const double cost = (double)rounds * (double)(len + ((ns > 1 || halo_always) ? P : 0) + 1) * step;
+          if (cost < best * (1.0 - 1e-9)) { best = cost; bn = n; bw = wc; }
+        }
+      nseg = bn;
+      pa.seg_len = (nw + nseg - 1) / nseg; pa.nseg = (nw + pa.seg_len - 1) / pa.seg_len;
+      if (bw == 4) { pa.wpb = 4; pa.free_run = 1; }
+      pa.blocks_per_seg = (int)((pencils + pa.wpb - 1) / pa.wpb);
+    }
     pa.ne_max = pa.seg_len + 3;
     pa.debug_noflush = s.env.debug_noflush;
     pa.debug_buf = nullptr;

@@ -32,6 +32,7 @@ EnvSwitches read_env_switches() {
   e.fuse_resid = num("IGX_FUSE_RESID", 0);
   e.patch = num("IGX_PATCH", 1);
   e.patch_state = num("IGX_PATCH_STATE", 0);
+  e.small_wpb = num("IGX_SMALL_WPB", 1);
   e.band_prio = num("IGX_BAND_PRIO", 0); e.band_rmw_prio = num("IGX_BAND_RMW_PRIO", 0);
   if (kDebug) { e.debug_feature = num("IGX_DEBUG_FEATURE", 0); e.debug_noflush = num("IGX_DEBUG_NOFLUSH", 0); e.debug_timing = getenv("IGX_DEBUG_TIMING") != nullptr; }
   return e;

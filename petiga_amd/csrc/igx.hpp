@@ -45,6 +45,7 @@ struct EnvSwitches {
   int band_prio = 0, band_rmw_prio = 0;      // IGX_BAND_PRIO=k: band_pt raises the priority of a workgroup's first k layers; IGX_BAND_RMW_PRIO=1: ... of its read-add-writes
   int patch = 1;             // IGX_PATCH=0: the p = 2 Gram walk keeps one pencil and one window per wavefront (bit-repeatable) instead of the patches of
                              // 4 x 3 pencils with one shared window (gram_patch.hpp, round 6: + 23 % on config 2, the order of its LDS adds is not fixed)
+  int small_wpb = 1;         // IGX_SMALL_WPB=0: launches that fill less than half the CUs keep eight-wavefront workgroups (gram_mfma.hpp, round 6)
   int patch_state = 0;       // IGX_PATCH_STATE=1: the Tangent of a p = 2 state form walks patches of 4 x 2 pencils (state_patch_p2) instead of state_pencil_k
   int fuse_resid = 0;        // IGX_FUSE_RESID=1: IGXComputeIFunctionIJacobian takes the fused walk (state_pencil_kr) where it exists; default: the two
                              // drivers one after the other -- measured in round 6: the fused launch costs 2.5 ms more than the Tangent's, the
