@@ -9,7 +9,8 @@ import petiga_amd as P
 
 REPS = int(os.environ.get("REPS", "40"))
 SIZES = os.environ.get("SIZES")
-for p, n in ([(3, int(x)) for x in SIZES.split()] if SIZES else ((3, 16), (3, 24), (3, 32), (3, 48), (2, 32), (2, 48))):
+DEG = int(os.environ.get("DEG", "3"))
+for p, n in ([(DEG, int(x)) for x in SIZES.split()] if SIZES else ((3, 16), (3, 24), (3, 32), (3, 48), (2, 32), (2, 48))):
     g = P.IGX(3, 1)
     for i in range(3):
         g.axis_uniform(i, p, n)
