@@ -94,9 +94,11 @@ template <int ORD, unsigned KMASK, int NS>
 __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf, const double *tab0, const double *tab1, const double *tab2, int lane, const VsLane &L) {
   const int i0 = L.i0, i1 = L.i1, i2 = L.i2;
   constexpr int T1s = NS, T2s = NS * NS;
-  double *Cb = buf + L.base, *S2 = buf + vs_popc(KMASK) * 64 + L.base, *S1 = buf + L.base;      // (S1 takes the place of Cb: nobody reads Cb after the first stage)
+  // (round 6: S2 takes the place of Cb -- every lane holds its sums in registers until all have read Cb -- and S1 sits behind S2:
+  //  max(popc, 9) buffers instead of popc + 6; with the forward stage's 10 that is 30 KB per workgroup, five workgroups per CU instead of four)
+  constexpr int NS2 = ORD >= 2 ? 6 : 3;
+  double *Cb = buf + L.base, *S2 = buf + L.base, *S1 = buf + NS2 * 64 + L.base;
   lane -= L.base;
-  static_assert(vs_popc(KMASK) >= 3, "S1 fits where Cb was");
   VS_SYNC();
 #pragma unroll
   for (int k = 0; k < 10; ++k) if (((KMASK >> k) & 1u) && vs_v0(k) + vs_v1(k) + vs_v2(k) <= ORD) Cb[vs_kc(KMASK, k) * 64 + lane] = C[k];
@@ -111,6 +113,7 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
         t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + T1s * i1 + T2s * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
       }
     }
+    VS_SYNC();      // (every lane has read Cb)
 #pragma unroll
     for (int m = 0; m < 6; ++m) if (vs_mv0(m) + vs_mv1(m) <= ORD) S2[m * 64 + lane] = t[m];
   }
@@ -166,8 +169,8 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // derivatives of the test functions that can carry a coefficient: without a geometry feature tf maps to one of them; with one, the
   // inverse Jacobian mixes the three first derivatives and the rational correction reaches the value
   constexpr unsigned KMASK = GEO ? (SECOND_T ? 0x3FFu : 0xFu) : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
-  constexpr int NBACK = vs_popc(KMASK) + (SECOND_T ? 6 : 3), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
-  __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard: 33 KB per workgroup, four workgroups per CU, two elements per wavefront
+  constexpr int NBACK = vs_popc(KMASK) > (SECOND_T ? 9 : 5) ? vs_popc(KMASK) : (SECOND_T ? 9 : 5), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
+  __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard without a geometry: 29 KB per workgroup, five workgroups per CU, two elements per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int esub = (EPW == 2 && lane >= NL) ? 1 : 0;                    // which of the wavefront's elements this lane works on
   // Round 6 (PIPE: scalar forms without a geometry): every global load of the unit -- the 1-D rows, the node's state and old F, the
@@ -178,7 +181,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // Off for the geometry variants: they are at their 256 registers already.
   constexpr bool PIPE = vs_pipe<Form, GEO>();
   constexpr bool EF = GEO && Form::DOF == 1;      // ... scalar forms on a geometry: old F and the product of the point's weights (three registers) leave early too
-  constexpr int TPL = (EPW * 3 * 48 + 63) / 64;                          // table entries per lane
+  constexpr int TPL = EPW * 3;                                           // table entries per lane: lane j < 48 holds entry j of each (element, axis) block
   const long long nunits = (nelem + EPW - 1) / EPW, ustride = (long long)gridDim.x * 4;
   long long unit = (long long)blockIdx.x * 4 + wave;
   if (unit >= nunits) return;
@@ -212,14 +215,16 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   };
   auto stageB = [&](long long un, Pre &P) {
     const long long w0n = un * EPW;
+    {      // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4 (the axis is a compile-time index: an index known only at run time sent nq / nb / the element to scratch and LDS)
+      const int j = lane < 48 ? lane : 0, q = j / 12, a = (j / 3) & 3, v = j % 3;
 #pragma unroll
-    for (int k = 0; k < TPL; ++k) {      // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4
-      const int i = lane + 64 * k;
-      P.tab[k] = 0.0;
-      if (i < EPW * 3 * 48) {
-        const int es = i / 144, r = i - es * 144, d = r / 48, j = r - d * 48, q = j / 12, a = (j / 3) & 3, v = j % 3;
+      for (int es = 0; es < EPW; ++es) {
         int e3[3]; element_at(w0n + es, w0n, e3);
-        if (q < nq[d] && a < nb[d]) P.tab[k] = S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          P.tab[es * 3 + d] = 0.0;
+          if (lane < 48 && q < nq[d] && a < nb[d]) P.tab[es * 3 + d] = S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v];
+        }
       }
     }
     P.row = 0; P.wgt = 0.0;
@@ -267,7 +272,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   int el[3] = {cur.el[0], cur.el[1], cur.el[2]};
   VS_SYNC();      // (the previous element's readers of the rows are done)
 #pragma unroll
-  for (int k = 0; k < TPL; ++k) { const int i = lane + 64 * k; if (i < EPW * 3 * 48) buf[NBUF * 64 + i] = cur.tab[k]; }
+  for (int k = 0; k < TPL; ++k) if (lane < 48) buf[NBUF * 64 + k * 48 + lane] = cur.tab[k];
   if (PIPE && more) stageA(unext, nxt);
   // Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
   const bool isnode = live && lanenode;
