@@ -35,7 +35,7 @@ __device__ __forceinline__ constexpr int vs_mv1(int m) { return (m == 2 || m == 
 #define VS_SYNC() do { __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); } while (0)
 
 // forward: D[k] = sum_a coef_a D_k N_a(q) at this lane's point; ORD = highest derivative order wanted.  buf: 10 x 64 doubles of this
-// wave; tab[d]: [q][a][3] (value, first, second derivative), zero padded to 4 x 4.
+// wave; tab[d]: [q][a][3] (value, first, second derivative), zero padded to NS x NS.
 // NS: lanes per axis -- 4: one element per wavefront; 3 (nen, nqp <= 3 on every axis): two elements per wavefront, lanes 0..26 and
 // 27..53.  L: this lane's (i0, i1, i2) and the first lane of its element.
 struct VsLane { int i0, i1, i2, base; };
@@ -54,7 +54,7 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
     for (int a0 = 0; a0 < NS; ++a0) {
       const double c = in[a0 + S1 * i1 + S2 * i2];
 #pragma unroll
-      for (int v = 0; v <= ORD; ++v) t[v] += c * tab0[(i0 * 4 + a0) * 3 + v];
+      for (int v = 0; v <= ORD; ++v) t[v] += c * tab0[(i0 * NS + a0) * 3 + v];
     }
 #pragma unroll
     for (int v = 0; v <= ORD; ++v) T1[v * 64 + lane] = t[v];
@@ -67,7 +67,7 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
-        t[m] += T1[vs_mv0(m) * 64 + i0 + S1 * a1 + S2 * i2] * tab1[(i1 * 4 + a1) * 3 + vs_mv1(m)];
+        t[m] += T1[vs_mv0(m) * 64 + i0 + S1 * a1 + S2 * i2] * tab1[(i1 * NS + a1) * 3 + vs_mv1(m)];
       }
     }
 #pragma unroll
@@ -81,7 +81,7 @@ __device__ __forceinline__ void vs_forward(double coef, double *buf, const doubl
 #pragma unroll
     for (int k = 0; k < 10; ++k) {
       if (vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
-      D[k] += T2[vs_m(vs_v0(k), vs_v1(k)) * 64 + i0 + S1 * i1 + S2 * a2] * tab2[(i2 * 4 + a2) * 3 + vs_v2(k)];
+      D[k] += T2[vs_m(vs_v0(k), vs_v1(k)) * 64 + i0 + S1 * i1 + S2 * a2] * tab2[(i2 * NS + a2) * 3 + vs_v2(k)];
     }
   }
 }
@@ -110,7 +110,7 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
 #pragma unroll
       for (int k = 0; k < 10; ++k) {
         if (!((KMASK >> k) & 1u) || vs_v0(k) + vs_v1(k) + vs_v2(k) > ORD) continue;
-        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + T1s * i1 + T2s * q2] * tab2[(q2 * 4 + i2) * 3 + vs_v2(k)];
+        t[vs_m(vs_v0(k), vs_v1(k))] += Cb[vs_kc(KMASK, k) * 64 + i0 + T1s * i1 + T2s * q2] * tab2[(q2 * NS + i2) * 3 + vs_v2(k)];
       }
     }
     VS_SYNC();      // (every lane has read Cb)
@@ -125,7 +125,7 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
 #pragma unroll
       for (int m = 0; m < 6; ++m) {
         if (vs_mv0(m) + vs_mv1(m) > ORD) continue;
-        t[vs_mv0(m)] += S2[m * 64 + i0 + T1s * q1 + T2s * i2] * tab1[(q1 * 4 + i1) * 3 + vs_mv1(m)];
+        t[vs_mv0(m)] += S2[m * 64 + i0 + T1s * q1 + T2s * i2] * tab1[(q1 * NS + i1) * 3 + vs_mv1(m)];
       }
     }
 #pragma unroll
@@ -136,7 +136,7 @@ __device__ __forceinline__ double vs_backward(const double (&C)[10], double *buf
 #pragma unroll
   for (int q0 = 0; q0 < NS; ++q0) {
 #pragma unroll
-    for (int v = 0; v <= ORD; ++v) f += S1[v * 64 + q0 + T1s * i1 + T2s * i2] * tab0[(q0 * 4 + i0) * 3 + v];
+    for (int v = 0; v <= ORD; ++v) f += S1[v * 64 + q0 + T1s * i1 + T2s * i2] * tab0[(q0 * NS + i0) * 3 + v];
   }
   return f;
 }
@@ -170,7 +170,8 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // inverse Jacobian mixes the three first derivatives and the rational correction reaches the value
   constexpr unsigned KMASK = GEO ? (SECOND_T ? 0x3FFu : 0xFu) : vs_kmask_ident(VMASK & ((1u << NFS) - 1u));
   constexpr int NBACK = vs_popc(KMASK) > (SECOND_T ? 9 : 5) ? vs_popc(KMASK) : (SECOND_T ? 9 : 5), NFWD = (UORD == 2 || GEO) ? 10 : 7, NBUF = NBACK > NFWD ? NBACK : NFWD;
-  __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * 48];      // Cahn-Hilliard without a geometry: 29 KB per workgroup, five workgroups per CU, two elements per wavefront
+  constexpr int TB = NS * NS * 3;                                        // doubles of one axis' rows [q][a][3], zero padded to NS x NS
+  __shared__ double sm_all[4][NBUF * 64 + EPW * 3 * TB];      // Cahn-Hilliard without a geometry: 25 KB per workgroup, two elements per wavefront (a sixth workgroup per CU measured no gain over five: 12.8 ms either way)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int esub = (EPW == 2 && lane >= NL) ? 1 : 0;                    // which of the wavefront's elements this lane works on
   // Round 6 (PIPE: scalar forms without a geometry): every global load of the unit -- the 1-D rows, the node's state and old F, the
@@ -181,11 +182,11 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   // Off for the geometry variants: they are at their 256 registers already.
   constexpr bool PIPE = vs_pipe<Form, GEO>();
   constexpr bool EF = GEO && Form::DOF == 1;      // ... scalar forms on a geometry: old F and the product of the point's weights (three registers) leave early too
-  constexpr int TPL = EPW * 3;                                           // table entries per lane: lane j < 48 holds entry j of each (element, axis) block
+  constexpr int TPL = EPW * 3;                                           // table entries per lane: lane j < TB holds entry j of each (element, axis) block
   const long long nunits = (nelem + EPW - 1) / EPW, ustride = (long long)gridDim.x * 4;
   long long unit = (long long)blockIdx.x * 4 + wave;
   if (unit >= nunits) return;
-  double *buf = sm_all[wave], *tab0 = buf + NBUF * 64 + esub * 144, *tab1 = tab0 + 48, *tab2 = tab1 + 48;
+  double *buf = sm_all[wave], *tab0 = buf + NBUF * 64 + esub * 3 * TB, *tab1 = tab0 + TB, *tab2 = tab1 + TB;
   auto element_at = [&](long long ww, long long wfirst, int (&e3)[3]) {
     long long b = ww < nelem ? ww : wfirst;
     const int t0 = (int)(b % cr.count[0]); b /= cr.count[0];
@@ -216,14 +217,14 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   auto stageB = [&](long long un, Pre &P) {
     const long long w0n = un * EPW;
     {      // 1-D rows of the element(s), [q][a][3], zero padded to 4 x 4 (the axis is a compile-time index: an index known only at run time sent nq / nb / the element to scratch and LDS)
-      const int j = lane < 48 ? lane : 0, q = j / 12, a = (j / 3) & 3, v = j % 3;
+      const int j = lane < TB ? lane : 0, q = j / (3 * NS), a = (j / 3) % NS, v = j % 3;
 #pragma unroll
       for (int es = 0; es < EPW; ++es) {
         int e3[3]; element_at(w0n + es, w0n, e3);
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
           P.tab[es * 3 + d] = 0.0;
-          if (lane < 48 && q < nq[d] && a < nb[d]) P.tab[es * 3 + d] = S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v];
+          if (lane < TB && q < nq[d] && a < nb[d]) P.tab[es * 3 + d] = S.ax[d].tab[((size_t)e3[d] * nq[d] * nb[d] + q * nb[d] + a) * NDER + v];
         }
       }
     }
@@ -272,7 +273,7 @@ vec_sumfact(SpaceDev S, ParamsDev prm, OutDev out, ColorRange cr, long long nele
   int el[3] = {cur.el[0], cur.el[1], cur.el[2]};
   VS_SYNC();      // (the previous element's readers of the rows are done)
 #pragma unroll
-  for (int k = 0; k < TPL; ++k) if (lane < 48) buf[NBUF * 64 + k * 48 + lane] = cur.tab[k];
+  for (int k = 0; k < TPL; ++k) if (lane < TB) buf[NBUF * 64 + k * TB + lane] = cur.tab[k];
   if (PIPE && more) stageA(unext, nxt);
   // Dirichlet flags (IGAElementBuildFix / FixValues, src/petigaelem.c:1214-1358)
   const bool isnode = live && lanenode;
