@@ -284,3 +284,108 @@ def test_user_shell_struct_on_the_cylinder():
     assert "generic_assemble" in eng.kernel_name()
     area = np.pi * R / 2 * h
     assert abs(abs(F.get().sum()) - area / R) < 1e-12 and abs(K.to_coo_global()[2].sum() - area / R ** 2) < 1e-12
+
+
+# ---------------------------------------------------------------- the additions next to the path's other features
+def _net_size(orc, dim):
+    """control points of the geometry grid (n + 1 per axis: a periodic axis keeps its wrapped copies, src/petigaio.c:187-199)"""
+    n = 1
+    for i in range(dim):
+        ax = orc.axis(i)
+        n *= len(ax["U"]) - 1 - ax["p"]
+    return n
+
+
+def test_property_array_on_a_periodic_axis_and_on_a_visited_face():
+    """The property array lives on the geometry grid (the wrapped copies of a periodic axis included); a boundary-form pass sees the
+    face element's nodal values like the interior pass does (src/petigaelem.c:745-752 is the closure of every element)."""
+    orc, eng = make_pair(2, 1, 2, [6, 5], periodic=[True, False])
+    A = 1.0 + np.random.default_rng(3).random((_net_size(orc, 2), 2))
+    orc.set_property(A); eng.set_property(A)
+    for g in (orc, eng):
+        g.set_boundary_value(1, 0, 0, 0.5)
+        g.set_boundary_form(1, 1, True)
+    K_o, F_o = orc.compute_system("orc_form_property")
+    eng.set_form("property")
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    compare_mats(K, K_o, 1e-12)
+    assert np.abs(F.get() - F_o).max() <= 1e-12 * max(np.abs(F_o).max(), 1.0)
+
+
+def test_third_order_form_over_a_visited_face():
+    orc, eng = make_pair(2, 1, 3, [4, 3], order=3)
+    X, W = warped_geometry(orc, 2, seed=8, rational=True)
+    orc.set_geometry(X, W); eng.set_geometry(X, W)
+    for g in (orc, eng):
+        g.set_boundary_form(0, 1, True); g.set_boundary_form(1, 0, True)
+    K_o, F_o = orc.compute_system("orc_form_der3", _prm(PRM))
+    eng.set_form("der3", PRM)
+    K, F = eng.create_mat(), eng.create_vec()
+    eng.compute_system(K, F)
+    compare_mats(K, K_o, 1e-11)
+    assert np.abs(F.get() - F_o).max() <= 1e-11 * max(np.abs(F_o).max(), 1.0)
+
+
+@pytest.mark.parametrize("size,dim,nsd,p,N,what", [(2, 2, 3, 2, (6, 5), "surface"), (3, 1, 2, 3, (9,), "surface"), (4, 3, 3, 2, (6, 5, 4), "reduced"), (2, 2, 2, 3, (7, 4), "der3")])
+def test_round6_additions_on_a_partition(size, dim, nsd, p, N, what):
+    """Every rank assembles its box (the ghosted box of the net for a surface in space; the GLOBAL first and last element of an axis keep
+    the full rule under IGA_RULE_REDUCED, src/petigabasis.c:163-170; third-order tabulation per rank); owned rows of all ranks after
+    the ghost-row exchange = the single-rank oracle."""
+    import torch
+    import scipy.sparse as sp
+    from test_gpu_parity import _rank_matrix_rows
+    orc, _ = make_pair(dim, 1, p, list(N), order=3 if what == "der3" else None, engine=False)
+    if what == "reduced":
+        for i in range(dim):
+            orc.set_rule_type(i, "reduced")
+        orc.setup()
+    X = W = None
+    if what != "reduced":
+        X, W = _lifted(orc, dim, nsd, seed=17) if nsd != dim else warped_geometry(orc, dim, seed=17, rational=True)
+        orc.set_geometry(X, W)
+    form, octx, prm = {"surface": ("surface", C.c_double(0.2), (0.2,)), "reduced": ("poisson", None, ()), "der3": ("der3", _prm(PRM), PRM)}[what]
+    orc.set_boundary_value(0, 0, 0, 0.5)
+    A_o, b_o = orc.compute_system("orc_form_" + form, octx)
+    engs, mats, vecs, sendbufs = [], [], [], {}
+    for r in range(size):
+        g = P.IGX(dim, 1)
+        for i in range(dim):
+            g.axis_uniform(i, p, N[i])
+            if what == "reduced":
+                g.set_rule_type(i, "reduced")
+        if what == "der3":
+            g.set_order(3)
+        g.set_comm(size, r)
+        g.setup()
+        if X is not None:
+            g.set_geometry(X, W)
+        g.set_boundary_value(0, 0, 0, 0.5)
+        g.set_form(form, prm)
+        A, b = g.create_mat(), g.create_vec()
+        g.compute_system(A, b)
+        for k, (peer, m, v) in enumerate(g.neighbors(True)):
+            buf = torch.empty(m + v, dtype=torch.float64, device="cuda")
+            g.pack_ghost_rows(A, b, k, buf.data_ptr())
+            sendbufs[(r, peer)] = buf
+        g.synchronize()
+        engs.append(g); mats.append(A); vecs.append(b)
+    for r, g in enumerate(engs):
+        for k, (peer, m, v) in enumerate(g.neighbors(False)):
+            g.unpack_ghost_rows(mats[r], vecs[r], k, sendbufs[(peer, r)].data_ptr())
+        g.synchronize()
+    n = orc.global_size()
+    M = sp.csr_matrix((n, n)); F = np.zeros(n); seen = np.zeros(n, dtype=int)
+    for r, g in enumerate(engs):
+        rows, cols, vals, own_e, own = _rank_matrix_rows(g, mats[r], vecs[r])
+        M = M + sp.coo_matrix((vals[own_e], (rows[own_e], cols[own_e])), shape=(n, n)).tocsr()
+        nrow, _, maps = mats[r].layout()
+        ns = g.sizes()["node_sizes"]
+        rr = np.arange(mats[r].nbrows)
+        grow = maps[0][0][rr % nrow[0]].astype(np.int64) + ns[0] * (maps[1][0][(rr // nrow[0]) % nrow[1]].astype(np.int64) + ns[1] * maps[2][0][rr // (nrow[0] * nrow[1])].astype(np.int64))
+        bv = vecs[r].get()
+        F[grow[own]] = bv[own]; seen[grow[own]] += 1
+    assert np.all(seen == 1)
+    Mo = A_o.scipy()
+    assert abs(M - Mo).max() <= 1e-11 * abs(Mo).max()
+    assert np.abs(F - b_o).max() <= 1e-11 * max(np.abs(b_o).max(), 1e-300)
